@@ -1,0 +1,180 @@
+/* mvlt_hip.h -- C ABI of libmvlt_hip.so: the MI355X (gfx950) kernels behind the MVLT hot path.
+ *
+ * The reference (GewelsJI/MVLT) is pure PyTorch: it has no FFI of its own.  Each entry point below names the
+ * reference call site(s) whose ATen kernels it replaces; INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - the caller owns every buffer (device pointers, contiguous in the stated layout); kernels never allocate
+ *   - everything is asynchronous on the hipStream_t passed as `void* stream` (NULL = default stream); no syncs
+ *   - returns 0 on success, <0 on error; mvlt_last_error() returns a thread-local description
+ *   - dtype codes: 0 = bf16, 1 = fp32.  All reductions/accumulations are fp32.
+ */
+#ifndef MVLT_HIP_H
+#define MVLT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVLT_DT_BF16 0
+#define MVLT_DT_FP32 1
+
+const char* mvlt_last_error(void);
+int mvlt_abi_version(void);
+/* sizeof(struct <name>) for binding self-checks; -1 if unknown */
+int mvlt_sizeof(const char* name);
+
+/* Row addressing of a GEMM operand / result.
+ *  mode 0: phys_row = m                                   when rows_per_batch == 0
+ *          phys_row = (m / rows_per_batch) * batch_stride + offset + m % rows_per_batch    otherwise
+ *          (a token sub-range of a (B, N, C) buffer: image tokens [0,HW) or text tokens [HW,HW+T))
+ *  mode 1: r x r non-overlapping patch gather over the image-token grid of a (B, tokens_in, c_seg) buffer:
+ *          logical row m = (b, oi, oj), logical column = (di*r + dj) * c_seg + c,
+ *          phys_row = b*tokens_in + (oi*r+di)*w_in + (oj*r+dj).  This is nn.Conv2d(kernel=stride=r) on
+ *          token-major data (reference libs/pvlt.py:92,104 Attention.sr and :162,168 PatchEmbed.proj);
+ *          the conv weight is used as [out][di][dj][c]. */
+typedef struct mvlt_rowmap {
+  int mode, rows_per_batch, batch_stride, offset;
+  int r, w_in, tokens_in, hw_out, w_out, c_seg;
+} mvlt_rowmap;
+
+/* C[M,N] = epi(A[M,K] . B[N,K]^T).   Replaces nn.Linear forward (reference libs/pvlt.py:66,69,98,108,118;
+ * libs/vl_heads.py:31,67,85,102), its input gradient (B = W^T), and the kernel==stride convolutions.
+ *   epi(v) = act(v + bias[n]) * row_scale[m / rows_per_scale] + R[m,n]
+ *   act 0: identity; 1: exact-erf GELU (pre-activation optionally stored to H); 2: v * gelu'(H[m,n])
+ *   R may alias C (accumulate).  C, R, H share c_map/ldc and out_dtype. */
+typedef struct mvlt_gemm_nt_args {
+  const void* A; const void* B; void* C;
+  int M, N, K, lda, ldb, ldc;
+  int dtype;                 /* of A and B */
+  int out_dtype;             /* of C, R, H */
+  mvlt_rowmap a_map, c_map;
+  const float* bias;         /* [N] fp32 or NULL */
+  int act;
+  void* H;
+  const float* row_scale;    /* [ceil(M / rows_per_scale)] fp32 or NULL (DropPath keep/(1-p) per sample) */
+  int rows_per_scale;
+  const void* R;
+} mvlt_gemm_nt_args;
+int mvlt_gemm_nt(const mvlt_gemm_nt_args* args, void* stream);
+
+/* C[N1,N2] += A[M,N1]^T . B[M,N2]  (fp32, atomic accumulate into a caller-zeroed buffer) and optionally
+ * colsum_a[N1] += sum_m A[m,:].   Weight / bias gradients of nn.Linear and of the kernel==stride convs
+ * (autograd of the call sites above).  b_map may be a patch gather (N2 = r*r*c_seg). */
+typedef struct mvlt_gemm_tn_args {
+  const void* A; const void* B; float* C;
+  int M, N1, N2, lda, ldb, ldc;
+  int dtype;
+  mvlt_rowmap a_map, b_map;
+  float* colsum_a;
+  int splits;                /* 0 = choose */
+} mvlt_gemm_tn_args;
+int mvlt_gemm_tn(const mvlt_gemm_tn_args* args, void* stream);
+
+/* y = LayerNorm(x) * gamma + beta (+ add[(row % add_rows)] ) over the last dim C; rows addressed through maps.
+ * Replaces nn.LayerNorm at reference libs/pvlt.py:105,141,142,169,208 and libs/vl_heads.py:33 (eps differs per
+ * site: 1e-6 block norms, 1e-5 others, 1e-12 BERT) plus the "+ pos_embed" and torch.cat of libs/pvlt.py:346
+ * (y_map writes straight into the concatenated token buffer).  mean/rstd (fp32, [rows]) are saved for backward. */
+typedef struct mvlt_layernorm_args {
+  const void* x; void* y;
+  const float* gamma; const float* beta;
+  float* mean; float* rstd;           /* optional outputs [rows] */
+  const float* add;                   /* optional fp32 [add_rows, C] added after the affine (pos-embed) */
+  int add_rows;
+  int rows, C, ldx, ldy;
+  mvlt_rowmap x_map, y_map;           /* mode 0 only */
+  float eps;
+  int dtype;                          /* of x and y */
+} mvlt_layernorm_args;
+int mvlt_layernorm_fwd(const mvlt_layernorm_args* args, void* stream);
+
+/* dx = LN backward; dgamma/dbeta (fp32 [C]) and dadd (fp32 [add_rows, C]) accumulate atomically into
+ * caller-zeroed buffers.  If dx_accumulate != 0, dx += result (several consumers of one tensor). */
+typedef struct mvlt_layernorm_bwd_args {
+  const void* dy; const void* x; void* dx;
+  const float* gamma; const float* mean; const float* rstd;
+  float* dgamma; float* dbeta;
+  float* dadd; int add_rows;
+  int rows, C, lddy, ldx, lddx;
+  mvlt_rowmap dy_map, x_map, dx_map;
+  int dx_accumulate;
+  int dtype;
+} mvlt_layernorm_bwd_args;
+int mvlt_layernorm_bwd(const mvlt_layernorm_bwd_args* args, void* stream);
+
+/* out[r,c] (fp32) = sum_b in[(b*batch_stride_rows + r) * ld + c]: gradient of the broadcast "+ pos_embed /
+ * text_pos_embed" of reference libs/pvlt.py:346 (reduction over the batch). */
+int mvlt_batch_sum(const void* in, float* out, int B, int R, int C, long batch_stride_rows, int ld, int dtype, void* stream);
+
+/* Spatial-reduction attention core: O = softmax(Q K^T * scale) V per (batch, head), head_dim = 64,
+ * M <= 320 keys (whole K/V of a head stays in LDS; single-pass softmax).  No mask (reference
+ * libs/pvlt.py:113-117 applies none).  Q: (B,N,ldq) with head h at columns [64h,64h+64); K,V: (B,M,ldkv)
+ * rows, head h at columns k_off+64h / v_off+64h of the kv buffer; O like Q.  lse[B,H,N] fp32 saved for bwd. */
+typedef struct mvlt_attn_args {
+  const void* Q; const void* KV; void* O; float* lse;
+  int B, H, N, M;
+  int ldq, ldkv, ldo;        /* row strides in elements */
+  int k_off, v_off;          /* column offsets of K and V inside a kv row */
+  float scale;
+  int dtype;
+} mvlt_attn_args;
+int mvlt_sr_attention_fwd(const mvlt_attn_args* args, void* stream);
+
+/* Backward of the above: dQ (like Q) and dKV (B,M,ldkv fp32, atomically accumulated, caller-zeroed). */
+typedef struct mvlt_attn_bwd_args {
+  const void* Q; const void* KV; const void* O; const void* dO; const float* lse;
+  void* dQ; float* dKV;
+  int B, H, N, M;
+  int ldq, ldkv, ldo, lddkv;
+  int k_off, v_off;
+  float scale;
+  int dtype;
+} mvlt_attn_bwd_args;
+int mvlt_sr_attention_bwd(const mvlt_attn_bwd_args* args, void* stream);
+
+/* ---- HBM-bound helpers (mvlt_amd/csrc/elementwise.hip) ------------------------------------------------------- */
+
+/* y[row,:] = dropout(LayerNorm(word[ids[row]] + type0 + pos[row % T])); hidden must be 768.  keep: optional
+ * uint8 [rows,768] keep-mask (train mode), drop_p its probability.  Replaces transformers BertEmbeddings.forward
+ * (call site reference libs/pvlt.py:326).  mean/rstd saved for backward. */
+int mvlt_bert_embed_fwd(const long* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                        const float* beta, const uint8_t* keep, float drop_p, void* y, float* mean, float* rstd,
+                        int rows, int T, int hidden, float eps, int dtype, void* stream);
+/* Backward of the above into caller-zeroed fp32 grads (atomics).  word row 0 (padding_idx) gets no gradient. */
+int mvlt_bert_embed_bwd(const void* dy, const long* ids, const float* word, const float* pos, const float* type0,
+                        const float* gamma, const uint8_t* keep, float drop_p, const float* mean, const float* rstd,
+                        float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
+                        int rows, int T, int hidden, int dtype, void* stream);
+
+/* out[(b,oi,oj), (c,di,dj)] = img[b,c,oi*k+di,oj*k+dj]: the stage-1 PatchEmbed conv (reference libs/pvlt.py:162,168,
+ * kernel=stride=4 on the NCHW fp32 image) becomes a K = 3*4*4 = 48 GEMM over this matrix. */
+int mvlt_patchify(const float* img, void* out, int B, int Cin, int H, int W, int k, int dtype, void* stream);
+
+/* Masked-index selection (bit-exact): idx[0..*count) = ascending p with labels[p] != ignore_index.  This is the row
+ * set CrossEntropyLoss(ignore_index=-1) averages over (reference engine_grid_masking.py:84). */
+int mvlt_masked_select(const long* labels, int n, long ignore_index, int* idx, int* count, void* stream);
+
+/* dst[r,:] = src[map(idx[r]),:]  and  dst[map(idx[r]),:] (+)= src[r,:]   (idx rows unique; map = mode-0 rowmap or NULL) */
+int mvlt_gather_rows(const void* src, const int* idx, void* dst, int rows, int C, int ld_src, const mvlt_rowmap* src_map, int dtype, void* stream);
+int mvlt_scatter_rows(const void* src, const int* idx, void* dst, int rows, int C, int ld_dst, const mvlt_rowmap* dst_map, int accumulate, int dtype, void* stream);
+
+/* Row-wise cross entropy.  fwd: lse[r]; loss_sum += lse - logit[label], count += 1 over rows with label != ignore.
+ * bwd: dlogits[r,c] = (softmax - onehot) * gscale[0] / max(count[0],1) (0 for ignored rows; columns [V,ldd) zeroed).
+ * Replaces torch CrossEntropyLoss at reference engine_grid_masking.py:84,90,94,95. */
+int mvlt_cross_entropy_fwd(const void* logits, const long* labels, long ignore_index, float* lse, float* loss_sum, float* count,
+                           int rows, int V, int ld, int dtype, void* stream);
+int mvlt_cross_entropy_bwd(const void* logits, const long* labels, long ignore_index, const float* lse, const float* gscale,
+                           const float* count, void* dlogits, int rows, int V, int ld, int ldd, int dtype, int out_dtype, void* stream);
+
+/* torch.optim.AdamW step over a flat fp32 buffer (+ optional bf16 re-cast of the updated parameters).
+ * hp (device, fp32[8]) = {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, grad_scale}.
+ * Replaces timm create_optimizer('adamw') stepping (reference main_vl.py:308, engine_grid_masking.py:126). */
+int mvlt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* hp, void* stream);
+int mvlt_cast_bf16(const float* src, void* dst, long n, void* stream);
+/* out[c*ld_out + r] = in[r*C + c] (fp32 master weight -> transposed compute-dtype operand for the dgrad GEMMs) */
+int mvlt_transpose_cast(const float* in, void* out, int R, int C, int ld_out, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,119 @@
+"""ctypes binding of libmvlt_hip.so (the C ABI declared in include/mvlt_hip.h).
+
+The product path has NO fallback: importing this module without the built library, or calling an op without a
+GPU, raises.  torch is used only for device memory and streams.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvlt_hip.so")
+
+
+class MVLTError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} is missing: build it with `python -m mvlt_amd.build` (hipcc, gfx950). "
+                      "mvlt_amd has no CPU or eager fallback.")
+lib = C.CDLL(LIB_PATH)
+
+c_int, c_float, c_void_p, c_long = C.c_int, C.c_float, C.c_void_p, C.c_long
+
+
+class RowMap(C.Structure):
+    _fields_ = [(n, c_int) for n in ("mode", "rows_per_batch", "batch_stride", "offset",
+                                     "r", "w_in", "tokens_in", "hw_out", "w_out", "c_seg")]
+
+
+class GemmNTArgs(C.Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
+                ("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int),
+                ("dtype", c_int), ("out_dtype", c_int),
+                ("a_map", RowMap), ("c_map", RowMap),
+                ("bias", c_void_p), ("act", c_int), ("H", c_void_p),
+                ("row_scale", c_void_p), ("rows_per_scale", c_int), ("R", c_void_p)]
+
+
+class GemmTNArgs(C.Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
+                ("M", c_int), ("N1", c_int), ("N2", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int),
+                ("dtype", c_int), ("a_map", RowMap), ("b_map", RowMap),
+                ("colsum_a", c_void_p), ("splits", c_int)]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [("x", c_void_p), ("y", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("mean", c_void_p), ("rstd", c_void_p), ("add", c_void_p), ("add_rows", c_int),
+                ("rows", c_int), ("C", c_int), ("ldx", c_int), ("ldy", c_int),
+                ("x_map", RowMap), ("y_map", RowMap), ("eps", c_float), ("dtype", c_int)]
+
+
+class LayerNormBwdArgs(C.Structure):
+    _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dx", c_void_p),
+                ("gamma", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
+                ("dgamma", c_void_p), ("dbeta", c_void_p), ("dadd", c_void_p), ("add_rows", c_int),
+                ("rows", c_int), ("C", c_int), ("lddy", c_int), ("ldx", c_int), ("lddx", c_int),
+                ("dy_map", RowMap), ("x_map", RowMap), ("dx_map", RowMap),
+                ("dx_accumulate", c_int), ("dtype", c_int)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("Q", c_void_p), ("KV", c_void_p), ("O", c_void_p), ("lse", c_void_p),
+                ("B", c_int), ("H", c_int), ("N", c_int), ("M", c_int),
+                ("ldq", c_int), ("ldkv", c_int), ("ldo", c_int), ("k_off", c_int), ("v_off", c_int),
+                ("scale", c_float), ("dtype", c_int)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("Q", c_void_p), ("KV", c_void_p), ("O", c_void_p), ("dO", c_void_p), ("lse", c_void_p),
+                ("dQ", c_void_p), ("dKV", c_void_p),
+                ("B", c_int), ("H", c_int), ("N", c_int), ("M", c_int),
+                ("ldq", c_int), ("ldkv", c_int), ("ldo", c_int), ("lddkv", c_int),
+                ("k_off", c_int), ("v_off", c_int), ("scale", c_float), ("dtype", c_int)]
+
+
+lib.mvlt_last_error.restype = C.c_char_p
+lib.mvlt_sizeof.argtypes = [C.c_char_p]
+for _name, _cls in (("mvlt_rowmap", RowMap), ("mvlt_gemm_nt_args", GemmNTArgs), ("mvlt_gemm_tn_args", GemmTNArgs),
+                    ("mvlt_layernorm_args", LayerNormArgs), ("mvlt_layernorm_bwd_args", LayerNormBwdArgs),
+                    ("mvlt_attn_args", AttnArgs), ("mvlt_attn_bwd_args", AttnBwdArgs)):
+    _n = lib.mvlt_sizeof(_name.encode())
+    if _n != C.sizeof(_cls):
+        raise ImportError(f"ABI mismatch for {_name}: library says {_n} bytes, binding has {C.sizeof(_cls)}")
+
+EXPORTS = ["mvlt_last_error", "mvlt_abi_version", "mvlt_sizeof", "mvlt_gemm_nt", "mvlt_gemm_tn",
+           "mvlt_layernorm_fwd", "mvlt_layernorm_bwd", "mvlt_batch_sum", "mvlt_sr_attention_fwd", "mvlt_sr_attention_bwd",
+           "mvlt_bert_embed_fwd", "mvlt_bert_embed_bwd", "mvlt_patchify", "mvlt_masked_select", "mvlt_gather_rows",
+           "mvlt_scatter_rows", "mvlt_cross_entropy_fwd", "mvlt_cross_entropy_bwd", "mvlt_adamw_step", "mvlt_cast_bf16",
+           "mvlt_transpose_cast"]
+
+DT = {torch.bfloat16: 0, torch.float32: 1}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MVLTError(f"{what} failed ({rc}): {lib.mvlt_last_error().decode()}")
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MVLTError("mvlt_amd ops need CUDA/HIP tensors (no CPU fallback)")
+    return c_void_p(t.data_ptr())
+
+
+def rowmap(rows_per_batch=0, batch_stride=0, offset=0):
+    return RowMap(0, rows_per_batch, batch_stride, offset, 0, 0, 0, 0, 0, 0)
+
+
+def patchmap(r, w_in, tokens_in, hw_out, w_out, c_seg):
+    return RowMap(1, 0, 0, 0, r, w_in, tokens_in, hw_out, w_out, c_seg)

@@ -1,0 +1,505 @@
+// Spatial-reduction attention core for MVLT (gfx950): O = softmax(Q K^T * scale) V, head_dim 64, M <= 320 keys.
+// Replaces reference libs/pvlt.py:113-117 (two bmm + softmax that materialise the (B,h,N,M) score tensor).
+//
+// PVT's spatial reduction keeps M = (H/r)^2 + T small (192 at 256 px, 272 at 384 px) in every stage, so the whole
+// K (M x 64) and V^T (64 x M) of one (batch, head) live in LDS for the lifetime of a workgroup and the softmax is
+// single-pass: a wave owns 32 queries, computes S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (so each lane holds the
+// scores of ONE query: the row reduction is lane-local plus one cross-half shuffle), exponentiates in registers,
+// and feeds P^T straight back as the B operand of O^T = V^T P^T.  Nothing but Q, K, V, O and the log-sum-exp
+// touches HBM.  fp32 instantiation (exact-f32 MFMA 32x32x2) serves the 1e-3 parity bar.
+#include "common.h"
+#include "../../include/mvlt_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int HD = 64;
+
+template <typename T> struct Frag;                 // 8 consecutive-K elements of one MFMA operand row
+template <> struct Frag<bf16> { bf16x8 v; };
+template <> struct Frag<float> { float v[8]; };
+
+__device__ __forceinline__ void mma32(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ Frag<T> load_frag8(const T* p);      // 8 contiguous elements
+template <> __device__ __forceinline__ Frag<bf16> load_frag8<bf16>(const bf16* p) {
+  Frag<bf16> f; f.v = *(const bf16x8*)p; return f;
+}
+template <> __device__ __forceinline__ Frag<float> load_frag8<float>(const float* p) {
+  Frag<float> f;
+  f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+  return f;
+}
+template <typename T> __device__ __forceinline__ Frag<T> zero_frag() {
+  Frag<T> f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = (T)0.f;
+  return f;
+}
+// 4 + 4 contiguous elements from two places (the V^T / transposed-tile fragments)
+template <typename T> __device__ __forceinline__ Frag<T> load_frag44(const T* p0, const T* p1);
+template <> __device__ __forceinline__ Frag<bf16> load_frag44<bf16>(const bf16* p0, const bf16* p1) {
+  bf16x4 a = *(const bf16x4*)p0, b = *(const bf16x4*)p1;
+  Frag<bf16> f;
+  f.v = bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return f;
+}
+template <> __device__ __forceinline__ Frag<float> load_frag44<float>(const float* p0, const float* p1) {
+  f32x4 a = *(const f32x4*)p0, b = *(const f32x4*)p1;
+  Frag<float> f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+  return f;
+}
+
+template <typename T> struct Lds {
+  static constexpr int PC = 16 / sizeof(T);             // elements per 16-B chunk
+  static constexpr int NCH = HD / PC;                   // chunks per 64-wide row (8 / 16)
+  static __device__ __forceinline__ int swz(int row, int chunk) {
+    // fp32: an 8-element fragment spans two adjacent chunks, so only even XOR masks keep it contiguous
+    return (sizeof(T) == 2) ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row & 7) << 1));
+  }
+  // element offset of (row, d) in a [rows][64] row-major swizzled tile; d must be a multiple of PC
+  static __device__ __forceinline__ int off(int row, int d) { return row * HD + swz(row, d / PC) * PC; }
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T, int NKT>
+__global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(mvlt_attn_args p, int nq_chunks, int q_per_wg) {
+  constexpr int MP = NKT * 32;                // padded key count
+  constexpr int VS = MP + 4;                  // V^T row stride (elements): conflict-free 8-B / 16-B column reads
+  constexpr int PC = Lds<T>::PC, NCH = Lds<T>::NCH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sK = (T*)smem;                           // [MP][64] swizzled
+  T* sVt = sK + MP * HD;                      // [64][VS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 5, l31 = lane & 31;
+  // XCD-aware placement: all query chunks of one (batch, head) run on the same XCD (block id % 8) and share K/V in its L2
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, j = bid >> 3;
+  const int gidx = xcd + 8 * (j / nq_chunks);
+  const int chunk_id = j % nq_chunks;
+  if (gidx >= p.B * p.H) return;
+  const int b = gidx / p.H, h = gidx % p.H;
+
+  const T* Qg = (const T*)p.Q + (long)b * p.N * p.ldq + h * HD;
+  const T* Kg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.k_off + h * HD;
+  const T* Vg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.v_off + h * HD;
+  T* Og = (T*)p.O + (long)b * p.N * p.ldo + h * HD;
+
+  // ---- stage K (swizzled rows) and V^T (transposed) in LDS; rows >= M are zero
+  for (int u = tid; u < MP * NCH; u += NT) {
+    int r = u / NCH, c = u % NCH;
+    u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+    if (r < p.M) {
+      kv = *(const u32x4*)(Kg + (long)r * p.ldkv + c * PC);
+      vv = *(const u32x4*)(Vg + (long)r * p.ldkv + c * PC);
+    }
+    *(u32x4*)(sK + Lds<T>::off(r, c * PC)) = kv;
+    T ve[PC];
+    *(u32x4*)ve = vv;
+#pragma unroll
+    for (int e = 0; e < PC; ++e) sVt[(c * PC + e) * VS + r] = ve[e];
+  }
+  __syncthreads();
+
+  const float sl2 = p.scale * 1.44269504088896340736f;
+  const int q_begin = chunk_id * q_per_wg;
+  const int q_end = min(p.N, q_begin + q_per_wg);
+  // Keys are walked in NBLK blocks of <= BT tiles (32 keys each).  NKT <= 7 is ONE block: plain single-pass softmax.
+  // Larger M (384-px inputs: 272 keys) uses two blocks merged with the usual running-max rescale, which keeps the
+  // score accumulators at <= 80 registers instead of 144-160 (no spills, 2 waves per SIMD).
+  constexpr int NBLK = (NKT <= 7) ? 1 : 2;
+  constexpr int BT = (NKT + NBLK - 1) / NBLK;
+  for (int q0 = q_begin + wave * 32; q0 < q_end; q0 += 4 * 32) {
+    const int q = q0 + l31;
+    const bool q_ok = q < q_end;
+    Frag<T> qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = q_ok ? load_frag8<T>(Qg + (long)q * p.ldq + 16 * s + 8 * g) : zero_frag<T>();
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    }
+    float m_run = -INFINITY, sum_loc = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk) {
+      const int t0 = blk * BT;
+      f32x16 acc[BT];
+#pragma unroll
+      for (int ti = 0; ti < BT; ++ti) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+        if (t0 + ti < NKT) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            Frag<T> kf = load_frag8<T>(sK + Lds<T>::off((t0 + ti) * 32 + l31, 16 * s + 8 * g));
+            mma32(acc[ti], kf, qf[s]);          // rows = keys, cols = queries
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep only one tile's K fragments live (register budget: 2 waves/SIMD)
+      }
+      // acc[ti][r] = S[q = l31][key = 32 (t0+ti) + (r&3) + 8 (r>>2) + 4 g]
+      float mb = -INFINITY;
+#pragma unroll
+      for (int ti = 0; ti < BT; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int key = 32 * (t0 + ti) + (r & 3) + 8 * (r >> 2) + 4 * g;
+          float sv = (t0 + ti < NKT && key < p.M) ? acc[ti][r] : -INFINITY;
+          acc[ti][r] = sv;
+          mb = fmaxf(mb, sv);
+        }
+      mb = fmaxf(mb, __shfl_xor(mb, 32));
+      const float m_new = fmaxf(m_run, mb);     // finite: every block holds >= 1 valid key
+      if (blk > 0) {
+        const float alpha = exp2f((m_run - m_new) * sl2);
+        sum_loc *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+      }
+      m_run = m_new;
+#pragma unroll
+      for (int ti = 0; ti < BT; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float e = exp2f((acc[ti][r] - m_new) * sl2);
+          acc[ti][r] = e;
+          sum_loc += e;
+        }
+#pragma unroll
+      for (int ti = 0; ti < BT; ++ti) {
+        if (t0 + ti >= NKT) continue;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          Frag<T> pf;                           // B operand: P^T, k-slot (g, jj) <-> key 32kt + 16 s2 + 4g + 8 (jj>>2) + (jj&3)
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) pf.v[jj] = (T)acc[ti][8 * s2 + jj];
+          const int kb = 32 * (t0 + ti) + 16 * s2 + 4 * g;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const T* vr = sVt + (32 * dt + l31) * VS + kb;
+            Frag<T> vf = load_frag44<T>(vr, vr + 8);
+            mma32(oacc[dt], vf, pf);            // rows = d, cols = queries
+          }
+          __builtin_amdgcn_sched_barrier(0);    // do not hoist every V^T fragment above the first PV MFMA
+        }
+      }
+    }
+    const float sum = sum_loc + __shfl_xor(sum_loc, 32);
+    const float inv = 1.0f / sum;
+    // oacc[dt][r] = O[q = l31][d = 32 dt + (r&3) + 8 (r>>2) + 4 g]
+    if (q_ok) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          T o4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = (T)(oacc[dt][4 * rq + e] * inv);
+          T* dst = Og + (long)q * p.ldo + 32 * dt + 8 * rq + 4 * g;
+          if constexpr (sizeof(T) == 2) *(u32x2*)dst = *(u32x2*)o4; else *(u32x4*)dst = *(u32x4*)o4;
+        }
+      if (g == 0 && p.lse) p.lse[((long)b * p.H + h) * p.N + q] = m_run * p.scale + logf(sum);
+    }
+  }
+}
+
+template <typename T, int NKT> int launch_fwd_n(const mvlt_attn_args& a, hipStream_t s) {
+  constexpr int MP = NKT * 32;
+  const size_t lds = (size_t)(MP * HD + HD * (MP + 4)) * sizeof(T);
+  MVLT_REQUIRE(lds <= 160 * 1024, "mvlt_sr_attention_fwd: M=%d needs %zu B of LDS (>160 KB) in this dtype", a.M, lds);
+  int q_per_wg = 256;
+  if (a.N <= 512) q_per_wg = 128 * ((a.N + 127) / 128);
+  const int nq = (a.N + q_per_wg - 1) / q_per_wg;
+  const int groups = a.B * a.H;
+  const int grid = 8 * ((groups + 7) / 8) * nq;
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NKT>), dim3(grid), dim3(NT), lds, s, a, nq, q_per_wg);
+  return mvlt_check_launch("mvlt_sr_attention_fwd");
+}
+
+template <typename T> int launch_fwd(const mvlt_attn_args& a, hipStream_t s) {
+  switch ((a.M + 31) / 32) {
+    case 1: return launch_fwd_n<T, 1>(a, s);
+    case 2: return launch_fwd_n<T, 2>(a, s);
+    case 3: return launch_fwd_n<T, 3>(a, s);
+    case 4: return launch_fwd_n<T, 4>(a, s);
+    case 5: return launch_fwd_n<T, 5>(a, s);
+    case 6: return launch_fwd_n<T, 6>(a, s);
+    case 7: return launch_fwd_n<T, 7>(a, s);
+    case 8: return launch_fwd_n<T, 8>(a, s);
+    case 9: return launch_fwd_n<T, 9>(a, s);
+    case 10: return launch_fwd_n<T, 10>(a, s);
+    default: break;
+  }
+  mvlt_set_error("mvlt_sr_attention_fwd: M=%d keys exceeds the 320-key LDS-resident design", a.M);
+  return MVLT_ERR_UNSUPPORTED;
+}
+
+
+// ------------------------------------------------------------------------------------------------ backward
+// dQ = dS K, dK = dS^T Q, dV = P^T dO with P = exp(S*scale - lse), dS = P (dP - D) scale, dP = dO V^T, D = rowsum(dO*O).
+// Work split (per (batch, head, query chunk) workgroup): wave w OWNS key tiles [w*TPW, (w+1)*TPW) x 16 keys: its K/V
+// fragments stay in registers for the whole kernel and its dK/dV tiles accumulate in registers over all query
+// tiles; one fp32 atomic flush at the end.  Per 32-query tile: S and dP via 16x16x32 MFMA (rows = queries), P/dS
+// are re-used from the accumulators as the A operand of dV/dK (k-slots = queries), dS is also parked in LDS as
+// [q][key] so that dQ (k = all keys) is computed by all waves against the LDS-resident K^T.
+template <typename T, int NW, int TPW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_kernel(mvlt_attn_bwd_args p, int nq_chunks, int q_per_wg) {
+  constexpr int NTH = NW * 64;
+  constexpr int MP = NW * TPW * 16;           // padded keys (multiple of 32)
+  constexpr int PC = Lds<T>::PC, NCH = Lds<T>::NCH;
+  constexpr int PAD = 16 / sizeof(T);         // 16 B of padding per row
+  constexpr int KS = MP + PAD;                // row stride of sKt and sdS (elements)
+  constexpr int QS = 32 + PAD;                // row stride of sQt / sdOt
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sKt = (T*)smem;                          // [64 d][KS]   K^T
+  T* sdS = sKt + HD * KS;                     // [32 q][KS]
+  T* sQt = sdS + 32 * KS;                     // [64 d][QS]   Q^T tile
+  T* sdOt = sQt + HD * QS;                    // [64 d][QS]   dO^T tile
+  float* sD = (float*)(sdOt + HD * QS);       // [32]
+  float* sL = sD + 32;                        // [32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, jb = bid >> 3;
+  const int gidx = xcd + 8 * (jb / nq_chunks);
+  const int chunk_id = jb % nq_chunks;
+  if (gidx >= p.B * p.H) return;
+  const int b = gidx / p.H, h = gidx % p.H;
+
+  const T* Qg = (const T*)p.Q + (long)b * p.N * p.ldq + h * HD;
+  const T* Og = (const T*)p.O + (long)b * p.N * p.ldo + h * HD;
+  const T* dOg = (const T*)p.dO + (long)b * p.N * p.ldo + h * HD;
+  const T* Kg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.k_off + h * HD;
+  const T* Vg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.v_off + h * HD;
+  T* dQg = (T*)p.dQ + (long)b * p.N * p.ldq + h * HD;
+  float* dKg = p.dKV + (long)b * p.M * p.lddkv + p.k_off + h * HD;
+  float* dVg = p.dKV + (long)b * p.M * p.lddkv + p.v_off + h * HD;
+  const float* Lg = p.lse + ((long)b * p.H + h) * p.N;
+
+  // K^T into LDS (all keys), zero beyond M
+  for (int u = tid; u < MP * NCH; u += NTH) {
+    int r = u / NCH, c = u % NCH;
+    u32x4 kv = {0u, 0u, 0u, 0u};
+    if (r < p.M) kv = *(const u32x4*)(Kg + (long)r * p.ldkv + c * PC);
+    T ke[PC];
+    *(u32x4*)ke = kv;
+#pragma unroll
+    for (int e = 0; e < PC; ++e) sKt[(c * PC + e) * KS + r] = ke[e];
+  }
+  // this wave's K / V fragments (B operands: n = key = fr, k = d)
+  Frag<T> kreg[TPW][2], vreg[TPW][2];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    int key = (wave * TPW + t) * 16 + fr;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (key < p.M) {
+        kreg[t][s] = load_frag8<T>(Kg + (long)key * p.ldkv + 32 * s + 8 * fg);
+        vreg[t][s] = load_frag8<T>(Vg + (long)key * p.ldkv + 32 * s + 8 * fg);
+      } else {
+        kreg[t][s] = zero_frag<T>();
+        vreg[t][s] = zero_frag<T>();
+      }
+    }
+  }
+  f32x4 dKacc[TPW][4], dVacc[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dKacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dVacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const float sl2 = p.scale * 1.44269504088896340736f;
+  const float l2e = 1.44269504088896340736f;
+  const int q_begin = chunk_id * q_per_wg;
+  const int q_end = min(p.N, q_begin + q_per_wg);
+
+  for (int q0 = q_begin; q0 < q_end; q0 += 32) {
+    // ---- (a) stage Q^T, dO^T tiles, D and lse for 32 queries
+    for (int u = tid; u < 32 * NCH; u += NTH) {
+      int r = u / NCH, c = u % NCH;
+      int q = q0 + r;
+      u32x4 qv = {0u, 0u, 0u, 0u}, dov = {0u, 0u, 0u, 0u}, ov = {0u, 0u, 0u, 0u};
+      if (q < q_end) {
+        qv = *(const u32x4*)(Qg + (long)q * p.ldq + c * PC);
+        dov = *(const u32x4*)(dOg + (long)q * p.ldo + c * PC);
+        ov = *(const u32x4*)(Og + (long)q * p.ldo + c * PC);
+      }
+      T qe[PC], de[PC], oe[PC];
+      *(u32x4*)qe = qv; *(u32x4*)de = dov; *(u32x4*)oe = ov;
+      float dsum = 0.f;
+#pragma unroll
+      for (int e = 0; e < PC; ++e) {
+        sQt[(c * PC + e) * QS + r] = qe[e];
+        sdOt[(c * PC + e) * QS + r] = de[e];
+        dsum += (float)de[e] * (float)oe[e];
+      }
+#pragma unroll
+      for (int o = NCH / 2; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
+      if (c == 0) sD[r] = dsum;
+    }
+    if (tid < 32) sL[tid] = (q0 + tid < q_end) ? Lg[q0 + tid] : 0.f;
+    // A-operand fragments of Q and dO (rows = queries) straight from global
+    Frag<T> qf[2][2], dof[2][2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      int q = q0 + qs * 16 + fr;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (q < q_end) {
+          qf[qs][s] = load_frag8<T>(Qg + (long)q * p.ldq + 32 * s + 8 * fg);
+          dof[qs][s] = load_frag8<T>(dOg + (long)q * p.ldo + 32 * s + 8 * fg);
+        } else {
+          qf[qs][s] = zero_frag<T>();
+          dof[qs][s] = zero_frag<T>();
+        }
+      }
+    }
+    __syncthreads();                                   // (b)
+
+    // ---- (c) per owned key tile: S, dP -> P, dS ; dV += P^T dO ; dK += dS^T Q ; park dS in LDS
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int key = (wave * TPW + t) * 16 + fr;
+      const bool key_ok = key < p.M;
+      Frag<T> pfrag, dsfrag;
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          mma16(sacc, qf[qs][s], kreg[t][s]);          // S[q = 16 qs + 4 fg + r][key]
+          mma16(pacc, dof[qs][s], vreg[t][s]);         // dP
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = qs * 16 + 4 * fg + r;
+          float pv = key_ok ? exp2f(sacc[r] * sl2 - sL[ql] * l2e) : 0.f;
+          float dsv = pv * (pacc[r] - sD[ql]) * p.scale;
+          pfrag.v[qs * 4 + r] = (T)pv;
+          dsfrag.v[qs * 4 + r] = (T)dsv;
+          sdS[ql * KS + key] = (T)dsv;
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        // B operands (n = d): k-slot (fg, j) <-> q = 16 (j>>2) + 4 fg + (j&3); re-read per tile to stay under 256 VGPRs
+        const T* a = sQt + (dt * 16 + fr) * QS + 4 * fg;
+        const T* c2 = sdOt + (dt * 16 + fr) * QS + 4 * fg;
+        Frag<T> dotf = load_frag44<T>(c2, c2 + 16);
+        Frag<T> qtf = load_frag44<T>(a, a + 16);
+        mma16(dVacc[t][dt], pfrag, dotf);              // dV[key = tile*16 + 4 fg + r][d = 16 dt + fr]
+        mma16(dKacc[t][dt], dsfrag, qtf);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                   // (d)
+
+    // ---- (e) dQ[32 x 64] = dS[32 x MP] K[MP x 64]: 8 output tiles (16 x 16) dealt round-robin to the waves
+    for (int tile = wave; tile < 8; tile += NW) {
+      const int qs = tile >> 2, dt = tile & 3;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int ks = 0; ks < MP / 32; ++ks) {
+        Frag<T> a = load_frag8<T>(sdS + (qs * 16 + fr) * KS + 32 * ks + 8 * fg);
+        Frag<T> bb = load_frag8<T>(sKt + (dt * 16 + fr) * KS + 32 * ks + 8 * fg);
+        mma16(acc, a, bb);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int q = q0 + qs * 16 + 4 * fg + r;
+        if (q < q_end) dQg[(long)q * p.ldq + dt * 16 + fr] = (T)acc[r];
+      }
+    }
+  }
+  // ---- flush dK / dV
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = (wave * TPW + t) * 16 + 4 * fg + r;
+        if (key < p.M) {
+          atomicAdd(&dKg[(long)key * p.lddkv + dt * 16 + fr], dKacc[t][dt][r]);
+          atomicAdd(&dVg[(long)key * p.lddkv + dt * 16 + fr], dVacc[t][dt][r]);
+        }
+      }
+}
+
+template <typename T, int NW, int TPW> int launch_bwd_n(const mvlt_attn_bwd_args& a, hipStream_t s) {
+  constexpr int MP = NW * TPW * 16;
+  constexpr int PAD = 16 / sizeof(T);
+  const size_t lds = (size_t)(HD * (MP + PAD) + 32 * (MP + PAD) + 2 * HD * (32 + PAD)) * sizeof(T) + 64 * sizeof(float);
+  MVLT_REQUIRE(lds <= 160 * 1024, "mvlt_sr_attention_bwd: LDS %zu B > 160 KB", lds);
+  // split the queries of one (batch, head) so that the grid has >= ~1024 workgroups, at most N/64 chunks
+  const int groups = a.B * a.H;
+  int nq = (1024 + groups - 1) / groups;
+  int maxq = (a.N + 63) / 64;
+  if (nq > maxq) nq = maxq;
+  if (nq < 1) nq = 1;
+  int q_per_wg = ((a.N + nq - 1) / nq + 31) / 32 * 32;
+  nq = (a.N + q_per_wg - 1) / q_per_wg;
+  const int grid = 8 * ((groups + 7) / 8) * nq;
+  hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NW, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_bwd_kernel<T, NW, TPW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
+  return mvlt_check_launch("mvlt_sr_attention_bwd");
+}
+
+template <typename T> int launch_bwd(const mvlt_attn_bwd_args& a, hipStream_t s) {
+  const int M = a.M;
+  if (M <= 64) return launch_bwd_n<T, 4, 1>(a, s);
+  if (M <= 128) return launch_bwd_n<T, 4, 2>(a, s);
+  if (M <= 192) return launch_bwd_n<T, 4, 3>(a, s);
+  if (M <= 256) return launch_bwd_n<T, 8, 2>(a, s);
+  if (M <= 288) return launch_bwd_n<T, 6, 3>(a, s);
+  if (M <= 320) return launch_bwd_n<T, 8, 3>(a, s);
+  mvlt_set_error("mvlt_sr_attention_bwd: M=%d keys exceeds the 320-key LDS-resident design", M);
+  return MVLT_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int mvlt_sr_attention_fwd(const mvlt_attn_args* a, void* stream) {
+  MVLT_REQUIRE(a && a->Q && a->KV && a->O, "mvlt_sr_attention_fwd: null pointer");
+  MVLT_REQUIRE(a->B > 0 && a->H > 0 && a->N > 0 && a->M > 0, "mvlt_sr_attention_fwd: bad shape");
+  MVLT_REQUIRE(a->dtype == 0 || a->dtype == 1, "mvlt_sr_attention_fwd: bad dtype");
+  const int pc = a->dtype == 0 ? 8 : 4;
+  MVLT_REQUIRE(a->ldq % pc == 0 && a->ldkv % pc == 0 && a->ldo % pc == 0 && a->k_off % pc == 0 && a->v_off % pc == 0,
+               "mvlt_sr_attention_fwd: strides/offsets must be multiples of %d elements", pc);
+  return a->dtype == 0 ? launch_fwd<bf16>(*a, (hipStream_t)stream) : launch_fwd<float>(*a, (hipStream_t)stream);
+}
+
+extern "C" int mvlt_sr_attention_bwd(const mvlt_attn_bwd_args* a, void* stream) {
+  MVLT_REQUIRE(a && a->Q && a->KV && a->O && a->dO && a->lse && a->dQ && a->dKV, "mvlt_sr_attention_bwd: null pointer");
+  MVLT_REQUIRE(a->B > 0 && a->H > 0 && a->N > 0 && a->M > 0, "mvlt_sr_attention_bwd: bad shape");
+  MVLT_REQUIRE(a->dtype == 0 || a->dtype == 1, "mvlt_sr_attention_bwd: bad dtype");
+  const int pc = a->dtype == 0 ? 8 : 4;
+  MVLT_REQUIRE(a->ldq % pc == 0 && a->ldkv % pc == 0 && a->ldo % pc == 0 && a->k_off % pc == 0 && a->v_off % pc == 0,
+               "mvlt_sr_attention_bwd: strides/offsets must be multiples of %d elements", pc);
+  return a->dtype == 0 ? launch_bwd<bf16>(*a, (hipStream_t)stream) : launch_bwd<float>(*a, (hipStream_t)stream);
+}

@@ -1,0 +1,88 @@
+// Shared device helpers for the MVLT gfx950 kernels (CDNA4 only: wave64, MFMA, 160 KB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define MVLT_OK 0
+#define MVLT_ERR_ARG -1
+#define MVLT_ERR_LAUNCH -2
+#define MVLT_ERR_UNSUPPORTED -3
+
+// thread-local last-error text (mvlt_last_error())
+void mvlt_set_error(const char* fmt, ...);
+int mvlt_check_launch(const char* what);
+
+#define MVLT_REQUIRE(cond, ...)                 \
+  do {                                          \
+    if (!(cond)) {                              \
+      mvlt_set_error(__VA_ARGS__);              \
+      return MVLT_ERR_ARG;                      \
+    }                                           \
+  } while (0)
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d/dx [0.5 x (1+erf(x/sqrt2))] = 0.5(1+erf(x/sqrt2)) + x * exp(-x^2/2)/sqrt(2 pi)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// Row addressing shared by the GEMM operands / outputs.
+//  mode 0: phys_row = m                                  (rows_per_batch == 0)
+//          phys_row = (m / rpb) * batch_stride + offset + m % rpb
+//  mode 1: non-overlapping r x r patch gather over a token grid (conv with kernel==stride):
+//          logical row m = (b, oi, oj) over B x Ho x Wo, logical column segment s = (di, dj),
+//          phys_row = b * tokens_in + (oi*r + di) * w_in + (oj*r + dj)
+struct RowMap {
+  int mode;
+  int rows_per_batch;   // mode 0: logical rows per batch (0 = identity)
+  int batch_stride;     // mode 0: physical rows per batch
+  int offset;           // mode 0: first physical row inside a batch
+  int r, w_in, tokens_in, hw_out, w_out, c_seg;   // mode 1
+};
+
+__device__ __forceinline__ long rowmap_base(const RowMap& rm, int m) {
+  if (rm.mode == 0) {
+    if (rm.rows_per_batch == 0) return m;
+    int b = m / rm.rows_per_batch;
+    return (long)b * rm.batch_stride + rm.offset + (m - b * rm.rows_per_batch);
+  }
+  int b = m / rm.hw_out;
+  int rem = m - b * rm.hw_out;
+  int oi = rem / rm.w_out, oj = rem - oi * rm.w_out;
+  return (long)b * rm.tokens_in + (long)(oi * rm.r) * rm.w_in + oj * rm.r;
+}
+// extra physical-row offset for patch segment s = di*r + dj (mode 1 only)
+__device__ __forceinline__ int rowmap_seg(const RowMap& rm, int seg) {
+  int di = seg / rm.r, dj = seg - di * rm.r;
+  return di * rm.w_in + dj;
+}

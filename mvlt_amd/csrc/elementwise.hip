@@ -1,0 +1,416 @@
+// HBM-bound helper kernels of the MVLT hot path (gfx950): BERT embedding (+LN +dropout), image patchify,
+// masked-index selection, row gather/scatter, cross-entropy (fwd + in-place grad), fused AdamW + bf16 re-cast.
+// Everything is coalesced 16-byte traffic with fp32 math; none of this is reshaped into a GEMM.
+#include "common.h"
+#include "../../include/mvlt_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------ BERT embeddings
+// y[b,t,:] = dropout(LN(word[ids[b,t]] + type[0] + pos[t])), hidden = 768 (one wave per token, 12 floats per lane).
+// Replaces transformers BertEmbeddings.forward (call site reference libs/pvlt.py:326).
+template <typename T, int HID>
+__global__ __launch_bounds__(NT) void bert_embed_fwd_kernel(const long* ids, const float* word, const float* pos, const float* type0,
+                                                            const float* gamma, const float* beta, const uint8_t* keep, float inv_keep,
+                                                            T* y, float* mean_out, float* rstd_out, int rows, int Tlen, float eps) {
+  constexpr int PER = HID / 64;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long id = ids[row];
+  const int t = row % Tlen;
+  float v[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    int c = lane + 64 * i;
+    v[i] = word[id * HID + c] + type0[c] + pos[(long)t * HID + c];
+    s += v[i];
+  }
+  const float mean = wave_sum(s) * (1.0f / HID);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { float d = v[i] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / HID) + eps);
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    int c = lane + 64 * i;
+    float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    if (keep) o = keep[(long)row * HID + c] ? o * inv_keep : 0.f;
+    y[(long)row * HID + c] = (T)o;
+  }
+}
+
+// backward: recompute x = word+type+pos, LN backward, then scatter: word[id] (skipping padding_idx 0, as
+// nn.Embedding(padding_idx=0) does), pos[t], type[0], gamma, beta -- all fp32 atomics into zeroed grads.
+template <typename T, int HID>
+__global__ __launch_bounds__(NT) void bert_embed_bwd_kernel(const T* dy, const long* ids, const float* word, const float* pos, const float* type0,
+                                                            const float* gamma, const uint8_t* keep, float inv_keep,
+                                                            const float* mean_in, const float* rstd_in,
+                                                            float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
+                                                            int rows, int Tlen) {
+  constexpr int PER = HID / 64;
+  __shared__ float s_g[HID], s_b[HID], s_t[HID];
+  for (int i = threadIdx.x; i < HID; i += NT) { s_g[i] = 0.f; s_b[i] = 0.f; s_t[i] = 0.f; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  float ag[PER], ab[PER], at[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { ag[i] = 0.f; ab[i] = 0.f; at[i] = 0.f; }
+  for (int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6); row < rows; row += gridDim.x * (NT / 64)) {
+    const long id = ids[row];
+    const int t = row % Tlen;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float g[PER], xh[PER];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int c = lane + 64 * i;
+      float d = (float)dy[(long)row * HID + c];
+      if (keep) d = keep[(long)row * HID + c] ? d * inv_keep : 0.f;
+      float x = word[id * HID + c] + type0[c] + pos[(long)t * HID + c];
+      float h = (x - mean) * rstd;
+      float gg = d * gamma[c];
+      xh[i] = h; g[i] = gg;
+      s1 += gg; s2 += gg * h;
+      ag[i] += d * h; ab[i] += d;
+    }
+    s1 = wave_sum(s1) * (1.0f / HID);
+    s2 = wave_sum(s2) * (1.0f / HID);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int c = lane + 64 * i;
+      float dx = rstd * (g[i] - s1 - xh[i] * s2);
+      if (id != 0) atomicAdd(&dword[id * HID + c], dx);
+      atomicAdd(&dpos[(long)t * HID + c], dx);
+      at[i] += dx;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    int c = lane + 64 * i;
+    atomicAdd(&s_g[c], ag[i]); atomicAdd(&s_b[c], ab[i]); atomicAdd(&s_t[c], at[i]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HID; i += NT) {
+    atomicAdd(&dgamma[i], s_g[i]); atomicAdd(&dbeta[i], s_b[i]); atomicAdd(&dtype0[i], s_t[i]);
+  }
+}
+
+// ------------------------------------------------------------------ image patchify (stage-1 PatchEmbed operand)
+// P[(b, oi, oj), (c, di, dj)] = img[b, c, oi*k+di, oj*k+dj]   (NCHW fp32 image -> row-major patch matrix, K = C*k*k)
+template <typename T>
+__global__ __launch_bounds__(NT) void patchify_kernel(const float* img, T* out, int B, int Cin, int H, int W, int k) {
+  const int Ho = H / k, Wo = W / k, K = Cin * k * k;
+  const long total = (long)B * Ho * Wo * Cin * k;      // one thread per (row, c, di): k contiguous pixels
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    int di = (int)(i % k);
+    long r1 = i / k;
+    int oj = (int)(r1 % Wo); r1 /= Wo;
+    int c = (int)(r1 % Cin); r1 /= Cin;
+    int oi = (int)(r1 % Ho);
+    int b = (int)(r1 / Ho);
+    const float* src = img + (((long)b * Cin + c) * H + (oi * k + di)) * W + oj * k;
+    T* dst = out + (((long)b * Ho + oi) * Wo + oj) * K + (c * k + di) * k;
+    for (int dj = 0; dj < k; ++dj) dst[dj] = (T)src[dj];
+  }
+}
+
+// ------------------------------------------------------------------ masked-index selection (bit-exact, ordered)
+// idx[0..count) = ascending positions p with labels[p] != ignore; one workgroup, ballot + prefix.
+__global__ __launch_bounds__(1024) void masked_select_kernel(const long* labels, int n, long ignore, int* idx, int* count) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int start = 0; start < n; start += 1024) {
+    int p = start + threadIdx.x;
+    bool sel = p < n && labels[p] != ignore;
+    unsigned long long m = __ballot(sel);
+    int within = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    if (sel) idx[off + within] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += s_wave[w]; s_base += t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = s_base;
+}
+
+// ------------------------------------------------------------------ row gather / scatter-add
+template <typename T>
+__global__ __launch_bounds__(NT) void gather_rows_kernel(const T* src, const int* idx, T* dst, int rows, int C, int ld_src, RowMap smap) {
+  constexpr int PC = 16 / sizeof(T);
+  const int nch = C / PC;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (long)rows * nch; i += (long)gridDim.x * NT) {
+    int r = (int)(i / nch), c = (int)(i % nch);
+    *(u32x4*)(dst + (long)r * C + c * PC) = *(const u32x4*)(src + rowmap_base(smap, idx[r]) * ld_src + c * PC);
+  }
+}
+// dst[map(idx[r])] (+)= src[r]   (rows in idx are unique)
+template <typename T>
+__global__ __launch_bounds__(NT) void scatter_rows_kernel(const T* src, const int* idx, T* dst, int rows, int C, int ld_dst, RowMap dmap, int accumulate) {
+  constexpr int PC = 16 / sizeof(T);
+  const int nch = C / PC;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (long)rows * nch; i += (long)gridDim.x * NT) {
+    int r = (int)(i / nch), c = (int)(i % nch);
+    T* d = dst + rowmap_base(dmap, idx[r]) * ld_dst + c * PC;
+    T v[PC];
+    *(u32x4*)v = *(const u32x4*)(src + (long)r * C + c * PC);
+    if (accumulate) {
+      T o[PC];
+      *(u32x4*)o = *(const u32x4*)d;
+#pragma unroll
+      for (int e = 0; e < PC; ++e) v[e] = (T)((float)v[e] + (float)o[e]);
+    }
+    *(u32x4*)d = *(u32x4*)v;
+  }
+}
+
+// ------------------------------------------------------------------ cross entropy over rows (one workgroup per row)
+// fwd : lse[r] = logsumexp(logits[r,:]); loss_sum += (lse - logits[r,label]) for label != ignore; count += 1
+// bwd : dlogits[r,c] = (exp(logits - lse) - [c==label]) * gscale[0] / max(count,1)   (0 for ignored rows)
+template <typename T>
+__global__ __launch_bounds__(NT) void ce_fwd_kernel(const T* logits, const long* labels, long ignore, float* lse, float* loss_sum, float* count,
+                                                    int rows, int V, int ld) {
+  __shared__ float s_m[NT / 64], s_s[NT / 64];
+  const int row = blockIdx.x;
+  const T* lr = logits + (long)row * ld;
+  float m = -INFINITY, s = 0.f;
+  for (int c = threadIdx.x; c < V; c += NT) {
+    float x = (float)lr[c];
+    float nm = fmaxf(m, x);
+    s = s * __expf(m - nm) + __expf(x - nm);
+    m = nm;
+  }
+  // combine (m, s) pairs: wave, then block
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float om = __shfl_xor(m, o), os = __shfl_xor(s, o);
+    float nm = fmaxf(m, om);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+    m = nm;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { s_m[wave] = m; s_s[wave] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float M = s_m[0], S = s_s[0];
+    for (int w = 1; w < NT / 64; ++w) {
+      float nm = fmaxf(M, s_m[w]);
+      S = (M == -INFINITY ? 0.f : S * __expf(M - nm)) + (s_m[w] == -INFINITY ? 0.f : s_s[w] * __expf(s_m[w] - nm));
+      M = nm;
+    }
+    float l = M + logf(S);
+    lse[row] = l;
+    long lab = labels[row];
+    if (lab != ignore) {
+      atomicAdd(loss_sum, l - (float)lr[lab]);
+      atomicAdd(count, 1.0f);
+    }
+  }
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* logits, const long* labels, long ignore, const float* lse, const float* gscale,
+                                                    const float* count, TO* dlogits, int rows, int V, int ld, int ldd) {
+  const int row = blockIdx.x;
+  const T* lr = logits + (long)row * ld;
+  TO* dr = dlogits + (long)row * ldd;
+  const long lab = labels[row];
+  const float l = lse[row];
+  const float sc = (lab == ignore) ? 0.f : gscale[0] / fmaxf(count[0], 1.0f);
+  for (int c = threadIdx.x; c < ldd; c += NT) {
+    float g = 0.f;
+    if (c < V) g = (__expf((float)lr[c] - l) - (c == lab ? 1.f : 0.f)) * sc;
+    dr[c] = (TO)g;                        // padding columns [V, ldd) are zeroed
+  }
+}
+
+// ------------------------------------------------------------------ fused AdamW over a flat fp32 buffer (+ bf16 re-cast)
+// torch.optim.AdamW semantics (reference main_vl.py:308 via timm create_optimizer): decoupled weight decay,
+// bias-corrected moments.  lr / step-dependent scalars come from a small device array so that a captured graph replays.
+// hp = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale}
+__global__ __launch_bounds__(NT) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* p16, long n, const float* hp) {
+  const float lr = hp[0], b1 = hp[1], b2 = hp[2], eps = hp[3], wd = hp[4], bc1 = hp[5], bc2 = hp[6], gs = hp[7];
+  const float step_size = lr / bc1;
+  const float inv_sqrt_bc2 = rsqrtf(bc2);
+  for (long i = ((long)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += (long)gridDim.x * NT * 4) {
+    f32x4 pv = *(f32x4*)(p + i), gv = *(const f32x4*)(g + i), mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gr = gv[e] * gs;
+      float pp = pv[e] * (1.0f - lr * wd);
+      float mm = b1 * mv[e] + (1.0f - b1) * gr;
+      float v2 = b2 * vv[e] + (1.0f - b2) * gr * gr;
+      float denom = sqrtf(v2) * inv_sqrt_bc2 + eps;
+      pv[e] = pp - step_size * mm / denom;
+      mv[e] = mm; vv[e] = v2;
+    }
+    *(f32x4*)(p + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
+    if (p16) {
+      bf16x4 o = {(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
+      *(bf16x4*)(p16 + i) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void cast_f32_bf16_kernel(const float* src, bf16* dst, long n) {
+  for (long i = ((long)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += (long)gridDim.x * NT * 4) {
+    f32x4 v = *(const f32x4*)(src + i);
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *(bf16x4*)(dst + i) = o;
+  }
+}
+
+// out[c][r] = (T) in[r][c]   (fp32 master weight [R,C] -> transposed compute copy for the dgrad GEMMs)
+template <typename T>
+__global__ __launch_bounds__(NT) void transpose_cast_kernel(const float* in, T* out, int R, int Ccols, int ld_out) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = ty; j < 32; j += 8) {
+    int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < R && c < Ccols) ? in[(long)r * Ccols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, r = r0 + tx;
+    if (c < Ccols && r < R) out[(long)c * ld_out + r] = (T)tile[tx][j];
+  }
+}
+
+RowMap host_rowmap(const mvlt_rowmap* m) {
+  RowMap r{};
+  if (m) { r.mode = m->mode; r.rows_per_batch = m->rows_per_batch; r.batch_stride = m->batch_stride; r.offset = m->offset; }
+  return r;
+}
+
+inline int grid_for(long work, int cap = 4096) {
+  long g = (work + NT - 1) / NT;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int mvlt_bert_embed_fwd(const long* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                                   const float* beta, const uint8_t* keep, float drop_p, void* y, float* mean, float* rstd,
+                                   int rows, int T, int hidden, float eps, int dtype, void* stream) {
+  MVLT_REQUIRE(ids && word && pos && type0 && gamma && beta && y && mean && rstd, "mvlt_bert_embed_fwd: null pointer");
+  MVLT_REQUIRE(hidden == 768, "mvlt_bert_embed_fwd: hidden must be 768 (bert-base), got %d", hidden);
+  MVLT_REQUIRE(T > 0 && T <= 512, "mvlt_bert_embed_fwd: T must be in (0,512]");
+  if (rows <= 0) return MVLT_OK;
+  const float inv_keep = 1.0f / (1.0f - drop_p);
+  dim3 grid((rows + 3) / 4), block(NT);
+  if (dtype == 0) hipLaunchKernelGGL((bert_embed_fwd_kernel<bf16, 768>), grid, block, 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta, keep, inv_keep, (bf16*)y, mean, rstd, rows, T, eps);
+  else hipLaunchKernelGGL((bert_embed_fwd_kernel<float, 768>), grid, block, 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta, keep, inv_keep, (float*)y, mean, rstd, rows, T, eps);
+  return mvlt_check_launch("mvlt_bert_embed_fwd");
+}
+
+extern "C" int mvlt_bert_embed_bwd(const void* dy, const long* ids, const float* word, const float* pos, const float* type0,
+                                   const float* gamma, const uint8_t* keep, float drop_p, const float* mean, const float* rstd,
+                                   float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
+                                   int rows, int T, int hidden, int dtype, void* stream) {
+  MVLT_REQUIRE(dy && ids && word && pos && type0 && gamma && mean && rstd && dword && dpos && dtype0 && dgamma && dbeta, "mvlt_bert_embed_bwd: null pointer");
+  MVLT_REQUIRE(hidden == 768, "mvlt_bert_embed_bwd: hidden must be 768");
+  if (rows <= 0) return MVLT_OK;
+  const float inv_keep = 1.0f / (1.0f - drop_p);
+  int g = (rows + 3) / 4; if (g > 2048) g = 2048;
+  dim3 grid(g), block(NT);
+  if (dtype == 0) hipLaunchKernelGGL((bert_embed_bwd_kernel<bf16, 768>), grid, block, 0, (hipStream_t)stream, (const bf16*)dy, ids, word, pos, type0, gamma, keep, inv_keep, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T);
+  else hipLaunchKernelGGL((bert_embed_bwd_kernel<float, 768>), grid, block, 0, (hipStream_t)stream, (const float*)dy, ids, word, pos, type0, gamma, keep, inv_keep, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T);
+  return mvlt_check_launch("mvlt_bert_embed_bwd");
+}
+
+extern "C" int mvlt_patchify(const float* img, void* out, int B, int Cin, int H, int W, int k, int dtype, void* stream) {
+  MVLT_REQUIRE(img && out && B > 0 && Cin > 0 && k > 0 && H % k == 0 && W % k == 0, "mvlt_patchify: bad arguments (H, W must be divisible by k)");
+  long total = (long)B * (H / k) * (W / k) * Cin * k;
+  dim3 grid(grid_for(total, 16384)), block(NT);
+  if (dtype == 0) hipLaunchKernelGGL((patchify_kernel<bf16>), grid, block, 0, (hipStream_t)stream, img, (bf16*)out, B, Cin, H, W, k);
+  else hipLaunchKernelGGL((patchify_kernel<float>), grid, block, 0, (hipStream_t)stream, img, (float*)out, B, Cin, H, W, k);
+  return mvlt_check_launch("mvlt_patchify");
+}
+
+extern "C" int mvlt_masked_select(const long* labels, int n, long ignore_index, int* idx, int* count, void* stream) {
+  MVLT_REQUIRE(labels && idx && count && n >= 0, "mvlt_masked_select: bad arguments");
+  hipLaunchKernelGGL(masked_select_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, n, ignore_index, idx, count);
+  return mvlt_check_launch("mvlt_masked_select");
+}
+
+extern "C" int mvlt_gather_rows(const void* src, const int* idx, void* dst, int rows, int C, int ld_src, const mvlt_rowmap* src_map, int dtype, void* stream) {
+  MVLT_REQUIRE(src && idx && dst, "mvlt_gather_rows: null pointer");
+  const int pc = dtype == 0 ? 8 : 4;
+  MVLT_REQUIRE(C % pc == 0 && ld_src % pc == 0, "mvlt_gather_rows: C/ld must be multiples of %d", pc);
+  if (rows <= 0) return MVLT_OK;
+  dim3 grid(grid_for((long)rows * (C / pc))), block(NT);
+  RowMap m = host_rowmap(src_map);
+  if (dtype == 0) hipLaunchKernelGGL((gather_rows_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16*)src, idx, (bf16*)dst, rows, C, ld_src, m);
+  else hipLaunchKernelGGL((gather_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, idx, (float*)dst, rows, C, ld_src, m);
+  return mvlt_check_launch("mvlt_gather_rows");
+}
+
+extern "C" int mvlt_scatter_rows(const void* src, const int* idx, void* dst, int rows, int C, int ld_dst, const mvlt_rowmap* dst_map, int accumulate, int dtype, void* stream) {
+  MVLT_REQUIRE(src && idx && dst, "mvlt_scatter_rows: null pointer");
+  const int pc = dtype == 0 ? 8 : 4;
+  MVLT_REQUIRE(C % pc == 0 && ld_dst % pc == 0, "mvlt_scatter_rows: C/ld must be multiples of %d", pc);
+  if (rows <= 0) return MVLT_OK;
+  dim3 grid(grid_for((long)rows * (C / pc))), block(NT);
+  RowMap m = host_rowmap(dst_map);
+  if (dtype == 0) hipLaunchKernelGGL((scatter_rows_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16*)src, idx, (bf16*)dst, rows, C, ld_dst, m, accumulate);
+  else hipLaunchKernelGGL((scatter_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, idx, (float*)dst, rows, C, ld_dst, m, accumulate);
+  return mvlt_check_launch("mvlt_scatter_rows");
+}
+
+extern "C" int mvlt_cross_entropy_fwd(const void* logits, const long* labels, long ignore_index, float* lse, float* loss_sum, float* count,
+                                      int rows, int V, int ld, int dtype, void* stream) {
+  MVLT_REQUIRE(logits && labels && lse && loss_sum && count && V > 0 && ld >= V, "mvlt_cross_entropy_fwd: bad arguments");
+  if (rows <= 0) return MVLT_OK;
+  dim3 grid(rows), block(NT);
+  if (dtype == 0) hipLaunchKernelGGL((ce_fwd_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16*)logits, labels, ignore_index, lse, loss_sum, count, rows, V, ld);
+  else hipLaunchKernelGGL((ce_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)logits, labels, ignore_index, lse, loss_sum, count, rows, V, ld);
+  return mvlt_check_launch("mvlt_cross_entropy_fwd");
+}
+
+extern "C" int mvlt_cross_entropy_bwd(const void* logits, const long* labels, long ignore_index, const float* lse, const float* gscale,
+                                      const float* count, void* dlogits, int rows, int V, int ld, int ldd, int dtype, int out_dtype, void* stream) {
+  MVLT_REQUIRE(logits && labels && lse && gscale && count && dlogits && V > 0 && ld >= V && ldd >= V, "mvlt_cross_entropy_bwd: bad arguments");
+  if (rows <= 0) return MVLT_OK;
+  dim3 grid(rows), block(NT);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == 0 && out_dtype == 0) hipLaunchKernelGGL((ce_bwd_kernel<bf16, bf16>), grid, block, 0, s, (const bf16*)logits, labels, ignore_index, lse, gscale, count, (bf16*)dlogits, rows, V, ld, ldd);
+  else if (dtype == 1 && out_dtype == 0) hipLaunchKernelGGL((ce_bwd_kernel<float, bf16>), grid, block, 0, s, (const float*)logits, labels, ignore_index, lse, gscale, count, (bf16*)dlogits, rows, V, ld, ldd);
+  else if (dtype == 1 && out_dtype == 1) hipLaunchKernelGGL((ce_bwd_kernel<float, float>), grid, block, 0, s, (const float*)logits, labels, ignore_index, lse, gscale, count, (float*)dlogits, rows, V, ld, ldd);
+  else hipLaunchKernelGGL((ce_bwd_kernel<bf16, float>), grid, block, 0, s, (const bf16*)logits, labels, ignore_index, lse, gscale, count, (float*)dlogits, rows, V, ld, ldd);
+  return mvlt_check_launch("mvlt_cross_entropy_bwd");
+}
+
+extern "C" int mvlt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* hp, void* stream) {
+  MVLT_REQUIRE(p && g && m && v && hp && n >= 0 && n % 4 == 0, "mvlt_adamw_step: bad arguments (n must be a multiple of 4)");
+  if (n == 0) return MVLT_OK;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, hp);
+  return mvlt_check_launch("mvlt_adamw_step");
+}
+
+extern "C" int mvlt_cast_bf16(const float* src, void* dst, long n, void* stream) {
+  MVLT_REQUIRE(src && dst && n >= 0 && n % 4 == 0, "mvlt_cast_bf16: bad arguments (n must be a multiple of 4)");
+  if (n == 0) return MVLT_OK;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, src, (bf16*)dst, n);
+  return mvlt_check_launch("mvlt_cast_bf16");
+}
+
+extern "C" int mvlt_transpose_cast(const float* in, void* out, int R, int Ccols, int ld_out, int dtype, void* stream) {
+  MVLT_REQUIRE(in && out && R > 0 && Ccols > 0 && ld_out >= R, "mvlt_transpose_cast: bad arguments");
+  dim3 grid((Ccols + 31) / 32, (R + 31) / 32), block(NT);
+  if (dtype == 0) hipLaunchKernelGGL((transpose_cast_kernel<bf16>), grid, block, 0, (hipStream_t)stream, in, (bf16*)out, R, Ccols, ld_out);
+  else hipLaunchKernelGGL((transpose_cast_kernel<float>), grid, block, 0, (hipStream_t)stream, in, (float*)out, R, Ccols, ld_out);
+  return mvlt_check_launch("mvlt_transpose_cast");
+}

@@ -1,0 +1,483 @@
+// MFMA GEMMs for the MVLT hot path (gfx950 / CDNA4, wave64).
+//
+//  mvlt_gemm_nt : C[M,N] = epilogue(A[M,K] . B[N,K]^T)      Linear forward / dgrad (with W^T) and the
+//                 kernel==stride convolutions (PatchEmbed, Attention.sr) as gathered-row GEMMs.
+//                 Replaces F.linear / nn.Conv2d call sites of reference libs/pvlt.py:66-69,98,104,108,118,168
+//                 and libs/vl_heads.py:31,67,85,102.
+//  mvlt_gemm_tn : C[N1,N2] += A[M,N1]^T . B[M,N2]  (fp32 atomics)   weight gradients (+ fused bias gradient).
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile 128 x BN (BN = 128 or 64), wave tile 64 x BN/2 built from
+// v_mfma_f32_16x16x32_bf16 (bf16) or 8 x v_mfma_f32_16x16x4_f32 (fp32: exact-f32 path for the 1e-3 parity bar).
+// LDS rows are 128 B (64 bf16 / 32 fp32 of K) = 8 x 16-B chunks, XOR-swizzled by row so the ds_read_b128
+// fragment reads are conflict-free; global->register->LDS staging is double-buffered (one barrier per K tile).
+#include "common.h"
+#include "../../include/mvlt_hip.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int NTHREADS = 256;
+constexpr int ROW_BYTES = 128;        // one LDS row = 128 B of K
+constexpr int CHUNKS = 8;             // 16-B chunks per LDS row
+
+template <typename T> struct Elem;
+template <> struct Elem<bf16> { static constexpr int BK = 64; static constexpr int PER_CHUNK = 8; };
+template <> struct Elem<float> { static constexpr int BK = 32; static constexpr int PER_CHUNK = 4; };
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+__device__ __forceinline__ RowMap to_rowmap(const mvlt_rowmap& m) {
+  RowMap r;
+  r.mode = m.mode; r.rows_per_batch = m.rows_per_batch; r.batch_stride = m.batch_stride; r.offset = m.offset;
+  r.r = m.r; r.w_in = m.w_in; r.tokens_in = m.tokens_in; r.hw_out = m.hw_out; r.w_out = m.w_out; r.c_seg = m.c_seg;
+  return r;
+}
+
+// one k32 MFMA step on a 16x16 tile: a/b fragments = 8 consecutive K elements of row (lane&15) at K offset 8*(lane>>4)
+__device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, bf16*) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, b0), acc, 0, 0, 0);
+  (void)a1; (void)b1;
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, float*) {
+  f32x4 fa0 = __builtin_bit_cast(f32x4, a0), fa1 = __builtin_bit_cast(f32x4, a1);
+  f32x4 fb0 = __builtin_bit_cast(f32x4, b0), fb1 = __builtin_bit_cast(f32x4, b1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[j], fb0[j], acc, 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[j], fb1[j], acc, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ void store_out(void* base, long idx, float v, int out_fp32) {
+  if (out_fp32) ((float*)base)[idx] = v; else ((bf16*)base)[idx] = (bf16)v;
+}
+__device__ __forceinline__ float load_out(const void* base, long idx, int out_fp32) {
+  return out_fp32 ? ((const float*)base)[idx] : (float)((const bf16*)base)[idx];
+}
+
+// ------------------------------------------------------------------------------------------------ NT
+template <typename T, int BN>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p) {
+  constexpr int BK = Elem<T>::BK;
+  constexpr int PC = Elem<T>::PER_CHUNK;
+  constexpr int WN = BN / 2;            // wave tile N
+  constexpr int TN_ = WN / 16;          // 16-wide MFMA tiles per wave in N
+  constexpr int A_ITERS = BM * CHUNKS / NTHREADS;   // 4
+  constexpr int B_ITERS = BN * CHUNKS / NTHREADS;   // 4 or 2
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                                   // 2 x BM x 128 B
+  char* sB = smem + 2 * BM * ROW_BYTES;              // 2 x BN x 128 B
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-friendly order: consecutive workgroup ids walk M first (they share the B panel, which is small)
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int bid = blockIdx.x;
+  const int tile_m = bid % tiles_m, tile_n = bid / tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const RowMap amap = to_rowmap(p.a_map);
+
+  const int chunk = tid & 7;
+  const int row_in = tid >> 3;          // 0..31
+  const T* Ag = (const T*)p.A;
+  const T* Bg = (const T*)p.B;
+
+  long a_base[A_ITERS];
+  bool a_ok[A_ITERS];
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) {
+    int m = m0 + row_in + 32 * i;
+    a_ok[i] = m < p.M;
+    a_base[i] = a_ok[i] ? rowmap_base(amap, m) : 0;
+  }
+  long b_base[B_ITERS];
+  bool b_ok[B_ITERS];
+#pragma unroll
+  for (int i = 0; i < B_ITERS; ++i) {
+    int n = n0 + row_in + 32 * i;
+    b_ok[i] = n < p.N;
+    b_base[i] = b_ok[i] ? (long)n * p.ldb : 0;
+  }
+
+  u32x4 ra[A_ITERS], rb[B_ITERS];
+  auto gload = [&](int kt) {
+    const int k = kt * BK + chunk * PC;
+    const bool k_ok = k < p.K;          // K % PER_CHUNK == 0 is required by the host wrapper
+    int seg_rows = 0, kk = k;
+    if (amap.mode == 1) {
+      int seg = k / amap.c_seg;
+      kk = k - seg * amap.c_seg;
+      seg_rows = rowmap_seg(amap, seg);
+    }
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (a_ok[i] && k_ok) v = *(const u32x4*)(Ag + (a_base[i] + seg_rows) * p.lda + kk);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (b_ok[i] && k_ok) v = *(const u32x4*)(Bg + b_base[i] + k);
+      rb[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      int r = row_in + 32 * i;
+      *(u32x4*)(sA + buf * BM * ROW_BYTES + r * ROW_BYTES + swz(r, chunk) * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      int r = row_in + 32 * i;
+      *(u32x4*)(sB + buf * BN * ROW_BYTES + r * ROW_BYTES + swz(r, chunk) * 16) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][TN_];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const char* a_s = sA + buf * BM * ROW_BYTES + (wm * 64) * ROW_BYTES;
+    const char* b_s = sB + buf * BN * ROW_BYTES + (wn * WN) * ROW_BYTES;
+    constexpr int KSTEPS = (sizeof(T) == 2) ? 2 : 1;     // k32 steps per LDS tile
+    constexpr int CPS = (sizeof(T) == 2) ? 1 : 2;        // 16-B chunks per fragment
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      u32x4 fa[4][2], fb[TN_][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int r = i * 16 + fr;
+        int rr = wm * 64 + r;           // swizzle uses the tile-level row
+#pragma unroll
+        for (int c = 0; c < CPS; ++c) {
+          int ch = (sizeof(T) == 2) ? (ks * 4 + fg) : (fg * 2 + c);
+          fa[i][c] = *(const u32x4*)(a_s + r * ROW_BYTES + swz(rr, ch) * 16);
+        }
+        if (CPS == 1) fa[i][1] = fa[i][0];
+      }
+#pragma unroll
+      for (int j = 0; j < TN_; ++j) {
+        int r = j * 16 + fr;
+        int rr = wn * WN + r;
+#pragma unroll
+        for (int c = 0; c < CPS; ++c) {
+          int ch = (sizeof(T) == 2) ? (ks * 4 + fg) : (fg * 2 + c);
+          fb[j][c] = *(const u32x4*)(b_s + r * ROW_BYTES + swz(rr, ch) * 16);
+        }
+        if (CPS == 1) fb[j][1] = fb[j][0];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) mma16(acc[i][j], fa[i][0], fa[i][1], fb[j][0], fb[j][1], (T*)nullptr);
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + 4*fg + r][n0 + wn*WN + j*16 + fr]
+  const RowMap cmap = to_rowmap(p.c_map);
+  const int ofp32 = p.out_dtype;
+#pragma unroll
+  for (int j = 0; j < TN_; ++j) {
+    const int nt0 = n0 + wn * WN + j * 16;
+    const int n = nt0 + fr;
+    const bool n_ok = n < p.N;
+    const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
+    int seg_rows = 0, ncol = n;
+    if (cmap.mode == 1) {               // scatter back through the patch map (dgrad of a kernel==stride conv)
+      int seg = nt0 / cmap.c_seg;
+      ncol = n - seg * cmap.c_seg;
+      seg_rows = rowmap_seg(cmap, seg);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + i * 16 + 4 * fg + r;
+        if (m >= p.M || !n_ok) continue;
+        const long idx = (rowmap_base(cmap, m) + seg_rows) * p.ldc + ncol;
+        float v = acc[i][j][r] + bias;
+        if (p.act == 1) {
+          if (p.H) store_out<T>(p.H, idx, v, ofp32);
+          v = gelu_erf(v);
+        } else if (p.act == 2) {
+          v *= gelu_erf_grad(load_out(p.H, idx, ofp32));
+        }
+        if (p.row_scale) v *= p.row_scale[m / p.rows_per_scale];
+        if (p.R) v += load_out(p.R, idx, ofp32);
+        store_out<T>(p.C, idx, v, ofp32);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ TN (wgrad)
+// C[n1, n2] += sum_m A[m, n1] * B[m, n2].  The reduction index m is the slow (row) index of both operands, so
+// tiles are transposed on their way into LDS (At[n1][m], Bt[n2][m], 64 m per tile) and the MFMA fragments again
+// read 8 consecutive m.  The m range is split across gridDim.z; partial tiles are combined with fp32 atomics.
+constexpr int TBK = 64;                         // m per LDS tile (both dtypes)
+template <typename T> struct TElem;
+template <> struct TElem<bf16> { static constexpr int ROWB = (TBK + 8) * 2; };     // 144 B rows (pad keeps 16-B alignment)
+template <> struct TElem<float> { static constexpr int ROWB = (TBK + 4) * 4; };    // 272 B rows
+
+template <typename T, int BN>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, int m_per_split) {
+  constexpr int PC = Elem<T>::PER_CHUNK;             // elements per 16-B global chunk
+  constexpr int ROWB = TElem<T>::ROWB;
+  constexpr int WN = BN / 2;
+  constexpr int TN_ = WN / 16;
+  constexpr int A_CH = BM / PC;                      // chunks per tile row (A): 16 (bf16) / 32 (fp32)
+  constexpr int B_CH = BN / PC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                                   // BM rows (n1) x ROWB
+  char* sB = smem + BM * ROWB;                       // BN rows (n2) x ROWB
+  float* s_colsum = (float*)(smem + (BM + BN) * ROWB);   // [BM]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n1_0 = blockIdx.x * BM, n2_0 = blockIdx.y * BN;
+  const int m_begin = blockIdx.z * m_per_split;
+  const int m_end = min(p.M, m_begin + m_per_split);
+  const RowMap amap = to_rowmap(p.a_map), bmap = to_rowmap(p.b_map);
+  const T* Ag = (const T*)p.A;
+  const T* Bg = (const T*)p.B;
+  const bool do_colsum = p.colsum_a != nullptr && blockIdx.y == 0;
+  if (do_colsum && tid < BM) s_colsum[tid] = 0.f;
+
+  f32x4 acc[4][TN_];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // loader geometry: a "unit" = one 16-B chunk of columns x 2 consecutive m rows (bf16) or 1 row (fp32)
+  constexpr int RPU = (sizeof(T) == 2) ? 2 : 1;      // m rows per unit
+  constexpr int A_UNITS = A_CH * (TBK / RPU);
+  constexpr int B_UNITS = B_CH * (TBK / RPU);
+  constexpr int A_IT = A_UNITS / NTHREADS;           // bf16: 16*32/256 = 2 ; fp32: 32*64/256 = 8
+  constexpr int B_IT = (B_UNITS + NTHREADS - 1) / NTHREADS;
+
+  // per-thread fixed column chunk for B (patch gather resolves the segment once)
+  const int fr = lane & 15, fg = lane >> 4;
+  float colsum_local[PC];
+#pragma unroll
+  for (int e = 0; e < PC; ++e) colsum_local[e] = 0.f;
+
+  for (int mt = m_begin; mt < m_end; mt += TBK) {
+    u32x4 va[A_IT][RPU], vb[B_IT][RPU];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      int u = tid + it * NTHREADS;
+      int c = u % A_CH, pr = u / A_CH;
+      int n1 = n1_0 + c * PC;
+#pragma unroll
+      for (int q = 0; q < RPU; ++q) {
+        int m = mt + pr * RPU + q;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (m < m_end && n1 < p.N1) v = *(const u32x4*)(Ag + rowmap_base(amap, m) * p.lda + n1);
+        va[it][q] = v;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      int u = tid + it * NTHREADS;
+      int c = u % B_CH, pr = u / B_CH;
+      int n2 = n2_0 + c * PC;
+      int seg_rows = 0, col = n2;
+      if (bmap.mode == 1) {
+        int seg = n2 / bmap.c_seg;
+        col = n2 - seg * bmap.c_seg;
+        seg_rows = rowmap_seg(bmap, seg);
+      }
+#pragma unroll
+      for (int q = 0; q < RPU; ++q) {
+        int m = mt + pr * RPU + q;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (u < B_UNITS && m < m_end && n2 < p.N2) v = *(const u32x4*)(Bg + (rowmap_base(bmap, m) + seg_rows) * p.ldb + col);
+        vb[it][q] = v;
+      }
+    }
+    __syncthreads();          // previous tile's fragment reads are done
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      int u = tid + it * NTHREADS;
+      int c = u % A_CH, pr = u / A_CH;
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 x0 = __builtin_bit_cast(bf16x8, va[it][0]), x1 = __builtin_bit_cast(bf16x8, va[it][1]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bf16x2 pk = {x0[e], x1[e]};
+          *(bf16x2*)(sA + (c * 8 + e) * ROWB + pr * 4) = pk;
+          if (do_colsum) colsum_local[e] += (float)x0[e] + (float)x1[e];
+        }
+      } else {
+        f32x4 x0 = __builtin_bit_cast(f32x4, va[it][0]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          *(float*)(sA + (c * 4 + e) * ROWB + pr * 4) = x0[e];
+          if (do_colsum) colsum_local[e] += x0[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      int u = tid + it * NTHREADS;
+      if (u >= B_UNITS) continue;
+      int c = u % B_CH, pr = u / B_CH;
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 x0 = __builtin_bit_cast(bf16x8, vb[it][0]), x1 = __builtin_bit_cast(bf16x8, vb[it][1]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bf16x2 pk = {x0[e], x1[e]};
+          *(bf16x2*)(sB + (c * 8 + e) * ROWB + pr * 4) = pk;
+        }
+      } else {
+        f32x4 x0 = __builtin_bit_cast(f32x4, vb[it][0]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *(float*)(sB + (c * 4 + e) * ROWB + pr * 4) = x0[e];
+      }
+    }
+    __syncthreads();
+    // fragments: row = n1 (or n2) index, 8 consecutive m at offset 32*ks + 8*fg
+#pragma unroll
+    for (int ks = 0; ks < TBK / 32; ++ks) {
+      u32x4 fa[4][2], fb[TN_][2];
+      constexpr int EB = sizeof(T);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const char* ptr = sA + (wm * 64 + i * 16 + fr) * ROWB + (ks * 32 + fg * 8) * EB;
+        fa[i][0] = *(const u32x4*)ptr;
+        fa[i][1] = (EB == 4) ? *(const u32x4*)(ptr + 16) : fa[i][0];
+      }
+#pragma unroll
+      for (int j = 0; j < TN_; ++j) {
+        const char* ptr = sB + (wn * WN + j * 16 + fr) * ROWB + (ks * 32 + fg * 8) * EB;
+        fb[j][0] = *(const u32x4*)ptr;
+        fb[j][1] = (EB == 4) ? *(const u32x4*)(ptr + 16) : fb[j][0];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) mma16(acc[i][j], fa[i][0], fa[i][1], fb[j][0], fb[j][1], (T*)nullptr);
+    }
+  }
+
+  if (do_colsum) {
+    // every A unit of this thread has the same column chunk c (A_CH divides NTHREADS)
+    int c = tid % A_CH;
+#pragma unroll
+    for (int e = 0; e < PC; ++e) atomicAdd(&s_colsum[c * PC + e], colsum_local[e]);
+    __syncthreads();
+    if (tid < BM && n1_0 + tid < p.N1) atomicAdd(&p.colsum_a[n1_0 + tid], s_colsum[tid]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN_; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int n1 = n1_0 + wm * 64 + i * 16 + 4 * fg + r;
+        int n2 = n2_0 + wn * WN + j * 16 + fr;
+        if (n1 < p.N1 && n2 < p.N2) atomicAdd(&p.C[(long)n1 * p.ldc + n2], acc[i][j][r]);
+      }
+}
+
+int check_rowmap(const mvlt_rowmap& m, const char* who) {
+  if (m.mode == 0) {
+    MVLT_REQUIRE(m.rows_per_batch >= 0, "%s: rows_per_batch < 0", who);
+  } else if (m.mode == 1) {
+    MVLT_REQUIRE(m.r > 0 && m.w_in > 0 && m.tokens_in > 0 && m.hw_out > 0 && m.w_out > 0 && m.c_seg > 0 && m.c_seg % 16 == 0,
+                 "%s: bad patch map (c_seg must be a positive multiple of 16)", who);
+  } else {
+    MVLT_REQUIRE(false, "%s: unknown rowmap mode %d", who, m.mode);
+  }
+  return MVLT_OK;
+}
+
+}  // namespace
+
+extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
+  MVLT_REQUIRE(a && a->A && a->B && a->C, "mvlt_gemm_nt: null operand");
+  MVLT_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "mvlt_gemm_nt: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+  MVLT_REQUIRE(a->dtype == 0 || a->dtype == 1, "mvlt_gemm_nt: dtype must be 0 (bf16) or 1 (fp32)");
+  const int pc = a->dtype == 0 ? 8 : 4;
+  MVLT_REQUIRE(a->K % pc == 0 && a->lda % pc == 0 && a->ldb % pc == 0, "mvlt_gemm_nt: K/lda/ldb must be multiples of %d elements (16 B)", pc);
+  MVLT_REQUIRE(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0, "mvlt_gemm_nt: A/B must be 16-byte aligned");
+  MVLT_REQUIRE(a->act >= 0 && a->act <= 2, "mvlt_gemm_nt: bad act");
+  MVLT_REQUIRE(a->act != 2 || a->H, "mvlt_gemm_nt: act=2 (gelu') needs H");
+  MVLT_REQUIRE(!a->row_scale || a->rows_per_scale > 0, "mvlt_gemm_nt: row_scale needs rows_per_scale");
+  if (int e = check_rowmap(a->a_map, "mvlt_gemm_nt a_map")) return e;
+  if (int e = check_rowmap(a->c_map, "mvlt_gemm_nt c_map")) return e;
+  MVLT_REQUIRE(a->a_map.mode == 0 || a->K == a->a_map.r * a->a_map.r * a->a_map.c_seg, "mvlt_gemm_nt: gather K != r*r*c_seg");
+  MVLT_REQUIRE(a->c_map.mode == 0 || a->N == a->c_map.r * a->c_map.r * a->c_map.c_seg, "mvlt_gemm_nt: scatter N != r*r*c_seg");
+  if (a->M == 0) return MVLT_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles_m = (a->M + BM - 1) / BM;
+  const bool narrow = a->N <= 64;
+  const int bn = narrow ? 64 : 128;
+  const int tiles_n = (a->N + bn - 1) / bn;
+  const size_t lds = 2 * (BM + bn) * ROW_BYTES;
+  dim3 grid((unsigned)(tiles_m * tiles_n)), block(NTHREADS);
+  if (a->dtype == 0) {
+    if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 64>), grid, block, lds, s, *a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<bf16, 128>), grid, block, lds, s, *a);
+  } else {
+    if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<float, 64>), grid, block, lds, s, *a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<float, 128>), grid, block, lds, s, *a);
+  }
+  return mvlt_check_launch("mvlt_gemm_nt");
+}
+
+extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
+  MVLT_REQUIRE(a && a->A && a->B && a->C, "mvlt_gemm_tn: null operand");
+  MVLT_REQUIRE(a->M >= 0 && a->N1 > 0 && a->N2 > 0, "mvlt_gemm_tn: bad shape");
+  MVLT_REQUIRE(a->dtype == 0 || a->dtype == 1, "mvlt_gemm_tn: dtype must be 0 (bf16) or 1 (fp32)");
+  const int pc = a->dtype == 0 ? 8 : 4;
+  // N1/N2 may be ragged (30522 vocabulary rows) as long as the padded row (lda/ldb) covers the last 16-B chunk
+  MVLT_REQUIRE(a->lda % pc == 0 && a->ldb % pc == 0, "mvlt_gemm_tn: lda/ldb must be multiples of %d elements (16 B)", pc);
+  MVLT_REQUIRE(a->lda >= (a->N1 + pc - 1) / pc * pc, "mvlt_gemm_tn: lda must cover N1 rounded up to %d", pc);
+  MVLT_REQUIRE(a->b_map.mode == 1 || a->ldb >= (a->N2 + pc - 1) / pc * pc, "mvlt_gemm_tn: ldb must cover N2 rounded up to %d", pc);
+  MVLT_REQUIRE(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0, "mvlt_gemm_tn: A/B must be 16-byte aligned");
+  if (int e = check_rowmap(a->a_map, "mvlt_gemm_tn a_map")) return e;
+  if (int e = check_rowmap(a->b_map, "mvlt_gemm_tn b_map")) return e;
+  MVLT_REQUIRE(a->a_map.mode == 0, "mvlt_gemm_tn: A cannot be a patch gather");
+  MVLT_REQUIRE(a->b_map.mode == 0 || a->N2 == a->b_map.r * a->b_map.r * a->b_map.c_seg, "mvlt_gemm_tn: gather N2 != r*r*c_seg");
+  if (a->M == 0) return MVLT_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const bool narrow = a->N2 <= 64;
+  const int bn = narrow ? 64 : 128;
+  const int t1 = (a->N1 + BM - 1) / BM, t2 = (a->N2 + bn - 1) / bn;
+  const int mtiles = (a->M + TBK - 1) / TBK;
+  int splits = a->splits;
+  if (splits <= 0) {
+    splits = (1024 + t1 * t2 - 1) / (t1 * t2);       // ~4 workgroups per CU in total
+    if (splits > mtiles) splits = mtiles;
+    if (splits > 4096) splits = 4096;
+    if (splits < 1) splits = 1;
+  }
+  int m_per_split = ((mtiles + splits - 1) / splits) * TBK;
+  splits = (a->M + m_per_split - 1) / m_per_split;
+  const int rowb = a->dtype == 0 ? TElem<bf16>::ROWB : TElem<float>::ROWB;
+  const size_t lds = (size_t)(BM + bn) * rowb + BM * sizeof(float);
+  dim3 grid((unsigned)t1, (unsigned)t2, (unsigned)splits), block(NTHREADS);
+  if (a->dtype == 0) {
+    if (narrow) hipLaunchKernelGGL((gemm_tn_kernel<bf16, 64>), grid, block, lds, s, *a, m_per_split);
+    else hipLaunchKernelGGL((gemm_tn_kernel<bf16, 128>), grid, block, lds, s, *a, m_per_split);
+  } else {
+    if (narrow) hipLaunchKernelGGL((gemm_tn_kernel<float, 64>), grid, block, lds, s, *a, m_per_split);
+    else hipLaunchKernelGGL((gemm_tn_kernel<float, 128>), grid, block, lds, s, *a, m_per_split);
+  }
+  return mvlt_check_launch("mvlt_gemm_tn");
+}

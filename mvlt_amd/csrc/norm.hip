@@ -1,0 +1,289 @@
+// LayerNorm forward / backward for the MVLT token matrices (gfx950).  HBM-bound: every row is read once with
+// 16-byte loads, kept in registers for the two-pass mean/variance, and written once.
+// A row (C = 64..768 channels) is owned by a group of G = 8/16/32/64 lanes so that small C still fills the wave.
+#include "common.h"
+#include "../../include/mvlt_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+template <typename T> struct MaxIt { static constexpr int V = sizeof(T) == 2 ? 2 : 3; };   // 16-B chunks per lane: C <= 64 * V * per_chunk (1024 / 768)
+
+__device__ __forceinline__ RowMap rm0(const mvlt_rowmap& m) {
+  RowMap r{};
+  r.mode = 0; r.rows_per_batch = m.rows_per_batch; r.batch_stride = m.batch_stride; r.offset = m.offset;
+  return r;
+}
+
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <typename T> struct Vec;
+template <> struct Vec<bf16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const bf16* p, float* f) {
+    bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+  }
+  static __device__ __forceinline__ void store(bf16* p, const float* f) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
+    *(bf16x8*)p = v;
+  }
+};
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float* f) {
+    f32x4 v = *(const f32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = v[i];
+  }
+  static __device__ __forceinline__ void store(float* p, const float* f) {
+    f32x4 v = {f[0], f[1], f[2], f[3]};
+    *(f32x4*)p = v;
+  }
+};
+
+template <typename T, int G>
+__global__ __launch_bounds__(NT) void ln_fwd_kernel(mvlt_layernorm_args p) {
+  constexpr int VN = Vec<T>::N;
+  constexpr int MAXIT = MaxIt<T>::V;
+  const int gl = threadIdx.x % G;                 // lane inside the row group
+  const int grp = threadIdx.x / G;                // row group inside the block
+  constexpr int GROUPS = NT / G;
+  const int nchunk = p.C / VN;
+  const RowMap xm = rm0(p.x_map), ym = rm0(p.y_map);
+  const float inv_c = 1.0f / (float)p.C;
+  for (int row = blockIdx.x * GROUPS + grp; row < p.rows; row += gridDim.x * GROUPS) {
+    const T* xr = (const T*)p.x + rowmap_base(xm, row) * p.ldx;
+    T* yr = (T*)p.y + rowmap_base(ym, row) * p.ldy;
+    float v[MAXIT][VN];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      int c = gl + it * G;
+      if (c < nchunk) {
+        Vec<T>::load(xr + c * VN, v[it]);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) s += v[it][e];
+      }
+    }
+    const float mean = group_sum<G>(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      int c = gl + it * G;
+      if (c < nchunk) {
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { float d = v[it][e] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(group_sum<G>(q) * inv_c + p.eps);
+    if (gl == 0) {
+      if (p.mean) p.mean[row] = mean;
+      if (p.rstd) p.rstd[row] = rstd;
+    }
+    const float* addr = p.add ? p.add + (long)(row % p.add_rows) * p.C : nullptr;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      int c = gl + it * G;
+      if (c < nchunk) {
+        float o[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+          int col = c * VN + e;
+          o[e] = (v[it][e] - mean) * rstd * p.gamma[col] + p.beta[col];
+          if (addr) o[e] += addr[col];
+        }
+        Vec<T>::store(yr + c * VN, o);
+      }
+    }
+  }
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
+  constexpr int VN = Vec<T>::N;
+  constexpr int MAXIT = MaxIt<T>::V;
+  constexpr int GROUPS = NT / G;
+  extern __shared__ __attribute__((aligned(16))) float s_part[];               // [2][C] block partials of dgamma / dbeta
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G;
+  const int nchunk = p.C / VN;
+  const RowMap dym = rm0(p.dy_map), xm = rm0(p.x_map), dxm = rm0(p.dx_map);
+  const float inv_c = 1.0f / (float)p.C;
+  for (int i = threadIdx.x; i < 2 * p.C; i += NT) s_part[i] = 0.f;
+  __syncthreads();
+  float dg[MAXIT][VN], db[MAXIT][VN];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+#pragma unroll
+    for (int e = 0; e < VN; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; }
+
+  for (int row = blockIdx.x * GROUPS + grp; row < p.rows; row += gridDim.x * GROUPS) {
+    const T* dyr = (const T*)p.dy + rowmap_base(dym, row) * p.lddy;
+    const T* xr = (const T*)p.x + rowmap_base(xm, row) * p.ldx;
+    T* dxr = (T*)p.dx + rowmap_base(dxm, row) * p.lddx;
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    float g[MAXIT][VN], xh[MAXIT][VN];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      int c = gl + it * G;
+      if (c < nchunk) {
+        float dyv[VN], xv[VN];
+        Vec<T>::load(dyr + c * VN, dyv);
+        Vec<T>::load(xr + c * VN, xv);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+          float h = (xv[e] - mean) * rstd;
+          float gg = dyv[e] * p.gamma[c * VN + e];
+          xh[it][e] = h; g[it][e] = gg;
+          s1 += gg; s2 += gg * h;
+          dg[it][e] += dyv[e] * h;
+          db[it][e] += dyv[e];
+        }
+      }
+    }
+    s1 = group_sum<G>(s1) * inv_c;
+    s2 = group_sum<G>(s2) * inv_c;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      int c = gl + it * G;
+      if (c < nchunk) {
+        float o[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) o[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
+        if (p.dx_accumulate) {
+          float old[VN];
+          Vec<T>::load(dxr + c * VN, old);
+#pragma unroll
+          for (int e = 0; e < VN; ++e) o[e] += old[e];
+        }
+        Vec<T>::store(dxr + c * VN, o);
+      }
+    }
+  }
+  if (p.dgamma) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      int c = gl + it * G;
+      if (c < nchunk) {
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+          atomicAdd(&s_part[c * VN + e], dg[it][e]);
+          atomicAdd(&s_part[p.C + c * VN + e], db[it][e]);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.C; i += NT) {
+      atomicAdd(&p.dgamma[i], s_part[i]);
+      atomicAdd(&p.dbeta[i], s_part[p.C + i]);
+    }
+  }
+}
+
+// out[r, c] = sum_b in[b*batch_stride_rows + r][c]   (gradient of a broadcast "+ pos_embed"); fp32 out
+template <typename T>
+__global__ __launch_bounds__(NT) void batch_sum_kernel(const T* in, float* out, int B, int R, int C, long batch_stride, int ld) {
+  constexpr int VN = Vec<T>::N;
+  constexpr int MAXIT = MaxIt<T>::V;
+  const int nchunk = C / VN;
+  const long total = (long)R * nchunk;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    int r = (int)(i / nchunk), c = (int)(i - (long)r * nchunk);
+    float acc[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float v[VN];
+      Vec<T>::load(in + ((long)b * batch_stride + r) * ld + c * VN, v);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) acc[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < VN; ++e) out[(long)r * C + c * VN + e] = acc[e];
+  }
+}
+
+template <typename T> int pick_group(int C) {
+  int chunks = C / Vec<T>::N;
+  int g = 8;
+  while (g < 64 && g * 2 <= chunks) g *= 2;      // largest power of two <= chunks (>= 8)
+  while (g * MaxIt<T>::V < chunks && g < 64) g *= 2;
+  return g;
+}
+
+template <typename T> int launch_fwd(const mvlt_layernorm_args& a, hipStream_t s) {
+  int g = pick_group<T>(a.C);
+  MVLT_REQUIRE(g * MaxIt<T>::V * Vec<T>::N >= a.C, "mvlt_layernorm_fwd: C=%d too large", a.C);
+  int groups = NT / g;
+  int grid = (a.rows + groups - 1) / groups;
+  if (grid > 8192) grid = 8192;
+  switch (g) {
+    case 8: hipLaunchKernelGGL((ln_fwd_kernel<T, 8>), dim3(grid), dim3(NT), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((ln_fwd_kernel<T, 16>), dim3(grid), dim3(NT), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((ln_fwd_kernel<T, 32>), dim3(grid), dim3(NT), 0, s, a); break;
+    default: hipLaunchKernelGGL((ln_fwd_kernel<T, 64>), dim3(grid), dim3(NT), 0, s, a); break;
+  }
+  return mvlt_check_launch("mvlt_layernorm_fwd");
+}
+
+template <typename T> int launch_bwd(const mvlt_layernorm_bwd_args& a, hipStream_t s) {
+  int g = pick_group<T>(a.C);
+  MVLT_REQUIRE(g * MaxIt<T>::V * Vec<T>::N >= a.C, "mvlt_layernorm_bwd: C=%d too large", a.C);
+  int groups = NT / g;
+  int grid = (a.rows + groups - 1) / groups;
+  if (grid > 1024) grid = 1024;                 // each block ends with 2*C global atomics
+  size_t lds = 2 * a.C * sizeof(float);
+  switch (g) {
+    case 8: hipLaunchKernelGGL((ln_bwd_kernel<T, 8>), dim3(grid), dim3(NT), lds, s, a); break;
+    case 16: hipLaunchKernelGGL((ln_bwd_kernel<T, 16>), dim3(grid), dim3(NT), lds, s, a); break;
+    case 32: hipLaunchKernelGGL((ln_bwd_kernel<T, 32>), dim3(grid), dim3(NT), lds, s, a); break;
+    default: hipLaunchKernelGGL((ln_bwd_kernel<T, 64>), dim3(grid), dim3(NT), lds, s, a); break;
+  }
+  return mvlt_check_launch("mvlt_layernorm_bwd");
+}
+
+}  // namespace
+
+extern "C" int mvlt_layernorm_fwd(const mvlt_layernorm_args* a, void* stream) {
+  MVLT_REQUIRE(a && a->x && a->y && a->gamma && a->beta, "mvlt_layernorm_fwd: null pointer");
+  MVLT_REQUIRE(a->dtype == 0 || a->dtype == 1, "mvlt_layernorm_fwd: bad dtype");
+  const int vn = a->dtype == 0 ? 8 : 4;
+  MVLT_REQUIRE(a->C > 0 && a->C % vn == 0 && a->ldx % vn == 0 && a->ldy % vn == 0, "mvlt_layernorm_fwd: C/ldx/ldy must be multiples of %d", vn);
+  MVLT_REQUIRE(a->x_map.mode == 0 && a->y_map.mode == 0, "mvlt_layernorm_fwd: only mode-0 row maps");
+  MVLT_REQUIRE(!a->add || a->add_rows > 0, "mvlt_layernorm_fwd: add needs add_rows");
+  if (a->rows <= 0) return MVLT_OK;
+  return a->dtype == 0 ? launch_fwd<bf16>(*a, (hipStream_t)stream) : launch_fwd<float>(*a, (hipStream_t)stream);
+}
+
+extern "C" int mvlt_layernorm_bwd(const mvlt_layernorm_bwd_args* a, void* stream) {
+  MVLT_REQUIRE(a && a->dy && a->x && a->dx && a->gamma && a->mean && a->rstd, "mvlt_layernorm_bwd: null pointer");
+  MVLT_REQUIRE((a->dgamma == nullptr) == (a->dbeta == nullptr), "mvlt_layernorm_bwd: dgamma and dbeta go together");
+  MVLT_REQUIRE(a->dtype == 0 || a->dtype == 1, "mvlt_layernorm_bwd: bad dtype");
+  const int vn = a->dtype == 0 ? 8 : 4;
+  MVLT_REQUIRE(a->C > 0 && a->C % vn == 0 && a->ldx % vn == 0 && a->lddy % vn == 0 && a->lddx % vn == 0,
+               "mvlt_layernorm_bwd: C/ld* must be multiples of %d", vn);
+  MVLT_REQUIRE(a->x_map.mode == 0 && a->dy_map.mode == 0 && a->dx_map.mode == 0, "mvlt_layernorm_bwd: only mode-0 row maps");
+  if (a->rows <= 0) return MVLT_OK;
+  return a->dtype == 0 ? launch_bwd<bf16>(*a, (hipStream_t)stream) : launch_bwd<float>(*a, (hipStream_t)stream);
+}
+
+extern "C" int mvlt_batch_sum(const void* in, float* out, int B, int R, int C, long batch_stride_rows, int ld, int dtype, void* stream) {
+  MVLT_REQUIRE(in && out && B > 0 && R >= 0 && C > 0, "mvlt_batch_sum: bad arguments");
+  const int vn = dtype == 0 ? 8 : 4;
+  MVLT_REQUIRE(C % vn == 0 && ld % vn == 0, "mvlt_batch_sum: C/ld must be multiples of %d", vn);
+  if (R == 0) return MVLT_OK;
+  long total = (long)R * (C / vn);
+  int grid = (int)((total + NT - 1) / NT);
+  if (grid > 4096) grid = 4096;
+  if (dtype == 0) hipLaunchKernelGGL((batch_sum_kernel<bf16>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const bf16*)in, out, B, R, C, batch_stride_rows, ld);
+  else hipLaunchKernelGGL((batch_sum_kernel<float>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const float*)in, out, B, R, C, batch_stride_rows, ld);
+  return mvlt_check_launch("mvlt_batch_sum");
+}

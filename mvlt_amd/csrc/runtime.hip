@@ -1,0 +1,34 @@
+// Error reporting and ABI version for libmvlt_hip.so.
+#include "common.h"
+#include "../../include/mvlt_hip.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void mvlt_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int mvlt_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    mvlt_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return MVLT_ERR_LAUNCH;
+  }
+  return MVLT_OK;
+}
+
+extern "C" const char* mvlt_last_error(void) { return g_err; }
+extern "C" int mvlt_abi_version(void) { return 1; }
+
+// sizeof() of every argument struct, so a foreign-language binding can verify its mirror of include/mvlt_hip.h
+extern "C" int mvlt_sizeof(const char* name) {
+#define S(T) if (strcmp(name, #T) == 0) return (int)sizeof(T);
+  S(mvlt_rowmap) S(mvlt_gemm_nt_args) S(mvlt_gemm_tn_args) S(mvlt_layernorm_args) S(mvlt_layernorm_bwd_args)
+  S(mvlt_attn_args) S(mvlt_attn_bwd_args)
+#undef S
+  return -1;
+}

@@ -1,0 +1,183 @@
+"""Thin Python calls over the C ABI (include/mvlt_hip.h).  Every function launches HIP kernels asynchronously on
+torch's current stream; tensors are only used as device buffers.  No fallbacks: a missing library or a CPU tensor
+raises (mvlt_amd/_lib.py)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import DT, check, patchmap, ptr, rowmap, stream_ptr
+
+_ID = rowmap()
+
+
+def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias=None, act=0, H=None,
+            row_scale=None, rows_per_scale=0, R=None):
+    """C[M,N] = epi(A[M,K] @ B[N,K]^T); see mvlt_gemm_nt in include/mvlt_hip.h."""
+    assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype in DT
+    if bias is not None:
+        assert bias.dtype == torch.float32
+    if row_scale is not None:
+        assert row_scale.dtype == torch.float32
+    if R is not None:
+        assert R.dtype == C_out.dtype
+    if H is not None:
+        assert H.dtype == C_out.dtype
+    a = L.GemmNTArgs(ptr(A), ptr(B), ptr(C_out), M, N, K, lda, ldb, ldc, DT[A.dtype], DT[C_out.dtype],
+                     a_map or _ID, c_map or _ID, ptr(bias), act, ptr(H), ptr(row_scale), rows_per_scale, ptr(R))
+    check(L.lib.mvlt_gemm_nt(C.byref(a), stream_ptr()), "mvlt_gemm_nt")
+    return C_out
+
+
+def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, colsum=None, splits=0):
+    """C[N1,N2] += A[M,N1]^T @ B[M,N2] (fp32 atomics); colsum[N1] += A.sum(0)."""
+    assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype == torch.float32
+    if colsum is not None:
+        assert colsum.dtype == torch.float32
+    a = L.GemmTNArgs(ptr(A), ptr(B), ptr(C_out), M, N1, N2, lda, ldb, ldc, DT[A.dtype],
+                     a_map or _ID, b_map or _ID, ptr(colsum), splits)
+    check(L.lib.mvlt_gemm_tn(C.byref(a), stream_ptr()), "mvlt_gemm_tn")
+    return C_out
+
+
+def layernorm_fwd(x, y, gamma, beta, rows, Cdim, ldx, ldy, eps, *, mean=None, rstd=None, add=None, add_rows=0,
+                  x_map=None, y_map=None):
+    assert x.dtype == y.dtype and x.dtype in DT and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    a = L.LayerNormArgs(ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(add), add_rows,
+                        rows, Cdim, ldx, ldy, x_map or _ID, y_map or _ID, eps, DT[x.dtype])
+    check(L.lib.mvlt_layernorm_fwd(C.byref(a), stream_ptr()), "mvlt_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy, x, dx, gamma, mean, rstd, rows, Cdim, lddy, ldx, lddx, *, dgamma=None, dbeta=None,
+                  dy_map=None, x_map=None, dx_map=None, accumulate=False):
+    assert dy.dtype == x.dtype == dx.dtype and x.dtype in DT
+    a = L.LayerNormBwdArgs(ptr(dy), ptr(x), ptr(dx), ptr(gamma), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta),
+                           None, 0, rows, Cdim, lddy, ldx, lddx, dy_map or _ID, x_map or _ID, dx_map or _ID,
+                           1 if accumulate else 0, DT[x.dtype])
+    check(L.lib.mvlt_layernorm_bwd(C.byref(a), stream_ptr()), "mvlt_layernorm_bwd")
+    return dx
+
+
+L.lib.mvlt_batch_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]
+
+
+def batch_sum(x, out, B, R, Cdim, batch_stride_rows, ld):
+    assert out.dtype == torch.float32
+    check(L.lib.mvlt_batch_sum(ptr(x), ptr(out), B, R, Cdim, batch_stride_rows, ld, DT[x.dtype], stream_ptr()), "mvlt_batch_sum")
+    return out
+
+
+def sr_attention_fwd(Q, KV, O, lse, B, H, N, M, ldq, ldkv, ldo, k_off, v_off, scale):
+    assert Q.dtype == KV.dtype == O.dtype and Q.dtype in DT
+    a = L.AttnArgs(ptr(Q), ptr(KV), ptr(O), ptr(lse), B, H, N, M, ldq, ldkv, ldo, k_off, v_off, scale, DT[Q.dtype])
+    check(L.lib.mvlt_sr_attention_fwd(C.byref(a), stream_ptr()), "mvlt_sr_attention_fwd")
+    return O
+
+
+def sr_attention_bwd(Q, KV, O, dO, lse, dQ, dKV, B, H, N, M, ldq, ldkv, ldo, lddkv, k_off, v_off, scale):
+    assert dKV.dtype == torch.float32
+    a = L.AttnBwdArgs(ptr(Q), ptr(KV), ptr(O), ptr(dO), ptr(lse), ptr(dQ), ptr(dKV), B, H, N, M,
+                      ldq, ldkv, ldo, lddkv, k_off, v_off, scale, DT[Q.dtype])
+    check(L.lib.mvlt_sr_attention_bwd(C.byref(a), stream_ptr()), "mvlt_sr_attention_bwd")
+    return dQ, dKV
+
+
+# ------------------------------------------------------------------ helpers of csrc/elementwise.hip
+_vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
+L.lib.mvlt_bert_embed_fwd.argtypes = [_vp] * 7 + [_f, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]
+L.lib.mvlt_bert_embed_bwd.argtypes = [_vp] * 7 + [_f] + [_vp] * 7 + [_i, _i, _i, _i, _vp]
+L.lib.mvlt_patchify.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+L.lib.mvlt_masked_select.argtypes = [_vp, _i, _l, _vp, _vp, _vp]
+L.lib.mvlt_gather_rows.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]
+L.lib.mvlt_scatter_rows.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]
+L.lib.mvlt_cross_entropy_fwd.argtypes = [_vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
+L.lib.mvlt_cross_entropy_bwd.argtypes = [_vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+L.lib.mvlt_adamw_step.argtypes = [_vp, _vp, _vp, _vp, _vp, _l, _vp, _vp]
+L.lib.mvlt_cast_bf16.argtypes = [_vp, _vp, _l, _vp]
+L.lib.mvlt_transpose_cast.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp]
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.MVLTError("mvlt_amd ops need CUDA/HIP tensors (no CPU fallback)")
+
+
+def bert_embed_fwd(ids, word, pos, type0, gamma, beta, keep, drop_p, y, mean, rstd, rows, T, eps):
+    _need_cuda(ids, word, y)
+    assert ids.dtype == torch.int64 and (keep is None or keep.dtype == torch.uint8)
+    check(L.lib.mvlt_bert_embed_fwd(_p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), _p(keep), drop_p,
+                                    _p(y), _p(mean), _p(rstd), rows, T, word.shape[1], eps, DT[y.dtype], stream_ptr()),
+          "mvlt_bert_embed_fwd")
+    return y
+
+
+def bert_embed_bwd(dy, ids, word, pos, type0, gamma, keep, drop_p, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T):
+    _need_cuda(dy, ids, dword)
+    check(L.lib.mvlt_bert_embed_bwd(_p(dy), _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(keep), drop_p,
+                                    _p(mean), _p(rstd), _p(dword), _p(dpos), _p(dtype0), _p(dgamma), _p(dbeta),
+                                    rows, T, word.shape[1], DT[dy.dtype], stream_ptr()), "mvlt_bert_embed_bwd")
+
+
+def patchify(img, out, B, Cin, H, W, k):
+    _need_cuda(img, out)
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    check(L.lib.mvlt_patchify(_p(img), _p(out), B, Cin, H, W, k, DT[out.dtype], stream_ptr()), "mvlt_patchify")
+    return out
+
+
+def masked_select(labels, idx, count, ignore_index=-1):
+    _need_cuda(labels, idx, count)
+    assert labels.dtype == torch.int64 and idx.dtype == torch.int32 and count.dtype == torch.int32 and labels.is_contiguous()
+    check(L.lib.mvlt_masked_select(_p(labels), labels.numel(), ignore_index, _p(idx), _p(count), stream_ptr()), "mvlt_masked_select")
+
+
+def gather_rows(src, idx, dst, rows, Cdim, ld_src, src_map=None):
+    _need_cuda(src, idx, dst)
+    assert idx.dtype == torch.int32 and src.dtype == dst.dtype
+    m = C.byref(src_map) if src_map is not None else None
+    check(L.lib.mvlt_gather_rows(_p(src), _p(idx), _p(dst), rows, Cdim, ld_src, m, DT[src.dtype], stream_ptr()), "mvlt_gather_rows")
+    return dst
+
+
+def scatter_rows(src, idx, dst, rows, Cdim, ld_dst, dst_map=None, accumulate=False):
+    _need_cuda(src, idx, dst)
+    assert idx.dtype == torch.int32 and src.dtype == dst.dtype
+    m = C.byref(dst_map) if dst_map is not None else None
+    check(L.lib.mvlt_scatter_rows(_p(src), _p(idx), _p(dst), rows, Cdim, ld_dst, m, 1 if accumulate else 0, DT[src.dtype], stream_ptr()),
+          "mvlt_scatter_rows")
+    return dst
+
+
+def cross_entropy_fwd(logits, labels, lse, loss_sum, count, rows, V, ld, ignore_index=-1):
+    _need_cuda(logits, labels, lse)
+    assert labels.dtype == torch.int64
+    check(L.lib.mvlt_cross_entropy_fwd(_p(logits), _p(labels), ignore_index, _p(lse), _p(loss_sum), _p(count), rows, V, ld,
+                                       DT[logits.dtype], stream_ptr()), "mvlt_cross_entropy_fwd")
+
+
+def cross_entropy_bwd(logits, labels, lse, gscale, count, dlogits, rows, V, ld, ldd, ignore_index=-1):
+    _need_cuda(logits, labels, dlogits)
+    check(L.lib.mvlt_cross_entropy_bwd(_p(logits), _p(labels), ignore_index, _p(lse), _p(gscale), _p(count), _p(dlogits), rows, V, ld, ldd,
+                                       DT[logits.dtype], DT[dlogits.dtype], stream_ptr()), "mvlt_cross_entropy_bwd")
+
+
+def adamw_step(p, g, m, v, p16, n, hp):
+    _need_cuda(p, g, m, v, hp)
+    check(L.lib.mvlt_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(p16), n, _p(hp), stream_ptr()), "mvlt_adamw_step")
+
+
+def cast_bf16(src, dst, n):
+    _need_cuda(src, dst)
+    check(L.lib.mvlt_cast_bf16(_p(src), _p(dst), n, stream_ptr()), "mvlt_cast_bf16")
+
+
+def transpose_cast(w, out, R, Ccols, ld_out):
+    _need_cuda(w, out)
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    check(L.lib.mvlt_transpose_cast(_p(w), _p(out), R, Ccols, ld_out, DT[out.dtype], stream_ptr()), "mvlt_transpose_cast")

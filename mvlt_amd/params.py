@@ -1,0 +1,185 @@
+"""Parameter holders and the flat parameter / gradient store of the MI355X MVLT model.
+
+The module tree below exists only to give every tensor the reference's state_dict name and shape
+(reference libs/pvlt.py:200-277, libs/vl_heads.py).  It has no forward of its own: the
+model's forward drives HIP kernels directly on the flat buffers.
+
+Memory layout (sized for 288 GB HBM: everything stays resident)
+  P   fp32 master parameters, one flat buffer, every tensor at an 8-element (32 B) aligned offset
+  G   fp32 gradients, same offsets; kernels accumulate into it with atomics (zeroed once per step)
+  C16 bf16 copy of P (same offsets) when the compute dtype is bf16; weights additionally get a transposed
+      copy W^T (dgrad operand) and conv weights a [out][kh][kw][cin] re-ordering (patch-GEMM operand)
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+ALIGN = 8
+
+
+class Holder(nn.Module):
+    """A named bag of parameters (no forward)."""
+
+    def __init__(self, **shapes):
+        super().__init__()
+        for name, shape in shapes.items():
+            self.register_parameter(name, nn.Parameter(torch.zeros(*shape)))
+
+
+def affine(n):          # LayerNorm-like holder
+    return Holder(weight=(n,), bias=(n,))
+
+
+def linear(n_out, n_in, bias=True):
+    return Holder(weight=(n_out, n_in), bias=(n_out,)) if bias else Holder(weight=(n_out, n_in))
+
+
+def trunc_normal_(t, std=0.02):
+    # timm==0.3.2 trunc_normal_: N(0, std) truncated to the ABSOLUTE interval [-2, 2]
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+def conv_default_init_(w, b):
+    # nn.Conv2d.reset_parameters (the reference leaves convs at PyTorch defaults, libs/pvlt.py:282-289)
+    nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+    if b is not None:
+        fan_in = w[0].numel()
+        bound = 1 / math.sqrt(fan_in)
+        nn.init.uniform_(b, -bound, bound)
+
+
+class FlatStore:
+    """Flat fp32 master/grad buffers behind a module's parameters, plus compute-dtype operand copies."""
+
+    def __init__(self, module, compute_dtype):
+        self.module = module
+        self.compute_dtype = compute_dtype
+        self.device = None
+        self.P = self.G = self.C = None
+        self.offsets = OrderedDict()      # name -> (offset, numel, shape)
+        self.params = OrderedDict()       # name -> Parameter (unique)
+        self.total = 0
+        self._cast_version = -1
+        self.extra = {}                   # derived operand copies: name -> tensor
+        self._finalize_queued = False
+        self.force_dirty = True
+
+    # ------------------------------------------------------------------ layout
+    def _index(self):
+        self.offsets.clear()
+        self.params.clear()
+        off = 0
+        seen = set()
+        for name, p in self.module.named_parameters():      # de-duplicates the tied decoder weight
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            n = p.numel()
+            self.offsets[name] = (off, n, tuple(p.shape))
+            self.params[name] = p
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+
+    def is_current(self):
+        if self.P is None:
+            return False
+        for name in (next(iter(self.params)), next(reversed(self.params))):
+            off, n, _ = self.offsets[name]
+            if self.params[name].data_ptr() != self.P.data_ptr() + 4 * off:
+                return False
+        return True
+
+    def materialize(self, device):
+        """(Re)build the flat buffers on `device` from the current parameter values and re-point every
+        Parameter at its slice.  Called lazily: nn.Module.to()/.cuda() replace parameter storage."""
+        self._index()
+        P = torch.zeros(self.total, device=device, dtype=torch.float32)
+        for name, p in self.params.items():
+            off, n, shape = self.offsets[name]
+            P[off:off + n].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
+        self.P = P
+        self.G = torch.zeros_like(P)
+        for name, p in self.params.items():
+            off, n, shape = self.offsets[name]
+            p.data = P[off:off + n].view(shape)
+            p.grad = None
+        self.C = torch.empty(self.total, device=device, dtype=torch.bfloat16) if self.compute_dtype == torch.bfloat16 else None
+        self.device = device
+        self.extra = {}
+        self._cast_version = -1
+        self.force_dirty = True
+
+    def ensure(self, device):
+        if self.device != device or not self.is_current():
+            self.materialize(device)
+
+    # ------------------------------------------------------------------ views
+    def master(self, name):
+        off, n, shape = self.offsets[name]
+        return self.P[off:off + n].view(shape)
+
+    def grad(self, name):
+        off, n, shape = self.offsets[name]
+        return self.G[off:off + n].view(shape)
+
+    def comp(self, name):
+        """parameter in the compute dtype, reference layout"""
+        off, n, shape = self.offsets[name]
+        src = self.C if self.C is not None else self.P
+        return src[off:off + n].view(shape)
+
+    # ------------------------------------------------------------------ operand copies
+    def refresh(self, transposed, conv_perm):
+        """Bring compute-dtype copies up to date with the fp32 masters.
+        transposed: names of 2-D weights needing W^T; conv_perm: names of conv weights used as patch GEMMs."""
+        if not self.force_dirty and self._cast_version == self.P._version:
+            return
+        if self.C is not None:
+            ops.cast_bf16(self.P, self.C, self.total)
+        dt = self.compute_dtype
+        for name in transposed:
+            w = self.master(name)
+            key = name + "::T"
+            if key not in self.extra:
+                ld = (w.shape[0] + 7) // 8 * 8               # rows of W^T padded to 16 B (vocab 30522 -> 30528)
+                self.extra[key] = torch.zeros(w.shape[1], ld, device=self.device, dtype=dt)
+            ops.transpose_cast(w, self.extra[key], w.shape[0], w.shape[1], ld_out=self.extra[key].shape[1])
+        for name in conv_perm:
+            w = self.master(name)                            # [out, cin, kh, kw]
+            wk = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)   # [out][kh][kw][cin]
+            self.extra[name + "::K"] = wk.to(dt).contiguous()
+            self.extra[name + "::KT"] = wk.t().to(dt).contiguous()
+        self._cast_version = self.P._version
+        self.force_dirty = False
+
+    # ------------------------------------------------------------------ gradients
+    def begin_step(self):
+        """Zero G when the caller has cleared the grads (optimizer.zero_grad(set_to_none=True) or first use)."""
+        first = next(iter(self.params.values()))
+        if first.grad is None:
+            self.G.zero_()
+
+    def queue_finalize(self):
+        """Called from inside a backward: at the end of this backward pass attach .grad views (and fold in any
+        gradient autograd produced on its own for parameters used by torch-autograd sub-graphs)."""
+        if self._finalize_queued:
+            return
+        self._finalize_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+
+    def _finalize(self):
+        self._finalize_queued = False
+        self.attach_grads()
+
+    def attach_grads(self):
+        for name, p in self.params.items():
+            gv = self.grad(name)
+            if p.grad is None:
+                p.grad = gv
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.add_(p.grad.to(gv.dtype))
+                p.grad = gv

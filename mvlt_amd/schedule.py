@@ -1,0 +1,656 @@
+"""Forward / backward kernel schedules of the MI355X PVLT (the work that reference libs/pvlt.py:322-401 and its
+autograd graph do with dozens of ATen kernels per block).
+
+Data layout: one token-major activation buffer (B, HW+T, C) per stage in the compute dtype; image tokens first.
+  * PatchEmbed / Attention.sr (kernel==stride convs) read it through a patch row-map inside the GEMM loader
+  * text tokens are the row range [HW, HW+T) (row-map), so there is no torch.cat / torch.split / NCHW permute
+  * LN(+pos-embed) epilogues write straight into the concatenated buffer
+Backward is scheduled by hand: every weight gradient is accumulated by the wgrad GEMM directly into the flat fp32
+gradient buffer (no autograd accumulate pass), input gradients reuse buffers in place.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import patchmap, rowmap
+from .pvlt import BERT_DROP, EPS_BERT, EPS_BLOCK, EPS_DEFAULT, VOCAB, VOCAB_LD
+
+
+def _empty(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+class Names:
+    """parameter-name helpers"""
+
+    @staticmethod
+    def blk(i, j):
+        return f"block{i+1}.{j}."
+
+
+# =============================================================================================== trunk
+class TrunkStep:
+    """One forward (and optionally backward) of the 4-stage trunk."""
+
+    def __init__(self, model, images, ids, need_grad):
+        self.m = model
+        self.S = model.store
+        self.dev = images.device
+        self.dt = model.compute_dtype
+        self.need_grad = need_grad
+        self.images = images.contiguous().float()
+        self.ids = ids.contiguous()
+        self.B = images.shape[0]
+        assert images.shape[1] == model.in_chans
+        Himg, Wimg = images.shape[2], images.shape[3]
+        assert Himg == Wimg, "square inputs only (the reference's pos-embed handling assumes them)"
+        assert Himg % (model.patch_size * 8) == 0, f"img_size {Himg} should be divided by patch_size {model.patch_size * 8}."
+        self.img = Himg
+        self.T = ids.shape[1]
+        assert self.T == model.T_num, "input_ids length must equal num_text_tokens"
+        self.side = [Himg // model.patch_size // (2 ** i) for i in range(4)]
+        self.saved = []          # per stage dict
+        self.training = model.training
+
+    # ---- parameter access
+    def w(self, name):
+        return self.S.comp(name)
+
+    def wT(self, name):
+        return self.S.extra[name + "::T"]
+
+    def wK(self, name):
+        return self.S.extra[name + "::K"]
+
+    def wKT(self, name):
+        return self.S.extra[name + "::KT"]
+
+    def f32(self, name):
+        return self.S.master(name)
+
+    def g(self, name):
+        return self.S.grad(name)
+
+    # ---- pos embed (tiny, parameter-only: torch bilinear; its backward is taken with torch.autograd on demand)
+    def _pos(self, i, param):
+        m = self.m
+        HW = self.side[i] ** 2
+        pe = param[:, 1:] if i == 3 else param
+        if HW == m.grids[0] ** 2:          # reference libs/pvlt.py:292 compares with stage-1's constructor grid
+            return pe[0].contiguous()
+        gsz = m.grids[i]
+        t = pe.reshape(1, gsz, gsz, -1).permute(0, 3, 1, 2)
+        t = F.interpolate(t, size=(self.side[i], self.side[i]), mode="bilinear")
+        return t.reshape(1, -1, HW).permute(0, 2, 1)[0].contiguous()
+
+    def _droppath_scales(self, blk_index):
+        m = self.m
+        rate = m.dpr[blk_index]
+        if not self.training or rate == 0.0:
+            return None, None
+        inj = m.injected_masks
+        if inj is not None:
+            k1 = inj["droppath"][blk_index].to(self.dev, torch.float32)
+            k2 = inj["droppath2"][blk_index].to(self.dev, torch.float32)
+        else:
+            k1 = (torch.rand(self.B, device=self.dev) >= rate).float()
+            k2 = (torch.rand(self.B, device=self.dev) >= rate).float()
+        return (k1 / (1.0 - rate)).contiguous(), (k2 / (1.0 - rate)).contiguous()
+
+    # ------------------------------------------------------------------ forward
+    def forward(self):
+        m, S, B, T, dt, dev = self.m, self.S, self.B, self.T, self.dt, self.dev
+        te = "text_embeddings."
+        # BERT embeddings (+LN eps 1e-12, +dropout in train mode)
+        rows = B * T
+        self.emb = _empty((rows, m.hidden), dt, dev)
+        self.emb_mean = _empty((rows,), torch.float32, dev)
+        self.emb_rstd = _empty((rows,), torch.float32, dev)
+        self.keep = None
+        if self.training:
+            inj = m.injected_masks
+            if inj is not None:
+                self.keep = inj["bert"].to(dev).reshape(rows, m.hidden).to(torch.uint8).contiguous()
+            else:
+                self.keep = (torch.rand(rows, m.hidden, device=dev) >= BERT_DROP).to(torch.uint8)
+        ops.bert_embed_fwd(self.ids, self.f32(te + "word_embeddings.weight"), self.f32(te + "position_embeddings.weight"),
+                           self.f32(te + "token_type_embeddings.weight"), self.f32(te + "LayerNorm.weight"),
+                           self.f32(te + "LayerNorm.bias"), self.keep, BERT_DROP, self.emb, self.emb_mean, self.emb_rstd,
+                           rows, T, EPS_BERT)
+        xp = None
+        blk_index = 0
+        outs = []
+        for i in range(4):
+            xp, blk_index = self._stage_forward(i, xp, blk_index)
+            outs.append(xp)
+        return outs
+
+    def _stage_forward(self, i, xp, blk_index):
+        m, B, T, dt, dev = self.m, self.B, self.T, self.dt, self.dev
+        C = m.dims[i]
+        side = self.side[i]
+        HW = side * side
+        N = HW + T
+        sv = dict(i=i, C=C, HW=HW, N=N, side=side)
+        pe, ten = f"patch_embed{i+1}.", f"text_embed{i+1}."
+        # ---- patch embed: kernel==stride conv as GEMM, then LN(1e-5) + pos-embed written into x[:, :HW]
+        pe_pre = _empty((B * HW, C), dt, dev)
+        if i == 0:
+            K = m.in_chans * m.patch_size ** 2
+            P1 = _empty((B * HW, K), dt, dev)
+            ops.patchify(self.images, P1, B, m.in_chans, self.img, self.img, m.patch_size)
+            ops.gemm_nt(P1, self.w(pe + "proj.weight"), pe_pre, B * HW, C, K, K, K, C, bias=self.f32(pe + "proj.bias"))
+            sv["P1"] = P1
+        else:
+            Cp, Np, sp = m.dims[i - 1], self.saved[i - 1]["N"], self.side[i - 1]
+            pm = patchmap(2, sp, Np, HW, side, Cp)
+            ops.gemm_nt(xp, self.wK(pe + "proj.weight"), pe_pre, B * HW, C, 4 * Cp, Cp, 4 * Cp, C, a_map=pm,
+                        bias=self.f32(pe + "proj.bias"))
+            sv["pm_in"] = pm
+        x = _empty((B, N, C), dt, dev)
+        pos = self._pos(i, self.f32(f"pos_embed{i+1}"))
+        sv["pe_pre"], sv["pe_mean"], sv["pe_rstd"] = pe_pre, _empty((B * HW,), torch.float32, dev), _empty((B * HW,), torch.float32, dev)
+        ops.layernorm_fwd(pe_pre, x, self.f32(pe + "norm.weight"), self.f32(pe + "norm.bias"), B * HW, C, C, C, EPS_DEFAULT,
+                          mean=sv["pe_mean"], rstd=sv["pe_rstd"], add=pos, add_rows=HW, y_map=rowmap(HW, N, 0))
+        # ---- text embed: Linear + LN(1e-5) + text pos-embed written into x[:, HW:]
+        te_pre = _empty((B * T, C), dt, dev)
+        if i == 0:
+            ops.gemm_nt(self.emb, self.w(ten + "0.weight"), te_pre, B * T, C, m.hidden, m.hidden, m.hidden, C,
+                        bias=self.f32(ten + "0.bias"))
+        else:
+            Cp, Np, HWp = m.dims[i - 1], self.saved[i - 1]["N"], self.saved[i - 1]["HW"]
+            ops.gemm_nt(xp, self.w(ten + "0.weight"), te_pre, B * T, C, Cp, Cp, Cp, C, a_map=rowmap(T, Np, HWp),
+                        bias=self.f32(ten + "0.bias"))
+        sv["te_pre"], sv["te_mean"], sv["te_rstd"] = te_pre, _empty((B * T,), torch.float32, dev), _empty((B * T,), torch.float32, dev)
+        ops.layernorm_fwd(te_pre, x, self.f32(ten + "1.weight"), self.f32(ten + "1.bias"), B * T, C, C, C, EPS_DEFAULT,
+                          mean=sv["te_mean"], rstd=sv["te_rstd"], add=self.f32(f"text_pos_embed{i+1}")[0], add_rows=T,
+                          y_map=rowmap(T, N, HW))
+        sv["x_in_prev"] = xp
+        sv["blocks"] = []
+        for j in range(m.depths[i]):
+            x, bsv = self._block_forward(i, j, x, blk_index)
+            sv["blocks"].append(bsv)
+            blk_index += 1
+        sv["x_out"] = x
+        taps = getattr(m, "_taps", None)
+        if taps is not None:            # tests: stage outputs in the reference's (img_feat NCHW, text_feat) form
+            taps[f"img_feat{i+1}"] = x[:, :HW].float().reshape(B, side, side, C).permute(0, 3, 1, 2)
+            taps[f"text_feat{i+1}"] = x[:, HW:].float()
+        self.saved.append(sv)
+        return x, blk_index
+
+    def _block_forward(self, i, j, x, blk_index):
+        m, B, T, dt, dev = self.m, self.B, self.T, self.dt, self.dev
+        C, h, r, hid = m.dims[i], m.heads[i], m.sr[i], m.hid[i]
+        side = self.side[i]
+        HW = side * side
+        N = HW + T
+        M = B * N
+        p = Names.blk(i, j)
+        f32 = torch.float32
+        bs = dict(x=x)
+        s1, s2 = self._droppath_scales(blk_index)
+        bs["s1"], bs["s2"] = s1, s2
+        # LN1
+        xn1 = _empty((B, N, C), dt, dev)
+        bs["m1"], bs["r1"] = _empty((M,), f32, dev), _empty((M,), f32, dev)
+        ops.layernorm_fwd(x, xn1, self.f32(p + "norm1.weight"), self.f32(p + "norm1.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m1"], rstd=bs["r1"])
+        bs["xn1"] = xn1
+        # q
+        q = _empty((B, N, C), dt, dev)
+        ops.gemm_nt(xn1, self.w(p + "attn.q.weight"), q, M, C, C, C, C, C, bias=self.f32(p + "attn.q.bias"))
+        bs["q"] = q
+        # k, v source: spatially reduced image tokens (conv r x r stride r + LN 1e-5) followed by the text tokens
+        if r > 1:
+            sr_side = side // r
+            HWr = sr_side * sr_side
+            Mk = HWr + T
+            pm = patchmap(r, side, N, HWr, sr_side, C)
+            sr_pre = _empty((B * HWr, C), dt, dev)
+            ops.gemm_nt(xn1, self.wK(p + "attn.sr.weight"), sr_pre, B * HWr, C, r * r * C, C, r * r * C, C, a_map=pm,
+                        bias=self.f32(p + "attn.sr.bias"))
+            kvin = _empty((B * HWr, C), dt, dev)
+            bs["msr"], bs["rsr"] = _empty((B * HWr,), f32, dev), _empty((B * HWr,), f32, dev)
+            ops.layernorm_fwd(sr_pre, kvin, self.f32(p + "attn.norm.weight"), self.f32(p + "attn.norm.bias"), B * HWr, C, C, C,
+                              EPS_DEFAULT, mean=bs["msr"], rstd=bs["rsr"])
+            kv = _empty((B, Mk, 2 * C), dt, dev)
+            wkv, bkv = self.w(p + "attn.kv.weight"), self.f32(p + "attn.kv.bias")
+            ops.gemm_nt(kvin, wkv, kv, B * HWr, 2 * C, C, C, C, 2 * C, c_map=rowmap(HWr, Mk, 0), bias=bkv)
+            ops.gemm_nt(xn1, wkv, kv, B * T, 2 * C, C, C, C, 2 * C, a_map=rowmap(T, N, HW), c_map=rowmap(T, Mk, HWr), bias=bkv)
+            bs.update(sr_pre=sr_pre, kvin=kvin, pm=pm, HWr=HWr)
+        else:
+            Mk = N
+            kv = _empty((B, Mk, 2 * C), dt, dev)
+            ops.gemm_nt(xn1, self.w(p + "attn.kv.weight"), kv, M, 2 * C, C, C, C, 2 * C, bias=self.f32(p + "attn.kv.bias"))
+        bs["kv"], bs["Mk"] = kv, Mk
+        # attention core
+        ao = _empty((B, N, C), dt, dev)
+        lse = _empty((B, h, N), f32, dev)
+        ops.sr_attention_fwd(q, kv, ao, lse, B, h, N, Mk, C, 2 * C, C, 0, C, 64 ** -0.5)
+        bs["ao"], bs["lse"] = ao, lse
+        # proj + DropPath + residual
+        xm = _empty((B, N, C), dt, dev)
+        ops.gemm_nt(ao, self.w(p + "attn.proj.weight"), xm, M, C, C, C, C, C, bias=self.f32(p + "attn.proj.bias"),
+                    row_scale=s1, rows_per_scale=N, R=x)
+        bs["xm"] = xm
+        # LN2 + MLP (fc1 + exact GELU, fc2) + DropPath + residual
+        xn2 = _empty((B, N, C), dt, dev)
+        bs["m2"], bs["r2"] = _empty((M,), f32, dev), _empty((M,), f32, dev)
+        ops.layernorm_fwd(xm, xn2, self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m2"], rstd=bs["r2"])
+        bs["xn2"] = xn2
+        hpre = _empty((M, hid), dt, dev) if self.need_grad else None
+        gact = _empty((M, hid), dt, dev)
+        ops.gemm_nt(xn2, self.w(p + "mlp.fc1.weight"), gact, M, hid, C, C, C, hid, bias=self.f32(p + "mlp.fc1.bias"), act=1, H=hpre)
+        bs["hpre"], bs["gact"] = hpre, gact
+        xo = _empty((B, N, C), dt, dev)
+        ops.gemm_nt(gact, self.w(p + "mlp.fc2.weight"), xo, M, C, hid, hid, hid, C, bias=self.f32(p + "mlp.fc2.bias"),
+                    row_scale=s2, rows_per_scale=N, R=xm)
+        if not self.need_grad:
+            bs.clear()
+        return xo, bs
+
+    # ------------------------------------------------------------------ backward
+    def _scaled(self, dy, scale, N):
+        """dy * scale[b] per sample (DropPath); identity when scale is None."""
+        if scale is None:
+            return dy
+        return (dy.view(self.B, N, -1) * scale.view(self.B, 1, 1).to(dy.dtype)).view_as(dy)
+
+    def backward(self, dxs):
+        """dxs: gradients w.r.t. the four stage outputs (None allowed).  Fills the flat gradient buffer."""
+        m, B, T, dt, dev = self.m, self.B, self.T, self.dt, self.dev
+        dx = None
+        for i in (3, 2, 1, 0):
+            sv = self.saved[i]
+            d_out = dxs[i]
+            if d_out is not None:
+                d_out = d_out.to(dt)
+                # never write into a gradient tensor autograd handed us: start from a private copy
+                dx = d_out.contiguous().clone() if dx is None else dx.add_(d_out)
+            if dx is None:
+                continue
+            dx = self._stage_backward(i, sv, dx.view(B, sv["N"], sv["C"]))
+        self.saved = []
+
+    def _stage_backward(self, i, sv, dx):
+        m, B, T, dt, dev = self.m, self.B, self.T, self.dt, self.dev
+        C, HW, N, side = sv["C"], sv["HW"], sv["N"], sv["side"]
+        for j in reversed(range(m.depths[i])):
+            dx = self._block_backward(i, j, sv["blocks"][j], dx)
+        pe, ten = f"patch_embed{i+1}.", f"text_embed{i+1}."
+        f32 = torch.float32
+        # pos-embed / text-pos-embed gradients: sum over the batch of d(x0)
+        dpos_all = _empty((N, C), f32, dev)
+        ops.batch_sum(dx, dpos_all, B, N, C, N, C)
+        self.g(f"text_pos_embed{i+1}")[0].add_(dpos_all[HW:])
+        self._pos_backward(i, dpos_all[:HW])
+        # patch-embed LN backward -> d(pe_pre)
+        d_pe = _empty((B * HW, C), dt, dev)
+        ops.layernorm_bwd(dx, sv["pe_pre"], d_pe, self.f32(pe + "norm.weight"), sv["pe_mean"], sv["pe_rstd"], B * HW, C, C, C, C,
+                          dgamma=self.g(pe + "norm.weight"), dbeta=self.g(pe + "norm.bias"), dy_map=rowmap(HW, N, 0))
+        d_te = _empty((B * T, C), dt, dev)
+        ops.layernorm_bwd(dx, sv["te_pre"], d_te, self.f32(ten + "1.weight"), sv["te_mean"], sv["te_rstd"], B * T, C, C, C, C,
+                          dgamma=self.g(ten + "1.weight"), dbeta=self.g(ten + "1.bias"), dy_map=rowmap(T, N, HW))
+        if i == 0:
+            K = m.in_chans * m.patch_size ** 2
+            ops.gemm_tn(d_pe, sv["P1"], self.g(pe + "proj.weight").view(C, K), B * HW, C, K, C, K, K, colsum=self.g(pe + "proj.bias"))
+            ops.gemm_tn(d_te, self.emb, self.g(ten + "0.weight"), B * T, C, m.hidden, C, m.hidden, m.hidden, colsum=self.g(ten + "0.bias"))
+            d_emb = _empty((B * T, m.hidden), dt, dev)
+            ops.gemm_nt(d_te, self.wT(ten + "0.weight"), d_emb, B * T, m.hidden, C, C, C, m.hidden)
+            self._bert_backward(d_emb)
+            return None
+        Cp, Np, HWp, sp = m.dims[i - 1], self.saved[i - 1]["N"], self.saved[i - 1]["HW"], self.side[i - 1]
+        xp = sv["x_in_prev"]
+        pm = sv["pm_in"]
+        # conv weight gradient in [out][kh][kw][cin] order, folded back to [out][cin][kh][kw]
+        dWk = torch.zeros(C, 4 * Cp, device=dev, dtype=f32)
+        ops.gemm_tn(d_pe, xp, dWk, B * HW, C, 4 * Cp, C, Cp, 4 * Cp, b_map=pm, colsum=self.g(pe + "proj.bias"))
+        self.g(pe + "proj.weight").add_(dWk.view(C, 2, 2, Cp).permute(0, 3, 1, 2))
+        ops.gemm_tn(d_te, xp, self.g(ten + "0.weight"), B * T, C, Cp, C, Cp, Cp, b_map=rowmap(T, Np, HWp), colsum=self.g(ten + "0.bias"))
+        dxp = _empty((B, Np, Cp), dt, dev)
+        ops.gemm_nt(d_pe, self.wKT(pe + "proj.weight"), dxp, B * HW, 4 * Cp, C, C, C, Cp, c_map=pm)          # image rows (each once)
+        ops.gemm_nt(d_te, self.wT(ten + "0.weight"), dxp, B * T, Cp, C, C, C, Cp, c_map=rowmap(T, Np, HWp))   # text rows
+        return dxp
+
+    def _pos_backward(self, i, dpos):
+        m = self.m
+        HW = self.side[i] ** 2
+        gname = f"pos_embed{i+1}"
+        gv = self.g(gname)
+        if HW == m.grids[0] ** 2:
+            (gv[:, 1:] if i == 3 else gv)[0].add_(dpos)
+            return
+        with torch.enable_grad():
+            p = self.f32(gname).detach().clone().requires_grad_(True)
+            out = self._pos(i, p)
+            out.backward(dpos)
+        gv.add_(p.grad)
+
+    def _bert_backward(self, d_emb):
+        m, B, T = self.m, self.B, self.T
+        te = "text_embeddings."
+        ops.bert_embed_bwd(d_emb, self.ids, self.f32(te + "word_embeddings.weight"), self.f32(te + "position_embeddings.weight"),
+                           self.f32(te + "token_type_embeddings.weight"), self.f32(te + "LayerNorm.weight"), self.keep, BERT_DROP,
+                           self.emb_mean, self.emb_rstd, self.g(te + "word_embeddings.weight"), self.g(te + "position_embeddings.weight"),
+                           self.g(te + "token_type_embeddings.weight"), self.g(te + "LayerNorm.weight"), self.g(te + "LayerNorm.bias"),
+                           B * T, T)
+
+    def _block_backward(self, i, j, bs, dx):
+        """dx: gradient w.r.t. the block output (B,N,C), overwritten in place with the gradient w.r.t. its input."""
+        m, B, T, dt, dev = self.m, self.B, self.T, self.dt, self.dev
+        C, h, r, hid = m.dims[i], m.heads[i], m.sr[i], m.hid[i]
+        side = self.side[i]
+        HW = side * side
+        N = HW + T
+        M = B * N
+        p = Names.blk(i, j)
+        f32 = torch.float32
+        # ---- MLP branch: x_out = x_mid + s2 * (fc2(gelu(fc1(LN2(x_mid)))))
+        dy2 = self._scaled(dx, bs["s2"], N)
+        ops.gemm_tn(dy2, bs["gact"], self.g(p + "mlp.fc2.weight"), M, C, hid, C, hid, hid, colsum=self.g(p + "mlp.fc2.bias"))
+        dh = _empty((M, hid), dt, dev)
+        ops.gemm_nt(dy2, self.wT(p + "mlp.fc2.weight"), dh, M, hid, C, C, C, hid, act=2, H=bs["hpre"])
+        bs["gact"] = bs["hpre"] = None
+        ops.gemm_tn(dh, bs["xn2"], self.g(p + "mlp.fc1.weight"), M, hid, C, hid, C, C, colsum=self.g(p + "mlp.fc1.bias"))
+        dxn2 = _empty((M, C), dt, dev)
+        ops.gemm_nt(dh, self.wT(p + "mlp.fc1.weight"), dxn2, M, C, hid, hid, hid, C)
+        del dh
+        ops.layernorm_bwd(dxn2, bs["xm"], dx, self.f32(p + "norm2.weight"), bs["m2"], bs["r2"], M, C, C, C, C,
+                          dgamma=self.g(p + "norm2.weight"), dbeta=self.g(p + "norm2.bias"), accumulate=True)
+        # dx now holds d(x_mid)
+        # ---- attention branch: x_mid = x + s1 * proj(attn(LN1(x)))
+        dy1 = self._scaled(dx, bs["s1"], N)
+        ops.gemm_tn(dy1, bs["ao"], self.g(p + "attn.proj.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.proj.bias"))
+        dao = dxn2          # reuse
+        ops.gemm_nt(dy1, self.wT(p + "attn.proj.weight"), dao, M, C, C, C, C, C)
+        Mk = bs["Mk"]
+        dq = _empty((B, N, C), dt, dev)
+        dkv32 = torch.zeros(B, Mk, 2 * C, device=dev, dtype=f32)
+        ops.sr_attention_bwd(bs["q"], bs["kv"], bs["ao"], dao, bs["lse"], dq, dkv32, B, h, N, Mk, C, 2 * C, C, 2 * C, 0, C, 64 ** -0.5)
+        dkv = dkv32.to(dt)
+        del dkv32
+        # q projection
+        ops.gemm_tn(dq, bs["xn1"], self.g(p + "attn.q.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.q.bias"))
+        dxn1 = dao          # reuse again: d(LN1 output), every row written by the q dgrad
+        ops.gemm_nt(dq, self.wT(p + "attn.q.weight"), dxn1, M, C, C, C, C, C)
+        gkvw, gkvb = self.g(p + "attn.kv.weight"), self.g(p + "attn.kv.bias")
+        wkvT = self.wT(p + "attn.kv.weight")
+        if r > 1:
+            HWr, pm = bs["HWr"], bs["pm"]
+            # text keys come straight from LN1(x)[text rows]
+            ops.gemm_tn(dkv, bs["xn1"], gkvw, B * T, 2 * C, C, 2 * C, C, C, a_map=rowmap(T, Mk, HWr), b_map=rowmap(T, N, HW), colsum=gkvb)
+            ops.gemm_nt(dkv, wkvT, dxn1, B * T, C, 2 * C, 2 * C, 2 * C, C, a_map=rowmap(T, Mk, HWr), c_map=rowmap(T, N, HW), R=dxn1)
+            # image keys: kv <- LN(sr conv(LN1(x)[image rows]))
+            ops.gemm_tn(dkv, bs["kvin"], gkvw, B * HWr, 2 * C, C, 2 * C, C, C, a_map=rowmap(HWr, Mk, 0), colsum=gkvb)
+            dkvin = _empty((B * HWr, C), dt, dev)
+            ops.gemm_nt(dkv, wkvT, dkvin, B * HWr, C, 2 * C, 2 * C, 2 * C, C, a_map=rowmap(HWr, Mk, 0))
+            dsr = _empty((B * HWr, C), dt, dev)
+            ops.layernorm_bwd(dkvin, bs["sr_pre"], dsr, self.f32(p + "attn.norm.weight"), bs["msr"], bs["rsr"], B * HWr, C, C, C, C,
+                              dgamma=self.g(p + "attn.norm.weight"), dbeta=self.g(p + "attn.norm.bias"))
+            K = r * r * C
+            dWk = torch.zeros(C, K, device=dev, dtype=f32)
+            ops.gemm_tn(dsr, bs["xn1"], dWk, B * HWr, C, K, C, C, K, b_map=pm, colsum=self.g(p + "attn.sr.bias"))
+            self.g(p + "attn.sr.weight").add_(dWk.view(C, r, r, C).permute(0, 3, 1, 2))
+            ops.gemm_nt(dsr, self.wKT(p + "attn.sr.weight"), dxn1, B * HWr, K, C, C, C, C, c_map=pm, R=dxn1)
+        else:
+            ops.gemm_tn(dkv, bs["xn1"], gkvw, M, 2 * C, C, 2 * C, C, C, colsum=gkvb)
+            ops.gemm_nt(dkv, wkvT, dxn1, M, C, 2 * C, 2 * C, 2 * C, C, R=dxn1)
+        ops.layernorm_bwd(dxn1, bs["x"], dx, self.f32(p + "norm1.weight"), bs["m1"], bs["r1"], M, C, C, C, C,
+                          dgamma=self.g(p + "norm1.weight"), dbeta=self.g(p + "norm1.bias"), accumulate=True)
+        bs.clear()
+        return dx
+
+
+class _TrunkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, images, ids, need_grad):
+        step = TrunkStep(model, images, ids, need_grad)
+        outs = step.forward()
+        ctx.step = step
+        ctx.mark_non_differentiable(outs[0])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d1, d2, d3, d4):
+        step = ctx.step
+        step.S.queue_finalize()
+        step.backward([None, d2, d3, d4])
+        ctx.step = None
+        return None, None, None, None, None
+
+
+# =============================================================================================== heads
+def _embed_ln_fwd(model, prefix, A, a_map, rows, lda):
+    """head_embed: Linear(512 -> 768) + LN(1e-5) on `rows` rows of A (through a_map)."""
+    S, dt, dev = model.store, model.compute_dtype, A.device
+    Hd, Cin = model.hidden, model.dims[3]
+    pre = _empty((rows, Hd), dt, dev)
+    ops.gemm_nt(A, S.comp(prefix + ".0.weight"), pre, rows, Hd, Cin, lda, Cin, Hd, a_map=a_map, bias=S.master(prefix + ".0.bias"))
+    y = _empty((rows, Hd), dt, dev)
+    mean, rstd = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
+    ops.layernorm_fwd(pre, y, S.master(prefix + ".1.weight"), S.master(prefix + ".1.bias"), rows, Hd, Hd, Hd, EPS_DEFAULT, mean=mean, rstd=rstd)
+    return y, (pre, mean, rstd)
+
+
+def _embed_ln_bwd(model, prefix, dy, saved, A, a_map, rows, lda, dA, c_map, accumulate):
+    S, dt, dev = model.store, model.compute_dtype, dy.device
+    Hd, Cin = model.hidden, model.dims[3]
+    pre, mean, rstd = saved
+    dpre = _empty((rows, Hd), dt, dev)
+    ops.layernorm_bwd(dy, pre, dpre, S.master(prefix + ".1.weight"), mean, rstd, rows, Hd, Hd, Hd, Hd,
+                      dgamma=S.grad(prefix + ".1.weight"), dbeta=S.grad(prefix + ".1.bias"))
+    ops.gemm_tn(dpre, A, S.grad(prefix + ".0.weight"), rows, Hd, Cin, Hd, lda, Cin, b_map=a_map, colsum=S.grad(prefix + ".0.bias"))
+    ops.gemm_nt(dpre, S.extra[prefix + ".0.weight::T"], dA, rows, Cin, Hd, Hd, Hd, Cin, c_map=c_map, R=dA if accumulate else None)
+
+
+class _ClsHeadFn(torch.autograd.Function):
+    """itm / sup_cls / sub_cls: Linear+LN embed of the [CLS] text token, then Linear + extra bias
+    (reference libs/pvlt.py:375-388, libs/vl_heads.py:73-104)."""
+
+    @staticmethod
+    def forward(ctx, x4, model, name, HW):
+        S, dt, dev = model.store, model.compute_dtype, x4.device
+        B, N, C = x4.shape
+        n_out = S.master(name + "_head.linear.weight").shape[0]
+        a_map = rowmap(1, N, HW)
+        e, saved = _embed_ln_fwd(model, name + "_head_embed", x4, a_map, B, C)
+        bias = (S.master(name + "_head.linear.bias") + S.master(name + "_head.linear_bias")).contiguous()
+        logits = _empty((B, n_out), torch.float32, dev)
+        ops.gemm_nt(e, S.comp(name + "_head.linear.weight"), logits, B, n_out, model.hidden, model.hidden, model.hidden, n_out, bias=bias)
+        ctx.pack = (model, name, HW, x4, e, saved, a_map)
+        return logits.view(B, 1, n_out)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model, name, HW, x4, e, saved, a_map = ctx.pack
+        S, dt, dev = model.store, model.compute_dtype, x4.device
+        S.queue_finalize()
+        B, N, C = x4.shape
+        Hd = model.hidden
+        n_out = dlogits.shape[-1]
+        n_pad = (n_out + 7) // 8 * 8
+        dl = torch.zeros(B, n_pad, device=dev, dtype=dt)
+        dl[:, :n_out] = dlogits.reshape(B, n_out).to(dt)
+        db = dlogits.reshape(B, n_out).float().sum(0)
+        S.grad(name + "_head.linear.bias").add_(db)
+        S.grad(name + "_head.linear_bias").add_(db)
+        ops.gemm_tn(dl, e, S.grad(name + "_head.linear.weight"), B, n_out, Hd, n_pad, Hd, Hd)
+        de = _empty((B, Hd), dt, dev)
+        wT = S.extra[name + "_head.linear.weight::T"]          # [768, n_pad]
+        ops.gemm_nt(dl, wT, de, B, Hd, n_pad, n_pad, wT.shape[1], Hd)
+        dx4 = torch.zeros_like(x4)
+        _embed_ln_bwd(model, name + "_head_embed", de, saved, x4, a_map, B, C, dx4, a_map, False)
+        ctx.pack = None
+        return dx4, None, None, None
+
+
+def _mlm_transform_fwd(model, rows_in, R):
+    """mlm_head_embed output (R,768) -> BertHeadTransform: dense + erf-GELU + LN(1e-5)."""
+    S, dt, dev = model.store, model.compute_dtype, rows_in.device
+    Hd = model.hidden
+    hp, ga = _empty((R, Hd), dt, dev), _empty((R, Hd), dt, dev)
+    ops.gemm_nt(rows_in, S.comp("mlm_head.transform.dense.weight"), ga, R, Hd, Hd, Hd, Hd, Hd,
+                bias=S.master("mlm_head.transform.dense.bias"), act=1, H=hp)
+    t = _empty((R, Hd), dt, dev)
+    mean, rstd = _empty((R,), torch.float32, dev), _empty((R,), torch.float32, dev)
+    ops.layernorm_fwd(ga, t, S.master("mlm_head.transform.LayerNorm.weight"), S.master("mlm_head.transform.LayerNorm.bias"),
+                      R, Hd, Hd, Hd, EPS_DEFAULT, mean=mean, rstd=rstd)
+    return t, (hp, ga, mean, rstd)
+
+
+def _mlm_transform_bwd(model, dt_, saved, rows_in, R):
+    S, dt, dev = model.store, model.compute_dtype, dt_.device
+    Hd = model.hidden
+    hp, ga, mean, rstd = saved
+    dga = _empty((R, Hd), dt, dev)
+    ops.layernorm_bwd(dt_, ga, dga, S.master("mlm_head.transform.LayerNorm.weight"), mean, rstd, R, Hd, Hd, Hd, Hd,
+                      dgamma=S.grad("mlm_head.transform.LayerNorm.weight"), dbeta=S.grad("mlm_head.transform.LayerNorm.bias"))
+    # d(pre-activation) = dga * gelu'(hp): run the (identity-weighted) product through the GEMM-free elementwise path
+    dhp = (dga.float() * _gelu_grad(hp.float())).to(dt)
+    ops.gemm_tn(dhp, rows_in, S.grad("mlm_head.transform.dense.weight"), R, Hd, Hd, Hd, Hd, Hd, colsum=S.grad("mlm_head.transform.dense.bias"))
+    din = _empty((R, Hd), dt, dev)
+    ops.gemm_nt(dhp, S.extra["mlm_head.transform.dense.weight::T"], din, R, Hd, Hd, Hd, Hd, Hd)
+    return din
+
+
+def _gelu_grad(x):
+    return 0.5 * (1.0 + torch.erf(x * 0.7071067811865476)) + x * 0.3989422804014327 * torch.exp(-0.5 * x * x)
+
+
+class _MLMFullFn(torch.autograd.Function):
+    """Reference-shaped MLM head: logits for every token, (B, T, 30522) (reference libs/pvlt.py:368-370)."""
+
+    @staticmethod
+    def forward(ctx, x4, model, HW):
+        S, dt, dev = model.store, model.compute_dtype, x4.device
+        B, N, C = x4.shape
+        T = N - HW
+        R = B * T
+        a_map = rowmap(T, N, HW)
+        e, sv_e = _embed_ln_fwd(model, "mlm_head_embed", x4, a_map, R, C)
+        t, sv_t = _mlm_transform_fwd(model, e, R)
+        buf = _empty((R, VOCAB_LD), torch.float32, dev)
+        ops.gemm_nt(t, S.comp("text_embeddings.word_embeddings.weight"), buf, R, VOCAB, model.hidden, model.hidden, model.hidden, VOCAB_LD,
+                    bias=S.master("mlm_head.bias"))
+        ctx.pack = (model, HW, x4, e, sv_e, t, sv_t, a_map)
+        return buf.view(B, T, VOCAB_LD)[:, :, :VOCAB]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model, HW, x4, e, sv_e, t, sv_t, a_map = ctx.pack
+        S, dt, dev = model.store, model.compute_dtype, x4.device
+        S.queue_finalize()
+        B, N, C = x4.shape
+        T = N - HW
+        R = B * T
+        dl = torch.zeros(R, VOCAB_LD, device=dev, dtype=dt)
+        dl[:, :VOCAB] = dlogits.reshape(R, VOCAB).to(dt)
+        dx4 = torch.zeros_like(x4)
+        _mlm_decoder_bwd(model, dl, t, sv_t, e, sv_e, x4, a_map, R, C, dx4)
+        ctx.pack = None
+        return dx4, None, None
+
+
+def _mlm_decoder_bwd(model, dl, t, sv_t, e, sv_e, A, a_map, R, lda, dA, c_map=None):
+    """shared tail of both MLM paths: dl (R, VOCAB_LD) in the compute dtype -> every MLM-head gradient + dA rows."""
+    S, dt, dev = model.store, model.compute_dtype, dl.device
+    Hd = model.hidden
+    wname = "text_embeddings.word_embeddings.weight"
+    ops.gemm_tn(dl, t, S.grad(wname), R, VOCAB, Hd, VOCAB_LD, Hd, Hd, colsum=S.grad("mlm_head.bias"))
+    dtr = _empty((R, Hd), dt, dev)
+    wT = S.extra[wname + "::T"]                                   # [768, VOCAB_LD], zero padded
+    ops.gemm_nt(dl, wT, dtr, R, Hd, VOCAB_LD, VOCAB_LD, VOCAB_LD, Hd)
+    de = _mlm_transform_bwd(model, dtr, sv_t, e, R)
+    _embed_ln_bwd(model, "mlm_head_embed", de, sv_e, A, a_map, R, lda, dA, c_map if c_map is not None else a_map, False)
+
+
+class _MLMFusedFn(torch.autograd.Function):
+    """MLM head + CrossEntropyLoss(ignore_index=-1) on the selected rows only.  `positions` (int32, ascending flat
+    b*T+t indices with label != -1) is the masked-index selection; rows CE would ignore are never computed."""
+
+    @staticmethod
+    def forward(ctx, x4, model, HW, positions, labels_sel):
+        S, dt, dev = model.store, model.compute_dtype, x4.device
+        B, N, C = x4.shape
+        T = N - HW
+        R = positions.numel()
+        rows = _empty((R, C), dt, dev)
+        tmap = rowmap(T, N, HW)
+        ops.gather_rows(x4, positions, rows, R, C, C, src_map=tmap)
+        e, sv_e = _embed_ln_fwd(model, "mlm_head_embed", rows, None, R, C)
+        t, sv_t = _mlm_transform_fwd(model, e, R)
+        logits = _empty((R, VOCAB_LD), torch.float32, dev)
+        ops.gemm_nt(t, S.comp("text_embeddings.word_embeddings.weight"), logits, R, VOCAB, model.hidden, model.hidden, model.hidden, VOCAB_LD,
+                    bias=S.master("mlm_head.bias"))
+        lse = _empty((R,), torch.float32, dev)
+        acc = torch.zeros(2, device=dev, dtype=torch.float32)          # [loss_sum, count]
+        ops.cross_entropy_fwd(logits, labels_sel, lse, acc[0:1], acc[1:2], R, VOCAB, VOCAB_LD)
+        ctx.pack = (model, HW, x4.shape, rows, e, sv_e, t, sv_t, logits, lse, acc, positions, labels_sel, tmap)
+        return acc[0] / acc[1]          # mean over selected rows (NaN when none, like torch)
+
+    @staticmethod
+    def backward(ctx, gloss):
+        model, HW, xshape, rows, e, sv_e, t, sv_t, logits, lse, acc, positions, labels_sel, tmap = ctx.pack
+        S, dt, dev = model.store, model.compute_dtype, rows.device
+        S.queue_finalize()
+        B, N, C = xshape
+        R = positions.numel()
+        dl = _empty((R, VOCAB_LD), dt, dev)
+        gs = gloss.reshape(1).float().contiguous()
+        ops.cross_entropy_bwd(logits, labels_sel, lse, gs, acc[1:2], dl, R, VOCAB, VOCAB_LD, VOCAB_LD)
+        drows = _empty((R, C), dt, dev)
+        _mlm_decoder_bwd(model, dl, t, sv_t, e, sv_e, rows, None, R, C, drows, c_map=None)
+        dx4 = torch.zeros(xshape, device=dev, dtype=dt)
+        ops.scatter_rows(drows, positions, dx4, R, C, C, dst_map=tmap)
+        ctx.pack = None
+        return dx4, None, None, None, None
+
+
+# =============================================================================================== top level
+def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None):
+    S = model.store
+    dev = images.device
+    S.ensure(dev)
+    S.refresh(model._transposed, model._conv_perm)
+    grad_on = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+    if grad_on:
+        S.begin_step()
+    if model._anchor is None or model._anchor.device != dev:
+        model._anchor = torch.zeros(1, device=dev, requires_grad=True)
+    anchor = model._anchor if grad_on else model._anchor.detach()
+    x1, x2, x3, x4 = _TrunkFn.apply(anchor, model, images, ids, grad_on)
+    lt = model.loss_type
+    B = images.shape[0]
+    side4 = images.shape[2] // model.patch_size // 8
+    HW4 = side4 * side4
+    out = dict(mlm_logits=None, itm_logits=None, sup_cls_logits=None, sub_cls_logits=None, t2i_logits=None)
+    if lt['mlm']:
+        if mlm_labels is not None:
+            flat = mlm_labels.reshape(-1).contiguous()
+            if mlm_positions is None:
+                cap = flat.numel()
+                idx = torch.empty(cap, device=dev, dtype=torch.int32)
+                cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+                ops.masked_select(flat, idx, cnt)
+                mlm_positions = idx[: int(cnt.item())]
+            labels_sel = flat[mlm_positions.long()].contiguous()
+            out["mlm_loss"] = _MLMFusedFn.apply(x4, model, HW4, mlm_positions.contiguous(), labels_sel)
+            out["mlm_positions"] = mlm_positions
+        else:
+            out["mlm_logits"] = _MLMFullFn.apply(x4, model, HW4)
+    if lt['itm']:
+        out["itm_logits"] = _ClsHeadFn.apply(x4, model, "itm", HW4)
+    if lt['cls']:
+        out["sup_cls_logits"] = _ClsHeadFn.apply(x4, model, "sup_cls", HW4)
+        out["sub_cls_logits"] = _ClsHeadFn.apply(x4, model, "sub_cls", HW4)
+    if lt['t2i']:
+        feats = []
+        for x, i in ((x2, 1), (x3, 2), (x4, 3)):
+            side = images.shape[2] // model.patch_size // (2 ** i)
+            f = x[:, : side * side, :].reshape(B, side, side, model.dims[i]).permute(0, 3, 1, 2)
+            feats.append(f)
+        head = model.t2i_head
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=model.compute_dtype == torch.bfloat16):
+            t2i = head.run(*feats)
+        out["t2i_logits"] = t2i.float()
+    return out

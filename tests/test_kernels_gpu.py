@@ -1,0 +1,267 @@
+"""GPU: every HIP kernel, called through the C ABI, against a plain PyTorch fp32 reference of the same op.
+Tolerances: fp32 instantiations 1e-3 relative (north_star fp32 bar), bf16 2e-2 (bf16 bar)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def maxrel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, dtype, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dev()).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mvlt_amd import ops as _ops
+    return _ops
+
+
+# ------------------------------------------------------------------ gemm_nt
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(300, 64, 64), (1000, 512, 64), (257, 320, 1280), (130, 30522, 768), (64, 2, 768),
+                                   (129, 48, 48), (4224 * 2, 64, 512), (5, 122, 768)])
+def test_gemm_nt_plain(ops, dtype, M, N, K):
+    A, B = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1)
+    bias = rnd(N, dtype=torch.float32, seed=2)
+    out = torch.empty(M, N, device=dev(), dtype=dtype)
+    ops.gemm_nt(A, B, out, M, N, K, K, K, N, bias=bias)
+    ref = A.float() @ B.float().t() + bias
+    assert maxrel(out.float(), ref) < TOL[dtype], (M, N, K)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_nt_epilogues(ops, dtype):
+    M, N, K, Bsz = 384, 256, 128, 3
+    A, W = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.2)
+    bias = rnd(N, dtype=torch.float32, seed=2)
+    ref_pre = A.float() @ W.float().t() + bias
+    # gelu with saved pre-activation
+    out = torch.empty(M, N, device=dev(), dtype=dtype)
+    H = torch.empty_like(out)
+    ops.gemm_nt(A, W, out, M, N, K, K, K, N, bias=bias, act=1, H=H)
+    assert maxrel(H.float(), ref_pre) < TOL[dtype]
+    assert maxrel(out.float(), F.gelu(ref_pre)) < TOL[dtype]
+    # gelu' multiply
+    Hin = rnd(M, N, dtype=dtype, seed=5)
+    out2 = torch.empty_like(out)
+    ops.gemm_nt(A, W, out2, M, N, K, K, K, N, act=2, H=Hin)
+    h = Hin.float().requires_grad_(True)
+    F.gelu(h).sum().backward()
+    assert maxrel(out2.float(), (A.float() @ W.float().t()) * h.grad) < TOL[dtype]
+    # residual + per-sample row scale, in place (R aliases C)
+    Rres = rnd(M, N, dtype=dtype, seed=7)
+    scale = torch.tensor([0.0, 1.0 / 0.9, 1.0], device=dev())
+    out3 = Rres.clone()
+    ops.gemm_nt(A, W, out3, M, N, K, K, K, N, bias=bias, row_scale=scale, rows_per_scale=M // Bsz, R=out3)
+    ref3 = ref_pre * scale.repeat_interleave(M // Bsz)[:, None] + Rres.float()
+    assert maxrel(out3.float(), ref3) < TOL[dtype]
+    # fp32 output from bf16 operands
+    out4 = torch.empty(M, N, device=dev(), dtype=torch.float32)
+    ops.gemm_nt(A, W, out4, M, N, K, K, K, N, bias=bias)
+    assert maxrel(out4, ref_pre) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_nt_token_subrange(ops, dtype):
+    """A = text tokens [HW, HW+T) of a (B, N, C) buffer; C written into another buffer's text range."""
+    from mvlt_amd._lib import rowmap
+    Bsz, HW, T, Cin, Cout = 3, 100, 20, 64, 128
+    X = rnd(Bsz, HW + T, Cin, dtype=dtype)
+    W = rnd(Cout, Cin, dtype=dtype, seed=1, scale=0.2)
+    Y = torch.zeros(Bsz, HW + T + 5, Cout, device=dev(), dtype=dtype)
+    ops.gemm_nt(X, W, Y, Bsz * T, Cout, Cin, Cin, Cin, Cout,
+                a_map=rowmap(T, HW + T, HW), c_map=rowmap(T, HW + T + 5, HW + 5))
+    ref = X[:, HW:].float() @ W.float().t()
+    assert maxrel(Y[:, HW + 5:].float(), ref) < TOL[dtype]
+    assert Y[:, :HW + 5].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("r,Hin,Cin,Cout,T", [(2, 8, 64, 128, 5), (8, 16, 64, 64, 3), (2, 6, 320, 512, 4), (4, 8, 128, 128, 0)])
+def test_gemm_nt_patch_gather_and_scatter(ops, dtype, r, Hin, Cin, Cout, T):
+    """kernel==stride conv on token-major data == F.conv2d on the NCHW view; scatter == its input gradient."""
+    from mvlt_amd._lib import patchmap
+    Bsz = 2
+    Win = Hin
+    HWi = Hin * Win
+    Ho = Hin // r
+    X = rnd(Bsz, HWi + T, Cin, dtype=dtype)
+    Wc = rnd(Cout, Cin, r, r, dtype=dtype, seed=1, scale=0.1)
+    bias = rnd(Cout, dtype=torch.float32, seed=2)
+    Wk = Wc.permute(0, 2, 3, 1).reshape(Cout, r * r * Cin).contiguous()       # [out][di][dj][c]
+    K = r * r * Cin
+    M = Bsz * Ho * Ho
+    pm = patchmap(r, Win, HWi + T, Ho * Ho, Ho, Cin)
+    out = torch.empty(M, Cout, device=dev(), dtype=dtype)
+    ops.gemm_nt(X, Wk, out, M, Cout, K, Cin, K, Cout, a_map=pm, bias=bias)
+    img = X[:, :HWi].float().transpose(1, 2).reshape(Bsz, Cin, Hin, Win)
+    ref = F.conv2d(img, Wc.float(), bias, stride=r).flatten(2).transpose(1, 2).reshape(M, Cout)
+    assert maxrel(out.float(), ref) < TOL[dtype]
+    # dgrad: dX(tokens) = scatter(dY @ Wk)   (B operand = Wk^T : [K, Cout])
+    dY = rnd(M, Cout, dtype=dtype, seed=3)
+    WkT = Wk.t().contiguous()
+    dX = torch.zeros(Bsz, HWi + T, Cin, device=dev(), dtype=dtype)
+    ops.gemm_nt(dY, WkT, dX, M, K, Cout, Cout, Cout, Cin, c_map=pm)
+    imgr = img.clone().requires_grad_(True)
+    y = F.conv2d(imgr, Wc.float(), None, stride=r).flatten(2).transpose(1, 2).reshape(M, Cout)
+    (y * dY.float()).sum().backward()
+    refdx = imgr.grad.reshape(Bsz, Cin, HWi).transpose(1, 2)
+    assert maxrel(dX[:, :HWi].float(), refdx) < TOL[dtype]
+    if T:
+        assert dX[:, HWi:].abs().max().item() == 0.0
+
+
+# ------------------------------------------------------------------ gemm_tn
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N1,N2", [(1000, 64, 64), (4224 * 3, 512, 64), (700, 64, 512), (333, 320, 1280), (129, 30522, 768), (77, 8, 768)])
+def test_gemm_tn(ops, dtype, M, N1, N2):
+    lda = (N1 + 7) // 8 * 8          # ragged N1 (vocabulary 30522) lives in rows padded to 16 B
+    Ap = rnd(M, lda, dtype=dtype)
+    A, B = Ap[:, :N1], rnd(M, N2, dtype=dtype, seed=1)
+    out = torch.zeros(N1, N2, device=dev(), dtype=torch.float32)
+    cs = torch.zeros(N1, device=dev(), dtype=torch.float32)
+    ops.gemm_tn(Ap, B, out, M, N1, N2, lda, N2, N2, colsum=cs)
+    ref = A.float().t() @ B.float()
+    assert maxrel(out, ref) < TOL[dtype]
+    assert maxrel(cs, A.float().sum(0)) < TOL[dtype]
+    # accumulate semantics: a second call doubles
+    ops.gemm_tn(Ap, B, out, M, N1, N2, lda, N2, N2)
+    assert maxrel(out, 2 * ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_tn_patch_gather(ops, dtype):
+    from mvlt_amd._lib import patchmap
+    Bsz, r, Hin, Cin, Cout, T = 2, 2, 8, 64, 128, 6
+    HWi, Ho = Hin * Hin, Hin // r
+    X = rnd(Bsz, HWi + T, Cin, dtype=dtype)
+    M, K = Bsz * Ho * Ho, r * r * Cin
+    dY = rnd(M, Cout, dtype=dtype, seed=3)
+    dW = torch.zeros(Cout, K, device=dev(), dtype=torch.float32)
+    ops.gemm_tn(dY, X, dW, M, Cout, K, Cout, Cin, K, b_map=patchmap(r, Hin, HWi + T, Ho * Ho, Ho, Cin))
+    img = X[:, :HWi].float().transpose(1, 2).reshape(Bsz, Cin, Hin, Hin)
+    Wc = torch.zeros(Cout, Cin, r, r, device=dev(), requires_grad=True)
+    y = F.conv2d(img, Wc, None, stride=r).flatten(2).transpose(1, 2).reshape(M, Cout)
+    (y * dY.float()).sum().backward()
+    ref = Wc.grad.permute(0, 2, 3, 1).reshape(Cout, K)
+    assert maxrel(dW, ref) < TOL[dtype]
+
+
+# ------------------------------------------------------------------ layernorm
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,Cdim,eps", [(1000, 64, 1e-6), (517, 128, 1e-5), (300, 320, 1e-5), (64, 512, 1e-6), (130, 768, 1e-12)])
+def test_layernorm_fwd_bwd(ops, dtype, rows, Cdim, eps):
+    x = rnd(rows, Cdim, dtype=dtype, scale=2.0) + 0.5
+    g = (1 + 0.2 * rnd(Cdim, dtype=torch.float32, seed=1))
+    b = 0.1 * rnd(Cdim, dtype=torch.float32, seed=2)
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=dev())
+    rstd = torch.empty(rows, device=dev())
+    ops.layernorm_fwd(x, y, g, b, rows, Cdim, Cdim, Cdim, eps, mean=mean, rstd=rstd)
+    xr = x.float().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (Cdim,), gr, br, eps)
+    assert maxrel(y.float(), ref) < TOL[dtype]
+    dy = rnd(rows, Cdim, dtype=dtype, seed=4)
+    ref.backward(dy.float())
+    dx = rnd(rows, Cdim, dtype=dtype, seed=5)       # pre-existing gradient (accumulate mode)
+    dx0 = dx.clone()
+    dg = torch.zeros(Cdim, device=dev())
+    db = torch.zeros(Cdim, device=dev())
+    ops.layernorm_bwd(dy, x, dx, g, mean, rstd, rows, Cdim, Cdim, Cdim, Cdim, dgamma=dg, dbeta=db, accumulate=True)
+    assert maxrel(dx.float() - dx0.float(), xr.grad) < (2 * TOL[dtype])
+    assert maxrel(dg, gr.grad) < TOL[dtype]
+    assert maxrel(db, br.grad) < TOL[dtype]
+    dx2 = torch.empty_like(x)
+    ops.layernorm_bwd(dy, x, dx2, g, mean, rstd, rows, Cdim, Cdim, Cdim, Cdim)
+    assert maxrel(dx2.float(), xr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_layernorm_into_concat_with_pos(ops, dtype):
+    """LN + pos-embed add + write into the image-token range of the concatenated (B, HW+T, C) buffer."""
+    from mvlt_amd._lib import rowmap
+    Bsz, HW, T, Cdim = 3, 50, 7, 128
+    x = rnd(Bsz * HW, Cdim, dtype=dtype)
+    g, b = 1 + 0.1 * rnd(Cdim, dtype=torch.float32, seed=1), 0.1 * rnd(Cdim, dtype=torch.float32, seed=2)
+    pos = rnd(HW, Cdim, dtype=torch.float32, seed=3)
+    out = torch.zeros(Bsz, HW + T, Cdim, device=dev(), dtype=dtype)
+    ops.layernorm_fwd(x, out, g, b, Bsz * HW, Cdim, Cdim, Cdim, 1e-5, add=pos, add_rows=HW, y_map=rowmap(HW, HW + T, 0))
+    ref = F.layer_norm(x.float(), (Cdim,), g, b, 1e-5).reshape(Bsz, HW, Cdim) + pos
+    assert maxrel(out[:, :HW].float(), ref) < TOL[dtype]
+    assert out[:, HW:].abs().max().item() == 0
+    s = torch.empty(HW + T, Cdim, device=dev())
+    ops.batch_sum(out, s, Bsz, HW + T, Cdim, HW + T, Cdim)
+    assert maxrel(s, out.float().sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------ attention
+def attn_ref(q, kv, H, scale):
+    B, N, Cdim = q.shape
+    M = kv.shape[1]
+    hd = Cdim // H
+    qh = q.float().reshape(B, N, H, hd).permute(0, 2, 1, 3)
+    k = kv.float()[..., :Cdim].reshape(B, M, H, hd).permute(0, 2, 1, 3)
+    v = kv.float()[..., Cdim:].reshape(B, M, H, hd).permute(0, 2, 1, 3)
+    s = (qh @ k.transpose(-1, -2)) * scale
+    o = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, N, Cdim)
+    return o, torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,H,N,M", [(2, 1, 4224, 192), (2, 2, 1152, 192), (1, 5, 384, 192), (3, 8, 192, 192),
+                                     (1, 1, 9344, 272), (2, 8, 272, 272), (2, 2, 29, 29), (1, 1, 596, 29), (1, 3, 100, 320)])
+def test_sr_attention_fwd(ops, dtype, B, H, N, M):
+    if dtype == torch.float32 and M > 288:
+        pytest.skip("fp32 K/V^T of 320 keys exceed 160 KB LDS")
+    Cdim = 64 * H
+    q = rnd(B, N, Cdim, dtype=dtype)
+    kv = rnd(B, M, 2 * Cdim, dtype=dtype, seed=1)
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, N, device=dev())
+    ops.sr_attention_fwd(q, kv, o, lse, B, H, N, M, Cdim, 2 * Cdim, Cdim, 0, Cdim, 0.125)
+    ref, ref_lse = attn_ref(q, kv, H, 0.125)
+    assert maxrel(o.float(), ref) < TOL[dtype]
+    assert (lse - ref_lse).abs().max().item() < (2e-2 if dtype == torch.bfloat16 else 1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,H,N,M", [(2, 1, 4224, 192), (2, 2, 1152, 192), (3, 8, 192, 192), (1, 1, 2000, 272), (2, 2, 29, 29), (1, 5, 300, 150)])
+def test_sr_attention_bwd(ops, dtype, B, H, N, M):
+    Cdim = 64 * H
+    q = rnd(B, N, Cdim, dtype=dtype)
+    kv = rnd(B, M, 2 * Cdim, dtype=dtype, seed=1)
+    do = rnd(B, N, Cdim, dtype=dtype, seed=2)
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, N, device=dev())
+    ops.sr_attention_fwd(q, kv, o, lse, B, H, N, M, Cdim, 2 * Cdim, Cdim, 0, Cdim, 0.125)
+    dq = torch.empty_like(q)
+    dkv = torch.zeros(B, M, 2 * Cdim, device=dev(), dtype=torch.float32)
+    ops.sr_attention_bwd(q, kv, o, do, lse, dq, dkv, B, H, N, M, Cdim, 2 * Cdim, Cdim, 2 * Cdim, 0, Cdim, 0.125)
+    qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    ref, _ = attn_ref(qr, kvr, H, 0.125)
+    ref.backward(do.float())
+    tol = 3e-2 if dtype == torch.bfloat16 else 2e-3
+    assert maxrel(dq.float(), qr.grad) < tol
+    assert maxrel(dkv, kvr.grad) < tol
