@@ -84,21 +84,22 @@ typedef struct mvlt_layernorm_args {
   int rows, C, ldx, ldy;
   mvlt_rowmap x_map, y_map;           /* mode 0 only */
   float eps;
-  int dtype;                          /* of x and y */
+  int dtype;                          /* of x */
+  int y_dtype;                        /* of y (bf16 GEMM operand out of an fp32 residual stream, or the reverse) */
 } mvlt_layernorm_args;
 int mvlt_layernorm_fwd(const mvlt_layernorm_args* args, void* stream);
 
-/* dx = LN backward; dgamma/dbeta (fp32 [C]) and dadd (fp32 [add_rows, C]) accumulate atomically into
- * caller-zeroed buffers.  If dx_accumulate != 0, dx += result (several consumers of one tensor). */
+/* dx = LN backward; dgamma/dbeta (fp32 [C]) accumulate atomically into caller-zeroed buffers (the "+ add" term's
+ * gradient is mvlt_batch_sum of dy).  If dx_accumulate != 0, dx += result (several consumers of one tensor). */
 typedef struct mvlt_layernorm_bwd_args {
   const void* dy; const void* x; void* dx;
   const float* gamma; const float* mean; const float* rstd;
   float* dgamma; float* dbeta;
-  float* dadd; int add_rows;
   int rows, C, lddy, ldx, lddx;
   mvlt_rowmap dy_map, x_map, dx_map;
   int dx_accumulate;
-  int dtype;
+  int dtype;                          /* of dy */
+  int x_dtype, dx_dtype;
 } mvlt_layernorm_bwd_args;
 int mvlt_layernorm_bwd(const mvlt_layernorm_bwd_args* args, void* stream);
 

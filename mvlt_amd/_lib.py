@@ -49,16 +49,16 @@ class LayerNormArgs(C.Structure):
     _fields_ = [("x", c_void_p), ("y", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
                 ("mean", c_void_p), ("rstd", c_void_p), ("add", c_void_p), ("add_rows", c_int),
                 ("rows", c_int), ("C", c_int), ("ldx", c_int), ("ldy", c_int),
-                ("x_map", RowMap), ("y_map", RowMap), ("eps", c_float), ("dtype", c_int)]
+                ("x_map", RowMap), ("y_map", RowMap), ("eps", c_float), ("dtype", c_int), ("y_dtype", c_int)]
 
 
 class LayerNormBwdArgs(C.Structure):
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dx", c_void_p),
                 ("gamma", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
-                ("dgamma", c_void_p), ("dbeta", c_void_p), ("dadd", c_void_p), ("add_rows", c_int),
+                ("dgamma", c_void_p), ("dbeta", c_void_p),
                 ("rows", c_int), ("C", c_int), ("lddy", c_int), ("ldx", c_int), ("lddx", c_int),
                 ("dy_map", RowMap), ("x_map", RowMap), ("dx_map", RowMap),
-                ("dx_accumulate", c_int), ("dtype", c_int)]
+                ("dx_accumulate", c_int), ("dtype", c_int), ("x_dtype", c_int), ("dx_dtype", c_int)]
 
 
 class AttnArgs(C.Structure):

@@ -7,7 +7,8 @@
 namespace {
 
 constexpr int NT = 256;
-template <typename T> struct MaxIt { static constexpr int V = sizeof(T) == 2 ? 2 : 3; };   // 16-B chunks per lane: C <= 64 * V * per_chunk (1024 / 768)
+constexpr int VN = 8;                  // elements per chunk
+constexpr int MAXIT = 2;               // chunks per lane: C <= 64 * 2 * 8 = 1024
 
 __device__ __forceinline__ RowMap rm0(const mvlt_rowmap& m) {
   RowMap r{};
@@ -37,22 +38,21 @@ template <> struct Vec<bf16> {
   }
 };
 template <> struct Vec<float> {
-  static constexpr int N = 4;
+  static constexpr int N = 8;            // same 8-element chunk as bf16 (two 16-B accesses) so mixed-dtype rows line up
   static __device__ __forceinline__ void load(const float* p, float* f) {
-    f32x4 v = *(const f32x4*)p;
+    f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = v[i];
+    for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
   }
   static __device__ __forceinline__ void store(float* p, const float* f) {
-    f32x4 v = {f[0], f[1], f[2], f[3]};
-    *(f32x4*)p = v;
+    f32x4 a = {f[0], f[1], f[2], f[3]}, b = {f[4], f[5], f[6], f[7]};
+    *(f32x4*)p = a;
+    *(f32x4*)(p + 4) = b;
   }
 };
 
-template <typename T, int G>
+template <typename T, typename TY, int G>
 __global__ __launch_bounds__(NT) void ln_fwd_kernel(mvlt_layernorm_args p) {
-  constexpr int VN = Vec<T>::N;
-  constexpr int MAXIT = MaxIt<T>::V;
   const int gl = threadIdx.x % G;                 // lane inside the row group
   const int grp = threadIdx.x / G;                // row group inside the block
   constexpr int GROUPS = NT / G;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(mvlt_layernorm_args p) {
   const float inv_c = 1.0f / (float)p.C;
   for (int row = blockIdx.x * GROUPS + grp; row < p.rows; row += gridDim.x * GROUPS) {
     const T* xr = (const T*)p.x + rowmap_base(xm, row) * p.ldx;
-    T* yr = (T*)p.y + rowmap_base(ym, row) * p.ldy;
+    TY* yr = (TY*)p.y + rowmap_base(ym, row) * p.ldy;
     float v[MAXIT][VN];
     float s = 0.f;
 #pragma unroll
@@ -100,16 +100,14 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(mvlt_layernorm_args p) {
           o[e] = (v[it][e] - mean) * rstd * p.gamma[col] + p.beta[col];
           if (addr) o[e] += addr[col];
         }
-        Vec<T>::store(yr + c * VN, o);
+        Vec<TY>::store(yr + c * VN, o);
       }
     }
   }
 }
 
-template <typename T, int G>
+template <typename T, typename TX, typename TDX, int G>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
-  constexpr int VN = Vec<T>::N;
-  constexpr int MAXIT = MaxIt<T>::V;
   constexpr int GROUPS = NT / G;
   extern __shared__ __attribute__((aligned(16))) float s_part[];               // [2][C] block partials of dgamma / dbeta
   const int gl = threadIdx.x % G, grp = threadIdx.x / G;
@@ -126,8 +124,8 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
 
   for (int row = blockIdx.x * GROUPS + grp; row < p.rows; row += gridDim.x * GROUPS) {
     const T* dyr = (const T*)p.dy + rowmap_base(dym, row) * p.lddy;
-    const T* xr = (const T*)p.x + rowmap_base(xm, row) * p.ldx;
-    T* dxr = (T*)p.dx + rowmap_base(dxm, row) * p.lddx;
+    const TX* xr = (const TX*)p.x + rowmap_base(xm, row) * p.ldx;
+    TDX* dxr = (TDX*)p.dx + rowmap_base(dxm, row) * p.lddx;
     const float mean = p.mean[row], rstd = p.rstd[row];
     float g[MAXIT][VN], xh[MAXIT][VN];
     float s1 = 0.f, s2 = 0.f;
@@ -137,7 +135,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
       if (c < nchunk) {
         float dyv[VN], xv[VN];
         Vec<T>::load(dyr + c * VN, dyv);
-        Vec<T>::load(xr + c * VN, xv);
+        Vec<TX>::load(xr + c * VN, xv);
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
           float h = (xv[e] - mean) * rstd;
@@ -160,11 +158,11 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
         for (int e = 0; e < VN; ++e) o[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
         if (p.dx_accumulate) {
           float old[VN];
-          Vec<T>::load(dxr + c * VN, old);
+          Vec<TDX>::load(dxr + c * VN, old);
 #pragma unroll
           for (int e = 0; e < VN; ++e) o[e] += old[e];
         }
-        Vec<T>::store(dxr + c * VN, o);
+        Vec<TDX>::store(dxr + c * VN, o);
       }
     }
   }
@@ -191,8 +189,6 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
 // out[r, c] = sum_b in[b*batch_stride_rows + r][c]   (gradient of a broadcast "+ pos_embed"); fp32 out
 template <typename T>
 __global__ __launch_bounds__(NT) void batch_sum_kernel(const T* in, float* out, int B, int R, int C, long batch_stride, int ld) {
-  constexpr int VN = Vec<T>::N;
-  constexpr int MAXIT = MaxIt<T>::V;
   const int nchunk = C / VN;
   const long total = (long)R * nchunk;
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
@@ -211,41 +207,41 @@ __global__ __launch_bounds__(NT) void batch_sum_kernel(const T* in, float* out, 
   }
 }
 
-template <typename T> int pick_group(int C) {
-  int chunks = C / Vec<T>::N;
+int pick_group(int C) {
+  int chunks = C / VN;
   int g = 8;
   while (g < 64 && g * 2 <= chunks) g *= 2;      // largest power of two <= chunks (>= 8)
-  while (g * MaxIt<T>::V < chunks && g < 64) g *= 2;
+  while (g * MAXIT < chunks && g < 64) g *= 2;
   return g;
 }
 
-template <typename T> int launch_fwd(const mvlt_layernorm_args& a, hipStream_t s) {
-  int g = pick_group<T>(a.C);
-  MVLT_REQUIRE(g * MaxIt<T>::V * Vec<T>::N >= a.C, "mvlt_layernorm_fwd: C=%d too large", a.C);
+template <typename T, typename TY> int launch_fwd(const mvlt_layernorm_args& a, hipStream_t s) {
+  int g = pick_group(a.C);
+  MVLT_REQUIRE(g * MAXIT * VN >= a.C, "mvlt_layernorm_fwd: C=%d too large", a.C);
   int groups = NT / g;
   int grid = (a.rows + groups - 1) / groups;
   if (grid > 8192) grid = 8192;
   switch (g) {
-    case 8: hipLaunchKernelGGL((ln_fwd_kernel<T, 8>), dim3(grid), dim3(NT), 0, s, a); break;
-    case 16: hipLaunchKernelGGL((ln_fwd_kernel<T, 16>), dim3(grid), dim3(NT), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((ln_fwd_kernel<T, 32>), dim3(grid), dim3(NT), 0, s, a); break;
-    default: hipLaunchKernelGGL((ln_fwd_kernel<T, 64>), dim3(grid), dim3(NT), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((ln_fwd_kernel<T, TY, 8>), dim3(grid), dim3(NT), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((ln_fwd_kernel<T, TY, 16>), dim3(grid), dim3(NT), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((ln_fwd_kernel<T, TY, 32>), dim3(grid), dim3(NT), 0, s, a); break;
+    default: hipLaunchKernelGGL((ln_fwd_kernel<T, TY, 64>), dim3(grid), dim3(NT), 0, s, a); break;
   }
   return mvlt_check_launch("mvlt_layernorm_fwd");
 }
 
-template <typename T> int launch_bwd(const mvlt_layernorm_bwd_args& a, hipStream_t s) {
-  int g = pick_group<T>(a.C);
-  MVLT_REQUIRE(g * MaxIt<T>::V * Vec<T>::N >= a.C, "mvlt_layernorm_bwd: C=%d too large", a.C);
+template <typename T, typename TX, typename TDX> int launch_bwd(const mvlt_layernorm_bwd_args& a, hipStream_t s) {
+  int g = pick_group(a.C);
+  MVLT_REQUIRE(g * MAXIT * VN >= a.C, "mvlt_layernorm_bwd: C=%d too large", a.C);
   int groups = NT / g;
   int grid = (a.rows + groups - 1) / groups;
   if (grid > 1024) grid = 1024;                 // each block ends with 2*C global atomics
   size_t lds = 2 * a.C * sizeof(float);
   switch (g) {
-    case 8: hipLaunchKernelGGL((ln_bwd_kernel<T, 8>), dim3(grid), dim3(NT), lds, s, a); break;
-    case 16: hipLaunchKernelGGL((ln_bwd_kernel<T, 16>), dim3(grid), dim3(NT), lds, s, a); break;
-    case 32: hipLaunchKernelGGL((ln_bwd_kernel<T, 32>), dim3(grid), dim3(NT), lds, s, a); break;
-    default: hipLaunchKernelGGL((ln_bwd_kernel<T, 64>), dim3(grid), dim3(NT), lds, s, a); break;
+    case 8: hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, 8>), dim3(grid), dim3(NT), lds, s, a); break;
+    case 16: hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, 16>), dim3(grid), dim3(NT), lds, s, a); break;
+    case 32: hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, 32>), dim3(grid), dim3(NT), lds, s, a); break;
+    default: hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, 64>), dim3(grid), dim3(NT), lds, s, a); break;
   }
   return mvlt_check_launch("mvlt_layernorm_bwd");
 }
@@ -254,33 +250,43 @@ template <typename T> int launch_bwd(const mvlt_layernorm_bwd_args& a, hipStream
 
 extern "C" int mvlt_layernorm_fwd(const mvlt_layernorm_args* a, void* stream) {
   MVLT_REQUIRE(a && a->x && a->y && a->gamma && a->beta, "mvlt_layernorm_fwd: null pointer");
-  MVLT_REQUIRE(a->dtype == 0 || a->dtype == 1, "mvlt_layernorm_fwd: bad dtype");
-  const int vn = a->dtype == 0 ? 8 : 4;
-  MVLT_REQUIRE(a->C > 0 && a->C % vn == 0 && a->ldx % vn == 0 && a->ldy % vn == 0, "mvlt_layernorm_fwd: C/ldx/ldy must be multiples of %d", vn);
+  MVLT_REQUIRE((a->dtype == 0 || a->dtype == 1) && (a->y_dtype == 0 || a->y_dtype == 1), "mvlt_layernorm_fwd: bad dtype");
+  MVLT_REQUIRE(a->C > 0 && a->C % 8 == 0 && a->ldx % 8 == 0 && a->ldy % 8 == 0, "mvlt_layernorm_fwd: C/ldx/ldy must be multiples of 8");
   MVLT_REQUIRE(a->x_map.mode == 0 && a->y_map.mode == 0, "mvlt_layernorm_fwd: only mode-0 row maps");
   MVLT_REQUIRE(!a->add || a->add_rows > 0, "mvlt_layernorm_fwd: add needs add_rows");
   if (a->rows <= 0) return MVLT_OK;
-  return a->dtype == 0 ? launch_fwd<bf16>(*a, (hipStream_t)stream) : launch_fwd<float>(*a, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->dtype == 0) return a->y_dtype == 0 ? launch_fwd<bf16, bf16>(*a, s) : launch_fwd<bf16, float>(*a, s);
+  return a->y_dtype == 0 ? launch_fwd<float, bf16>(*a, s) : launch_fwd<float, float>(*a, s);
 }
 
 extern "C" int mvlt_layernorm_bwd(const mvlt_layernorm_bwd_args* a, void* stream) {
   MVLT_REQUIRE(a && a->dy && a->x && a->dx && a->gamma && a->mean && a->rstd, "mvlt_layernorm_bwd: null pointer");
   MVLT_REQUIRE((a->dgamma == nullptr) == (a->dbeta == nullptr), "mvlt_layernorm_bwd: dgamma and dbeta go together");
-  MVLT_REQUIRE(a->dtype == 0 || a->dtype == 1, "mvlt_layernorm_bwd: bad dtype");
-  const int vn = a->dtype == 0 ? 8 : 4;
-  MVLT_REQUIRE(a->C > 0 && a->C % vn == 0 && a->ldx % vn == 0 && a->lddy % vn == 0 && a->lddx % vn == 0,
-               "mvlt_layernorm_bwd: C/ld* must be multiples of %d", vn);
+  MVLT_REQUIRE((a->dtype == 0 || a->dtype == 1) && (a->x_dtype == 0 || a->x_dtype == 1) && (a->dx_dtype == 0 || a->dx_dtype == 1),
+               "mvlt_layernorm_bwd: bad dtype");
+  MVLT_REQUIRE(a->C > 0 && a->C % 8 == 0 && a->ldx % 8 == 0 && a->lddy % 8 == 0 && a->lddx % 8 == 0, "mvlt_layernorm_bwd: C/ld* must be multiples of 8");
   MVLT_REQUIRE(a->x_map.mode == 0 && a->dy_map.mode == 0 && a->dx_map.mode == 0, "mvlt_layernorm_bwd: only mode-0 row maps");
   if (a->rows <= 0) return MVLT_OK;
-  return a->dtype == 0 ? launch_bwd<bf16>(*a, (hipStream_t)stream) : launch_bwd<float>(*a, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  const int key = a->dtype * 4 + a->x_dtype * 2 + a->dx_dtype;
+  switch (key) {
+    case 0: return launch_bwd<bf16, bf16, bf16>(*a, s);
+    case 1: return launch_bwd<bf16, bf16, float>(*a, s);
+    case 2: return launch_bwd<bf16, float, bf16>(*a, s);
+    case 3: return launch_bwd<bf16, float, float>(*a, s);
+    case 4: return launch_bwd<float, bf16, bf16>(*a, s);
+    case 5: return launch_bwd<float, bf16, float>(*a, s);
+    case 6: return launch_bwd<float, float, bf16>(*a, s);
+    default: return launch_bwd<float, float, float>(*a, s);
+  }
 }
 
 extern "C" int mvlt_batch_sum(const void* in, float* out, int B, int R, int C, long batch_stride_rows, int ld, int dtype, void* stream) {
   MVLT_REQUIRE(in && out && B > 0 && R >= 0 && C > 0, "mvlt_batch_sum: bad arguments");
-  const int vn = dtype == 0 ? 8 : 4;
-  MVLT_REQUIRE(C % vn == 0 && ld % vn == 0, "mvlt_batch_sum: C/ld must be multiples of %d", vn);
+  MVLT_REQUIRE(C % 8 == 0 && ld % 8 == 0, "mvlt_batch_sum: C/ld must be multiples of 8");
   if (R == 0) return MVLT_OK;
-  long total = (long)R * (C / vn);
+  long total = (long)R * (C / 8);
   int grid = (int)((total + NT - 1) / NT);
   if (grid > 4096) grid = 4096;
   if (dtype == 0) hipLaunchKernelGGL((batch_sum_kernel<bf16>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const bf16*)in, out, B, R, C, batch_stride_rows, ld);

@@ -1,0 +1,86 @@
+"""Data-parallel gradient exchange for the MI355X MVLT model: one process per GPU, RCCL over xGMI through
+torch.distributed (backend "nccl" IS RCCL on ROCm).
+
+The path shards naturally over the batch: the only exchange step is the gradient all-reduce
+(reference: torch DistributedDataParallel's reducer, main_vl.py:298-302).  Here the flat fp32 gradient buffer is
+cut into contiguous ranges in gradient-READY order -- heads, stage 4, 3, 2, 1, embeddings -- and each range is
+all-reduced (SUM, then the 1/world average is folded in) as soon as the backward schedule has finished writing it.
+ProcessGroupNCCL runs collectives on its own HIP stream behind an event on the compute stream, so the transfers
+overlap the remaining backward kernels; the xGMI links are point-to-point (7 x ~153 GB/s per GPU), so ranges are
+kept large (>= 16 MB where the layout allows) instead of DDP's 25 MB + 1 MB first bucket pattern.
+
+Stock torch DistributedDataParallel also works on the model (its reducer hooks fire from the trunk's autograd node);
+this wrapper is the overlapped, copy-free path.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class DataParallel(nn.Module):
+    """`model = DataParallel(model)`; exposes `.module` like DDP (reference main_vl.py:302 reads model.module)."""
+
+    def __init__(self, module, process_group=None, broadcast_buffers=True):
+        super().__init__()
+        self.module = module
+        self.pg = process_group
+        self.broadcast_buffers = broadcast_buffers
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._works = []
+        self._synced_init = False
+        module.store.on_backward_done = self._finish
+        module.store.on_range_ready = self._range_ready
+
+    # parameters start identical on every rank (DDP broadcasts rank 0's at construction)
+    def _sync_init(self):
+        if self.world > 1:
+            S = self.module.store
+            dist.broadcast(S.P, 0, group=self.pg)
+            S.force_dirty = True
+        self._synced_init = True
+
+    def forward(self, *a, **k):
+        if self.world > 1:
+            S = self.module.store
+            dev = a[0].device
+            S.ensure(dev)
+            if not self._synced_init:
+                self._sync_init()
+            if self.broadcast_buffers and self.module.training:
+                for b in self.module.buffers():           # BatchNorm running stats of the MIM decoder
+                    if b.is_floating_point():
+                        dist.broadcast(b, 0, group=self.pg)
+        return self.module(*a, **k)
+
+    def _range_ready(self, store, lo, hi):
+        """called by the backward schedule when G[lo:hi] is final on the compute stream"""
+        if self.world > 1 and hi > lo:
+            self._works.append(dist.all_reduce(store.G[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _finish(self, store):
+        if self.world <= 1:
+            return
+        store.sync_grads()                                 # MIM-decoder grads that autograd produced itself
+        done = getattr(store, "_ranges_done", [])
+        # whatever the schedule did not announce (decoder head, padding gaps): reduce the remaining ranges
+        cur = 0
+        for lo, hi in sorted(done) + [(store.total, store.total)]:
+            if lo > cur:
+                self._works.append(dist.all_reduce(store.G[cur:lo], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            cur = max(cur, hi)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        store._ranges_done = []
+        store.G.mul_(1.0 / self.world)
+
+
+def allreduce_meter(count, total, device):
+    """[count, total] float64 all-reduce used by the metric logger (reference libs/utils.py:38-47)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return count, total
+    t = torch.tensor([count, total], dtype=torch.float64, device=device)
+    dist.barrier()
+    dist.all_reduce(t)
+    t = t.tolist()
+    return int(t[0]), t[1]

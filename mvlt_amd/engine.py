@@ -1,0 +1,125 @@
+"""Train / eval loops: the MI355X counterpart of reference engine_grid_masking.py.
+
+`train_one_epoch_vl` keeps the reference signature and return value (engine_grid_masking.py:27-32,150) so
+main_vl.py:431-437 calls it unchanged.  What differs, on purpose:
+  * the MLM loss goes through the model's fused masked-row path (`model(images, ids, mlm_labels=...)`): only rows
+    CrossEntropyLoss(ignore_index=-1) keeps are projected onto the 30522-word vocabulary -- same loss value, same
+    gradients, no (B, T, 30522) logits tensor.  Models without that keyword get the reference's full-logits path.
+  * a forward runs on EVERY iteration (the shipped engine reuses stale outputs on odd iterations when t2i is off
+    and crashes in backward -- SURVEY.md App. D #1)
+  * one device->host transfer per iteration for the six logged scalars instead of six `.item()` syncs
+  * no unconditional torch.cuda.synchronize(): the transfer above is the only sync
+The compute dtype is a property of the model (bf16 by default, fp32 when `fp32=True`), not an autocast region.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .metrics import MetricLogger, SmoothedValue
+
+MLM_LOSS_WEIGHT, ITM_LOSS_WEIGHT, T2I_LOSS_WEIGHT = 1, 1, 10      # reference engine_grid_masking.py:23
+USE_ORI_INPUT_IDS = False
+
+
+def _core(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def compute_losses(outputs, images, mlm_labels, itm_labels, sup_cls_labels, sub_cls_labels):
+    """Loss composition of reference engine_grid_masking.py:81-102.  Returns (total, dict of the five parts)."""
+    dev = images.device
+    zero = torch.zeros((), device=dev)
+    parts = dict(loss_mlm=zero, loss_itm=zero, loss_sup_cls=zero, loss_sub_cls=zero, loss_t2i=zero)
+    total = 0
+    if outputs.get("mlm_loss") is not None:
+        parts["loss_mlm"] = MLM_LOSS_WEIGHT * outputs["mlm_loss"]
+        total = total + parts["loss_mlm"]
+    elif outputs["mlm_logits"] is not None:
+        parts["loss_mlm"] = MLM_LOSS_WEIGHT * F.cross_entropy(outputs["mlm_logits"].reshape(-1, 30522).float(), mlm_labels.view(-1), ignore_index=-1)
+        total = total + parts["loss_mlm"]
+    if outputs["itm_logits"] is not None:
+        parts["loss_itm"] = ITM_LOSS_WEIGHT * F.cross_entropy(outputs["itm_logits"].view(-1, 2).float(), itm_labels.view(-1))
+        total = total + parts["loss_itm"]
+    if outputs["sup_cls_logits"] is not None:
+        parts["loss_sup_cls"] = F.cross_entropy(outputs["sup_cls_logits"].view(-1, 48).float(), sup_cls_labels.view(-1))
+        parts["loss_sub_cls"] = F.cross_entropy(outputs["sub_cls_logits"].view(-1, 122).float(), sub_cls_labels.view(-1))
+        total = total + parts["loss_sup_cls"] + parts["loss_sub_cls"]
+    if outputs["t2i_logits"] is not None:
+        parts["loss_t2i"] = T2I_LOSS_WEIGHT * F.smooth_l1_loss(outputs["t2i_logits"].float(), images)
+        total = total + parts["loss_t2i"]
+    return total, parts
+
+
+def train_step(model, batch, idx, t2i_on, fused=True):
+    """forward + losses of engine iteration `idx` on device tensors; returns (total_loss, parts)."""
+    images = batch["image"]
+    use_masked = (idx % 2 == 1) and t2i_on          # engine_grid_masking.py:72-78
+    inp = batch["masked_images"] if use_masked else images
+    core = _core(model)
+    if fused and hasattr(core, "store") and core.loss_type.get("mlm"):
+        outputs = model(inp, batch["input_ids"], mlm_labels=batch["mlm_labels"], mlm_positions=batch.get("mlm_positions"))
+    else:
+        outputs = model(inp, batch["input_ids"])
+    return compute_losses(outputs, images, batch["mlm_labels"], batch["itm_labels"], batch["sup_cls_labels"], batch["sub_cls_labels"])
+
+
+def train_one_epoch_vl(model, criterion, data_loader, optimizer, device, epoch, loss_scaler, max_norm=0,
+                       model_ema=None, mixup_fn=None, set_training_mode=True, fp32=False, args=None):
+    model.train(set_training_mode)
+    core = _core(model)
+    if fp32 and getattr(core, "compute_dtype", None) not in (None, torch.float32):
+        core.set_compute_dtype(torch.float32)
+    logger = MetricLogger(delimiter="  ")
+    logger.add_meter("lr", SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    header = f"Epoch: [{epoch}]"
+    loss_type = getattr(args, "loss_type", None) or core.loss_type
+    t2i_on = loss_type.get("t2i", 0) == 1
+    keys = ("image", "mlm_labels", "i2t_labels", "masked_images", "itm_labels", "sup_cls_labels", "sub_cls_labels")
+    for idx, samples in enumerate(logger.log_every(data_loader, 10, header)):
+        batch = {k: samples[k].to(device, non_blocking=True) for k in keys if k in samples}
+        batch["input_ids"] = samples["ori_input_ids" if USE_ORI_INPUT_IDS else "input_ids"].to(device, non_blocking=True)
+        if "mlm_positions" in samples:
+            batch["mlm_positions"] = samples["mlm_positions"].to(device, non_blocking=True)
+        total, parts = train_step(model, batch, idx, t2i_on)
+        vals = torch.stack([total.detach().float()] + [parts[k].detach().float() for k in
+                                                      ("loss_mlm", "loss_itm", "loss_sup_cls", "loss_sub_cls", "loss_t2i")]).tolist()
+        if not math.isfinite(vals[0]):
+            print(f" [ Warning!!! ] Total Loss is {vals[0]} (loss_mlm={vals[1]} | loss_itm={vals[2]} | loss_sup_cls={vals[3]} | "
+                  f"loss_sub_cls={vals[4]} | loss_t2i={vals[5]}), non-finite value")
+        optimizer.zero_grad()
+        is_second_order = hasattr(optimizer, "is_second_order") and optimizer.is_second_order
+        loss_scaler(total, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=is_second_order)
+        if model_ema is not None:
+            model_ema.update(model)
+        logger.update(total_loss=vals[0], loss_mlm=vals[1], loss_itm=vals[2], loss_sup_cls=vals[3], loss_sub_cls=vals[4], loss_t2i=vals[5])
+        logger.update(lr=optimizer.param_groups[0]["lr"])
+    logger.synchronize_between_processes(device)
+    print("Averaged stats:", logger)
+    return {k: m.global_avg for k, m in logger.meters.items()}
+
+
+train_one_epoch = train_one_epoch_vl      # BASELINE.json's north_star calls it by this name
+
+
+class BF16Scaler:
+    """loss_scaler for bf16 training: the callable / state_dict interface of timm.utils.NativeScaler
+    (reference main_vl.py:309,346,426,453; engine_grid_masking.py:126) without fp16 loss scaling, which bf16 does
+    not need.  `_scaler` exists because main_vl.py:426 re-assigns it every epoch."""
+    state_dict_key = "amp_scaler"
+
+    def __init__(self):
+        self._scaler = None
+
+    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False):
+        loss.backward(create_graph=create_graph)
+        if clip_grad:
+            assert parameters is not None
+            torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
+        optimizer.step()
+
+    def state_dict(self):
+        return {}
+
+    def load_state_dict(self, sd):
+        pass

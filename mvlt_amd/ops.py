@@ -42,19 +42,19 @@ def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, co
 
 def layernorm_fwd(x, y, gamma, beta, rows, Cdim, ldx, ldy, eps, *, mean=None, rstd=None, add=None, add_rows=0,
                   x_map=None, y_map=None):
-    assert x.dtype == y.dtype and x.dtype in DT and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    assert x.dtype in DT and y.dtype in DT and gamma.dtype == torch.float32 and beta.dtype == torch.float32
     a = L.LayerNormArgs(ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(add), add_rows,
-                        rows, Cdim, ldx, ldy, x_map or _ID, y_map or _ID, eps, DT[x.dtype])
+                        rows, Cdim, ldx, ldy, x_map or _ID, y_map or _ID, eps, DT[x.dtype], DT[y.dtype])
     check(L.lib.mvlt_layernorm_fwd(C.byref(a), stream_ptr()), "mvlt_layernorm_fwd")
     return y
 
 
 def layernorm_bwd(dy, x, dx, gamma, mean, rstd, rows, Cdim, lddy, ldx, lddx, *, dgamma=None, dbeta=None,
                   dy_map=None, x_map=None, dx_map=None, accumulate=False):
-    assert dy.dtype == x.dtype == dx.dtype and x.dtype in DT
+    assert dy.dtype in DT and x.dtype in DT and dx.dtype in DT
     a = L.LayerNormBwdArgs(ptr(dy), ptr(x), ptr(dx), ptr(gamma), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta),
-                           None, 0, rows, Cdim, lddy, ldx, lddx, dy_map or _ID, x_map or _ID, dx_map or _ID,
-                           1 if accumulate else 0, DT[x.dtype])
+                           rows, Cdim, lddy, ldx, lddx, dy_map or _ID, x_map or _ID, dx_map or _ID,
+                           1 if accumulate else 0, DT[dy.dtype], DT[x.dtype], DT[dx.dtype])
     check(L.lib.mvlt_layernorm_bwd(C.byref(a), stream_ptr()), "mvlt_layernorm_bwd")
     return dx
 

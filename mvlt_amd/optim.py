@@ -1,0 +1,92 @@
+"""Fused AdamW over the model's flat fp32 parameter / gradient buffers (one HIP kernel per step, plus the bf16
+re-cast of the updated weights in the same pass).
+
+Semantics = torch.optim.AdamW as the reference builds it through timm.optim.create_optimizer (main_vl.py:308):
+decoupled weight decay, bias-corrected moments, eps 1e-8, and timm's param-group split -- 1-D tensors and `.bias`
+get weight_decay 0, everything else args.weight_decay.  It is a torch.optim.Optimizer, so GradScaler.step(),
+lr schedulers (`param_groups[i]['lr']`) and state_dict()/load_state_dict() keep working; `param_groups[0]` is the
+no-decay group and `[1]` the decay group, like timm's add_weight_decay.
+"""
+import torch
+
+from . import ops
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") and not hasattr(model, "store") else model
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        model = _unwrap(model)
+        self.model = model
+        no_decay, decay = [], []
+        for name, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            (no_decay if (p.dim() == 1 or name.endswith(".bias")) else decay).append(p)
+        groups = [dict(params=no_decay, weight_decay=0.0), dict(params=decay, weight_decay=weight_decay)]
+        super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._step = 0
+        self._m = self._v = self._wd_mask = None
+        self._hp = None
+
+    def _ensure(self):
+        S = self.model.store
+        if S.P is None:
+            raise RuntimeError("FusedAdamW: run a forward first (the flat parameter store is built lazily)")
+        if self._m is None or self._m.numel() != S.total or self._m.device != S.P.device:
+            self._m = torch.zeros_like(S.P)
+            self._v = torch.zeros_like(S.P)
+            self._hp = torch.zeros(2, 8, device=S.P.device)
+            # contiguous runs of equal weight-decay setting -> one launch per run
+            ids_nd = {id(p) for p in self.param_groups[0]["params"]}
+            runs = []
+            for name, p in S.params.items():
+                off, n, _ = S.offsets[name]
+                nd = id(p) in ids_nd
+                end = off + (n + 7) // 8 * 8
+                if runs and runs[-1][2] == nd and runs[-1][1] == off:
+                    runs[-1][1] = end
+                else:
+                    runs.append([off, end, nd])
+            self._runs = runs
+        return S
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        S = self._ensure()
+        S.sync_grads()
+        self._step += 1
+        b1, b2 = self.param_groups[0]["betas"]
+        rows = []
+        for gi in (0, 1):
+            g = self.param_groups[gi]
+            rows.append([g["lr"], b1, b2, g["eps"], g["weight_decay"], 1 - b1 ** self._step, 1 - b2 ** self._step, 1.0])
+        self._hp.copy_(torch.tensor(rows, dtype=torch.float32), non_blocking=True)
+        for off, end, nd in self._runs:
+            n = end - off
+            ops.adamw_step(S.P[off:end], S.G[off:end], self._m[off:end], self._v[off:end],
+                           S.C[off:end] if S.C is not None else None, n, self._hp[0 if nd else 1])
+        # W^T / permuted conv operand copies are refreshed by the next forward
+        S.force_dirty = True
+        return loss
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=set_to_none)
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["fused"] = dict(step=self._step, m=None if self._m is None else self._m.cpu(), v=None if self._v is None else self._v.cpu())
+        return sd
+
+    def load_state_dict(self, sd):
+        fused = sd.pop("fused", None)
+        super().load_state_dict(sd)
+        if fused is not None:
+            self._step = fused["step"]
+            if fused["m"] is not None and self.model.store.P is not None:
+                self._ensure()
+                self._m.copy_(fused["m"])
+                self._v.copy_(fused["v"])

@@ -67,6 +67,10 @@ class FlatStore:
         self.extra = {}                   # derived operand copies: name -> tensor
         self._finalize_queued = False
         self.force_dirty = True
+        self.fn_params = []
+        self.on_backward_done = None      # optional callable(store): data-parallel gradient exchange hook
+        self.on_range_ready = None        # optional callable(store, lo, hi): G[lo:hi] is final (overlapped all-reduce)
+        self._ranges_done = []
 
     # ------------------------------------------------------------------ layout
     def _index(self):
@@ -83,6 +87,8 @@ class FlatStore:
             self.params[name] = p
             off += (n + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
+        # parameters whose gradients the HIP schedule writes itself (everything but the torch-autograd MIM decoder)
+        self.fn_params = [(n, p) for n, p in self.params.items() if not n.startswith("t2i_head.")]
 
     def is_current(self):
         if self.P is None:
@@ -158,14 +164,14 @@ class FlatStore:
 
     # ------------------------------------------------------------------ gradients
     def begin_step(self):
-        """Zero G when the caller has cleared the grads (optimizer.zero_grad(set_to_none=True) or first use)."""
-        first = next(iter(self.params.values()))
-        if first.grad is None:
+        """Zero G unless the caller is deliberately accumulating into .grad tensors that alias it
+        (optimizer.zero_grad(set_to_none=True) leaves .grad None: the usual case)."""
+        name, first = next(iter(self.params.items()))
+        if first.grad is None or first.grad.data_ptr() != self.grad(name).data_ptr():
             self.G.zero_()
 
     def queue_finalize(self):
-        """Called from inside a backward: at the end of this backward pass attach .grad views (and fold in any
-        gradient autograd produced on its own for parameters used by torch-autograd sub-graphs)."""
+        """Called from inside a backward node: run `on_backward_done` once, when this backward pass ends."""
         if self._finalize_queued:
             return
         self._finalize_queued = True
@@ -173,13 +179,32 @@ class FlatStore:
 
     def _finalize(self):
         self._finalize_queued = False
-        self.attach_grads()
+        if self.on_backward_done is not None:
+            self.on_backward_done(self)
 
-    def attach_grads(self):
+    def stage_range(self, i):
+        """[lo, hi) of the flat buffers holding patch_embed{i+1}, text_embed{i+1} and block{i+1} (contiguous)."""
+        names = [n for n in self.offsets if n.startswith((f"patch_embed{i+1}.", f"text_embed{i+1}.", f"block{i+1}."))]
+        lo = self.offsets[names[0]][0]
+        o, n, _ = self.offsets[names[-1]]
+        return lo, o + (n + ALIGN - 1) // ALIGN * ALIGN
+
+    def announce_stage(self, i):
+        """backward of stage i finished: its parameter gradients are final -> let the data-parallel wrapper start
+        reducing them while the earlier stages are still running."""
+        if self.on_range_ready is not None:
+            lo, hi = self.stage_range(i)
+            self._ranges_done.append((lo, hi))
+            self.on_range_ready(self, lo, hi)
+
+    def sync_grads(self):
+        """Make G the truth for every parameter (flat-buffer optimizers call this before stepping): gradients that
+        autograd produced on its own (the torch-autograd MIM decoder) or that were cloned / averaged elsewhere
+        are copied into their slice and .grad is re-pointed at it."""
         for name, p in self.params.items():
             gv = self.grad(name)
             if p.grad is None:
-                p.grad = gv
-            elif p.grad.data_ptr() != gv.data_ptr():
-                gv.add_(p.grad.to(gv.dtype))
+                continue
+            if p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
                 p.grad = gv

@@ -250,6 +250,14 @@ class PyramidVisionLanguageTransformer(nn.Module):
     def store(self):
         return self._store
 
+    def set_compute_dtype(self, dtype):
+        """bf16 (default) or fp32 (exact-f32 MFMA path; the reference's `fp32=True` / --fp32-resume switch)."""
+        assert dtype in (torch.bfloat16, torch.float32)
+        if dtype != self.compute_dtype:
+            self.compute_dtype = dtype
+            self._store.compute_dtype = dtype
+            self._store.P = None
+
     # ------------------------------------------------------------------ forward
     def forward(self, input_images, input_ids, mlm_labels=None, mlm_positions=None):
         if not input_images.is_cuda:

@@ -36,7 +36,9 @@ class TrunkStep:
         self.m = model
         self.S = model.store
         self.dev = images.device
-        self.dt = model.compute_dtype
+        self.dt = model.compute_dtype       # GEMM / attention operand dtype
+        self.rt = torch.float32             # residual-stream dtype: adds and LayerNorm inputs stay fp32 (what the
+        #                                     reference's autocast region does too); only MFMA operands are bf16
         self.need_grad = need_grad
         self.images = images.contiguous().float()
         self.ids = ids.contiguous()
@@ -147,7 +149,7 @@ class TrunkStep:
             ops.gemm_nt(xp, self.wK(pe + "proj.weight"), pe_pre, B * HW, C, 4 * Cp, Cp, 4 * Cp, C, a_map=pm,
                         bias=self.f32(pe + "proj.bias"))
             sv["pm_in"] = pm
-        x = _empty((B, N, C), dt, dev)
+        x = _empty((B, N, C), self.rt, dev)
         pos = self._pos(i, self.f32(f"pos_embed{i+1}"))
         sv["pe_pre"], sv["pe_mean"], sv["pe_rstd"] = pe_pre, _empty((B * HW,), torch.float32, dev), _empty((B * HW,), torch.float32, dev)
         ops.layernorm_fwd(pe_pre, x, self.f32(pe + "norm.weight"), self.f32(pe + "norm.bias"), B * HW, C, C, C, EPS_DEFAULT,
@@ -171,6 +173,10 @@ class TrunkStep:
             x, bsv = self._block_forward(i, j, x, blk_index)
             sv["blocks"].append(bsv)
             blk_index += 1
+        if self.dt != self.rt:               # MFMA-operand copy of the stage output (next stage's convs, the heads)
+            xb = _empty((B, N, C), dt, dev)
+            ops.cast_bf16(x, xb, x.numel())
+            x = xb
         sv["x_out"] = x
         taps = getattr(m, "_taps", None)
         if taps is not None:            # tests: stage outputs in the reference's (img_feat NCHW, text_feat) form
@@ -229,7 +235,7 @@ class TrunkStep:
         ops.sr_attention_fwd(q, kv, ao, lse, B, h, N, Mk, C, 2 * C, C, 0, C, 64 ** -0.5)
         bs["ao"], bs["lse"] = ao, lse
         # proj + DropPath + residual
-        xm = _empty((B, N, C), dt, dev)
+        xm = _empty((B, N, C), self.rt, dev)
         ops.gemm_nt(ao, self.w(p + "attn.proj.weight"), xm, M, C, C, C, C, C, bias=self.f32(p + "attn.proj.bias"),
                     row_scale=s1, rows_per_scale=N, R=x)
         bs["xm"] = xm
@@ -242,7 +248,7 @@ class TrunkStep:
         gact = _empty((M, hid), dt, dev)
         ops.gemm_nt(xn2, self.w(p + "mlp.fc1.weight"), gact, M, hid, C, C, C, hid, bias=self.f32(p + "mlp.fc1.bias"), act=1, H=hpre)
         bs["hpre"], bs["gact"] = hpre, gact
-        xo = _empty((B, N, C), dt, dev)
+        xo = _empty((B, N, C), self.rt, dev)
         ops.gemm_nt(gact, self.w(p + "mlp.fc2.weight"), xo, M, C, hid, hid, hid, C, bias=self.f32(p + "mlp.fc2.bias"),
                     row_scale=s2, rows_per_scale=N, R=xm)
         if not self.need_grad:
@@ -270,6 +276,7 @@ class TrunkStep:
             if dx is None:
                 continue
             dx = self._stage_backward(i, sv, dx.view(B, sv["N"], sv["C"]))
+            self.S.announce_stage(i)
         self.saved = []
 
     def _stage_backward(self, i, sv, dx):
@@ -402,8 +409,14 @@ class TrunkStep:
 
 
 class _TrunkFn(torch.autograd.Function):
+    """The trunk as ONE autograd node.  Every parameter of the HIP-scheduled part of the model (trunk AND heads) is an
+    input of this node: its backward runs after all head nodes, so it can hand autograd the finished slices of the flat
+    gradient buffer.  That keeps stock torch machinery working unchanged on top of the side-effect gradient writes:
+    AccumulateGrad (and therefore torch DistributedDataParallel's reducer hooks, reference main_vl.py:301), GradScaler,
+    clip_grad_norm_ and torch.optim all see ordinary .grad tensors -- which alias the flat buffer, no copies."""
+
     @staticmethod
-    def forward(ctx, anchor, model, images, ids, need_grad):
+    def forward(ctx, model, images, ids, need_grad, *params):
         step = TrunkStep(model, images, ids, need_grad)
         outs = step.forward()
         ctx.step = step
@@ -413,10 +426,20 @@ class _TrunkFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d1, d2, d3, d4):
         step = ctx.step
-        step.S.queue_finalize()
+        S = step.S
+        S.queue_finalize()
         step.backward([None, d2, d3, d4])
         ctx.step = None
-        return None, None, None, None, None
+        grads = []
+        for k, (name, p) in enumerate(S.fn_params):
+            gv = S.grad(name)
+            if not ctx.needs_input_grad[4 + k]:
+                grads.append(None)
+            elif p.grad is not None and p.grad.data_ptr() == gv.data_ptr():
+                grads.append(None)          # .grad already aliases the flat buffer (accumulation without zero_grad)
+            else:
+                grads.append(gv)
+        return (None, None, None, None, *grads)
 
 
 # =============================================================================================== heads
@@ -615,10 +638,7 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None):
     grad_on = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
     if grad_on:
         S.begin_step()
-    if model._anchor is None or model._anchor.device != dev:
-        model._anchor = torch.zeros(1, device=dev, requires_grad=True)
-    anchor = model._anchor if grad_on else model._anchor.detach()
-    x1, x2, x3, x4 = _TrunkFn.apply(anchor, model, images, ids, grad_on)
+    x1, x2, x3, x4 = _TrunkFn.apply(model, images, ids, grad_on, *[p for _, p in S.fn_params])
     lt = model.loss_type
     B = images.shape[0]
     side4 = images.shape[2] // model.patch_size // 8

@@ -1,0 +1,85 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient exchange (mvlt_amd/dist.py) -- ranges announced in
+gradient-ready order are all-reduced as they complete, the rest at the end, and the result is the DDP average
+(reference main_vl.py:298-302 semantics); rank-0 parameters are broadcast at start."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Toy(nn.Module):
+    """smallest module with the stage-named parameters the store's range logic looks for"""
+
+    def __init__(self):
+        super().__init__()
+        from mvlt_amd.params import FlatStore, Holder
+        self.pos_embed1 = nn.Parameter(torch.zeros(1, 4, 8))
+        for i in range(4):
+            setattr(self, f"patch_embed{i+1}", Holder(weight=(8, 8), bias=(8,)))
+            setattr(self, f"text_embed{i+1}", Holder(weight=(8, 8)))
+            setattr(self, f"block{i+1}", Holder(weight=(16, 8), bias=(3,)))
+        self.head = Holder(weight=(5, 8))
+        self._store = FlatStore(self, torch.float32)
+
+    @property
+    def store(self):
+        return self._store
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mvlt_amd.dist import DataParallel, allreduce_meter
+        torch.manual_seed(100 + rank)
+        m = _Toy()
+        for p in m.parameters():
+            p.data.normal_()
+        S = m.store
+        S.materialize(torch.device("cpu"))
+        dp = DataParallel(m, broadcast_buffers=False)
+        dp._sync_init()
+        p0 = S.P.clone()
+        # emulate one backward: every rank writes rank-dependent gradients, stages complete 4 -> 1
+        S.G.copy_(torch.arange(S.total, dtype=torch.float32) * (rank + 1))
+        for i in (3, 2, 1, 0):
+            S.announce_stage(i)
+        S._finalize()
+        expect = torch.arange(S.total, dtype=torch.float32) * (sum(r + 1 for r in range(world)) / world)
+        ok_grad = torch.allclose(S.G, expect)
+        lo, hi = S.stage_range(2)
+        names = [n for n, (o, k, _) in S.offsets.items() if lo <= o < hi]
+        cnt, tot = allreduce_meter(3, 1.5 * (rank + 1), "cpu")
+        q.put((rank, ok_grad, p0.sum().item(), names, cnt, tot))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_exchange_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), "all-reduced gradients are not the cross-rank average"
+    assert res[0][2] == pytest.approx(res[1][2]), "parameters were not broadcast from rank 0"
+    assert res[0][3] == ["patch_embed3.weight", "patch_embed3.bias", "text_embed3.weight", "block3.weight", "block3.bias"]
+    assert res[0][4] == 6 and res[0][5] == pytest.approx(4.5)

@@ -265,3 +265,143 @@ def test_sr_attention_bwd(ops, dtype, B, H, N, M):
     tol = 3e-2 if dtype == torch.bfloat16 else 2e-3
     assert maxrel(dq.float(), qr.grad) < tol
     assert maxrel(dkv, kvr.grad) < tol
+
+
+# ------------------------------------------------------------------ mixed-dtype LayerNorm (fp32 residual stream, bf16 operands)
+def test_layernorm_mixed_dtypes(ops):
+    rows, Cdim, eps = 777, 320, 1e-6
+    x = rnd(rows, Cdim, dtype=torch.float32, scale=2.0) + 0.5
+    g, b = 1 + 0.2 * rnd(Cdim, dtype=torch.float32, seed=1), 0.1 * rnd(Cdim, dtype=torch.float32, seed=2)
+    y = torch.empty(rows, Cdim, device=dev(), dtype=torch.bfloat16)
+    mean, rstd = torch.empty(rows, device=dev()), torch.empty(rows, device=dev())
+    ops.layernorm_fwd(x, y, g, b, rows, Cdim, Cdim, Cdim, eps, mean=mean, rstd=rstd)
+    xr = x.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (Cdim,), g, b, eps)
+    assert maxrel(y.float(), ref) < 1e-2
+    dy = rnd(rows, Cdim, dtype=torch.bfloat16, seed=4)
+    ref.backward(dy.float())
+    dx = torch.zeros(rows, Cdim, device=dev(), dtype=torch.bfloat16)
+    ops.layernorm_bwd(dy, x, dx, g, mean, rstd, rows, Cdim, Cdim, Cdim, Cdim, accumulate=True)
+    assert maxrel(dx.float(), xr.grad) < 1e-2
+    # bf16 input -> fp32 output (patch-embed LN writing into the fp32 token buffer)
+    xb = x.to(torch.bfloat16)
+    y32 = torch.empty(rows, Cdim, device=dev(), dtype=torch.float32)
+    ops.layernorm_fwd(xb, y32, g, b, rows, Cdim, Cdim, Cdim, 1e-5)
+    assert maxrel(y32, F.layer_norm(xb.float(), (Cdim,), g, b, 1e-5)) < 1e-5
+
+
+# ------------------------------------------------------------------ BERT embeddings
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_bert_embed_fwd_bwd(ops, dtype):
+    B, T, Hd, V = 3, 20, 768, 1000
+    ids = torch.randint(1, V, (B, T), device=dev())
+    ids[:, -5:] = 0                                           # PAD tail: no gradient into row 0 (padding_idx)
+    word = rnd(V, Hd, dtype=torch.float32, scale=0.1)
+    pos = rnd(512, Hd, dtype=torch.float32, seed=1, scale=0.1)
+    typ = rnd(2, Hd, dtype=torch.float32, seed=2, scale=0.1)
+    g, b = 1 + 0.2 * rnd(Hd, dtype=torch.float32, seed=3), 0.1 * rnd(Hd, dtype=torch.float32, seed=4)
+    keep = (torch.rand(B * T, Hd, device=dev()) >= 0.1).to(torch.uint8)
+    y = torch.empty(B * T, Hd, device=dev(), dtype=dtype)
+    mean, rstd = torch.empty(B * T, device=dev()), torch.empty(B * T, device=dev())
+    ops.bert_embed_fwd(ids, word, pos, typ, g, b, keep, 0.1, y, mean, rstd, B * T, T, 1e-12)
+    wr, pr, tr = word.clone().requires_grad_(True), pos.clone().requires_grad_(True), typ.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    e = F.embedding(ids, wr, padding_idx=0) + tr[0] + pr[:T]
+    ref = F.layer_norm(e, (Hd,), gr, br, 1e-12).reshape(B * T, Hd) * keep.float() / 0.9
+    assert maxrel(y.float(), ref) < TOL[dtype]
+    dy = rnd(B * T, Hd, dtype=dtype, seed=9)
+    ref.backward(dy.float())
+    dw, dp, dtp = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)
+    dg, db = torch.zeros_like(g), torch.zeros_like(b)
+    ops.bert_embed_bwd(dy, ids, word, pos, typ, g, keep, 0.1, mean, rstd, dw, dp, dtp[0], dg, db, B * T, T)
+    for a, r in ((dw, wr.grad), (dp, pr.grad), (dtp, tr.grad), (dg, gr.grad), (db, br.grad)):
+        assert maxrel(a, r) < 2e-3
+    assert dw[0].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_patchify_matches_conv(ops, dtype):
+    B, S, k, Cout = 2, 32, 4, 64
+    img = torch.rand(B, 3, S, S, device=dev())
+    P = torch.empty(B * (S // k) ** 2, 3 * k * k, device=dev(), dtype=dtype)
+    ops.patchify(img, P, B, 3, S, S, k)
+    W = rnd(Cout, 3, k, k, dtype=torch.float32, scale=0.2)
+    ref = F.conv2d(img, W, stride=k).flatten(2).transpose(1, 2).reshape(-1, Cout)
+    assert maxrel(P.float() @ W.reshape(Cout, -1).t(), ref) < TOL[dtype]
+
+
+def test_masked_select_bit_exact(ops):
+    for n, frac in ((128 * 4, 0.05), (32768, 0.04), (1000, 0.0), (5000, 1.0), (1, 1.0)):
+        lab = torch.where(torch.rand(n, device=dev()) < frac, torch.randint(0, 30522, (n,), device=dev()), torch.full((n,), -1, device=dev()))
+        idx = torch.full((n,), -7, device=dev(), dtype=torch.int32)
+        cnt = torch.zeros(1, device=dev(), dtype=torch.int32)
+        ops.masked_select(lab, idx, cnt)
+        want = torch.nonzero(lab != -1).flatten().to(torch.int32)
+        assert int(cnt.item()) == want.numel()
+        assert torch.equal(idx[: want.numel()], want)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gather_scatter_rows(ops, dtype):
+    from mvlt_amd._lib import rowmap
+    B, HW, T, Cdim = 3, 10, 8, 512
+    x = rnd(B, HW + T, Cdim, dtype=dtype)
+    pos = torch.tensor([1, 5, 9, 17, 23], device=dev(), dtype=torch.int32)      # flat b*T+t
+    out = torch.empty(5, Cdim, device=dev(), dtype=dtype)
+    ops.gather_rows(x, pos, out, 5, Cdim, Cdim, src_map=rowmap(T, HW + T, HW))
+    ref = x[:, HW:].reshape(B * T, Cdim)[pos.long()]
+    assert torch.equal(out, ref)
+    dst = torch.zeros_like(x)
+    ops.scatter_rows(out, pos, dst, 5, Cdim, Cdim, dst_map=rowmap(T, HW + T, HW))
+    assert torch.equal(dst[:, HW:].reshape(B * T, Cdim)[pos.long()], ref)
+    assert dst.float().abs().sum().item() == ref.float().abs().sum().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("V,ld", [(30522, 30528), (2, 8), (122, 128)])
+def test_cross_entropy(ops, dtype, V, ld):
+    R = 37
+    buf = rnd(R, ld, dtype=dtype, scale=3.0)
+    labels = torch.randint(0, V, (R,), device=dev())
+    labels[::5] = -1
+    lse = torch.empty(R, device=dev())
+    acc = torch.zeros(2, device=dev())
+    ops.cross_entropy_fwd(buf, labels, lse, acc[0:1], acc[1:2], R, V, ld)
+    lg = buf[:, :V].float().requires_grad_(True)
+    ref = F.cross_entropy(lg, labels, ignore_index=-1)
+    assert abs((acc[0] / acc[1]).item() - ref.item()) < 1e-4 * max(1, abs(ref.item()))
+    ref.backward()
+    dl = torch.full((R, ld), 7.0, device=dev(), dtype=torch.float32)
+    gs = torch.tensor([1.0], device=dev())
+    ops.cross_entropy_bwd(buf, labels, lse, gs, acc[1:2], dl, R, V, ld, ld)
+    assert maxrel(dl[:, :V], lg.grad) < 1e-4
+    assert dl[:, V:].abs().max().item() == 0.0
+
+
+def test_adamw_matches_torch(ops):
+    n = 4096 + 8
+    p0 = rnd(n, dtype=torch.float32)
+    p = p0.clone()
+    g = rnd(n, dtype=torch.float32, seed=1)
+    m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    p16 = torch.empty(n, device=dev(), dtype=torch.bfloat16)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for t in range(1, 4):
+        ref_p.grad = g.clone()
+        opt.step()
+        hp = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.01, 1 - 0.9 ** t, 1 - 0.999 ** t, 1.0], device=dev())
+        ops.adamw_step(p, g, m, v, p16, n, hp)
+    assert maxrel(p, ref_p.detach()) < 1e-6
+    assert torch.equal(p16, p.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_transpose_cast(ops, dtype):
+    R, Cc = 30522, 768
+    w = rnd(R, Cc, dtype=torch.float32)
+    ld = (R + 7) // 8 * 8
+    out = torch.zeros(Cc, ld, device=dev(), dtype=dtype)
+    ops.transpose_cast(w, out, R, Cc, ld_out=ld)
+    assert torch.equal(out[:, :R], w.t().to(dtype))
+    assert out[:, R:].abs().max().item() == 0
