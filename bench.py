@@ -67,7 +67,8 @@ def cpu_baseline(seconds=20.0):
     """The oracle's train step (forward + loss + backward) at BASELINE config #1 shapes on the host cores."""
     from oracle import filler
     from oracle import pvlt_oracle as O
-    cores = os.cpu_count() or 1
+    from oracle.hostinfo import usable_cores
+    cores = usable_cores()
     torch.set_num_threads(cores)
     cfg = O.Cfg("pvlt_tiny", dict(mlm=1, itm=1, t2i=1, cls=0), 224, 768, 128, 0.0)
     sd = O.filled_state_dict(cfg, 7)

@@ -187,37 +187,108 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p) 
   }
 
   // ---------------- epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + 4*fg + r][n0 + wn*WN + j*16 + fr]
+  // The MFMA C layout gives each lane one column and 4 rows: stored directly that is 2-byte pieces, 32 B per row.
+  // Instead every wave parks its tile in the (now free) staging LDS, 32 rows at a time, and re-reads it row-major:
+  // each lane then owns 8 consecutive columns of one row, so bias / GELU / residual / H traffic and the C store are
+  // 16-byte accesses that cover a full 128-B (bf16) or 256-B (fp32) row segment per 8 lanes.
   const RowMap cmap = to_rowmap(p.c_map);
   const int ofp32 = p.out_dtype;
+  constexpr int LDW = WN + 4;                         // fp32 words per staged row (pad: <=2-way ds_write conflicts)
+  constexpr int CPR = WN / 8;                         // 8-column chunks per row
+  constexpr int RPI = 64 / CPR;                       // rows covered per wave iteration
+  float* stage = (float*)smem + wave * 32 * LDW;
+  const bool vec_ok = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.R || ((uintptr_t)p.R & 15) == 0) &&
+                      (!p.H || ((uintptr_t)p.H & 15) == 0);
 #pragma unroll
-  for (int j = 0; j < TN_; ++j) {
-    const int nt0 = n0 + wn * WN + j * 16;
-    const int n = nt0 + fr;
-    const bool n_ok = n < p.N;
-    const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
-    int seg_rows = 0, ncol = n;
-    if (cmap.mode == 1) {               // scatter back through the patch map (dgrad of a kernel==stride conv)
-      int seg = nt0 / cmap.c_seg;
-      ncol = n - seg * cmap.c_seg;
-      seg_rows = rowmap_seg(cmap, seg);
-    }
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();                                  // staging buffers / previous half are no longer being read
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 64 + i * 16 + 4 * fg + r;
-        if (m >= p.M || !n_ok) continue;
-        const long idx = (rowmap_base(cmap, m) + seg_rows) * p.ldc + ncol;
-        float v = acc[i][j][r] + bias;
+      for (int j = 0; j < TN_; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(ii * 16 + 4 * fg + r) * LDW + j * 16 + fr] = acc[half * 2 + ii][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int rl = it * RPI + lane / CPR;           // row inside this 32-row half
+      const int ch = lane % CPR;
+      const int m = m0 + wm * 64 + half * 32 + rl;
+      const int nc = n0 + wn * WN + ch * 8;           // first of this lane's 8 columns
+      if (m >= p.M || nc >= p.N) continue;
+      f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      int seg_rows = 0, ncol = nc;
+      if (cmap.mode == 1) {                           // scatter back through the patch map (dgrad of a kernel==stride conv)
+        int seg = nc / cmap.c_seg;
+        ncol = nc - seg * cmap.c_seg;
+        seg_rows = rowmap_seg(cmap, seg);
+      }
+      const long idx = (rowmap_base(cmap, m) + seg_rows) * p.ldc + ncol;
+      const bool full = vec_ok && (nc + 8 <= p.N);
+      const float rs = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (nc + e < p.N) v[e] += p.bias[nc + e];
+      }
+      if (full) {
+        auto load8 = [&](const void* base, float* o) {
+          if (ofp32) {
+            f32x4 a = *(const f32x4*)((const float*)base + idx), b = *(const f32x4*)((const float*)base + idx + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+          } else {
+            bf16x8 a = *(const bf16x8*)((const bf16*)base + idx);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (float)a[e];
+          }
+        };
+        auto store8 = [&](void* base, const float* o) {
+          if (ofp32) {
+            *(f32x4*)((float*)base + idx) = f32x4{o[0], o[1], o[2], o[3]};
+            *(f32x4*)((float*)base + idx + 4) = f32x4{o[4], o[5], o[6], o[7]};
+          } else {
+            bf16x8 a;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = (bf16)o[e];
+            *(bf16x8*)((bf16*)base + idx) = a;
+          }
+        };
         if (p.act == 1) {
-          if (p.H) store_out<T>(p.H, idx, v, ofp32);
-          v = gelu_erf(v);
+          if (p.H) store8(p.H, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
         } else if (p.act == 2) {
-          v *= gelu_erf_grad(load_out(p.H, idx, ofp32));
+          float h8[8];
+          load8(p.H, h8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(h8[e]);
         }
-        if (p.row_scale) v *= p.row_scale[m / p.rows_per_scale];
-        if (p.R) v += load_out(p.R, idx, ofp32);
-        store_out<T>(p.C, idx, v, ofp32);
+        if (p.row_scale) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= rs;
+        }
+        if (p.R) {
+          float r8[8];
+          load8(p.R, r8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r8[e];
+        }
+        store8(p.C, v);
+      } else {                                        // ragged N (vocabulary tail, 2/48/122-way heads) or unaligned rows
+        for (int e = 0; e < 8; ++e) {
+          if (nc + e >= p.N) break;
+          float x = v[e];
+          if (p.act == 1) {
+            if (p.H) store_out<T>(p.H, idx + e, x, ofp32);
+            x = gelu_erf(x);
+          } else if (p.act == 2) {
+            x *= gelu_erf_grad(load_out(p.H, idx + e, ofp32));
+          }
+          x *= rs;
+          if (p.R) x += load_out(p.R, idx + e, ofp32);
+          store_out<T>(p.C, idx + e, x, ofp32);
+        }
       }
     }
   }

@@ -327,11 +327,12 @@ class TrunkStep:
         if HW == m.grids[0] ** 2:
             (gv[:, 1:] if i == 3 else gv)[0].add_(dpos)
             return
-        with torch.enable_grad():
-            p = self.f32(gname).detach().clone().requires_grad_(True)
-            out = self._pos(i, p)
-            out.backward(dpos)
-        gv.add_(p.grad)
+        # adjoint of the bilinear resize, called directly (no nested autograd inside a backward node)
+        gsz, side, C = m.grids[i], self.side[i], dpos.shape[1]
+        g_out = dpos.t().reshape(1, C, side, side).contiguous()
+        g_in = torch.ops.aten.upsample_bilinear2d_backward(g_out, [side, side], [1, C, gsz, gsz], False, None, None)
+        g_in = g_in.reshape(C, gsz * gsz).t()
+        (gv[:, 1:] if i == 3 else gv)[0].add_(g_in)
 
     def _bert_backward(self, d_emb):
         m, B, T = self.m, self.B, self.T

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from oracle import filler
+from oracle.hostinfo import usable_cores
 from oracle import pvlt_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -26,6 +27,34 @@ CASES = {
 }
 
 
+_ORACLE_CACHE = {}      # the CPU oracle is the slow part of this file: run it once per case, not once per dtype
+
+
+def oracle_eval(name, sd, cfg, batch):
+    key = ("eval", name)
+    if key not in _ORACLE_CACHE:
+        taps = {}
+        torch.set_num_threads(usable_cores())
+        with torch.no_grad():
+            ref = O.forward(sd, cfg, batch["image"], batch["input_ids"], taps=taps)
+        _ORACLE_CACHE[key] = (ref, taps)
+    return _ORACLE_CACHE[key]
+
+
+def oracle_train(name, sd, cfg, batch, step_idx, masks):
+    key = ("train", name, step_idx)
+    if key not in _ORACLE_CACHE:
+        sdg = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running_" not in k) else v)
+               for k, v in sd.items() if k != O.TIED[0]}
+        if cfg.loss_type["mlm"]:
+            sdg[O.TIED[0]] = sdg[O.TIED[1]]
+        torch.set_num_threads(usable_cores())
+        lo, _ = O.step_loss(sdg, cfg, batch, step_idx, train=True, masks=masks, bn_out={})
+        lo["total_loss"].backward()
+        _ORACLE_CACHE[key] = ({k: float(v) for k, v in lo.items()}, {k: v.grad for k, v in sdg.items() if v.is_floating_point() and v.grad is not None})
+    return _ORACLE_CACHE[key]
+
+
 def maxrel(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
@@ -33,7 +62,7 @@ def maxrel(a, b):
 
 def sample(t, n=64):
     f = t.detach().reshape(-1).to(torch.float32).cpu()
-    stride = max(1, f.numel() // n)
+    stride = max(1, f.numel() // n) | 1
     return f[::stride][:n].numpy()
 
 
@@ -53,9 +82,20 @@ def build(name, golden_dir, dtype):
     return model, cfg, sd, batch, g, seed
 
 
+LIVE_ORACLE = ("small96_T20_ragged",)      # cases small enough to re-run the CPU oracle on the GPU box (full tensors)
+
+
+def golden_close(a, b, tol):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(1e-6, np.abs(b).max()) < tol
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("name", list(CASES))
 def test_eval_forward_parity(golden_dir, name, dtype):
+    """eval forward vs the REFERENCE's own numbers (golden fixture: strided samples of every stage output and head
+    output, full small-head logits, MLM top-8 at the masked positions, a 16x16 grid of the MIM output); the small
+    ragged case is additionally compared tensor-for-tensor with the oracle run live on this box's CPU."""
     model, cfg, sd, batch, g, seed = build(name, golden_dir, dtype)
     model.eval()
     model._taps = {}
@@ -63,33 +103,52 @@ def test_eval_forward_parity(golden_dir, name, dtype):
     with torch.no_grad():
         out = model(batch["image"].to(dev), batch["input_ids"].to(dev))
     torch.cuda.synchronize()
-    taps_o = {}
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
-    with torch.no_grad():
-        ref = O.forward(sd, cfg, batch["image"], batch["input_ids"], taps=taps_o)
     tol = TOL[dtype]
-    errs = {}
-    for i in range(4):
-        for k in (f"img_feat{i+1}", f"text_feat{i+1}"):
-            errs[k] = maxrel(model._taps[k], taps_o[k])
-    for k, v in ref.items():
-        if v is None:
-            assert out[k] is None, k
-        else:
-            assert tuple(out[k].shape) == tuple(v.shape), (k, out[k].shape, v.shape)
-            errs[k] = maxrel(out[k].float(), v)
-    bad = {k: e for k, e in errs.items() if not e < tol}
-    assert not bad, (name, dtype, bad, errs)
-    # against the reference's own numbers (golden fixture)
+    bad = {}
     for k in g.files:
+        if k.startswith("eval/tap/") and k.endswith("/sample"):
+            tap = k.split("/")[2]
+            if tap in model._taps and not golden_close(sample(model._taps[tap]), g[k], tol):
+                bad[k] = float(np.abs(sample(model._taps[tap]) - g[k]).max() / np.abs(g[k]).max())
         if k.startswith("eval/out/") and k.endswith("/sample"):
             key = k.split("/")[2]
-            a, b = sample(out[key].float(), 256), g[k]
-            assert np.abs(a - b).max() / max(1e-6, np.abs(b).max()) < 2 * tol, k
+            if not golden_close(sample(out[key].float(), 256), g[k], tol):
+                bad[k] = float(np.abs(sample(out[key].float(), 256) - g[k]).max() / np.abs(g[k]).max())
         if k.startswith("eval/full/"):
             key = k.split("/")[2]
-            a, b = out[key].float().cpu().numpy(), g[k]
-            assert np.abs(a - b).max() / max(1e-6, np.abs(b).max()) < 2 * tol, k
+            assert tuple(out[key].shape) == tuple(g[k].shape), (key, out[key].shape)
+            if not golden_close(out[key].float().cpu().numpy(), g[k], tol):
+                bad[k] = float(np.abs(out[key].float().cpu().numpy() - g[k]).max() / np.abs(g[k]).max())
+    for key in ("mlm_logits", "itm_logits", "sup_cls_logits", "sub_cls_logits", "t2i_logits"):
+        assert (out[key] is None) == (f"eval/out/{key}/sample" not in g.files), key
+    pos = torch.from_numpy(g["masked_positions"])
+    if out["mlm_logits"] is not None:
+        B, T = batch["input_ids"].shape
+        assert tuple(out["mlm_logits"].shape) == (B, T, 30522)
+        rows = out["mlm_logits"].reshape(-1, 30522)[pos.to(dev)].float().cpu()
+        tv, ti = rows.topk(8, dim=-1)
+        if not golden_close(tv.numpy(), g["eval/mlm/top8_val"], tol):
+            bad["mlm_top8"] = float(np.abs(tv.numpy() - g["eval/mlm/top8_val"]).max() / np.abs(g["eval/mlm/top8_val"]).max())
+        agree = float((ti.numpy()[:, 0] == g["eval/mlm/top8_idx"][:, 0]).mean())
+        assert agree >= (0.99 if dtype == torch.float32 else 0.9), ("MLM argmax agreement", agree)
+    if out["t2i_logits"] is not None:
+        s_ = max(1, batch["image"].shape[-1] // 16)
+        grid = out["t2i_logits"][:, :, ::s_, ::s_].float().cpu().numpy()
+        if not golden_close(grid, g["eval/t2i/grid"], tol):
+            bad["t2i_grid"] = float(np.abs(grid - g["eval/t2i/grid"]).max() / np.abs(g["eval/t2i/grid"]).max())
+    if name in LIVE_ORACLE:
+        ref, taps_o = oracle_eval(name, sd, cfg, batch)
+        for i in range(4):
+            for k in (f"img_feat{i+1}", f"text_feat{i+1}"):
+                e = maxrel(model._taps[k], taps_o[k])
+                if not e < tol:
+                    bad["oracle/" + k] = e
+        for k, v in ref.items():
+            if v is not None:
+                e = maxrel(out[k].float(), v)
+                if not e < tol:
+                    bad["oracle/" + k] = e
+    assert not bad, (name, str(dtype), bad)
     # masked-index selection, bit-exact
     from mvlt_amd import ops
     lab = batch["mlm_labels"].to(dev).reshape(-1).contiguous()
@@ -101,26 +160,10 @@ def test_eval_forward_parity(golden_dir, name, dtype):
 
 
 def _losses_like_engine(out, batch, dev):
-    """same composition as reference engine_grid_masking.py:81-102 (fused MLM loss when present)."""
-    import torch.nn.functional as F
-    total = 0
-    res = {}
-    if out.get("mlm_loss") is not None:
-        res["loss_mlm"] = out["mlm_loss"]
-        total = total + res["loss_mlm"]
-    elif out["mlm_logits"] is not None:
-        res["loss_mlm"] = F.cross_entropy(out["mlm_logits"].reshape(-1, 30522).float(), batch["mlm_labels"].to(dev).reshape(-1), ignore_index=-1)
-        total = total + res["loss_mlm"]
-    if out["itm_logits"] is not None:
-        res["loss_itm"] = F.cross_entropy(out["itm_logits"].reshape(-1, 2).float(), batch["itm_labels"].to(dev).reshape(-1))
-        total = total + res["loss_itm"]
-    if out["sup_cls_logits"] is not None:
-        res["loss_sup_cls"] = F.cross_entropy(out["sup_cls_logits"].reshape(-1, 48).float(), batch["sup_cls_labels"].to(dev).reshape(-1))
-        res["loss_sub_cls"] = F.cross_entropy(out["sub_cls_logits"].reshape(-1, 122).float(), batch["sub_cls_labels"].to(dev).reshape(-1))
-        total = total + res["loss_sup_cls"] + res["loss_sub_cls"]
-    if out["t2i_logits"] is not None:
-        res["loss_t2i"] = 10 * F.smooth_l1_loss(out["t2i_logits"].float(), batch["image"].to(dev))
-        total = total + res["loss_t2i"]
+    from mvlt_amd.engine import compute_losses
+    db = {k: v.to(dev) for k, v in batch.items()}
+    total, parts = compute_losses(out, db["image"], db["mlm_labels"], db["itm_labels"], db["sup_cls_labels"], db["sub_cls_labels"])
+    res = {k: v for k, v in parts.items()}
     res["total_loss"] = total
     return res
 
@@ -129,8 +172,9 @@ def _losses_like_engine(out, batch, dev):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("name", ["tiny256_pretrain", "small96_T20_ragged", "tiny256_ft"])
 def test_train_step_parity(golden_dir, name, dtype, fused):
-    """one train-mode step (injected dropout / DropPath masks): losses and every parameter gradient vs the oracle,
-    and vs the reference's gradient norms in the golden fixture."""
+    """one train-mode step with injected dropout / DropPath masks: losses, every parameter-gradient norm and a strided
+    sample of every gradient vs the REFERENCE's values in the golden fixture; the small ragged case also compares every
+    full gradient tensor with the oracle run live."""
     from tests.golden.make_golden import make_masks
     model, cfg, sd, batch, g, seed = build(name, golden_dir, dtype)
     if fused and not cfg.loss_type["mlm"]:
@@ -146,34 +190,42 @@ def test_train_step_parity(golden_dir, name, dtype, fused):
     ls = _losses_like_engine(out, batch, dev)
     ls["total_loss"].backward()
     torch.cuda.synchronize()
-    # oracle
-    sdg = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running_" not in k) else v)
-           for k, v in sd.items() if k != O.TIED[0]}
-    if cfg.loss_type["mlm"]:
-        sdg[O.TIED[0]] = sdg[O.TIED[1]]
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
-    lo, _ = O.step_loss(sdg, cfg, batch, step_idx, train=True, masks=masks, bn_out={})
-    lo["total_loss"].backward()
     tol = TOL[dtype]
-    for k, v in lo.items():
-        assert abs(float(ls[k]) - float(v)) <= 2 * tol * max(1.0, abs(float(v))), (k, float(ls[k]), float(v))
+    for k in ("loss_mlm", "loss_itm", "loss_sup_cls", "loss_sub_cls", "loss_t2i", "total_loss"):
+        gk = f"train{step_idx}/loss/{k}"
+        if gk in g.files:
+            ref = float(g[gk])
+            assert abs(float(ls[k]) - ref) <= 2 * tol * max(1.0, abs(ref)), (k, float(ls[k]), ref)
     gtol = 5e-3 if dtype == torch.float32 else 8e-2
-    worst = {}
+    bad, n_checked = {}, 0
     for k, p in model.named_parameters():
-        ref_g = sdg[k].grad
-        if ref_g is None:
+        gk = f"train{step_idx}/grad/{k}/norm"
+        if gk not in g.files:
+            continue
+        refn = float(g[gk])
+        if refn < 1e-7:
             continue
         assert p.grad is not None, k
-        e = ((p.grad.detach().double().cpu() - ref_g.double()).norm() / ref_g.double().norm().clamp_min(1e-12)).item()
-        if ref_g.double().norm().item() < 1e-7:
-            continue
-        worst[k] = e
-        gk = f"train{step_idx}/grad/{k}/norm"
-        if gk in g.files:
-            refn = float(g[gk])
-            assert abs(p.grad.double().norm().item() - refn) <= 2 * gtol * max(refn, 1e-6), (k, p.grad.double().norm().item(), refn)
-    bad = {k: e for k, e in worst.items() if not e < gtol}
-    assert not bad, (name, dtype, sorted(bad.items(), key=lambda kv: -kv[1])[:12])
+        n_checked += 1
+        gn = p.grad.double().norm().item()
+        smp = sample(p.grad, 32)
+        ref_s = g[f"train{step_idx}/grad/{k}/sample"]
+        es = float(np.abs(smp - ref_s).max() / max(np.abs(ref_s).max(), 1e-3 * refn / max(1.0, p.numel() ** 0.5)))
+        if abs(gn - refn) > gtol * refn or es > 4 * gtol:
+            bad[k] = (gn, refn, es)
+    assert n_checked > 50
+    assert not bad, (name, str(dtype), len(bad), sorted(bad.items(), key=lambda kv: -abs(kv[1][0] - kv[1][1]) / kv[1][1])[:10])
+    if name in LIVE_ORACLE:
+        lo, ograds = oracle_train(name, sd, cfg, batch, step_idx, masks)
+        worst = {}
+        for k, p in model.named_parameters():
+            ref_g = ograds.get(k)
+            if ref_g is None or ref_g.double().norm().item() < 1e-7:
+                continue
+            e = ((p.grad.detach().double().cpu() - ref_g.double()).norm() / ref_g.double().norm()).item()
+            if not e < gtol:
+                worst[k] = e
+        assert not worst, (name, str(dtype), sorted(worst.items(), key=lambda kv: -kv[1])[:12])
 
 
 def test_missing_gpu_path_is_loud():
