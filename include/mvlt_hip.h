@@ -170,7 +170,8 @@ int mvlt_cross_entropy_bwd(const void* logits, const long* labels, long ignore_i
 /* torch.optim.AdamW step over a flat fp32 buffer (+ optional bf16 re-cast of the updated parameters).
  * hp (device, fp32[8]) = {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, grad_scale}.
  * Replaces timm create_optimizer('adamw') stepping (reference main_vl.py:308, engine_grid_masking.py:126). */
-int mvlt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* hp, void* stream);
+int mvlt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* hp,
+                    const uint8_t* decay_mask /* [n] 1 = apply weight decay (NULL = all), timm's no-decay split */, void* stream);
 int mvlt_cast_bf16(const float* src, void* dst, long n, void* stream);
 /* out[c*ld_out + r] = in[r*C + c] (fp32 master weight -> transposed compute-dtype operand for the dgrad GEMMs) */
 int mvlt_transpose_cast(const float* in, void* out, int R, int C, int ld_out, int dtype, void* stream);

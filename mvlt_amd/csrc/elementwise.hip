@@ -238,16 +238,18 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* logits, const long*
 // torch.optim.AdamW semantics (reference main_vl.py:308 via timm create_optimizer): decoupled weight decay,
 // bias-corrected moments.  lr / step-dependent scalars come from a small device array so that a captured graph replays.
 // hp = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale}
-__global__ __launch_bounds__(NT) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* p16, long n, const float* hp) {
+__global__ __launch_bounds__(NT) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* p16, long n, const float* hp,
+                                                   const uint8_t* decay_mask) {
   const float lr = hp[0], b1 = hp[1], b2 = hp[2], eps = hp[3], wd = hp[4], bc1 = hp[5], bc2 = hp[6], gs = hp[7];
   const float step_size = lr / bc1;
   const float inv_sqrt_bc2 = rsqrtf(bc2);
   for (long i = ((long)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += (long)gridDim.x * NT * 4) {
     f32x4 pv = *(f32x4*)(p + i), gv = *(const f32x4*)(g + i), mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+    const uint32_t dm = decay_mask ? *(const uint32_t*)(decay_mask + i) : 0x01010101u;   // 1 byte per parameter
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float gr = gv[e] * gs;
-      float pp = pv[e] * (1.0f - lr * wd);
+      float pp = ((dm >> (8 * e)) & 1u) ? pv[e] * (1.0f - lr * wd) : pv[e];
       float mm = b1 * mv[e] + (1.0f - b1) * gr;
       float v2 = b2 * vv[e] + (1.0f - b2) * gr * gr;
       float denom = sqrtf(v2) * inv_sqrt_bc2 + eps;
@@ -393,10 +395,11 @@ extern "C" int mvlt_cross_entropy_bwd(const void* logits, const long* labels, lo
   return mvlt_check_launch("mvlt_cross_entropy_bwd");
 }
 
-extern "C" int mvlt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* hp, void* stream) {
+extern "C" int mvlt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* hp,
+                               const uint8_t* decay_mask, void* stream) {
   MVLT_REQUIRE(p && g && m && v && hp && n >= 0 && n % 4 == 0, "mvlt_adamw_step: bad arguments (n must be a multiple of 4)");
   if (n == 0) return MVLT_OK;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, hp);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, hp, decay_mask);
   return mvlt_check_launch("mvlt_adamw_step");
 }
 

@@ -56,7 +56,7 @@ __device__ __forceinline__ float load_out(const void* base, long idx, int out_fp
 
 // ------------------------------------------------------------------------------------------------ NT
 template <typename T, int BN>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p) {
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p, int nbuf) {
   constexpr int BK = Elem<T>::BK;
   constexpr int PC = Elem<T>::PER_CHUNK;
   constexpr int WN = BN / 2;            // wave tile N
@@ -64,8 +64,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p) 
   constexpr int A_ITERS = BM * CHUNKS / NTHREADS;   // 4
   constexpr int B_ITERS = BN * CHUNKS / NTHREADS;   // 4 or 2
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sA = smem;                                   // 2 x BM x 128 B
-  char* sB = smem + 2 * BM * ROW_BYTES;              // 2 x BN x 128 B
+  char* sA = smem;                                   // nbuf x BM x 128 B  (nbuf = 1 when K fits one tile: 2x the
+  char* sB = smem + nbuf * BM * ROW_BYTES;           // nbuf x BN x 128 B   workgroups per CU for the K=64 stage-1 GEMMs)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
 #pragma unroll
   for (int e = 0; e < PC; ++e) colsum_local[e] = 0.f;
 
-  for (int mt = m_begin; mt < m_end; mt += TBK) {
-    u32x4 va[A_IT][RPU], vb[B_IT][RPU];
+  u32x4 va[A_IT][RPU], vb[B_IT][RPU];
+  auto gload = [&](int mt) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       int u = tid + it * NTHREADS;
@@ -380,6 +380,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
         vb[it][q] = v;
       }
     }
+  };
+  gload(m_begin);
+  for (int mt = m_begin; mt < m_end; mt += TBK) {
     __syncthreads();          // previous tile's fragment reads are done
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -421,6 +424,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
       }
     }
     __syncthreads();
+    if (mt + TBK < m_end) gload(mt + TBK);       // next tile's HBM reads fly while this tile's MFMAs run
     // fragments: row = n1 (or n2) index, 8 consecutive m at offset 32*ks + 8*fg
 #pragma unroll
     for (int ks = 0; ks < TBK / 32; ++ks) {
@@ -499,14 +503,18 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   const bool narrow = a->N <= 64;
   const int bn = narrow ? 64 : 128;
   const int tiles_n = (a->N + bn - 1) / bn;
-  const size_t lds = 2 * (BM + bn) * ROW_BYTES;
+  const int bk = a->dtype == 0 ? 64 : 32;
+  const int nbuf = a->K <= bk ? 1 : 2;
+  size_t lds = (size_t)nbuf * (BM + bn) * ROW_BYTES;
+  const size_t stage = (size_t)4 * 32 * (bn / 2 + 4) * sizeof(float);      // epilogue staging (4 waves x 32 rows)
+  if (lds < stage) lds = stage;
   dim3 grid((unsigned)(tiles_m * tiles_n)), block(NTHREADS);
   if (a->dtype == 0) {
-    if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 64>), grid, block, lds, s, *a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<bf16, 128>), grid, block, lds, s, *a);
+    if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 64>), grid, block, lds, s, *a, nbuf);
+    else hipLaunchKernelGGL((gemm_nt_kernel<bf16, 128>), grid, block, lds, s, *a, nbuf);
   } else {
-    if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<float, 64>), grid, block, lds, s, *a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<float, 128>), grid, block, lds, s, *a);
+    if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<float, 64>), grid, block, lds, s, *a, nbuf);
+    else hipLaunchKernelGGL((gemm_nt_kernel<float, 128>), grid, block, lds, s, *a, nbuf);
   }
   return mvlt_check_launch("mvlt_gemm_nt");
 }

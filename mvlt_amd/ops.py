@@ -93,7 +93,7 @@ L.lib.mvlt_gather_rows.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]
 L.lib.mvlt_scatter_rows.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]
 L.lib.mvlt_cross_entropy_fwd.argtypes = [_vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
 L.lib.mvlt_cross_entropy_bwd.argtypes = [_vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
-L.lib.mvlt_adamw_step.argtypes = [_vp, _vp, _vp, _vp, _vp, _l, _vp, _vp]
+L.lib.mvlt_adamw_step.argtypes = [_vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp]
 L.lib.mvlt_cast_bf16.argtypes = [_vp, _vp, _l, _vp]
 L.lib.mvlt_transpose_cast.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp]
 
@@ -167,9 +167,10 @@ def cross_entropy_bwd(logits, labels, lse, gscale, count, dlogits, rows, V, ld, 
                                        DT[logits.dtype], DT[dlogits.dtype], stream_ptr()), "mvlt_cross_entropy_bwd")
 
 
-def adamw_step(p, g, m, v, p16, n, hp):
+def adamw_step(p, g, m, v, p16, n, hp, decay_mask=None):
     _need_cuda(p, g, m, v, hp)
-    check(L.lib.mvlt_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(p16), n, _p(hp), stream_ptr()), "mvlt_adamw_step")
+    assert decay_mask is None or decay_mask.dtype == torch.uint8
+    check(L.lib.mvlt_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(p16), n, _p(hp), _p(decay_mask), stream_ptr()), "mvlt_adamw_step")
 
 
 def cast_bf16(src, dst, n):

@@ -38,19 +38,15 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._m is None or self._m.numel() != S.total or self._m.device != S.P.device:
             self._m = torch.zeros_like(S.P)
             self._v = torch.zeros_like(S.P)
-            self._hp = torch.zeros(2, 8, device=S.P.device)
-            # contiguous runs of equal weight-decay setting -> one launch per run
+            self._hp = torch.zeros(8, device=S.P.device)
+            # one byte per parameter: 1 = weight decay applies (timm's split: not for 1-D tensors / biases)
             ids_nd = {id(p) for p in self.param_groups[0]["params"]}
-            runs = []
+            mask = torch.zeros(S.total, dtype=torch.uint8)
             for name, p in S.params.items():
                 off, n, _ = S.offsets[name]
-                nd = id(p) in ids_nd
-                end = off + (n + 7) // 8 * 8
-                if runs and runs[-1][2] == nd and runs[-1][1] == off:
-                    runs[-1][1] = end
-                else:
-                    runs.append([off, end, nd])
-            self._runs = runs
+                if id(p) not in ids_nd:
+                    mask[off:off + n] = 1
+            self._wd_mask = mask.to(S.P.device)
         return S
 
     @torch.no_grad()
@@ -59,16 +55,12 @@ class FusedAdamW(torch.optim.Optimizer):
         S = self._ensure()
         S.sync_grads()
         self._step += 1
-        b1, b2 = self.param_groups[0]["betas"]
-        rows = []
-        for gi in (0, 1):
-            g = self.param_groups[gi]
-            rows.append([g["lr"], b1, b2, g["eps"], g["weight_decay"], 1 - b1 ** self._step, 1 - b2 ** self._step, 1.0])
-        self._hp.copy_(torch.tensor(rows, dtype=torch.float32), non_blocking=True)
-        for off, end, nd in self._runs:
-            n = end - off
-            ops.adamw_step(S.P[off:end], S.G[off:end], self._m[off:end], self._v[off:end],
-                           S.C[off:end] if S.C is not None else None, n, self._hp[0 if nd else 1])
+        g0, g1 = self.param_groups
+        b1, b2 = g0["betas"]
+        assert g0["lr"] == g1["lr"], "FusedAdamW steps both param groups with one learning rate (as timm's scheduler sets them)"
+        row = [g0["lr"], b1, b2, g0["eps"], g1["weight_decay"], 1 - b1 ** self._step, 1 - b2 ** self._step, 1.0]
+        self._hp.copy_(torch.tensor(row, dtype=torch.float32), non_blocking=True)
+        ops.adamw_step(S.P, S.G, self._m, self._v, S.C, S.total, self._hp, self._wd_mask)
         # W^T / permuted conv operand copies are refreshed by the next forward
         S.force_dirty = True
         return loss

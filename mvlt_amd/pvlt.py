@@ -122,14 +122,22 @@ class _ITGHead(nn.Module):
         self.conv4 = _conv_bn(3 * ch, 3 * ch)
         self.score = nn.Sequential(nn.Conv2d(3 * ch, 3, 1))
 
-    def run(self, f1, f2, f3):
+    def run(self, f1, f2, f3, conv_dtype):
+        """conv3x3 operands in `conv_dtype` (bf16 MFMA on MIOpen), everything else -- BatchNorm statistics and
+        normalisation, the align_corners bilinear resizes, the three-way feature products -- in fp32."""
+        def cb(seq, t):
+            y = F.conv2d(t.to(conv_dtype), seq[0].weight.to(conv_dtype), None, padding=1).float()
+            return seq[1](y)
         up = lambda t, s=2: F.interpolate(t, scale_factor=s, mode="bilinear", align_corners=True)
-        low, mid, high = self.reduction1(f1), self.reduction2(f2), self.reduction3(f3)
-        a = self.conv_upsample1(up(high)) * mid
-        b = self.conv_upsample2(up(mid)) * self.conv_upsample3(up(a)) * low
-        c = self.conv_concat2(torch.cat((a, self.conv_upsample4(up(high))), 1))
-        d = self.conv_concat3(torch.cat((b, self.conv_upsample5(up(c))), 1))
-        return up(self.score(self.conv4(d)), 8)
+        low, mid, high = cb(self.reduction1, f1), cb(self.reduction2, f2), cb(self.reduction3, f3)
+        a = cb(self.conv_upsample1, up(high)) * mid
+        b = cb(self.conv_upsample2, up(mid)) * cb(self.conv_upsample3, up(a)) * low
+        c = cb(self.conv_concat2, torch.cat((a, cb(self.conv_upsample4, up(high))), 1))
+        d = cb(self.conv_concat3, torch.cat((b, cb(self.conv_upsample5, up(c))), 1))
+        e = cb(self.conv4, d)
+        sc = self.score[0]
+        s = F.conv2d(e.to(conv_dtype), sc.weight.to(conv_dtype), None).float() + sc.bias.view(1, -1, 1, 1)
+        return up(s, 8)
 
 
 # =============================================================================================== the model

@@ -670,8 +670,5 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None):
             side = images.shape[2] // model.patch_size // (2 ** i)
             f = x[:, : side * side, :].reshape(B, side, side, model.dims[i]).permute(0, 3, 1, 2)
             feats.append(f)
-        head = model.t2i_head
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=model.compute_dtype == torch.bfloat16):
-            t2i = head.run(*feats)
-        out["t2i_logits"] = t2i.float()
+        out["t2i_logits"] = model.t2i_head.run(*feats, conv_dtype=model.compute_dtype)
     return out

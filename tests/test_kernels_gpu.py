@@ -394,6 +394,17 @@ def test_adamw_matches_torch(ops):
         ops.adamw_step(p, g, m, v, p16, n, hp)
     assert maxrel(p, ref_p.detach()) < 1e-6
     assert torch.equal(p16, p.to(torch.bfloat16))
+    # per-parameter weight-decay mask (timm's no-decay split for biases / 1-D tensors)
+    mask = (torch.arange(n, device=dev()) % 3 == 0).to(torch.uint8)
+    pa, pb = p0.clone(), p0.clone()
+    ma, va, mb, vb = (torch.zeros(n, device=dev()) for _ in range(4))
+    hp = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.5, 0.1, 0.001, 1.0], device=dev())
+    hp0 = hp.clone(); hp0[4] = 0.0
+    ops.adamw_step(pa, g, ma, va, None, n, hp, mask)
+    ops.adamw_step(pb, g, mb, vb, None, n, hp)
+    pc = p0.clone(); mc, vc = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    ops.adamw_step(pc, g, mc, vc, None, n, hp0)
+    assert torch.equal(pa[mask.bool()], pb[mask.bool()]) and torch.equal(pa[~mask.bool()], pc[~mask.bool()])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
