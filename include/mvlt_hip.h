@@ -32,10 +32,15 @@ int mvlt_sizeof(const char* name);
  *          logical row m = (b, oi, oj), logical column = (di*r + dj) * c_seg + c,
  *          phys_row = b*tokens_in + (oi*r+di)*w_in + (oj*r+dj).  This is nn.Conv2d(kernel=stride=r) on
  *          token-major data (reference libs/pvlt.py:92,104 Attention.sr and :162,168 PatchEmbed.proj);
- *          the conv weight is used as [out][di][dj][c]. */
+ *          the conv weight is used as [out][di][dj][c].
+ *  mode 2: 3x3 / stride 1 / zero-padded neighbourhood gather over an h_in x w_in pixel grid of a (B, tokens_in, c_seg)
+ *          buffer (hw_out = h_in*w_in, w_out = w_in): logical row m = (b, y, x), logical column = (dy*3+dx)*c_seg + c,
+ *          phys_row = b*tokens_in + (y+dy-1)*w_in + (x+dx-1), zero outside the grid.  This is nn.Conv2d(3, padding=1)
+ *          of the MIM decoder on pixel-major data (reference libs/vl_heads.py:116-129,148-152); weight as [out][dy][dx][c]. */
 typedef struct mvlt_rowmap {
   int mode, rows_per_batch, batch_stride, offset;
   int r, w_in, tokens_in, hw_out, w_out, c_seg;
+  int h_in;
 } mvlt_rowmap;
 
 /* C[M,N] = epi(A[M,K] . B[N,K]^T).   Replaces nn.Linear forward (reference libs/pvlt.py:66,69,98,108,118;
@@ -59,7 +64,7 @@ typedef struct mvlt_gemm_nt_args {
 int mvlt_gemm_nt(const mvlt_gemm_nt_args* args, void* stream);
 
 /* C[N1,N2] += A[M,N1]^T . B[M,N2]  (fp32, atomic accumulate into a caller-zeroed buffer) and optionally
- * colsum_a[N1] += sum_m A[m,:].   Weight / bias gradients of nn.Linear and of the kernel==stride convs
+ * colsum_a[N1] += sum_m A[m,:] (or colsum_b over B).   Weight / bias gradients of nn.Linear and of the kernel==stride convs
  * (autograd of the call sites above).  b_map may be a patch gather (N2 = r*r*c_seg). */
 typedef struct mvlt_gemm_tn_args {
   const void* A; const void* B; float* C;
@@ -68,6 +73,8 @@ typedef struct mvlt_gemm_tn_args {
   mvlt_rowmap a_map, b_map;
   float* colsum_a;
   int splits;                /* 0 = choose */
+  float* colsum_b;           /* optional [N2] += sum_m B[m,:] (at most one of colsum_a / colsum_b) */
+  int trans_c;               /* store C transposed: C[n2*ldc + n1] (lets the narrow operand take the 64-wide tile side) */
 } mvlt_gemm_tn_args;
 int mvlt_gemm_tn(const mvlt_gemm_tn_args* args, void* stream);
 
@@ -175,6 +182,26 @@ int mvlt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, 
 int mvlt_cast_bf16(const float* src, void* dst, long n, void* stream);
 /* out[c*ld_out + r] = in[r*C + c] (fp32 master weight -> transposed compute-dtype operand for the dgrad GEMMs) */
 int mvlt_transpose_cast(const float* in, void* out, int R, int C, int ld_out, int dtype, void* stream);
+
+/* ---- MIM decoder helpers (mvlt_amd/csrc/mim.hip): train-mode BatchNorm over pixel-major [M, C] fp32 matrices, the
+ * align_corners=True bilinear resizes and the feature products of reference libs/vl_heads.py:136-165.  The conv3x3
+ * themselves are mvlt_gemm_nt / mvlt_gemm_tn with the mode-2 row map. --------------------------------------------- */
+int mvlt_col_stats(const float* z, int ldz, long M, int C, float* sum, float* sumsq, void* stream);         /* += */
+int mvlt_bn_finalize(const float* sum, const float* sumsq, long M, int C, float eps, float momentum, float* mean, float* rstd,
+                     float* running_mean, float* running_var /* nullable pair: updated like nn.BatchNorm2d */, void* stream);
+int mvlt_bn_norm(const float* z, int ldz, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
+                 float* y32, int ld32, void* y_op, int ld_op, int op_dtype /* dtype of y_op: the MFMA-operand copy */, void* stream);
+int mvlt_bn_bwd_reduce(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, long M, int C,
+                       float* s1 /* += sum dy = dbeta */, float* s2 /* += sum dy*xhat = dgamma */, void* stream);
+int mvlt_bn_bwd_apply(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, const float* gamma,
+                      const float* s1, const float* s2, long M, int C, void* dz_op, int lddz, int op_dtype, void* stream);
+/* out (+)= a*b(*c) elementwise over [M, C] fp32 with row strides; optional operand-dtype copy of the result */
+int mvlt_ew_mul(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c, int ldc, long M, int C,
+                int accumulate, void* out_op, int ld_op, int op_dtype, void* stream);
+/* bilinear resize by an integer factor, align_corners=True.  x fp32 [B,H,W,C] (row stride ldx) -> [B,sH,sW,C] (bf16/fp32,
+ * row stride ldo) or NCHW fp32 [B,C,sH,sW]; bwd is the exact adjoint in gather form (no atomics). */
+int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, int C, int scale, void* out, int ldo, int out_dtype, int nchw, void* stream);
+int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int H, int W, int C, int scale, float* dx, int lddx, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ c_int, c_float, c_void_p, c_long = C.c_int, C.c_float, C.c_void_p, C.c_long
 
 class RowMap(C.Structure):
     _fields_ = [(n, c_int) for n in ("mode", "rows_per_batch", "batch_stride", "offset",
-                                     "r", "w_in", "tokens_in", "hw_out", "w_out", "c_seg")]
+                                     "r", "w_in", "tokens_in", "hw_out", "w_out", "c_seg", "h_in")]
 
 
 class GemmNTArgs(C.Structure):
@@ -42,7 +42,7 @@ class GemmTNArgs(C.Structure):
     _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
                 ("M", c_int), ("N1", c_int), ("N2", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int),
                 ("dtype", c_int), ("a_map", RowMap), ("b_map", RowMap),
-                ("colsum_a", c_void_p), ("splits", c_int)]
+                ("colsum_a", c_void_p), ("splits", c_int), ("colsum_b", c_void_p), ("trans_c", c_int)]
 
 
 class LayerNormArgs(C.Structure):
@@ -89,7 +89,8 @@ EXPORTS = ["mvlt_last_error", "mvlt_abi_version", "mvlt_sizeof", "mvlt_gemm_nt",
            "mvlt_layernorm_fwd", "mvlt_layernorm_bwd", "mvlt_batch_sum", "mvlt_sr_attention_fwd", "mvlt_sr_attention_bwd",
            "mvlt_bert_embed_fwd", "mvlt_bert_embed_bwd", "mvlt_patchify", "mvlt_masked_select", "mvlt_gather_rows",
            "mvlt_scatter_rows", "mvlt_cross_entropy_fwd", "mvlt_cross_entropy_bwd", "mvlt_adamw_step", "mvlt_cast_bf16",
-           "mvlt_transpose_cast"]
+           "mvlt_transpose_cast", "mvlt_col_stats", "mvlt_bn_finalize", "mvlt_bn_norm", "mvlt_bn_bwd_reduce", "mvlt_bn_bwd_apply",
+           "mvlt_ew_mul", "mvlt_upsample_fwd", "mvlt_upsample_bwd"]
 
 DT = {torch.bfloat16: 0, torch.float32: 1}
 
@@ -112,8 +113,13 @@ def ptr(t):
 
 
 def rowmap(rows_per_batch=0, batch_stride=0, offset=0):
-    return RowMap(0, rows_per_batch, batch_stride, offset, 0, 0, 0, 0, 0, 0)
+    return RowMap(0, rows_per_batch, batch_stride, offset, 0, 0, 0, 0, 0, 0, 0)
 
 
 def patchmap(r, w_in, tokens_in, hw_out, w_out, c_seg):
-    return RowMap(1, 0, 0, 0, r, w_in, tokens_in, hw_out, w_out, c_seg)
+    return RowMap(1, 0, 0, 0, r, w_in, tokens_in, hw_out, w_out, c_seg, 0)
+
+
+def conv3map(h, w, tokens_in, c_seg):
+    """3x3 / pad 1 neighbourhood gather over an h x w pixel grid stored pixel-major with `tokens_in` rows per batch"""
+    return RowMap(2, 0, 0, 0, 3, w, tokens_in, h * w, w, c_seg, h)

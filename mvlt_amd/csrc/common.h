@@ -71,12 +71,16 @@ template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf
 //  mode 1: non-overlapping r x r patch gather over a token grid (conv with kernel==stride):
 //          logical row m = (b, oi, oj) over B x Ho x Wo, logical column segment s = (di, dj),
 //          phys_row = b * tokens_in + (oi*r + di) * w_in + (oj*r + dj)
+//  mode 2: 3 x 3, stride 1, zero-padded neighbourhood gather over an H x W pixel grid stored pixel-major:
+//          logical row m = (b, y, x), logical column segment s = (dy, dx) in 0..2 x 0..2,
+//          phys_row = b * tokens_in + (y+dy-1) * w_in + (x+dx-1), and the segment reads as ZERO outside the grid
 struct RowMap {
   int mode;
   int rows_per_batch;   // mode 0: logical rows per batch (0 = identity)
   int batch_stride;     // mode 0: physical rows per batch
   int offset;           // mode 0: first physical row inside a batch
-  int r, w_in, tokens_in, hw_out, w_out, c_seg;   // mode 1
+  int r, w_in, tokens_in, hw_out, w_out, c_seg;   // mode 1 / 2
+  int h_in;             // mode 2
 };
 
 __device__ __forceinline__ long rowmap_base(const RowMap& rm, int m) {
@@ -88,7 +92,20 @@ __device__ __forceinline__ long rowmap_base(const RowMap& rm, int m) {
   int b = m / rm.hw_out;
   int rem = m - b * rm.hw_out;
   int oi = rem / rm.w_out, oj = rem - oi * rm.w_out;
+  if (rm.mode == 2) return (long)b * rm.tokens_in + (long)oi * rm.w_in + oj;     // centre pixel
   return (long)b * rm.tokens_in + (long)(oi * rm.r) * rm.w_in + oj * rm.r;
+}
+// mode 2: pixel coordinates of logical row m
+__device__ __forceinline__ void rowmap_yx(const RowMap& rm, int m, int& y, int& x) {
+  int rem = m % rm.hw_out;
+  y = rem / rm.w_out;
+  x = rem - y * rm.w_out;
+}
+// mode 2: is neighbour (dy, dx) of pixel (y, x) inside the grid, and its physical-row offset from the centre
+__device__ __forceinline__ bool rowmap_nb(const RowMap& rm, int seg, int y, int x, int& off) {
+  int dy = seg / 3, dx = seg - dy * 3;
+  off = (dy - 1) * rm.w_in + (dx - 1);
+  return (unsigned)(y + dy - 1) < (unsigned)rm.h_in && (unsigned)(x + dx - 1) < (unsigned)rm.w_in;
 }
 // extra physical-row offset for patch segment s = di*r + dj (mode 1 only)
 __device__ __forceinline__ int rowmap_seg(const RowMap& rm, int seg) {

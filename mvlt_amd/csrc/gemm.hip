@@ -30,6 +30,7 @@ __device__ __forceinline__ RowMap to_rowmap(const mvlt_rowmap& m) {
   RowMap r;
   r.mode = m.mode; r.rows_per_batch = m.rows_per_batch; r.batch_stride = m.batch_stride; r.offset = m.offset;
   r.r = m.r; r.w_in = m.w_in; r.tokens_in = m.tokens_in; r.hw_out = m.hw_out; r.w_out = m.w_out; r.c_seg = m.c_seg;
+  r.h_in = m.h_in;
   return r;
 }
 
@@ -83,11 +84,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p, 
 
   long a_base[A_ITERS];
   bool a_ok[A_ITERS];
+  int a_y[A_ITERS], a_x[A_ITERS];       // mode 2 only: pixel coordinates (zero-padding test per 3x3 tap)
 #pragma unroll
   for (int i = 0; i < A_ITERS; ++i) {
     int m = m0 + row_in + 32 * i;
     a_ok[i] = m < p.M;
     a_base[i] = a_ok[i] ? rowmap_base(amap, m) : 0;
+    a_y[i] = 0; a_x[i] = 0;
+    if (amap.mode == 2 && a_ok[i]) rowmap_yx(amap, m, a_y[i], a_x[i]);
   }
   long b_base[B_ITERS];
   bool b_ok[B_ITERS];
@@ -102,16 +106,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p, 
   auto gload = [&](int kt) {
     const int k = kt * BK + chunk * PC;
     const bool k_ok = k < p.K;          // K % PER_CHUNK == 0 is required by the host wrapper
-    int seg_rows = 0, kk = k;
-    if (amap.mode == 1) {
-      int seg = k / amap.c_seg;
+    int seg_rows = 0, kk = k, seg = 0;
+    if (amap.mode != 0) {
+      seg = k / amap.c_seg;
       kk = k - seg * amap.c_seg;
-      seg_rows = rowmap_seg(amap, seg);
+      if (amap.mode == 1) seg_rows = rowmap_seg(amap, seg);
     }
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (a_ok[i] && k_ok) v = *(const u32x4*)(Ag + (a_base[i] + seg_rows) * p.lda + kk);
+      bool ok = a_ok[i] && k_ok;
+      int off = seg_rows;
+      if (amap.mode == 2) ok = ok && rowmap_nb(amap, seg, a_y[i], a_x[i], off);
+      if (ok) v = *(const u32x4*)(Ag + (a_base[i] + off) * p.lda + kk);
       ra[i] = v;
     }
 #pragma unroll
@@ -303,6 +310,12 @@ template <typename T> struct TElem;
 template <> struct TElem<bf16> { static constexpr int ROWB = (TBK + 8) * 2; };     // 144 B rows (pad keeps 16-B alignment)
 template <> struct TElem<float> { static constexpr int ROWB = (TBK + 4) * 4; };    // 272 B rows
 
+// bf16 transposed tiles hold (m, m+1) pairs as 32-bit words: row n = output index, 32 pair-columns.  Every 8 rows share
+// the 4 low bank bits (row stride 144 B = 36 dwords), so the 16 lanes that write the same pair-column of 16 different
+// row-groups would hit ONE bank; XOR-ing the pair-column with the row-group index (in units of 4 pairs = one 16-B
+// fragment read, which therefore stays contiguous) spreads them over 8 banks (2-way on ds_write_b32 is free).
+__device__ __forceinline__ int tsw(int n, int pair) { return pair ^ (((n >> 3) & 7) << 2); }
+
 template <typename T, int BN>
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, int m_per_split) {
   constexpr int PC = Elem<T>::PER_CHUNK;             // elements per 16-B global chunk
@@ -325,7 +338,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
   const T* Ag = (const T*)p.A;
   const T* Bg = (const T*)p.B;
   const bool do_colsum = p.colsum_a != nullptr && blockIdx.y == 0;
-  if (do_colsum && tid < BM) s_colsum[tid] = 0.f;
+  const bool do_colsum_b = p.colsum_b != nullptr && blockIdx.x == 0;
+  if ((do_colsum || do_colsum_b) && tid < BM) s_colsum[tid] = 0.f;
 
   f32x4 acc[4][TN_];
 #pragma unroll
@@ -342,9 +356,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
 
   // per-thread fixed column chunk for B (patch gather resolves the segment once)
   const int fr = lane & 15, fg = lane >> 4;
-  float colsum_local[PC];
+  float colsum_local[PC], colsum_local_b[PC];
 #pragma unroll
-  for (int e = 0; e < PC; ++e) colsum_local[e] = 0.f;
+  for (int e = 0; e < PC; ++e) { colsum_local[e] = 0.f; colsum_local_b[e] = 0.f; }
 
   u32x4 va[A_IT][RPU], vb[B_IT][RPU];
   auto gload = [&](int mt) {
@@ -366,17 +380,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
       int u = tid + it * NTHREADS;
       int c = u % B_CH, pr = u / B_CH;
       int n2 = n2_0 + c * PC;
-      int seg_rows = 0, col = n2;
-      if (bmap.mode == 1) {
-        int seg = n2 / bmap.c_seg;
+      int seg_rows = 0, col = n2, seg = 0;
+      if (bmap.mode != 0) {
+        seg = n2 / bmap.c_seg;
         col = n2 - seg * bmap.c_seg;
-        seg_rows = rowmap_seg(bmap, seg);
+        if (bmap.mode == 1) seg_rows = rowmap_seg(bmap, seg);
       }
 #pragma unroll
       for (int q = 0; q < RPU; ++q) {
         int m = mt + pr * RPU + q;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (u < B_UNITS && m < m_end && n2 < p.N2) v = *(const u32x4*)(Bg + (rowmap_base(bmap, m) + seg_rows) * p.ldb + col);
+        bool ok = u < B_UNITS && m < m_end && n2 < p.N2;
+        int off = seg_rows;
+        if (bmap.mode == 2 && ok) {
+          int y, x;
+          rowmap_yx(bmap, m, y, x);
+          ok = rowmap_nb(bmap, seg, y, x, off);
+        }
+        if (ok) v = *(const u32x4*)(Bg + (rowmap_base(bmap, m) + off) * p.ldb + col);
         vb[it][q] = v;
       }
     }
@@ -393,7 +414,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           bf16x2 pk = {x0[e], x1[e]};
-          *(bf16x2*)(sA + (c * 8 + e) * ROWB + pr * 4) = pk;
+          *(bf16x2*)(sA + (c * 8 + e) * ROWB + tsw(c * 8 + e, pr) * 4) = pk;
           if (do_colsum) colsum_local[e] += (float)x0[e] + (float)x1[e];
         }
       } else {
@@ -415,12 +436,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           bf16x2 pk = {x0[e], x1[e]};
-          *(bf16x2*)(sB + (c * 8 + e) * ROWB + pr * 4) = pk;
+          *(bf16x2*)(sB + (c * 8 + e) * ROWB + tsw(c * 8 + e, pr) * 4) = pk;
+          if (do_colsum_b) colsum_local_b[e] += (float)x0[e] + (float)x1[e];
         }
       } else {
         f32x4 x0 = __builtin_bit_cast(f32x4, vb[it][0]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) *(float*)(sB + (c * 4 + e) * ROWB + pr * 4) = x0[e];
+        for (int e = 0; e < 4; ++e) {
+          *(float*)(sB + (c * 4 + e) * ROWB + pr * 4) = x0[e];
+          if (do_colsum_b) colsum_local_b[e] += x0[e];
+        }
       }
     }
     __syncthreads();
@@ -432,13 +457,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
       constexpr int EB = sizeof(T);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const char* ptr = sA + (wm * 64 + i * 16 + fr) * ROWB + (ks * 32 + fg * 8) * EB;
+        const int n = wm * 64 + i * 16 + fr;
+        const char* ptr = (EB == 2) ? sA + n * ROWB + tsw(n, ks * 16 + fg * 4) * 4 : sA + n * ROWB + (ks * 32 + fg * 8) * EB;
         fa[i][0] = *(const u32x4*)ptr;
         fa[i][1] = (EB == 4) ? *(const u32x4*)(ptr + 16) : fa[i][0];
       }
 #pragma unroll
       for (int j = 0; j < TN_; ++j) {
-        const char* ptr = sB + (wn * WN + j * 16 + fr) * ROWB + (ks * 32 + fg * 8) * EB;
+        const int n = wn * WN + j * 16 + fr;
+        const char* ptr = (EB == 2) ? sB + n * ROWB + tsw(n, ks * 16 + fg * 4) * 4 : sB + n * ROWB + (ks * 32 + fg * 8) * EB;
         fb[j][0] = *(const u32x4*)ptr;
         fb[j][1] = (EB == 4) ? *(const u32x4*)(ptr + 16) : fb[j][0];
       }
@@ -457,6 +484,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
     __syncthreads();
     if (tid < BM && n1_0 + tid < p.N1) atomicAdd(&p.colsum_a[n1_0 + tid], s_colsum[tid]);
   }
+  if (do_colsum_b) {                 // only one of colsum_a / colsum_b is used per call (host wrapper checks)
+    if (B_IT * NTHREADS == B_UNITS || tid < B_UNITS) {
+      int c = tid % B_CH;
+#pragma unroll
+      for (int e = 0; e < PC; ++e) atomicAdd(&s_colsum[c * PC + e], colsum_local_b[e]);
+    }
+    __syncthreads();
+    if (tid < BN && n2_0 + tid < p.N2) atomicAdd(&p.colsum_b[n2_0 + tid], s_colsum[tid]);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -465,7 +501,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
       for (int r = 0; r < 4; ++r) {
         int n1 = n1_0 + wm * 64 + i * 16 + 4 * fg + r;
         int n2 = n2_0 + wn * WN + j * 16 + fr;
-        if (n1 < p.N1 && n2 < p.N2) atomicAdd(&p.C[(long)n1 * p.ldc + n2], acc[i][j][r]);
+        if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.trans_c ? &p.C[(long)n2 * p.ldc + n1] : &p.C[(long)n1 * p.ldc + n2], acc[i][j][r]);
       }
 }
 
@@ -475,6 +511,9 @@ int check_rowmap(const mvlt_rowmap& m, const char* who) {
   } else if (m.mode == 1) {
     MVLT_REQUIRE(m.r > 0 && m.w_in > 0 && m.tokens_in > 0 && m.hw_out > 0 && m.w_out > 0 && m.c_seg > 0 && m.c_seg % 16 == 0,
                  "%s: bad patch map (c_seg must be a positive multiple of 16)", who);
+  } else if (m.mode == 2) {
+    MVLT_REQUIRE(m.r == 3 && m.w_in > 0 && m.h_in > 0 && m.tokens_in >= m.h_in * m.w_in && m.hw_out == m.h_in * m.w_in &&
+                 m.w_out == m.w_in && m.c_seg > 0 && m.c_seg % 8 == 0, "%s: bad 3x3 neighbourhood map", who);
   } else {
     MVLT_REQUIRE(false, "%s: unknown rowmap mode %d", who, m.mode);
   }
@@ -497,6 +536,7 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   if (int e = check_rowmap(a->c_map, "mvlt_gemm_nt c_map")) return e;
   MVLT_REQUIRE(a->a_map.mode == 0 || a->K == a->a_map.r * a->a_map.r * a->a_map.c_seg, "mvlt_gemm_nt: gather K != r*r*c_seg");
   MVLT_REQUIRE(a->c_map.mode == 0 || a->N == a->c_map.r * a->c_map.r * a->c_map.c_seg, "mvlt_gemm_nt: scatter N != r*r*c_seg");
+  MVLT_REQUIRE(a->c_map.mode != 2, "mvlt_gemm_nt: the 3x3 map is a gather only (its dgrad is a gather with flipped taps)");
   if (a->M == 0) return MVLT_OK;
   hipStream_t s = (hipStream_t)stream;
   const int tiles_m = (a->M + BM - 1) / BM;
@@ -527,11 +567,12 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
   // N1/N2 may be ragged (30522 vocabulary rows) as long as the padded row (lda/ldb) covers the last 16-B chunk
   MVLT_REQUIRE(a->lda % pc == 0 && a->ldb % pc == 0, "mvlt_gemm_tn: lda/ldb must be multiples of %d elements (16 B)", pc);
   MVLT_REQUIRE(a->lda >= (a->N1 + pc - 1) / pc * pc, "mvlt_gemm_tn: lda must cover N1 rounded up to %d", pc);
-  MVLT_REQUIRE(a->b_map.mode == 1 || a->ldb >= (a->N2 + pc - 1) / pc * pc, "mvlt_gemm_tn: ldb must cover N2 rounded up to %d", pc);
+  MVLT_REQUIRE(a->b_map.mode != 0 || a->ldb >= (a->N2 + pc - 1) / pc * pc, "mvlt_gemm_tn: ldb must cover N2 rounded up to %d", pc);
   MVLT_REQUIRE(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0, "mvlt_gemm_tn: A/B must be 16-byte aligned");
   if (int e = check_rowmap(a->a_map, "mvlt_gemm_tn a_map")) return e;
   if (int e = check_rowmap(a->b_map, "mvlt_gemm_tn b_map")) return e;
   MVLT_REQUIRE(a->a_map.mode == 0, "mvlt_gemm_tn: A cannot be a patch gather");
+  MVLT_REQUIRE(!(a->colsum_a && a->colsum_b), "mvlt_gemm_tn: at most one of colsum_a / colsum_b");
   MVLT_REQUIRE(a->b_map.mode == 0 || a->N2 == a->b_map.r * a->b_map.r * a->b_map.c_seg, "mvlt_gemm_tn: gather N2 != r*r*c_seg");
   if (a->M == 0) return MVLT_OK;
   hipStream_t s = (hipStream_t)stream;

@@ -1,0 +1,267 @@
+// HBM-bound kernels of the MIM decoder (reference libs/vl_heads.py:107-165, "ITGHead"): train-mode BatchNorm over
+// pixel-major [M = B*H*W, C] fp32 matrices (the conv3x3 themselves are mvlt_gemm_nt with the 3x3 row map), the
+// align_corners=True bilinear resizes, and the feature products.  fp32 math throughout; bf16 copies are written only
+// where the next consumer is an MFMA operand.
+#include "common.h"
+#include "../../include/mvlt_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+template <typename TO> __device__ __forceinline__ void store4(TO* p, const f32x4& v);
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const f32x4& v) {
+  *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+}
+template <> __device__ __forceinline__ void store4<float>(float* p, const f32x4& v) { *(f32x4*)p = v; }
+
+// ---- per-column sum / sum of squares (BatchNorm batch statistics) and the two backward reductions
+// mode 0: s1 += sum z, s2 += sum z^2          mode 1: s1 += sum dy, s2 += sum dy * xhat  (xhat = (z-mean)*rstd)
+template <int MODE>
+__global__ __launch_bounds__(NT) void col_reduce_kernel(const float* z, int ldz, const float* dy, int lddy, const float* mean, const float* rstd,
+                                                        int M, int C, float* s1, float* s2) {
+  extern __shared__ float sm[];             // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += NT) sm[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int MAXC = 4;                   // C <= 256
+  float a1[MAXC], a2[MAXC], mu[MAXC], rs[MAXC];
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    a1[k] = 0.f; a2[k] = 0.f;
+    int c = lane + 64 * k;
+    mu[k] = (MODE == 1 && c < C) ? mean[c] : 0.f;
+    rs[k] = (MODE == 1 && c < C) ? rstd[c] : 0.f;
+  }
+  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      int c = lane + 64 * k;
+      if (c < C) {
+        float zv = z[row * ldz + c];
+        if (MODE == 0) { a1[k] += zv; a2[k] += zv * zv; }
+        else { float d = dy[row * lddy + c]; a1[k] += d; a2[k] += d * (zv - mu[k]) * rs[k]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    int c = lane + 64 * k;
+    if (c < C) { atomicAdd(&sm[c], a1[k]); atomicAdd(&sm[C + c], a2[k]); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += NT) { atomicAdd(&s1[i], sm[i]); atomicAdd(&s2[i], sm[C + i]); }
+}
+
+// mean / rstd from (sum, sumsq) and the running-stat update of nn.BatchNorm2d (momentum 0.1, unbiased running var)
+__global__ void bn_finalize_kernel(const float* sum, const float* sumsq, int M, int C, float eps, float momentum,
+                                   float* mean, float* rstd, float* running_mean, float* running_var) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float m = sum[c] / M;
+  float var = fmaxf(sumsq[c] / M - m * m, 0.f);
+  mean[c] = m;
+  rstd[c] = rsqrtf(var + eps);
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+  }
+}
+
+// y = (z - mean) * rstd * gamma + beta   -> fp32 (optional) and / or bf16 (optional), each with its own row stride
+template <typename TO>
+__global__ __launch_bounds__(NT) void bn_norm_kernel(const float* z, int ldz, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                                     long M, int C, float* y32, int ld32, TO* y16, int ld16) {
+  const int cq = C / 4;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
+    long r = i / cq; int c = (int)(i - r * cq) * 4;
+    f32x4 v = *(const f32x4*)(z + r * ldz + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean[c + e]) * rstd[c + e] * gamma[c + e] + beta[c + e];
+    if (y32) *(f32x4*)(y32 + r * ld32 + c) = o;
+    if (y16) store4<TO>(y16 + r * ld16 + c, o);
+  }
+}
+
+// dz = gamma * rstd * (dy - s1/M - xhat * s2/M)   (bf16: it is the A operand of the conv dgrad / wgrad GEMMs)
+template <typename TO>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd,
+                                                          const float* gamma, const float* s1, const float* s2, long M, int C, TO* dz, int lddz) {
+  const int cq = C / 4;
+  const float invM = 1.0f / (float)M;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
+    long r = i / cq; int c = (int)(i - r * cq) * 4;
+    f32x4 d = *(const f32x4*)(dy + r * lddy + c), zv = *(const f32x4*)(z + r * ldz + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float xh = (zv[e] - mean[c + e]) * rstd[c + e];
+      o[e] = gamma[c + e] * rstd[c + e] * (d[e] - s1[c + e] * invM - xh * s2[c + e] * invM);
+    }
+    store4<TO>(dz + r * lddz + c, o);
+  }
+}
+
+// out (+)= a * b (* c)   fp32, optional bf16 copy of the final value
+template <typename TO>
+__global__ __launch_bounds__(NT) void ew_mul_kernel(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c3, int ldc,
+                                                    long M, int C, int accumulate, TO* o16, int ld16) {
+  const int cq = C / 4;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
+    long r = i / cq; int c = (int)(i - r * cq) * 4;
+    f32x4 v = *(const f32x4*)(a + r * lda + c);
+    f32x4 w = *(const f32x4*)(b + r * ldb + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= w[e];
+    if (c3) {
+      f32x4 u = *(const f32x4*)(c3 + r * ldc + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= u[e];
+    }
+    if (accumulate) {
+      f32x4 o = *(const f32x4*)(out + r * ldo + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += o[e];
+    }
+    if (out) *(f32x4*)(out + r * ldo + c) = v;
+    if (o16) store4<TO>(o16 + r * ld16 + c, v);
+  }
+}
+
+// ---- bilinear resize by an integer factor, align_corners=True (nn.Upsample in reference libs/vl_heads.py:114,134)
+// forward: x fp32 pixel-major [B, H, W, C] (row stride ldx)  ->  out [B, sH, sW, C] (bf16 or fp32, row stride ldo)
+//          or NCHW fp32 [B, C, sH, sW] when nchw != 0
+template <typename TO>
+__global__ __launch_bounds__(NT) void upsample_fwd_kernel(const float* x, int ldx, int B, int H, int W, int C, int s, TO* out, int ldo, int nchw) {
+  const int Ho = H * s, Wo = W * s;
+  const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const long total = (long)B * Ho * Wo * C;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    int c, ox, oy, b;
+    if (nchw) { ox = (int)(i % Wo); long t = i / Wo; oy = (int)(t % Ho); t /= Ho; c = (int)(t % C); b = (int)(t / C); }
+    else { c = (int)(i % C); long t = i / C; ox = (int)(t % Wo); t /= Wo; oy = (int)(t % Ho); b = (int)(t / Ho); }
+    float fy = oy * ry, fx = ox * rx;
+    int y0 = (int)fy, x0 = (int)fx;
+    int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    float wy = fy - y0, wx = fx - x0;
+    const float* xb = x + (long)b * H * W * ldx + c;
+    float v00 = xb[((long)y0 * W + x0) * ldx], v01 = xb[((long)y0 * W + x1) * ldx];
+    float v10 = xb[((long)y1 * W + x0) * ldx], v11 = xb[((long)y1 * W + x1) * ldx];
+    float v = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+    if (nchw) out[i] = (TO)v;
+    else out[(((long)b * Ho + oy) * Wo + ox) * ldo + c] = (TO)v;
+  }
+}
+
+// backward (adjoint, gather form): dx[b, iy, ix, c] (+)= sum over the output pixels whose bilinear footprint touches (iy, ix)
+__global__ __launch_bounds__(NT) void upsample_bwd_kernel(const float* dy, int lddy, int nchw, int B, int H, int W, int C, int s, float* dx, int lddx, int accumulate) {
+  const int Ho = H * s, Wo = W * s;
+  const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const long total = (long)B * H * W * C;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    int c = (int)(i % C); long t = i / C; int ix = (int)(t % W); t /= W; int iy = (int)(t % H); int b = (int)(t / H);
+    // output rows oy with |oy*ry - iy| < 1 : conservative integer window, exact weights decide
+    int oy_lo = ry > 0.f ? max(0, (int)floorf((iy - 1) / ry)) : 0, oy_hi = ry > 0.f ? min(Ho - 1, (int)ceilf((iy + 1) / ry)) : Ho - 1;
+    int ox_lo = rx > 0.f ? max(0, (int)floorf((ix - 1) / rx)) : 0, ox_hi = rx > 0.f ? min(Wo - 1, (int)ceilf((ix + 1) / rx)) : Wo - 1;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      float fy = oy * ry;
+      int y0 = (int)fy; int y1 = min(y0 + 1, H - 1); float wy = fy - y0;
+      float wyi = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);      // y0 == y1 at the last row: weights add to 1
+      if (wyi == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        float fx = ox * rx;
+        int x0 = (int)fx; int x1 = min(x0 + 1, W - 1); float wx = fx - x0;
+        float wxi = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
+        if (wxi == 0.f) continue;
+        float g = nchw ? dy[(((long)b * C + c) * Ho + oy) * Wo + ox] : dy[(((long)b * Ho + oy) * Wo + ox) * lddy + c];
+        acc += wyi * wxi * g;
+      }
+    }
+    float* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
+    *d = accumulate ? *d + acc : acc;
+  }
+}
+
+inline int grid_for(long work, int cap = 8192) {
+  long g = (work + NT - 1) / NT;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int mvlt_col_stats(const float* z, int ldz, long M, int C, float* sum, float* sumsq, void* stream) {
+  MVLT_REQUIRE(z && sum && sumsq && C > 0 && C <= 256 && ldz >= C, "mvlt_col_stats: bad arguments (C <= 256)");
+  if (M <= 0) return MVLT_OK;
+  int grid = (int)((M + 63) / 64); if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(grid), dim3(NT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, nullptr, 0, nullptr, nullptr, (int)M, C, sum, sumsq);
+  return mvlt_check_launch("mvlt_col_stats");
+}
+
+extern "C" int mvlt_bn_finalize(const float* sum, const float* sumsq, long M, int C, float eps, float momentum, float* mean, float* rstd,
+                                float* running_mean, float* running_var, void* stream) {
+  MVLT_REQUIRE(sum && sumsq && mean && rstd && M > 0 && C > 0, "mvlt_bn_finalize: bad arguments");
+  MVLT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mvlt_bn_finalize: running_mean and running_var go together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sum, sumsq, (int)M, C, eps, momentum, mean, rstd, running_mean, running_var);
+  return mvlt_check_launch("mvlt_bn_finalize");
+}
+
+extern "C" int mvlt_bn_norm(const float* z, int ldz, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
+                            float* y32, int ld32, void* y16, int ld16, int op_dtype, void* stream) {
+  MVLT_REQUIRE(z && mean && rstd && gamma && beta && (y32 || y16) && C % 4 == 0 && ldz % 4 == 0, "mvlt_bn_norm: bad arguments (C, ld multiples of 4)");
+  MVLT_REQUIRE((!y32 || ld32 % 4 == 0) && (!y16 || ld16 % 4 == 0), "mvlt_bn_norm: output strides must be multiples of 4");
+  if (M <= 0) return MVLT_OK;
+  if (op_dtype == 0) hipLaunchKernelGGL((bn_norm_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
+  else hipLaunchKernelGGL((bn_norm_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (float*)y16, ld16);
+  return mvlt_check_launch("mvlt_bn_norm");
+}
+
+extern "C" int mvlt_bn_bwd_reduce(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, long M, int C,
+                                  float* s1, float* s2, void* stream) {
+  MVLT_REQUIRE(dy && z && mean && rstd && s1 && s2 && C > 0 && C <= 256, "mvlt_bn_bwd_reduce: bad arguments (C <= 256)");
+  if (M <= 0) return MVLT_OK;
+  int grid = (int)((M + 63) / 64); if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(grid), dim3(NT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, (int)M, C, s1, s2);
+  return mvlt_check_launch("mvlt_bn_bwd_reduce");
+}
+
+extern "C" int mvlt_bn_bwd_apply(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, const float* gamma,
+                                 const float* s1, const float* s2, long M, int C, void* dz_bf16, int lddz, int op_dtype, void* stream) {
+  MVLT_REQUIRE(dy && z && mean && rstd && gamma && s1 && s2 && dz_bf16 && C % 4 == 0 && lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0,
+               "mvlt_bn_bwd_apply: bad arguments");
+  if (M <= 0) return MVLT_OK;
+  if (op_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (float*)dz_bf16, lddz);
+  return mvlt_check_launch("mvlt_bn_bwd_apply");
+}
+
+extern "C" int mvlt_ew_mul(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c, int ldc, long M, int C,
+                           int accumulate, void* out_bf16, int ld16, int op_dtype, void* stream) {
+  MVLT_REQUIRE((out || out_bf16) && a && b && C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (!c || ldc % 4 == 0) && (!out || ldo % 4 == 0) &&
+               (!out_bf16 || ld16 % 4 == 0), "mvlt_ew_mul: bad arguments");
+  MVLT_REQUIRE(!accumulate || out, "mvlt_ew_mul: accumulate needs the fp32 output");
+  if (M <= 0) return MVLT_OK;
+  if (op_dtype == 0) hipLaunchKernelGGL((ew_mul_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, c, ldc, M, C, accumulate, (bf16*)out_bf16, ld16);
+  else hipLaunchKernelGGL((ew_mul_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, c, ldc, M, C, accumulate, (float*)out_bf16, ld16);
+  return mvlt_check_launch("mvlt_ew_mul");
+}
+
+extern "C" int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, int C, int scale, void* out, int ldo, int out_dtype, int nchw, void* stream) {
+  MVLT_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1, "mvlt_upsample_fwd: bad arguments");
+  MVLT_REQUIRE(!nchw || out_dtype == 1, "mvlt_upsample_fwd: NCHW output is fp32");
+  long total = (long)B * H * scale * W * scale * C;
+  if (out_dtype == 0) hipLaunchKernelGGL((upsample_fwd_kernel<bf16>), dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, x, ldx, B, H, W, C, scale, (bf16*)out, ldo, nchw);
+  else hipLaunchKernelGGL((upsample_fwd_kernel<float>), dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, x, ldx, B, H, W, C, scale, (float*)out, ldo, nchw);
+  return mvlt_check_launch("mvlt_upsample_fwd");
+}
+
+extern "C" int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int H, int W, int C, int scale, float* dx, int lddx, int accumulate, void* stream) {
+  MVLT_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1, "mvlt_upsample_bwd: bad arguments");
+  long total = (long)B * H * W * C;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, nchw, B, H, W, C, scale, dx, lddx, accumulate);
+  return mvlt_check_launch("mvlt_upsample_bwd");
+}

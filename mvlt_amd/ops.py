@@ -34,8 +34,13 @@ def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, co
     assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype == torch.float32
     if colsum is not None:
         assert colsum.dtype == torch.float32
-    a = L.GemmTNArgs(ptr(A), ptr(B), ptr(C_out), M, N1, N2, lda, ldb, ldc, DT[A.dtype],
-                     a_map or _ID, b_map or _ID, ptr(colsum), splits)
+    a_map, b_map = a_map or _ID, b_map or _ID
+    if N1 <= 64 < N2 and b_map.mode == 0:
+        # the kernel's tile is 128 (N1 side) x 64/128 (N2 side): give the narrow operand the 64-wide side by computing
+        # C^T = B^T A and storing it transposed; the bias gradient becomes the column sum of the (now) B operand
+        a = L.GemmTNArgs(ptr(B), ptr(A), ptr(C_out), M, N2, N1, ldb, lda, ldc, DT[A.dtype], b_map, a_map, None, splits, ptr(colsum), 1)
+    else:
+        a = L.GemmTNArgs(ptr(A), ptr(B), ptr(C_out), M, N1, N2, lda, ldb, ldc, DT[A.dtype], a_map, b_map, ptr(colsum), splits, None, 0)
     check(L.lib.mvlt_gemm_tn(C.byref(a), stream_ptr()), "mvlt_gemm_tn")
     return C_out
 
@@ -182,3 +187,52 @@ def transpose_cast(w, out, R, Ccols, ld_out):
     _need_cuda(w, out)
     assert w.dtype == torch.float32 and w.is_contiguous()
     check(L.lib.mvlt_transpose_cast(_p(w), _p(out), R, Ccols, ld_out, DT[out.dtype], stream_ptr()), "mvlt_transpose_cast")
+
+
+# ------------------------------------------------------------------ MIM decoder helpers (csrc/mim.hip)
+L.lib.mvlt_col_stats.argtypes = [_vp, _i, _l, _i, _vp, _vp, _vp]
+L.lib.mvlt_bn_finalize.argtypes = [_vp, _vp, _l, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]
+L.lib.mvlt_bn_norm.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _i, _i, _vp]
+L.lib.mvlt_bn_bwd_reduce.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _l, _i, _vp, _vp, _vp]
+L.lib.mvlt_bn_bwd_apply.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _i, _vp]
+L.lib.mvlt_ew_mul.argtypes = [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _l, _i, _i, _vp, _i, _i, _vp]
+L.lib.mvlt_upsample_fwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]
+L.lib.mvlt_upsample_bwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]
+
+
+def col_stats(z, ldz, M, Cdim, s, ss):
+    _need_cuda(z, s, ss)
+    check(L.lib.mvlt_col_stats(_p(z), ldz, M, Cdim, _p(s), _p(ss), stream_ptr()), "mvlt_col_stats")
+
+
+def bn_finalize(s, ss, M, Cdim, eps, momentum, mean, rstd, running_mean=None, running_var=None):
+    check(L.lib.mvlt_bn_finalize(_p(s), _p(ss), M, Cdim, eps, momentum, _p(mean), _p(rstd), _p(running_mean), _p(running_var), stream_ptr()),
+          "mvlt_bn_finalize")
+
+
+def bn_norm(z, ldz, mean, rstd, gamma, beta, M, Cdim, y32=None, ld32=0, y16=None, ld16=0):
+    check(L.lib.mvlt_bn_norm(_p(z), ldz, _p(mean), _p(rstd), _p(gamma), _p(beta), M, Cdim, _p(y32), ld32, _p(y16), ld16,
+                             DT[y16.dtype] if y16 is not None else 0, stream_ptr()), "mvlt_bn_norm")
+
+
+def bn_bwd_reduce(dy, lddy, z, ldz, mean, rstd, M, Cdim, s1, s2):
+    check(L.lib.mvlt_bn_bwd_reduce(_p(dy), lddy, _p(z), ldz, _p(mean), _p(rstd), M, Cdim, _p(s1), _p(s2), stream_ptr()), "mvlt_bn_bwd_reduce")
+
+
+def bn_bwd_apply(dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, Cdim, dz16, lddz):
+    check(L.lib.mvlt_bn_bwd_apply(_p(dy), lddy, _p(z), ldz, _p(mean), _p(rstd), _p(gamma), _p(s1), _p(s2), M, Cdim, _p(dz16), lddz, DT[dz16.dtype], stream_ptr()),
+          "mvlt_bn_bwd_apply")
+
+
+def ew_mul(out, ldo, a, lda, b, ldb, c=None, ldc=0, *, M, Cdim, accumulate=False, out16=None, ld16=0):
+    check(L.lib.mvlt_ew_mul(_p(out), ldo, _p(a), lda, _p(b), ldb, _p(c), ldc, M, Cdim, 1 if accumulate else 0, _p(out16), ld16,
+                            DT[out16.dtype] if out16 is not None else 0, stream_ptr()), "mvlt_ew_mul")
+
+
+def upsample_fwd(x, ldx, B, H, W, Cdim, scale, out, ldo, nchw=False):
+    check(L.lib.mvlt_upsample_fwd(_p(x), ldx, B, H, W, Cdim, scale, _p(out), ldo, DT[out.dtype], 1 if nchw else 0, stream_ptr()), "mvlt_upsample_fwd")
+
+
+def upsample_bwd(dy, lddy, nchw, B, H, W, Cdim, scale, dx, lddx, accumulate=False):
+    check(L.lib.mvlt_upsample_bwd(_p(dy), lddy, 1 if nchw else 0, B, H, W, Cdim, scale, _p(dx), lddx, 1 if accumulate else 0, stream_ptr()),
+          "mvlt_upsample_bwd")

@@ -88,7 +88,8 @@ class FlatStore:
             off += (n + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
         # parameters whose gradients the HIP schedule writes itself (everything but the torch-autograd MIM decoder)
-        self.fn_params = [(n, p) for n, p in self.params.items() if not n.startswith("t2i_head.")]
+        hip_mim = getattr(self.module, "mim_impl", "hip") == "hip"
+        self.fn_params = [(n, p) for n, p in self.params.items() if hip_mim or not n.startswith("t2i_head.")]
 
     def is_current(self):
         if self.P is None:
@@ -139,9 +140,10 @@ class FlatStore:
         return src[off:off + n].view(shape)
 
     # ------------------------------------------------------------------ operand copies
-    def refresh(self, transposed, conv_perm):
+    def refresh(self, transposed, conv_perm, conv3=()):
         """Bring compute-dtype copies up to date with the fp32 masters.
-        transposed: names of 2-D weights needing W^T; conv_perm: names of conv weights used as patch GEMMs."""
+        transposed: names of 2-D weights needing W^T; conv_perm: names of kernel==stride conv weights used as patch
+        GEMMs; conv3: names of the MIM decoder's 3x3 conv weights (forward taps + flipped/transposed dgrad taps)."""
         if not self.force_dirty and self._cast_version == self.P._version:
             return
         if self.C is not None:
@@ -159,6 +161,16 @@ class FlatStore:
             wk = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)   # [out][kh][kw][cin]
             self.extra[name + "::K"] = wk.to(dt).contiguous()
             self.extra[name + "::KT"] = wk.t().to(dt).contiguous()
+        for name in conv3:
+            w = self.master(name)                            # [out, cin, 3, 3]
+            self.extra[name + "::K"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()       # [out][dy][dx][cin]
+            self.extra[name + "::F"] = w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(dt).contiguous()  # [cin][2-dy][2-dx][out]
+        if "t2i_head.score.0.weight" in self.offsets and conv3:
+            w = self.master("t2i_head.score.0.weight").view(3, -1)
+            self.extra["t2i_head.score.0.weight::W"] = w.to(dt).contiguous()
+            wt = torch.zeros(w.shape[1], 8, device=self.device, dtype=dt)
+            wt[:, :3] = w.t().to(dt)
+            self.extra["t2i_head.score.0.weight::T"] = wt
         self._cast_version = self.P._version
         self.force_dirty = False
 

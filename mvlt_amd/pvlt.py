@@ -103,9 +103,9 @@ def _conv_bn(cin, cout):
 
 
 class _ITGHead(nn.Module):
-    """MIM decoder parameters (reference libs/vl_heads.py:107-134).  Round-1 status: its conv3x3 + BatchNorm +
-    bilinear graph runs on PyTorch-ROCm (MIOpen) in the compute dtype, channels-last, under autograd -- the next
-    kernel to move to hand-written HIP (implicit-GEMM conv); see DESIGN.md."""
+    """MIM decoder parameters (reference libs/vl_heads.py:107-134).  The product path evaluates them with the HIP
+    schedule in mvlt_amd/mim.py; `run` below is the same graph on PyTorch-ROCm ops, used only as an A/B reference
+    in tests (model.mim_impl = "torch")."""
 
     def __init__(self, dims, ch=64):
         super().__init__()
@@ -199,9 +199,13 @@ class PyramidVisionLanguageTransformer(nn.Module):
         self._init_weights()
         self.register_load_state_dict_pre_hook(self._drop_legacy_keys)
 
+        # "hip": the MIM decoder runs as the explicit kernel schedule of mvlt_amd/mim.py (default).  "torch": its
+        # PyTorch-ROCm twin (_ITGHead.run, MIOpen convs under autograd) -- kept as the A/B reference for tests only.
+        self.mim_impl = "hip"
         self._store = FlatStore(self, compute_dtype)
         self._anchor = None
         self._transposed, self._conv_perm = self._operand_lists()
+        self._conv3 = [n for n, p in self.named_parameters() if n.startswith("t2i_head.") and p.dim() == 4 and p.shape[-1] == 3]
         self.injected_masks = None      # tests: {'bert': (B,T,768) keep, 'droppath': [...], 'droppath2': [...]}
 
     # ------------------------------------------------------------------ init / state

@@ -635,7 +635,7 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None):
     S = model.store
     dev = images.device
     S.ensure(dev)
-    S.refresh(model._transposed, model._conv_perm)
+    S.refresh(model._transposed, model._conv_perm, model._conv3 if model.mim_impl == "hip" else ())
     grad_on = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
     if grad_on:
         S.begin_step()
@@ -670,5 +670,12 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None):
             side = images.shape[2] // model.patch_size // (2 ** i)
             f = x[:, : side * side, :].reshape(B, side, side, model.dims[i]).permute(0, 3, 1, 2)
             feats.append(f)
-        out["t2i_logits"] = model.t2i_head.run(*feats, conv_dtype=model.compute_dtype)
+        if model.mim_impl == "hip":
+            from .mim import mim_head
+            if grad_on and not model.training:
+                raise NotImplementedError("MIM decoder backward with eval-mode BatchNorm is not scheduled (no reference config needs it)")
+            sides = tuple(images.shape[2] // model.patch_size // (2 ** i) for i in (1, 2, 3))
+            out["t2i_logits"] = mim_head(model, x2, x3, x4, sides, grad_on)
+        else:
+            out["t2i_logits"] = model.t2i_head.run(*feats, conv_dtype=model.compute_dtype)
     return out

@@ -272,3 +272,47 @@ def test_missing_gpu_path_is_loud():
                        loss_type=dict(mlm=1, itm=1, t2i=0, cls=0), pretrained_pth=None)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 16, dtype=torch.long))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("img,B", [(96, 3), (256, 2)])
+def test_mim_decoder_hip_vs_torch_twin(dtype, tol, img, B):
+    """The HIP schedule of the MIM decoder (mvlt_amd/mim.py: conv3x3 as 3x3-gather GEMMs, batch-stat BatchNorm, bilinear
+    resizes, products) against the same graph on PyTorch-ROCm ops: output, BN running stats and every gradient
+    (the twin itself is pinned to the reference by the golden tests when mim_impl='torch')."""
+    import torch.nn.functional as F
+    from mvlt_amd import pvlt
+    lt = dict(mlm=0, itm=0, t2i=1, cls=0)
+    T = 16
+    cfg = O.Cfg("pvlt_tiny", lt, 224, 768, T, 0.0)
+    sd = O.filled_state_dict(cfg, 5)
+    batch = O.to_torch_batch(filler.make_batch(5, B, img, T))
+    dev = torch.device("cuda:0")
+    res = {}
+    for impl in ("torch", "hip"):
+        m = pvlt.pvlt_tiny(pretrained=False, token_hidden_size=768, num_text_tokens=T, loss_type=lt, pretrained_pth=None,
+                           drop_path_rate=0.0, compute_dtype=dtype)
+        m.mim_impl = impl
+        m.load_state_dict(sd, strict=True)
+        m.cuda().train()
+        m.injected_masks = dict(bert=torch.ones(B, T, 768), droppath=[torch.ones(B)] * 8, droppath2=[torch.ones(B)] * 8)
+        out = m(batch["masked_images"].to(dev), batch["input_ids"].to(dev))["t2i_logits"]
+        loss = 10 * F.smooth_l1_loss(out.float(), batch["image"].to(dev))
+        loss.backward()
+        torch.cuda.synchronize()
+        res[impl] = (out.detach().float().cpu(), {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if p.grad is not None},
+                     {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items() if "running_" in k})
+    o_t, g_t, r_t = res["torch"]
+    o_h, g_h, r_h = res["hip"]
+    assert tuple(o_h.shape) == (B, 3, img, img)
+    assert ((o_h - o_t).norm() / o_t.norm()).item() < tol
+    for k, v in r_t.items():
+        assert ((r_h[k] - v).norm() / v.norm().clamp_min(1e-12)).item() < max(tol, 1e-3), k
+    bad = {}
+    for k, v in g_t.items():
+        if v.norm().item() < 1e-8:
+            continue
+        e = ((g_h[k] - v).norm() / v.norm()).item()
+        if not e < 4 * tol:
+            bad[k] = e
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
