@@ -70,10 +70,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p, 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-friendly order: consecutive workgroup ids walk M first (they share the B panel, which is small)
+  // XCD-aware order (block b runs on XCD b % 8): the column tiles of one 128-row panel get consecutive slots on ONE XCD,
+  // so the A panel is fetched into that XCD's L2 once and a row block of C is written as a whole (all its column tiles
+  // close together in time) instead of as 256-byte slivers revisited tiles_m workgroups later.
   const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = blockIdx.x;
-  const int tile_m = bid % tiles_m, tile_n = bid / tiles_m;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int tile_m = (slot / tiles_n) * 8 + xcd, tile_n = slot % tiles_n;
+  if (tile_m >= tiles_m) return;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const RowMap amap = to_rowmap(p.a_map);
 
@@ -206,16 +211,35 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p, 
   float* stage = (float*)smem + wave * 32 * LDW;
   const bool vec_ok = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.R || ((uintptr_t)p.R & 15) == 0) &&
                       (!p.H || ((uintptr_t)p.H & 15) == 0);
+  // this lane's 8 output columns are the same in every iteration: fetch their bias once (two 16-B loads when aligned)
+  const int nc_lane = n0 + wn * WN + (lane % CPR) * 8;
+  float bias8[8];
 #pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  if (p.bias) {
+    if (nc_lane + 8 <= p.N && (((uintptr_t)p.bias & 15) == 0)) {
+      f32x4 b0 = *(const f32x4*)(p.bias + nc_lane), b1 = *(const f32x4*)(p.bias + nc_lane + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (nc_lane + e < p.N) bias8[e] = p.bias[nc_lane + e];
+    }
+  }
+#pragma unroll
+  // (the K loop ended with a workgroup barrier: nobody reads the operand tiles any more.  From here on every wave
+  //  touches only its own staging slice, so only wave-level ordering is needed and the waves drift apart freely.)
   for (int half = 0; half < 2; ++half) {
-    __syncthreads();                                  // staging buffers / previous half are no longer being read
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
       for (int j = 0; j < TN_; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) stage[(ii * 16 + 4 * fg + r) * LDW + j * 16 + fr] = acc[half * 2 + ii][j][r];
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int it = 0; it < 32 / RPI; ++it) {
       const int rl = it * RPI + lane / CPR;           // row inside this 32-row half
@@ -234,10 +258,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p, 
       const long idx = (rowmap_base(cmap, m) + seg_rows) * p.ldc + ncol;
       const bool full = vec_ok && (nc + 8 <= p.N);
       const float rs = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.0f;
-      if (p.bias) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (nc + e < p.N) v[e] += p.bias[nc + e];
-      }
+      for (int e = 0; e < 8; ++e) v[e] += bias8[e];
       if (full) {
         auto load8 = [&](const void* base, float* o) {
           if (ofp32) {
@@ -548,7 +570,7 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   size_t lds = (size_t)nbuf * (BM + bn) * ROW_BYTES;
   const size_t stage = (size_t)4 * 32 * (bn / 2 + 4) * sizeof(float);      // epilogue staging (4 waves x 32 rows)
   if (lds < stage) lds = stage;
-  dim3 grid((unsigned)(tiles_m * tiles_n)), block(NTHREADS);
+  dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n)), block(NTHREADS);
   if (a->dtype == 0) {
     if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 64>), grid, block, lds, s, *a, nbuf);
     else hipLaunchKernelGGL((gemm_nt_kernel<bf16, 128>), grid, block, lds, s, *a, nbuf);

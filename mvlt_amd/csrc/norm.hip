@@ -59,6 +59,17 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(mvlt_layernorm_args p) {
   const int nchunk = p.C / VN;
   const RowMap xm = rm0(p.x_map), ym = rm0(p.y_map);
   const float inv_c = 1.0f / (float)p.C;
+  // a lane owns the same columns in every row: keep their gamma / beta in registers
+  float gam[MAXIT][VN], bet[MAXIT][VN];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    int c = gl + it * G;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) {
+      gam[it][e] = c < nchunk ? p.gamma[c * VN + e] : 0.f;
+      bet[it][e] = c < nchunk ? p.beta[c * VN + e] : 0.f;
+    }
+  }
   for (int row = blockIdx.x * GROUPS + grp; row < p.rows; row += gridDim.x * GROUPS) {
     const T* xr = (const T*)p.x + rowmap_base(xm, row) * p.ldx;
     TY* yr = (TY*)p.y + rowmap_base(ym, row) * p.ldy;
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(mvlt_layernorm_args p) {
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
           int col = c * VN + e;
-          o[e] = (v[it][e] - mean) * rstd * p.gamma[col] + p.beta[col];
+          o[e] = (v[it][e] - mean) * rstd * gam[it][e] + bet[it][e];
           if (addr) o[e] += addr[col];
         }
         Vec<TY>::store(yr + c * VN, o);
@@ -116,11 +127,13 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
   const float inv_c = 1.0f / (float)p.C;
   for (int i = threadIdx.x; i < 2 * p.C; i += NT) s_part[i] = 0.f;
   __syncthreads();
-  float dg[MAXIT][VN], db[MAXIT][VN];
+  float dg[MAXIT][VN], db[MAXIT][VN], gam[MAXIT][VN];
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
+  for (int it = 0; it < MAXIT; ++it) {
+    int c = gl + it * G;
 #pragma unroll
-    for (int e = 0; e < VN; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; }
+    for (int e = 0; e < VN; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; gam[it][e] = c < nchunk ? p.gamma[c * VN + e] : 0.f; }
+  }
 
   for (int row = blockIdx.x * GROUPS + grp; row < p.rows; row += gridDim.x * GROUPS) {
     const T* dyr = (const T*)p.dy + rowmap_base(dym, row) * p.lddy;
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
           float h = (xv[e] - mean) * rstd;
-          float gg = dyv[e] * p.gamma[c * VN + e];
+          float gg = dyv[e] * gam[it][e];
           xh[it][e] = h; g[it][e] = gg;
           s1 += gg; s2 += gg * h;
           dg[it][e] += dyv[e] * h;
