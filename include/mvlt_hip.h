@@ -183,6 +183,30 @@ int mvlt_cast_bf16(const float* src, void* dst, long n, void* stream);
 /* out[c*ld_out + r] = in[r*C + c] (fp32 master weight -> transposed compute-dtype operand for the dgrad GEMMs) */
 int mvlt_transpose_cast(const float* in, void* out, int R, int C, int ld_out, int dtype, void* stream);
 
+/* ---- fused MLP for the narrow stages (mvlt_amd/csrc/mlp.hip), bf16 operands, C = 64 or 128 ------------------------
+ * Replaces fc1 -> nn.GELU -> fc2 (+ DropPath + residual) of reference libs/pvlt.py:65-71,142 and their autograd: the
+ * (tokens x hidden) activation stays in LDS / registers.
+ *   mvlt_mlp_fwd    : out[M,C] (fp32) = (gelu(x W1^T + b1) W2^T + b2) * row_scale + residual ; optional h_out = x W1^T + b1
+ *                     x [M,C] bf16, w1 = W1 [hid,C], wb = W2 [C,hid]
+ *   mvlt_mlp_bwd_dx : out[M,C] (bf16) = ((dy W2) * gelu'(x W1^T + b1)) W1 * row_scale
+ *                     w1 = W1 [hid,C], wb = W1^T [C,hid], wc = W2^T [hid,C]
+ *   mvlt_mlp_bwd_dw : dW1[hid,C] += dh^T x, db1 += colsum dh, dW2[C,hid] += (dy*row_scale)^T gelu(h), db2 += colsum dy*row_scale
+ *                     (fp32 atomics into caller-zeroed buffers; dh, h recomputed on chip)  w1 = W1, wc = W2^T */
+typedef struct mvlt_mlp_args {
+  const void* x; const void* dy;
+  const void* w1; const void* wb; const void* wc;
+  const float* b1; const float* b2;
+  const void* residual;               /* fwd: fp32 [M,C] */
+  const float* row_scale; int rows_per_scale;
+  void* out;
+  void* h_out;                        /* fwd: optional bf16 [M,hid] pre-activation */
+  float* dw1; float* db1; float* dw2; float* db2;      /* bwd_dw */
+  int M, C, hid;
+} mvlt_mlp_args;
+int mvlt_mlp_fwd(const mvlt_mlp_args* args, void* stream);
+int mvlt_mlp_bwd_dx(const mvlt_mlp_args* args, void* stream);
+int mvlt_mlp_bwd_dw(const mvlt_mlp_args* args, void* stream);
+
 /* ---- MIM decoder helpers (mvlt_amd/csrc/mim.hip): train-mode BatchNorm over pixel-major [M, C] fp32 matrices, the
  * align_corners=True bilinear resizes and the feature products of reference libs/vl_heads.py:136-165.  The conv3x3
  * themselves are mvlt_gemm_nt / mvlt_gemm_tn with the mode-2 row map. --------------------------------------------- */

@@ -76,11 +76,18 @@ class AttnBwdArgs(C.Structure):
                 ("k_off", c_int), ("v_off", c_int), ("scale", c_float), ("dtype", c_int)]
 
 
+class MlpArgs(C.Structure):
+    _fields_ = [("x", c_void_p), ("dy", c_void_p), ("w1", c_void_p), ("wb", c_void_p), ("wc", c_void_p),
+                ("b1", c_void_p), ("b2", c_void_p), ("residual", c_void_p), ("row_scale", c_void_p), ("rows_per_scale", c_int),
+                ("out", c_void_p), ("h_out", c_void_p), ("dw1", c_void_p), ("db1", c_void_p), ("dw2", c_void_p), ("db2", c_void_p),
+                ("M", c_int), ("C", c_int), ("hid", c_int)]
+
+
 lib.mvlt_last_error.restype = C.c_char_p
 lib.mvlt_sizeof.argtypes = [C.c_char_p]
 for _name, _cls in (("mvlt_rowmap", RowMap), ("mvlt_gemm_nt_args", GemmNTArgs), ("mvlt_gemm_tn_args", GemmTNArgs),
                     ("mvlt_layernorm_args", LayerNormArgs), ("mvlt_layernorm_bwd_args", LayerNormBwdArgs),
-                    ("mvlt_attn_args", AttnArgs), ("mvlt_attn_bwd_args", AttnBwdArgs)):
+                    ("mvlt_attn_args", AttnArgs), ("mvlt_attn_bwd_args", AttnBwdArgs), ("mvlt_mlp_args", MlpArgs)):
     _n = lib.mvlt_sizeof(_name.encode())
     if _n != C.sizeof(_cls):
         raise ImportError(f"ABI mismatch for {_name}: library says {_n} bytes, binding has {C.sizeof(_cls)}")
@@ -90,7 +97,7 @@ EXPORTS = ["mvlt_last_error", "mvlt_abi_version", "mvlt_sizeof", "mvlt_gemm_nt",
            "mvlt_bert_embed_fwd", "mvlt_bert_embed_bwd", "mvlt_patchify", "mvlt_masked_select", "mvlt_gather_rows",
            "mvlt_scatter_rows", "mvlt_cross_entropy_fwd", "mvlt_cross_entropy_bwd", "mvlt_adamw_step", "mvlt_cast_bf16",
            "mvlt_transpose_cast", "mvlt_col_stats", "mvlt_bn_finalize", "mvlt_bn_norm", "mvlt_bn_bwd_reduce", "mvlt_bn_bwd_apply",
-           "mvlt_ew_mul", "mvlt_upsample_fwd", "mvlt_upsample_bwd"]
+           "mvlt_ew_mul", "mvlt_upsample_fwd", "mvlt_upsample_bwd", "mvlt_mlp_fwd", "mvlt_mlp_bwd_dx", "mvlt_mlp_bwd_dw"]
 
 DT = {torch.bfloat16: 0, torch.float32: 1}
 

@@ -36,7 +36,7 @@ int mvlt_check_launch(const char* what);
 // ~40-instruction erff.  The GELU epilogues are VALU-bound otherwise (554 M activations per stage-1 fc1 launch).
 __device__ __forceinline__ float erf_as(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);   // v_rcp_f32 (1 ulp): __frcp_rn expands to the full IEEE division sequence
   const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
   const float y = 1.0f - poly * __expf(-ax * ax);
   return copysignf(y, x);

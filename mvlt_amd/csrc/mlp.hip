@@ -1,0 +1,447 @@
+// Fused MLP kernels for the narrow stages (C = 64 / 128: stage 1 and 2 of PVLT), gfx950.
+//
+// Reference libs/pvlt.py:65-71 runs fc1 -> GELU -> fc2 as three kernels and round-trips the (tokens x hidden) activation
+// through HBM three times (18.4 MB per pair per block in stage 1).  With C = 64/128 the GEMMs have
+// K = C: far below the MFMA/HBM ridge, so the hidden activation is the whole cost.  Here a workgroup owns 128 (C=64)
+// or 64 (C=128) token rows, keeps their x tile in LDS, and walks the hidden dimension in chunks of 64 units:
+//
+//   forward  (mode 0):  G_c = gelu(x W1_c^T + b1_c)           producer MFMAs -> bf16 tile in LDS
+//                       out += G_c W2[:, c]^T                 consumer MFMAs (accumulators live across chunks)
+//                       out = (out + b2) * droppath + residual            (fp32 residual stream)
+//   backward (mode 1):  H_c = x W1_c^T + b1_c ; dG_c = dy W2[:, c]        two producers
+//                       dH_c = dG_c * gelu'(H_c)                          -> bf16 tile in LDS
+//                       dx += dH_c W1_c                                   consumer; dx *= droppath
+//
+// so the hidden activation never leaves the CU (forward can optionally still store the pre-activation for the unfused
+// backward).  Producers are computed transposed (rows = hidden units, columns = tokens) so that each lane ends up with
+// four consecutive hidden units of one token: one 8-byte LDS store into the consumer's A-operand tile.
+#include "common.h"
+#include "../../include/mvlt_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int JC = 64;                       // hidden units per chunk
+
+// element offset inside a [rows][K] bf16 tile with 16-B chunks XOR-swizzled by row (conflict-free fragment reads)
+template <int K> __device__ __forceinline__ int toff(int row, int k) {
+  constexpr int NCH = K / 8;                 // 16-B chunks per row: 8 (K=64) or 16 (K=128)
+  int ch = k >> 3;
+  int sw = (NCH == 8) ? (ch ^ ((row >> 1) & 7)) : (ch ^ (row & 15));
+  return row * K + sw * 8 + (k & 7);
+}
+
+__device__ __forceinline__ bf16x8 ldfrag(const bf16* tile_base_elem) { return *(const bf16x8*)tile_base_elem; }
+
+template <int C, int MODE>
+__global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
+  constexpr int BM = (C == 64) ? 128 : 64;   // token rows per workgroup
+  constexpr int WR = BM / 4;                 // token rows per wave: each wave is self-contained (producer AND consumer of its rows)
+  constexpr int MT = WR / 16;                // 16-token tiles per wave: 2 (C=64) / 1 (C=128)
+  constexpr int CT = C / 16;                 // 16-col output tiles (all of C)
+  constexpr int KS_C = C / 32;               // k32 steps over C
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sX = (bf16*)smem;                                    // [BM][C]
+  bf16* sDY = sX + BM * C;                                   // [BM][C]      (mode 1 only)
+  bf16* sWa = sDY + (MODE == 1 ? BM * C : 0);                // [2][JC][C]   W1 chunk
+  bf16* sWb = sWa + 2 * JC * C;                              // [2][C][JC]   W2[:, chunk] (mode 0) / W1^T[:, chunk] (mode 1)
+  bf16* sWc = sWb + 2 * C * JC;                              // [2][JC][C]   W2^T chunk   (mode 1 only)
+  bf16* sG = sWc + (MODE == 1 ? 2 * JC * C : 0);             // [BM][JC]     each wave touches only its own WR rows
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int m0 = blockIdx.x * BM;
+  const bf16* X = (const bf16*)p.x;
+  const bf16* DY = (const bf16*)p.dy;
+  const bf16* Wa = (const bf16*)p.w1;        // [hid][C]
+  const bf16* Wb = (const bf16*)p.wb;        // [C][hid]
+  const bf16* Wc = (const bf16*)p.wc;        // [hid][C]
+  const int hid = p.hid;
+
+  // ---- token tiles (x and, for the backward, dy) into LDS once
+  for (int u = tid; u < BM * (C / 8); u += NT) {
+    int r = u / (C / 8), ch = u % (C / 8);
+    u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
+    if (m0 + r < p.M) {
+      v = *(const u32x4*)(X + (long)(m0 + r) * C + ch * 8);
+      if (MODE == 1) w = *(const u32x4*)(DY + (long)(m0 + r) * C + ch * 8);
+    }
+    *(u32x4*)(sX + toff<C>(r, ch * 8)) = v;
+    if (MODE == 1) *(u32x4*)(sDY + toff<C>(r, ch * 8)) = w;
+  }
+  // ---- weight-chunk staging (global -> registers -> LDS), double buffered
+  constexpr int WA_IT = JC * (C / 8) / NT;   // 2 (C=64) / 4 (C=128)
+  constexpr int WB_IT = C * (JC / 8) / NT;   // 2 / 4
+  u32x4 ra[WA_IT], rb[WB_IT], rc[MODE == 1 ? WA_IT : 1];
+  auto wload = [&](int jc) {
+#pragma unroll
+    for (int it = 0; it < WA_IT; ++it) {
+      int u = tid + it * NT, r = u / (C / 8), ch = u % (C / 8);
+      ra[it] = *(const u32x4*)(Wa + (long)(jc * JC + r) * C + ch * 8);
+      if (MODE == 1) rc[it] = *(const u32x4*)(Wc + (long)(jc * JC + r) * C + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < WB_IT; ++it) {
+      int u = tid + it * NT, r = u / (JC / 8), ch = u % (JC / 8);
+      rb[it] = *(const u32x4*)(Wb + (long)r * hid + jc * JC + ch * 8);
+    }
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < WA_IT; ++it) {
+      int u = tid + it * NT, r = u / (C / 8), ch = u % (C / 8);
+      *(u32x4*)(sWa + buf * JC * C + toff<C>(r, ch * 8)) = ra[it];
+      if (MODE == 1) *(u32x4*)(sWc + buf * JC * C + toff<C>(r, ch * 8)) = rc[it];
+    }
+#pragma unroll
+    for (int it = 0; it < WB_IT; ++it) {
+      int u = tid + it * NT, r = u / (JC / 8), ch = u % (JC / 8);
+      *(u32x4*)(sWb + buf * C * JC + toff<JC>(r, ch * 8)) = rb[it];
+    }
+  };
+  wload(0);
+  wstore(0);
+  __syncthreads();
+
+  // B-operand fragments of this wave's tokens (x, and dy for the backward) do not change across hidden chunks
+  bf16x8 xfr[MT][KS_C], yfr[MODE == 1 ? MT : 1][KS_C];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < KS_C; ++ks) {
+      const int mrow = wave * WR + mt * 16 + fr;
+      xfr[mt][ks] = ldfrag(sX + toff<C>(mrow, ks * 32 + fg * 8));
+      if (MODE == 1) yfr[mt][ks] = ldfrag(sDY + toff<C>(mrow, ks * 32 + fg * 8));
+    }
+  f32x4 oacc[MT][CT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = hid / JC;
+  for (int jc = 0; jc < nchunks; ++jc) {
+    const int buf = jc & 1;
+    if (jc + 1 < nchunks) wload(jc + 1);
+    // ---- producers, transposed: tile (jt, mt): rows = hidden units 16 jt.. of the chunk, cols = this wave's tokens 16 mt..
+    const bf16* wa = sWa + buf * JC * C;
+    const bf16* wc = sWc + buf * JC * C;
+#pragma unroll
+    for (int jt = 0; jt < JC / 16; ++jt) {
+      const int jrow = jt * 16 + fr;                   // A-operand row (hidden unit inside the chunk)
+      bf16x8 af[KS_C], cf[MODE == 1 ? KS_C : 1];
+#pragma unroll
+      for (int ks = 0; ks < KS_C; ++ks) {
+        af[ks] = ldfrag(wa + toff<C>(jrow, ks * 32 + fg * 8));
+        if (MODE == 1) cf[ks] = ldfrag(wc + toff<C>(jrow, ks * 32 + fg * 8));
+      }
+      const int jl = jt * 16 + 4 * fg;                 // the four hidden units this lane ends up with: jl + r
+      f32x4 b1v = *(const f32x4*)(p.b1 + jc * JC + jl);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int mrow = wave * WR + mt * 16 + fr;     // token (column fr of the tile)
+        f32x4 h = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS_C; ++ks) {
+          h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], xfr[mt][ks], h, 0, 0, 0);
+          if (MODE == 1) dg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[ks], yfr[mt][ks], dg, 0, 0, 0);
+        }
+        bf16x4 g4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float hv = h[r] + b1v[r];
+          g4[r] = (bf16)((MODE == 0) ? gelu_erf(hv) : dg[r] * gelu_erf_grad(hv));
+          h[r] = hv;
+        }
+        *(bf16x4*)(sG + toff<JC>(mrow, jl)) = g4;
+        if (MODE == 0 && p.h_out && m0 + mrow < p.M) {
+          bf16x4 h4 = {(bf16)h[0], (bf16)h[1], (bf16)h[2], (bf16)h[3]};
+          *(bf16x4*)((bf16*)p.h_out + (long)(m0 + mrow) * hid + jc * JC + jl) = h4;
+        }
+      }
+    }
+    // the G rows written above are read back only by this wave: wave-level ordering, no workgroup barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- consumer: out[this wave's tokens][C] += G[tokens][64] . Wb[C][64]^T
+    const bf16* wb = sWb + buf * C * JC;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 gf[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) gf[i] = ldfrag(sG + toff<JC>(wave * WR + i * 16 + fr, ks * 32 + fg * 8));
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        bf16x8 bfr = ldfrag(wb + toff<JC>(j * 16 + fr, ks * 32 + fg * 8));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) oacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], bfr, oacc[i][j], 0, 0, 0);
+      }
+    }
+    if (jc + 1 < nchunks) wstore(buf ^ 1);
+    __syncthreads();                                   // weight double buffer: next chunk visible, this one free next time
+  }
+
+  // ---- epilogue: oacc[i][j][r] = out[token wave*WR + 16 i + 4 fg + r][c = 16 j + fr]
+  // staged per wave through LDS (the operand tiles are dead) so that global traffic is 16-byte, row-contiguous
+  constexpr int LDW = C + 4, CPR = C / 8, RPI = 64 / CPR;
+  float* stage = (float*)smem + wave * WR * LDW;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stage[(i * 16 + 4 * fg + r) * LDW + j * 16 + fr] = oacc[i][j][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int ch = lane % CPR;
+  const int nc = ch * 8;
+  float b2v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) b2v[e] = (MODE == 0) ? p.b2[nc + e] : 0.f;
+#pragma unroll
+  for (int it = 0; it < WR / RPI; ++it) {
+    const int rl = it * RPI + lane / CPR;
+    const int m = m0 + wave * WR + rl;
+    if (m >= p.M) continue;
+    f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    const float rs = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+    const long idx = (long)m * C + nc;
+    if (MODE == 0) {
+      const float* R = (const float*)p.residual + idx;
+      f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
+      float rr[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (v[e] + b2v[e]) * rs + rr[e];
+      float* O = (float*)p.out + idx;
+      *(f32x4*)O = f32x4{v[0], v[1], v[2], v[3]};
+      *(f32x4*)(O + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)(v[e] * rs);
+      *(bf16x8*)((bf16*)p.out + idx) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradients
+// dW1[j][c] += sum_m dh[m][j] x[m][c]      db1[j] += sum_m dh[m][j]
+// dW2[c][j] += sum_m dy[m][c] g[m][j]      db2[c] += sum_m dy[m][c]          (dy already multiplied by the DropPath scale)
+// A workgroup owns 128 hidden units (blockIdx.y) and a range of tokens (blockIdx.x); W1 / W2^T rows of its hidden range stay
+// in LDS.  Per 64-token tile it recomputes h and dg for its hidden units (MFMA, rows = tokens), turns them into g and dh
+// in registers and feeds those straight back as MFMA operands of the two weight-gradient products (k = tokens): the C
+// layout (4 consecutive tokens per lane) IS the operand layout once two 16-token tiles are paired.  The other operands are
+// x^T / dy^T tiles in LDS.  Nothing of size (tokens x hidden) is ever written.
+constexpr int TS = 72;                       // row stride (elements) of the transposed [C][64] tiles: 144 B
+__device__ __forceinline__ int tsw2(int c, int pair) { return pair ^ (((c >> 3) & 7) << 2); }
+
+template <int C>
+__global__ __launch_bounds__(NT) void mlp_wgrad_kernel(mvlt_mlp_args p, int m_per_split) {
+  constexpr int KS_C = C / 32, CT16 = C / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sX = (bf16*)smem;                    // [64][C]
+  bf16* sDY = sX + 64 * C;                   // [64][C]
+  bf16* sXt = sDY + 64 * C;                  // [C][TS]
+  bf16* sDYt = sXt + C * TS;                 // [C][TS]
+  bf16* sW1 = sDYt + C * TS;                 // [128][C]
+  bf16* sW2T = sW1 + 128 * C;                // [128][C]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int j0 = blockIdx.y * 128;
+  const int m_begin = blockIdx.x * m_per_split, m_end = min(p.M, m_begin + m_per_split);
+  const bf16* X = (const bf16*)p.x;
+  const bf16* DY = (const bf16*)p.dy;
+  for (int u = tid; u < 128 * (C / 8); u += NT) {
+    int r = u / (C / 8), ch = u % (C / 8);
+    *(u32x4*)(sW1 + toff<C>(r, ch * 8)) = *(const u32x4*)((const bf16*)p.w1 + (long)(j0 + r) * C + ch * 8);
+    *(u32x4*)(sW2T + toff<C>(r, ch * 8)) = *(const u32x4*)((const bf16*)p.wc + (long)(j0 + r) * C + ch * 8);
+  }
+  float b1v[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) b1v[jt] = p.b1[j0 + wave * 32 + jt * 16 + fr];
+
+  f32x4 dw1[2][CT16], dw2[CT16][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < CT16; ++b) { dw1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; dw2[b][a] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  float db1acc[2] = {0.f, 0.f};
+  float db2acc[CT16];
+#pragma unroll
+  for (int b = 0; b < CT16; ++b) db2acc[b] = 0.f;
+  const bool do_db2 = (blockIdx.y == 0) && (wave == 0);
+
+  constexpr int UNITS = 32 * (C / 8);        // (token pair, 8-channel chunk)
+  for (int mt0 = m_begin; mt0 < m_end; mt0 += 64) {
+    __syncthreads();                         // previous tile fully consumed
+    for (int u = tid; u < UNITS; u += NT) {
+      int ch = u % (C / 8), pr = u / (C / 8);
+      bf16x8 x0, x1, y0, y1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x0[e] = (bf16)0.f; x1[e] = (bf16)0.f; y0[e] = (bf16)0.f; y1[e] = (bf16)0.f; }
+      const int ma = mt0 + 2 * pr, mb = ma + 1;
+      if (ma < m_end) {
+        x0 = *(const bf16x8*)(X + (long)ma * C + ch * 8);
+        y0 = *(const bf16x8*)(DY + (long)ma * C + ch * 8);
+        if (p.row_scale) { float s0 = p.row_scale[ma / p.rows_per_scale];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y0[e] = (bf16)((float)y0[e] * s0); }
+      }
+      if (mb < m_end) {
+        x1 = *(const bf16x8*)(X + (long)mb * C + ch * 8);
+        y1 = *(const bf16x8*)(DY + (long)mb * C + ch * 8);
+        if (p.row_scale) { float s1 = p.row_scale[mb / p.rows_per_scale];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y1[e] = (bf16)((float)y1[e] * s1); }
+      }
+      *(bf16x8*)(sX + toff<C>(2 * pr, ch * 8)) = x0;
+      *(bf16x8*)(sX + toff<C>(2 * pr + 1, ch * 8)) = x1;
+      *(bf16x8*)(sDY + toff<C>(2 * pr, ch * 8)) = y0;
+      *(bf16x8*)(sDY + toff<C>(2 * pr + 1, ch * 8)) = y1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = ch * 8 + e;
+        *(bf16x2*)(sXt + c * TS + tsw2(c, pr) * 2) = bf16x2{x0[e], x1[e]};
+        *(bf16x2*)(sDYt + c * TS + tsw2(c, pr) * 2) = bf16x2{y0[e], y1[e]};
+      }
+    }
+    __syncthreads();
+    // ---- producers: h, dg for this wave's 32 hidden units x 64 tokens; rows = tokens (4 fg + r), cols = hidden (fr)
+    bf16x8 gfrag[2][2], dhfrag[2][2];        // [hidden tile][token-tile pair]: k-slot (fg, jj) <-> token 32 pair + 16 (jj>>2) + 4 fg + (jj&3)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      bf16x8 w1f[KS_C], w2f[KS_C];
+#pragma unroll
+      for (int ks = 0; ks < KS_C; ++ks) {
+        w1f[ks] = ldfrag(sW1 + toff<C>(wave * 32 + jt * 16 + fr, ks * 32 + fg * 8));
+        w2f[ks] = ldfrag(sW2T + toff<C>(wave * 32 + jt * 16 + fr, ks * 32 + fg * 8));
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        f32x4 h = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS_C; ++ks) {
+          bf16x8 xf = ldfrag(sX + toff<C>(mt * 16 + fr, ks * 32 + fg * 8));
+          bf16x8 yf = ldfrag(sDY + toff<C>(mt * 16 + fr, ks * 32 + fg * 8));
+          h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, w1f[ks], h, 0, 0, 0);
+          dg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, w2f[ks], dg, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float hv = h[r] + b1v[jt];
+          const float dhv = dg[r] * gelu_erf_grad(hv);
+          db1acc[jt] += dhv;
+          gfrag[jt][mt >> 1][(mt & 1) * 4 + r] = (bf16)gelu_erf(hv);
+          dhfrag[jt][mt >> 1][(mt & 1) * 4 + r] = (bf16)dhv;
+        }
+      }
+    }
+    // ---- weight-gradient products, k = tokens (two k32 steps per 64-token tile)
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair) {
+#pragma unroll
+      for (int ct = 0; ct < CT16; ++ct) {
+        const int c = ct * 16 + fr;
+        const int pA = tsw2(c, 16 * pair + 2 * fg), pB = tsw2(c, 16 * pair + 8 + 2 * fg);
+        bf16x4 xa = *(const bf16x4*)(sXt + c * TS + pA * 2), xb = *(const bf16x4*)(sXt + c * TS + pB * 2);
+        bf16x4 ya = *(const bf16x4*)(sDYt + c * TS + pA * 2), yb = *(const bf16x4*)(sDYt + c * TS + pB * 2);
+        bf16x8 xt = {xa[0], xa[1], xa[2], xa[3], xb[0], xb[1], xb[2], xb[3]};
+        bf16x8 yt = {ya[0], ya[1], ya[2], ya[3], yb[0], yb[1], yb[2], yb[3]};
+        if (do_db2) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) db2acc[ct] += (float)yt[e];
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          dw1[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dhfrag[jt][pair], xt, dw1[jt][ct], 0, 0, 0);   // rows j, cols c
+          dw2[ct][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yt, gfrag[jt][pair], dw2[ct][jt], 0, 0, 0);    // rows c, cols j
+        }
+      }
+    }
+  }
+  // ---- flush
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int jb = j0 + wave * 32 + jt * 16;
+#pragma unroll
+    for (int ct = 0; ct < CT16; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        atomicAdd(&p.dw1[(long)(jb + 4 * fg + r) * C + ct * 16 + fr], dw1[jt][ct][r]);
+        atomicAdd(&p.dw2[(long)(ct * 16 + 4 * fg + r) * p.hid + jb + fr], dw2[ct][jt][r]);
+      }
+    float v = db1acc[jt];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (fg == 0) atomicAdd(&p.db1[jb + fr], v);
+  }
+  if (do_db2) {
+#pragma unroll
+    for (int ct = 0; ct < CT16; ++ct) {
+      float v = db2acc[ct];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (fg == 0) atomicAdd(&p.db2[ct * 16 + fr], v);
+    }
+  }
+}
+
+template <int C> int launch_wgrad(const mvlt_mlp_args& a, hipStream_t s) {
+  const size_t lds = (size_t)(2 * 64 * C + 2 * C * TS + 2 * 128 * C) * 2;
+  const int ny = a.hid / 128;
+  int splits = (1024 + ny - 1) / ny;
+  const int mtiles = (a.M + 63) / 64;
+  if (splits > mtiles) splits = mtiles;
+  if (splits < 1) splits = 1;
+  const int m_per_split = ((mtiles + splits - 1) / splits) * 64;
+  splits = (a.M + m_per_split - 1) / m_per_split;
+  hipFuncSetAttribute((const void*)mlp_wgrad_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((mlp_wgrad_kernel<C>), dim3(splits, ny), dim3(NT), lds, s, a, m_per_split);
+  return mvlt_check_launch("mvlt_mlp_bwd_dw");
+}
+
+template <int C, int MODE> int launch(const mvlt_mlp_args& a, hipStream_t s) {
+  constexpr int BM = (C == 64) ? 128 : 64;
+  size_t lds = (size_t)(BM * C * (MODE == 1 ? 2 : 1) + 2 * JC * C * (MODE == 1 ? 2 : 1) + 2 * C * JC + BM * JC) * 2;
+  const size_t stage = (size_t)BM * (C + 4) * 4;
+  if (lds < stage) lds = stage;
+  hipFuncSetAttribute((const void*)mlp_fused_kernel<C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((mlp_fused_kernel<C, MODE>), dim3((a.M + BM - 1) / BM), dim3(NT), lds, s, a);
+  return mvlt_check_launch(MODE == 0 ? "mvlt_mlp_fwd" : "mvlt_mlp_bwd_dx");
+}
+
+int check(const mvlt_mlp_args* a, const char* who) {
+  MVLT_REQUIRE(a && a->x && a->w1 && a->wb && a->b1 && a->out, "%s: null pointer", who);
+  MVLT_REQUIRE(a->C == 64 || a->C == 128, "%s: C must be 64 or 128 (stage 1 / 2), got %d", who, a->C);
+  MVLT_REQUIRE(a->hid > 0 && a->hid % 64 == 0, "%s: hidden size must be a multiple of 64", who);
+  MVLT_REQUIRE(!a->row_scale || a->rows_per_scale > 0, "%s: row_scale needs rows_per_scale", who);
+  return MVLT_OK;
+}
+
+}  // namespace
+
+extern "C" int mvlt_mlp_fwd(const mvlt_mlp_args* a, void* stream) {
+  if (int e = check(a, "mvlt_mlp_fwd")) return e;
+  MVLT_REQUIRE(a->b2 && a->residual, "mvlt_mlp_fwd: b2 and residual are required");
+  if (a->M <= 0) return MVLT_OK;
+  return a->C == 64 ? launch<64, 0>(*a, (hipStream_t)stream) : launch<128, 0>(*a, (hipStream_t)stream);
+}
+
+extern "C" int mvlt_mlp_bwd_dx(const mvlt_mlp_args* a, void* stream) {
+  if (int e = check(a, "mvlt_mlp_bwd_dx")) return e;
+  MVLT_REQUIRE(a->dy && a->wc, "mvlt_mlp_bwd_dx: dy and wc (W2^T) are required");
+  if (a->M <= 0) return MVLT_OK;
+  return a->C == 64 ? launch<64, 1>(*a, (hipStream_t)stream) : launch<128, 1>(*a, (hipStream_t)stream);
+}
+
+extern "C" int mvlt_mlp_bwd_dw(const mvlt_mlp_args* a, void* stream) {
+  MVLT_REQUIRE(a && a->x && a->dy && a->w1 && a->wc && a->b1 && a->dw1 && a->db1 && a->dw2 && a->db2, "mvlt_mlp_bwd_dw: null pointer");
+  MVLT_REQUIRE(a->C == 64 || a->C == 128, "mvlt_mlp_bwd_dw: C must be 64 or 128, got %d", a->C);
+  MVLT_REQUIRE(a->hid > 0 && a->hid % 128 == 0, "mvlt_mlp_bwd_dw: hidden size must be a multiple of 128");
+  MVLT_REQUIRE(!a->row_scale || a->rows_per_scale > 0, "mvlt_mlp_bwd_dw: row_scale needs rows_per_scale");
+  if (a->M <= 0) return MVLT_OK;
+  return a->C == 64 ? launch_wgrad<64>(*a, (hipStream_t)stream) : launch_wgrad<128>(*a, (hipStream_t)stream);
+}

@@ -236,3 +236,28 @@ def upsample_fwd(x, ldx, B, H, W, Cdim, scale, out, ldo, nchw=False):
 def upsample_bwd(dy, lddy, nchw, B, H, W, Cdim, scale, dx, lddx, accumulate=False):
     check(L.lib.mvlt_upsample_bwd(_p(dy), lddy, 1 if nchw else 0, B, H, W, Cdim, scale, _p(dx), lddx, 1 if accumulate else 0, stream_ptr()),
           "mvlt_upsample_bwd")
+
+
+# ------------------------------------------------------------------ fused MLP (csrc/mlp.hip), bf16, C in {64, 128}
+def mlp_fwd(x, w1, b1, w2, b2, residual, out, M, Cdim, hid, *, row_scale=None, rows_per_scale=0, h_out=None):
+    assert x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
+    assert residual.dtype == torch.float32 and out.dtype == torch.float32
+    a = L.MlpArgs(ptr(x), None, ptr(w1), ptr(w2), None, ptr(b1), ptr(b2), ptr(residual), ptr(row_scale), rows_per_scale,
+                  ptr(out), ptr(h_out), None, None, None, None, M, Cdim, hid)
+    check(L.lib.mvlt_mlp_fwd(C.byref(a), stream_ptr()), "mvlt_mlp_fwd")
+    return out
+
+
+def mlp_bwd_dx(x, dy, w1, w1t, w2t, b1, out, M, Cdim, hid, *, row_scale=None, rows_per_scale=0):
+    assert x.dtype == dy.dtype == out.dtype == torch.bfloat16
+    a = L.MlpArgs(ptr(x), ptr(dy), ptr(w1), ptr(w1t), ptr(w2t), ptr(b1), None, None, ptr(row_scale), rows_per_scale,
+                  ptr(out), None, None, None, None, None, M, Cdim, hid)
+    check(L.lib.mvlt_mlp_bwd_dx(C.byref(a), stream_ptr()), "mvlt_mlp_bwd_dx")
+    return out
+
+
+def mlp_bwd_dw(x, dy, w1, w2t, b1, dw1, db1, dw2, db2, M, Cdim, hid, *, row_scale=None, rows_per_scale=0):
+    assert x.dtype == dy.dtype == torch.bfloat16 and dw1.dtype == torch.float32
+    a = L.MlpArgs(ptr(x), ptr(dy), ptr(w1), None, ptr(w2t), ptr(b1), None, None, ptr(row_scale), rows_per_scale,
+                  None, None, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), M, Cdim, hid)
+    check(L.lib.mvlt_mlp_bwd_dw(C.byref(a), stream_ptr()), "mvlt_mlp_bwd_dw")

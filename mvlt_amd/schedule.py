@@ -244,13 +244,20 @@ class TrunkStep:
         bs["m2"], bs["r2"] = _empty((M,), f32, dev), _empty((M,), f32, dev)
         ops.layernorm_fwd(xm, xn2, self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m2"], rstd=bs["r2"])
         bs["xn2"] = xn2
-        hpre = _empty((M, hid), dt, dev) if self.need_grad else None
-        gact = _empty((M, hid), dt, dev)
-        ops.gemm_nt(xn2, self.w(p + "mlp.fc1.weight"), gact, M, hid, C, C, C, hid, bias=self.f32(p + "mlp.fc1.bias"), act=1, H=hpre)
-        bs["hpre"], bs["gact"] = hpre, gact
         xo = _empty((B, N, C), self.rt, dev)
-        ops.gemm_nt(gact, self.w(p + "mlp.fc2.weight"), xo, M, C, hid, hid, hid, C, bias=self.f32(p + "mlp.fc2.bias"),
-                    row_scale=s2, rows_per_scale=N, R=xm)
+        bs["fused_mlp"] = fused = (dt == torch.bfloat16 and C in (64, 128))
+        if fused:
+            # stages 1-2: fc1 -> GELU -> fc2 -> DropPath -> +residual in ONE kernel; the (tokens x hidden) activation stays
+            # on chip and is recomputed by the fused backward kernels (nothing saved but LN2's output)
+            ops.mlp_fwd(xn2, self.w(p + "mlp.fc1.weight"), self.f32(p + "mlp.fc1.bias"), self.w(p + "mlp.fc2.weight"),
+                        self.f32(p + "mlp.fc2.bias"), xm, xo, M, C, hid, row_scale=s2, rows_per_scale=N)
+        else:
+            hpre = _empty((M, hid), dt, dev) if self.need_grad else None
+            gact = _empty((M, hid), dt, dev)
+            ops.gemm_nt(xn2, self.w(p + "mlp.fc1.weight"), gact, M, hid, C, C, C, hid, bias=self.f32(p + "mlp.fc1.bias"), act=1, H=hpre)
+            bs["hpre"], bs["gact"] = hpre, gact
+            ops.gemm_nt(gact, self.w(p + "mlp.fc2.weight"), xo, M, C, hid, hid, hid, C, bias=self.f32(p + "mlp.fc2.bias"),
+                        row_scale=s2, rows_per_scale=N, R=xm)
         if not self.need_grad:
             bs.clear()
         return xo, bs
@@ -354,15 +361,22 @@ class TrunkStep:
         p = Names.blk(i, j)
         f32 = torch.float32
         # ---- MLP branch: x_out = x_mid + s2 * (fc2(gelu(fc1(LN2(x_mid)))))
-        dy2 = self._scaled(dx, bs["s2"], N)
-        ops.gemm_tn(dy2, bs["gact"], self.g(p + "mlp.fc2.weight"), M, C, hid, C, hid, hid, colsum=self.g(p + "mlp.fc2.bias"))
-        dh = _empty((M, hid), dt, dev)
-        ops.gemm_nt(dy2, self.wT(p + "mlp.fc2.weight"), dh, M, hid, C, C, C, hid, act=2, H=bs["hpre"])
-        bs["gact"] = bs["hpre"] = None
-        ops.gemm_tn(dh, bs["xn2"], self.g(p + "mlp.fc1.weight"), M, hid, C, hid, C, C, colsum=self.g(p + "mlp.fc1.bias"))
         dxn2 = _empty((M, C), dt, dev)
-        ops.gemm_nt(dh, self.wT(p + "mlp.fc1.weight"), dxn2, M, C, hid, hid, hid, C)
-        del dh
+        if bs["fused_mlp"]:
+            w1, w2t = self.w(p + "mlp.fc1.weight"), self.wT(p + "mlp.fc2.weight")
+            ops.mlp_bwd_dw(bs["xn2"], dx, w1, w2t, self.f32(p + "mlp.fc1.bias"), self.g(p + "mlp.fc1.weight"), self.g(p + "mlp.fc1.bias"),
+                           self.g(p + "mlp.fc2.weight"), self.g(p + "mlp.fc2.bias"), M, C, hid, row_scale=bs["s2"], rows_per_scale=N)
+            ops.mlp_bwd_dx(bs["xn2"], dx, w1, self.wT(p + "mlp.fc1.weight"), w2t, self.f32(p + "mlp.fc1.bias"), dxn2, M, C, hid,
+                           row_scale=bs["s2"], rows_per_scale=N)
+        else:
+            dy2 = self._scaled(dx, bs["s2"], N)
+            ops.gemm_tn(dy2, bs["gact"], self.g(p + "mlp.fc2.weight"), M, C, hid, C, hid, hid, colsum=self.g(p + "mlp.fc2.bias"))
+            dh = _empty((M, hid), dt, dev)
+            ops.gemm_nt(dy2, self.wT(p + "mlp.fc2.weight"), dh, M, hid, C, C, C, hid, act=2, H=bs["hpre"])
+            bs["gact"] = bs["hpre"] = None
+            ops.gemm_tn(dh, bs["xn2"], self.g(p + "mlp.fc1.weight"), M, hid, C, hid, C, C, colsum=self.g(p + "mlp.fc1.bias"))
+            ops.gemm_nt(dh, self.wT(p + "mlp.fc1.weight"), dxn2, M, C, hid, hid, hid, C)
+            del dh
         ops.layernorm_bwd(dxn2, bs["xm"], dx, self.f32(p + "norm2.weight"), bs["m2"], bs["r2"], M, C, C, C, C,
                           dgamma=self.g(p + "norm2.weight"), dbeta=self.g(p + "norm2.bias"), accumulate=True)
         # dx now holds d(x_mid)

@@ -416,3 +416,37 @@ def test_transpose_cast(ops, dtype):
     ops.transpose_cast(w, out, R, Cc, ld_out=ld)
     assert torch.equal(out[:, :R], w.t().to(dtype))
     assert out[:, R:].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------ fused MLP (stages 1 / 2)
+@pytest.mark.parametrize("Cdim,hid,M,Bsz", [(64, 512, 3 * 400, 3), (128, 1024, 2 * 333, 2), (64, 512, 130, 1)])
+def test_fused_mlp(ops, Cdim, hid, M, Bsz):
+    bf = torch.bfloat16
+    x = rnd(M, Cdim, dtype=bf)
+    w1, w2 = rnd(hid, Cdim, dtype=bf, seed=1, scale=Cdim ** -0.5), rnd(Cdim, hid, dtype=bf, seed=2, scale=hid ** -0.5)
+    b1, b2 = 0.1 * rnd(hid, dtype=torch.float32, seed=3), 0.1 * rnd(Cdim, dtype=torch.float32, seed=4)
+    res = rnd(M, Cdim, dtype=torch.float32, seed=5)
+    scale = torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.9][:Bsz], device=dev())
+    rps = M // Bsz
+    out = torch.empty(M, Cdim, device=dev())
+    hbuf = torch.empty(M, hid, device=dev(), dtype=bf)
+    ops.mlp_fwd(x, w1, b1, w2, b2, res, out, M, Cdim, hid, row_scale=scale, rows_per_scale=rps, h_out=hbuf)
+    xr = x.float().requires_grad_(True)
+    w1r, w2r = w1.float().requires_grad_(True), w2.float().requires_grad_(True)
+    b1r, b2r = b1.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+    h = xr @ w1r.t() + b1r
+    rowscale = scale.repeat_interleave(rps)[:, None]
+    branch = (F.gelu(h) @ w2r.t() + b2r) * rowscale
+    ref = branch + res
+    assert maxrel(hbuf.float(), h) < 2e-2
+    assert maxrel(out - res, branch) < 2e-2
+    dy = rnd(M, Cdim, dtype=bf, seed=7)
+    ref.backward(dy.float())
+    dx = torch.empty(M, Cdim, device=dev(), dtype=bf)
+    ops.mlp_bwd_dx(x, dy, w1, w1.t().contiguous(), w2.t().contiguous(), b1, dx, M, Cdim, hid, row_scale=scale, rows_per_scale=rps)
+    assert maxrel(dx.float(), xr.grad) < 3e-2
+    dw1, db1 = torch.zeros(hid, Cdim, device=dev()), torch.zeros(hid, device=dev())
+    dw2, db2 = torch.zeros(Cdim, hid, device=dev()), torch.zeros(Cdim, device=dev())
+    ops.mlp_bwd_dw(x, dy, w1, w2.t().contiguous(), b1, dw1, db1, dw2, db2, M, Cdim, hid, row_scale=scale, rows_per_scale=rps)
+    for a, r, nm in ((dw1, w1r.grad, "dw1"), (db1, b1r.grad, "db1"), (dw2, w2r.grad, "dw2"), (db2, b2r.grad, "db2")):
+        assert maxrel(a, r) < 3e-2, nm
