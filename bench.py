@@ -92,36 +92,50 @@ def cpu_baseline(seconds=20.0):
                 sample=f"{n} train steps (fwd+loss+bwd, fp32) of 4 pairs 256x256+128 tok on the CPU oracle, {dt:.1f} s")
 
 
-def time_dominant_kernel(model, B, device):
-    """Roofline of the kernel family that dominates the step: the MLP fc1 GEMM of stage 1 (M = B*4224, N = 512, K = 64,
-    bias + erf-GELU epilogue storing activation and pre-activation) is the single largest launch; time it with HIP
-    events on torch's current stream, which is the stream mvlt_gemm_nt is launched on."""
-    from mvlt_amd import ops
-    S = model.store
-    M, N, K = B * (64 * 64 + 128), 512, 64
-    x = torch.randn(M, K, device=device).to(torch.bfloat16)
-    w = S.comp("block1.0.mlp.fc1.weight")
-    b = S.master("block1.0.mlp.fc1.bias")
-    out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
-    h = torch.empty_like(out)
+def _time_launch(fn, reps=20):
     for _ in range(3):
-        ops.gemm_nt(x, w, out, M, N, K, K, K, N, bias=b, act=1, H=h)
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    e0.record()
+    e0.record()                    # torch's current stream == the stream the C ABI launches on
     for _ in range(reps):
-        ops.gemm_nt(x, w, out, M, N, K, K, K, N, bias=b, act=1, H=h)
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    flops = 2.0 * M * N * K
-    bytes_alg = 2.0 * (M * K + N * K + 2 * M * N)            # read x, W; write gelu(h) and h (bf16)
+    return e0.elapsed_time(e1) / reps
+
+
+def time_dominant_kernel(model, B, device):
+    """Roofline of the dominant kernel of the step, `gemm_nt_kernel<bf16,128>` (~27 % of GPU time in profiles/): its
+    largest in-step launch is the MIM decoder's 192->192 conv3x3 at 32x32 (conv4 / conv_concat3 forward and their
+    input gradients, 8 launches per step) = a gathered-row GEMM with M = B*1024, N = 192, K = 9*192, MFMA-bound
+    (AI ~ 600 F/B).  Timed with HIP events on torch's current stream, which is the stream mvlt_gemm_nt launches on.
+    Also reported: the HBM-bound K=64 shape (stage-1 q/proj-like projection) of the same kernel family."""
+    from mvlt_amd import ops
+    from mvlt_amd._lib import conv3map
+    bf = torch.bfloat16
+    M, C = B * 32 * 32, 192
+    x = torch.randn(M, C, device=device).to(bf)
+    w = (torch.randn(C, 9 * C, device=device) * (9 * C) ** -0.5).to(bf)
+    out = torch.empty(M, C, device=device, dtype=torch.float32)
+    amap = conv3map(32, 32, 32 * 32, C)
+    ms = _time_launch(lambda: ops.gemm_nt(x, w, out, M, C, 9 * C, C, 9 * C, C, a_map=amap))
+    flops = 2.0 * M * C * 9 * C                           # algorithmic conv FLOPs (all 9 taps)
     tf = flops / (ms * 1e-3) / 1e12
-    gbs = bytes_alg / (ms * 1e-3) / 1e9
-    # this launch is HBM-bound by construction (AI = 2MNK / bytes ~ 31 F/B): report it against the HBM roof
-    return dict(kernel="gemm_nt_kernel<bf16,128> (stage-1 fc1 + GELU)", bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
-                unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, ms_per_launch=round(ms, 4),
-                tflops=round(tf, 1), algorithmic_bytes=bytes_alg)
+    # HBM-bound sibling: K = 64 projection with bias, bf16 in / bf16 out, M = B*4224 (stage-1 token matrix)
+    M2 = B * 4224
+    x2 = torch.randn(M2, 64, device=device).to(bf)
+    w2 = (torch.randn(64, 64, device=device) * 0.125).to(bf)
+    b2 = torch.randn(64, device=device)
+    o2 = torch.empty(M2, 64, device=device, dtype=bf)
+    ms2 = _time_launch(lambda: ops.gemm_nt(x2, w2, o2, M2, 64, 64, 64, 64, 64, bias=b2))
+    bytes2 = 2.0 * (2 * M2 * 64 + 64 * 64)
+    return dict(kernel="gemm_nt_kernel<bf16,128> (+<bf16,64> for columns 128..191): MIM conv3x3 192->192 @32x32 as 3x3-gather GEMM (M=B*1024, N=192, K=1728)",
+                bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_BF16_TFLOPS, 4),
+                traffic=None, ms_per_launch=round(ms, 4), algorithmic_flops=flops,
+                hbm_bound_sibling=dict(kernel="gemm_nt_kernel<bf16,64>: K=64 N=64 projection, M=B*4224", bound="hbm",
+                                       achieved=round(bytes2 / (ms2 * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                                       frac=round(bytes2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), ms_per_launch=round(ms2, 4),
+                                       algorithmic_bytes=bytes2))
 
 
 def main():

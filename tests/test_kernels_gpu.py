@@ -51,8 +51,9 @@ def test_gemm_nt_plain(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_gemm_nt_epilogues(ops, dtype):
-    M, N, K, Bsz = 384, 256, 128, 3
+@pytest.mark.parametrize("N", [256, 192, 320])        # 192 / 320 run as a 128-wide + a 64-wide launch (ops.gemm_nt)
+def test_gemm_nt_epilogues(ops, dtype, N):
+    M, K, Bsz = 384, 128, 3
     A, W = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.2)
     bias = rnd(N, dtype=torch.float32, seed=2)
     ref_pre = A.float() @ W.float().t() + bias
