@@ -104,12 +104,8 @@ def _time_launch(fn, reps=20):
     return e0.elapsed_time(e1) / reps
 
 
-def time_dominant_kernel(model, B, device):
-    """Roofline of the dominant kernel of the step, `gemm_nt_kernel<bf16,128>` (~27 % of GPU time in profiles/): its
-    largest in-step launch is the MIM decoder's 192->192 conv3x3 at 32x32 (conv4 / conv_concat3 forward and their
-    input gradients, 8 launches per step) = a gathered-row GEMM with M = B*1024, N = 192, K = 9*192, MFMA-bound
-    (AI ~ 600 F/B).  Timed with HIP events on torch's current stream, which is the stream mvlt_gemm_nt launches on.
-    Also reported: the HBM-bound K=64 shape (stage-1 q/proj-like projection) of the same kernel family."""
+def roofline_cases(B, device):
+    """(name, launch closure, algorithmic work) of the two roofline launches; also used by tools/roofline_launch.py."""
     from mvlt_amd import ops
     from mvlt_amd._lib import conv3map
     bf = torch.bfloat16
@@ -118,24 +114,38 @@ def time_dominant_kernel(model, B, device):
     w = (torch.randn(C, 9 * C, device=device) * (9 * C) ** -0.5).to(bf)
     out = torch.empty(M, C, device=device, dtype=torch.float32)
     amap = conv3map(32, 32, 32 * 32, C)
-    ms = _time_launch(lambda: ops.gemm_nt(x, w, out, M, C, 9 * C, C, 9 * C, C, a_map=amap))
-    flops = 2.0 * M * C * 9 * C                           # algorithmic conv FLOPs (all 9 taps)
-    tf = flops / (ms * 1e-3) / 1e12
-    # HBM-bound sibling: K = 64 projection with bias, bf16 in / bf16 out, M = B*4224 (stage-1 token matrix)
     M2 = B * 4224
     x2 = torch.randn(M2, 64, device=device).to(bf)
     w2 = (torch.randn(64, 64, device=device) * 0.125).to(bf)
     b2 = torch.randn(64, device=device)
     o2 = torch.empty(M2, 64, device=device, dtype=bf)
-    ms2 = _time_launch(lambda: ops.gemm_nt(x2, w2, o2, M2, 64, 64, 64, 64, 64, bias=b2))
-    bytes2 = 2.0 * (2 * M2 * 64 + 64 * 64)
-    return dict(kernel="gemm_nt_kernel<bf16,128> (+<bf16,64> for columns 128..191): MIM conv3x3 192->192 @32x32 as 3x3-gather GEMM (M=B*1024, N=192, K=1728)",
+    return [("conv192", lambda: ops.gemm_nt(x, w, out, M, C, 9 * C, C, 9 * C, C, a_map=amap), 2.0 * M * C * 9 * C),
+            ("proj64", lambda: ops.gemm_nt(x2, w2, o2, M2, 64, 64, 64, 64, 64, bias=b2), 2.0 * (2 * M2 * 64 + 64 * 64))]
+
+
+def time_dominant_kernel(model, B, device):
+    """Roofline of the dominant kernel of the step, `gemm_nt_kernel<bf16,128>` (~21 % of GPU time in profiles/): its
+    largest in-step launch is the MIM decoder's 192->192 conv3x3 at 32x32 (conv4 / conv_concat3 forward and their
+    input gradients) = a gathered-row GEMM with M = B*1024, N = 192, K = 9*192, MFMA-bound (AI ~ 575 F/B).  Timed
+    with HIP events on torch's current stream, which is the stream mvlt_gemm_nt launches on.  `traffic` = HBM bytes
+    per launch from the committed PMC passes (profiles/*_roofline_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, collected
+    offline because counters cannot be read inside this process).  Also reported: the HBM-bound K=64 shape
+    (stage-1 q/proj-like projection) of the same kernel family."""
+    (_, f1, flops), (_, f2, bytes2) = roofline_cases(B, device)
+    ms, ms2 = _time_launch(f1), _time_launch(f2)
+    tf = flops / (ms * 1e-3) / 1e12
+    traffic = traffic2 = None
+    tj = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_roofline_traffic.json")) if B == 256 else []
+    if tj:
+        t = json.load(open(os.path.join(ROOT, "profiles", tj[-1])))
+        traffic, traffic2 = t.get("conv192", {}).get("hbm_bytes"), t.get("proj64", {}).get("hbm_bytes")
+    return dict(kernel="gemm_nt_kernel<bf16,128>: MIM conv3x3 192->192 @32x32 as 3x3-gather GEMM (M=B*1024, N=192, K=1728)",
                 bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_BF16_TFLOPS, 4),
-                traffic=None, ms_per_launch=round(ms, 4), algorithmic_flops=flops,
+                traffic=traffic, ms_per_launch=round(ms, 4), algorithmic_flops=flops,
                 hbm_bound_sibling=dict(kernel="gemm_nt_kernel<bf16,64>: K=64 N=64 projection, M=B*4224", bound="hbm",
                                        achieved=round(bytes2 / (ms2 * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                        frac=round(bytes2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), ms_per_launch=round(ms2, 4),
-                                       algorithmic_bytes=bytes2))
+                                       algorithmic_bytes=bytes2, traffic=traffic2))
 
 
 def main():
