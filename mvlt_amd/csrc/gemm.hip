@@ -527,6 +527,288 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
       }
 }
 
+// ------------------------------------------------------------------------------------------------ TN, bf16, LDS-DMA
+// Same contract as gemm_tn_kernel<bf16,BN>, different data path: tiles stay in their natural [m][n] layout and are
+// filled by global_load_lds_dwordx4 (no VGPR round trip, no ds_write: the 2-byte transposing stores of the kernel
+// above cost as many LDS cycles as the MFMAs they feed); the MFMA fragments (8 consecutive m of one n per lane) come
+// from two ds_read_b64_tr_b16 each.  LDS-DMA writes lane-linear (base + 16*lane), so the bank swizzle is applied to
+// the SOURCE column chunk: LDS slot s of tile row m holds global 16-B chunk s ^ (h(m) << 1), h spreading the 8 rows a
+// 32-lane read group touches (m..m+3 and m+8..m+11) over the eight 32-B bank windows.  Rows past m_end / columns past
+// N / out-of-image 3x3 taps are zero-filled by the owning lane.  Two buffers, one barrier per 64-row tile.  Column sums
+// (bias gradients) are one extra MFMA against an all-ones fragment, shared between the two waves of a tile row.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 tr_frag(const char* lds_addr, int rowb) {
+  typedef __attribute__((address_space(3))) s16x4* lptr;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_addr));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_addr + 4 * rowb));
+  unsigned long long l = __builtin_bit_cast(unsigned long long, lo), h = __builtin_bit_cast(unsigned long long, hi);
+  return u32x4{(unsigned)l, (unsigned)(l >> 32), (unsigned)h, (unsigned)(h >> 32)};
+}
+// LDS-DMA of 16 B per lane to lds_wave_base + 16*lane_id.  Inline asm on purpose: for the builtin hipcc orders every
+// later LDS read after the DMA with s_waitcnt vmcnt(0) (it cannot prove the two buffers disjoint), which serialises
+// the prefetch behind the MFMAs; the kernel waits vmcnt(0) itself, once per tile, in front of its barrier.
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_wave_base) : "memory");
+}
+// Logical row m of a row map as (b, y, x) digits, advanced by a fixed stride with carries instead of divisions: the
+// loader of a thread visits rows m0, m0+64, m0+128, ... and one division per row would cost more than the MFMAs it
+// feeds.  plain rows: x = m; batch-strided rows: (b, x) base rows_per_batch; patch / 3x3 maps: (b, y, x) in the
+// output grid.
+struct RowIt { int b, y, x; };
+struct RowStep { int w, h, db, dy, dx; };
+__device__ __forceinline__ RowStep row_step(const RowMap& rm, int delta) {
+  RowStep s;
+  if (rm.mode == 0) {
+    if (rm.rows_per_batch == 0) { s.w = 0x7fffffff; s.h = 1; s.db = 0; s.dy = 0; s.dx = delta; }
+    else { s.w = rm.rows_per_batch; s.h = 1; s.db = delta / s.w; s.dy = 0; s.dx = delta - s.db * s.w; }
+  } else {
+    s.w = rm.w_out; s.h = rm.hw_out / rm.w_out;
+    s.db = delta / rm.hw_out;
+    int rem = delta - s.db * rm.hw_out;
+    s.dy = rem / s.w; s.dx = rem - s.dy * s.w;
+  }
+  return s;
+}
+__device__ __forceinline__ RowIt row_init(const RowMap& rm, int m) {
+  RowIt it;
+  if (rm.mode == 0) {
+    if (rm.rows_per_batch == 0) { it.b = 0; it.y = 0; it.x = m; }
+    else { it.b = m / rm.rows_per_batch; it.y = 0; it.x = m - it.b * rm.rows_per_batch; }
+  } else {
+    it.b = m / rm.hw_out;
+    int rem = m - it.b * rm.hw_out;
+    it.y = rem / rm.w_out; it.x = rem - it.y * rm.w_out;
+  }
+  return it;
+}
+__device__ __forceinline__ void row_advance(RowIt& it, const RowStep& s) {
+  it.x += s.dx;
+  int c = it.x >= s.w;
+  it.x -= c ? s.w : 0;
+  it.y += s.dy + c;
+  int c2 = it.y >= s.h;
+  it.y -= c2 ? s.h : 0;
+  it.b += s.db + c2;
+}
+// physical row for the thread's column segment (tap dy,dx for the 3x3 map; seg_rows for the patch map); false = zero.
+// MODE is a template parameter so that the per-tile loader has no mode branches (plain rows are mode 0 with b = 0).
+template <int MODE>
+__device__ __forceinline__ bool row_phys(const RowMap& rm, const RowIt& it, int tap_dy, int tap_dx, int seg_rows, int& phys) {
+  if constexpr (MODE == 0) {
+    phys = it.b * rm.batch_stride + rm.offset + it.x;
+    return true;
+  } else if constexpr (MODE == 1) {
+    phys = it.b * rm.tokens_in + (it.y * rm.r) * rm.w_in + it.x * rm.r + seg_rows;
+    return true;
+  } else {
+    int y = it.y + tap_dy, x = it.x + tap_dx;
+    phys = it.b * rm.tokens_in + y * rm.w_in + x;
+    return (unsigned)y < (unsigned)rm.h_in && (unsigned)x < (unsigned)rm.w_in;
+  }
+}
+
+// geometry of one [64 m][W n] bf16 tile (W = 128 or 64): 16-B slots per row, rows per 256-thread pass, bank hash
+template <int W> struct DmaTile {
+  static constexpr int CH = W / 8, RPP = NTHREADS / CH, IT = TBK / RPP, ROWB = W * 2, BYTES = TBK * ROWB;
+  // 256-B rows (W=128): rows m..m+3, m+8..m+11 of a read group all start on bank 0 -> spread by (m&3, bit 3);
+  // 128-B rows (W=64): bit 0 of the row already picks the bank half -> spread by (bit 1, bit 3)
+  static __device__ __forceinline__ int h(int row) {
+    return W == 128 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+  }
+  static __device__ __forceinline__ int frag_off(int frow, int window, int L) {
+    return frow * ROWB + ((window ^ h(frow)) << 5) + ((L & 3) << 3);
+  }
+};
+
+// zero source for slots whose row / column / 3x3 tap does not exist: every thread issues the same number of DMAs per
+// tile (the pipeline below counts them with s_waitcnt vmcnt(N)); 64 KB so that the reads spread over L2 channels
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[65536];
+
+template <int BMT, int BN, int BMODE, int NS>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_dma_kernel(mvlt_gemm_tn_args p, int m_per_split, int t1, int t2, int splits) {
+  using TA = DmaTile<BMT>;
+  using TB = DmaTile<BN>;
+  constexpr int WM = BMT / 2, TM_ = WM / 16;             // wave tile rows: 64 (4 fragments) or 32 (2)
+  constexpr int WN = BN / 2, TN_ = WN / 16;
+  constexpr int STAGE = TA::BYTES + TB::BYTES;
+  constexpr int LPT = TA::IT + TB::IT;                    // DMA instructions per thread per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // [NS][A tile | B tile]
+
+  // XCD-aware order: workgroup b runs on XCD b % 8.  All t1*t2 output tiles of one m-split read the same rows of A
+  // and B, so a whole split is given to ONE XCD (its tiles are consecutive in that XCD's queue and co-resident) and
+  // the operands come through that XCD's L2 once instead of once per tile.
+  // With fewer than 8 splits (M small, many output tiles: the vocabulary decoder) the natural order is kept instead:
+  // x fastest, so the tiles sharing an A column slab (same x) meet on XCD x % 8.
+  const int txy = t1 * t2;
+  int bz, xy;
+  if (splits >= 8) {
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    const int zq = kq / txy;
+    xy = kq - zq * txy;
+    bz = zq * 8 + xcd;
+    if (bz >= splits) return;
+  } else {
+    bz = blockIdx.x / txy;
+    xy = blockIdx.x - bz * txy;
+  }
+  const int bx = xy % t1, by = xy / t1;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n1_0 = bx * BMT, n2_0 = by * BN;
+  const unsigned smem_lds = (unsigned)(uintptr_t)smem;      // LDS byte address of the dynamic segment
+  const int m_begin = bz * m_per_split;
+  const int m_end = min(p.M, m_begin + m_per_split);
+  const RowMap amap = to_rowmap(p.a_map), bmap = to_rowmap(p.b_map);
+  // bias gradients: every tile row (column) of workgroups sees the same A (B) rows; the t2 (t1) workgroups that share
+  // them take turns, one 64-row tile each, so the extra MFMAs are spread evenly over the launch
+  const bool do_colsum = p.colsum_a != nullptr;
+  const bool do_colsum_b = p.colsum_b != nullptr;
+
+  // ---- loader geometry (fixed per thread): LDS slot -> source column chunk
+  const int a_row0 = tid / TA::CH;                                        // + RPP * j
+  const int a_col = n1_0 + ((((tid % TA::CH)) ^ (TA::h(a_row0) << 1)) << 3);
+  const bool a_col_ok = a_col < p.N1;
+  const int b_row0 = tid / TB::CH;
+  const int b_colg = n2_0 + ((((tid % TB::CH)) ^ (TB::h(b_row0) << 1)) << 3);
+  const bool b_col_ok = b_colg < p.N2;
+  int b_col = b_colg, b_seg_rows = 0, tap_dy = 0, tap_dx = 0;
+  if constexpr (BMODE != 0) {
+    const int b_seg = b_colg / bmap.c_seg;
+    b_col = b_colg - b_seg * bmap.c_seg;
+    if constexpr (BMODE == 1) b_seg_rows = rowmap_seg(bmap, b_seg);
+    else { tap_dy = b_seg / 3 - 1; tap_dx = b_seg - (b_seg / 3) * 3 - 1; }
+  }
+  const char* zsrc = (const char*)g_zero_page + ((tid * 16 + (blockIdx.x & 15) * 4096) & 65535);
+  const char* a_src = (const char*)p.A + 2 * a_col;            // + physical row * row bytes
+  const char* b_src = (const char*)p.B + 2 * b_col;
+  const unsigned a_rowb = 2u * (unsigned)p.lda, b_rowb = 2u * (unsigned)p.ldb;
+  const RowStep astep = row_step(amap, TBK), bstep = row_step(bmap, TBK);
+  RowIt ait[TA::IT], bit[TB::IT];
+#pragma unroll
+  for (int j = 0; j < TA::IT; ++j) ait[j] = row_init(amap, m_begin + j * TA::RPP + a_row0);
+#pragma unroll
+  for (int j = 0; j < TB::IT; ++j) bit[j] = row_init(bmap, m_begin + j * TB::RPP + b_row0);
+
+  // tiles are issued in order m_begin, m_begin + 64, ... (the row iterators advance by one tile per call); calls past
+  // the last tile still issue their LPT DMAs (from the zero page, into a ring slot nobody reads) to keep vmcnt uniform
+  auto issue = [&](int mt, int slot) {
+#pragma unroll
+    for (int j = 0; j < TA::IT; ++j) {
+      int m = mt + j * TA::RPP + a_row0;
+      int phys;
+      bool ok = row_phys<0>(amap, ait[j], 0, 0, 0, phys) && m < m_end && a_col_ok;
+      row_advance(ait[j], astep);
+      const int woff = slot * STAGE + (j * NTHREADS + wave * 64) * 16;
+      glds16(ok ? a_src + (unsigned long long)(unsigned)phys * a_rowb : zsrc, __builtin_amdgcn_readfirstlane(smem_lds + woff));
+    }
+#pragma unroll
+    for (int j = 0; j < TB::IT; ++j) {
+      int m = mt + j * TB::RPP + b_row0;
+      int phys;
+      bool ok = row_phys<BMODE>(bmap, bit[j], tap_dy, tap_dx, b_seg_rows, phys) && m < m_end && b_col_ok;
+      row_advance(bit[j], bstep);
+      const int woff = slot * STAGE + TA::BYTES + (j * NTHREADS + wave * 64) * 16;
+      glds16(ok ? b_src + (unsigned long long)(unsigned)phys * b_rowb : zsrc, __builtin_amdgcn_readfirstlane(smem_lds + woff));
+    }
+  };
+
+  // ---- fragment geometry: lane (g = lane>>4, L = lane&15) supplies tile row 8g + (L>>2), 8-B piece (L&3) of the
+  //      16-column window of the n tile; second read 4 rows below; ks adds 32 rows
+  const int g = lane >> 4, L = lane & 15;
+  const int frow = 8 * g + (L >> 2);
+  int aoff[TM_], boff[TN_];
+#pragma unroll
+  for (int i = 0; i < TM_; ++i) aoff[i] = TA::frag_off(frow, wm * TM_ + i, L);
+#pragma unroll
+  for (int j = 0; j < TN_; ++j) boff[j] = TB::frag_off(frow, wn * TN_ + j, L);
+
+  f32x4 acc[TM_][TN_];
+#pragma unroll
+  for (int i = 0; i < TM_; ++i)
+#pragma unroll
+    for (int j = 0; j < TN_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 cs[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  bf16* const nb = nullptr;
+
+  // NS-deep ring: tile t+NS-1 is issued while tile t is consumed; the wait leaves the NS-2 younger tiles in flight
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st) issue(m_begin + st * TBK, st);
+  int slot = 0, islot = NS - 1;
+  for (int mt = m_begin; mt < m_end; mt += TBK) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (NS - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();    // tile `mt` has landed for every wave; everyone is done reading the slot refilled next
+    asm volatile("" ::: "memory");
+    issue(mt + (NS - 1) * TBK, islot);
+    islot = islot + 1 == NS ? 0 : islot + 1;
+    const char* sA = smem + slot * STAGE;
+    const char* sB = sA + TA::BYTES;
+    slot = slot + 1 == NS ? 0 : slot + 1;
+    const int cs_turn = ((mt - m_begin) / TBK) % (do_colsum ? t2 : t1);
+#pragma unroll
+    for (int ks = 0; ks < TBK / 32; ++ks) {
+      u32x4 fa[TM_], fb[TN_];
+#pragma unroll
+      for (int i = 0; i < TM_; ++i) fa[i] = tr_frag(sA + aoff[i] + ks * 32 * TA::ROWB, TA::ROWB);
+#pragma unroll
+      for (int j = 0; j < TN_; ++j) fb[j] = tr_frag(sB + boff[j] + ks * 32 * TB::ROWB, TB::ROWB);
+#pragma unroll
+      for (int i = 0; i < TM_; ++i)
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) mma16(acc[i][j], fa[i], fa[i], fb[j], fb[j], nb);
+      // column sums: the TM_ (TN_) fragments of a tile row (column) are shared by two waves; each takes half of them
+      if (do_colsum && cs_turn == by) {
+#pragma unroll
+        for (int t = 0; t < TM_ / 2; ++t) {
+          if (wn == 0) mma16(cs[t], fa[t], fa[t], ones, ones, nb);
+          else mma16(cs[t], fa[TM_ / 2 + t], fa[TM_ / 2 + t], ones, ones, nb);
+        }
+      }
+      if (do_colsum_b && cs_turn == bx) {
+#pragma unroll
+        for (int t = 0; t < TN_ / 2; ++t) {
+          if (wm == 0) mma16(cs[t], ones, ones, fb[t], fb[t], nb);
+          else mma16(cs[t], ones, ones, fb[TN_ / 2 + t], fb[TN_ / 2 + t], nb);
+        }
+      }
+    }
+  }
+
+  const int fr = lane & 15, fg = lane >> 4;
+  // column sums leave through LDS so that a workgroup sends one 64-lane atomic per 64 columns: every workgroup of the
+  // launch adds into the same few cache lines, and those requests serialise at the memory side
+  if (do_colsum || do_colsum_b) {
+    float* s_cs = (float*)smem;
+    __syncthreads();                 // all tile reads are done (uniform branch: by / bx are per workgroup)
+    if (do_colsum && fr == 0) {      // cs[t][r]: tile row (wn*TM_/2+t)*16 + 4*fg + r, identical in every lane column
+#pragma unroll
+      for (int t = 0; t < TM_ / 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_cs[wm * WM + (wn * (TM_ / 2) + t) * 16 + 4 * fg + r] = cs[t][r];
+    }
+    if (do_colsum_b && fg == 0) {    // cs[t][0]: tile column (wm*TN_/2+t)*16 + fr
+#pragma unroll
+      for (int t = 0; t < TN_ / 2; ++t) s_cs[wn * WN + (wm * (TN_ / 2) + t) * 16 + fr] = cs[t][0];
+    }
+    __syncthreads();
+    if (do_colsum && tid < BMT && n1_0 + tid < p.N1) atomicAdd(&p.colsum_a[n1_0 + tid], s_cs[tid]);
+    if (do_colsum_b && tid < BN && n2_0 + tid < p.N2) atomicAdd(&p.colsum_b[n2_0 + tid], s_cs[tid]);
+  }
+#pragma unroll
+  for (int i = 0; i < TM_; ++i)
+#pragma unroll
+    for (int j = 0; j < TN_; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int n1 = n1_0 + wm * WM + i * 16 + 4 * fg + r;
+        int n2 = n2_0 + wn * WN + j * 16 + fr;
+        if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.trans_c ? &p.C[(long)n2 * p.ldc + n1] : &p.C[(long)n1 * p.ldc + n2], acc[i][j][r]);
+      }
+}
+
 int check_rowmap(const mvlt_rowmap& m, const char* who) {
   if (m.mode == 0) {
     MVLT_REQUIRE(m.rows_per_batch >= 0, "%s: rows_per_batch < 0", who);
@@ -598,10 +880,41 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
   MVLT_REQUIRE(a->b_map.mode == 0 || a->N2 == a->b_map.r * a->b_map.r * a->b_map.c_seg, "mvlt_gemm_tn: gather N2 != r*r*c_seg");
   if (a->M == 0) return MVLT_OK;
   hipStream_t s = (hipStream_t)stream;
+  const int mtiles = (a->M + TBK - 1) / TBK;
+  if (a->dtype == 0 && a->M < (1 << 24) && !getenv("MVLT_TN_LEGACY")) {
+    // LDS-DMA kernel: A tile 128 or 64 wide, B tile 128 or 64 wide; ~1024 workgroups, splits a multiple of the 8 XCDs
+    const int bmt = a->N1 <= 64 ? 64 : 128, bn = a->N2 <= 64 ? 64 : 128;
+    const int t1 = (a->N1 + bmt - 1) / bmt, t2 = (a->N2 + bn - 1) / bn;
+    int splits = a->splits;
+    if (splits <= 0) {
+      // 2 workgroups per CU in one round: every extra split is another N1*N2 fp32 atomics through the fabric
+      splits = (512 + t1 * t2 - 1) / (t1 * t2);
+      if (splits >= 8) splits = (splits + 4) / 8 * 8;
+      if (splits > 4096) splits = 4096;
+    }
+    if (splits > mtiles) splits = mtiles;
+    if (splits < 1) splits = 1;
+    int m_per_split = ((mtiles + splits - 1) / splits) * TBK;
+    splits = (a->M + m_per_split - 1) / m_per_split;
+    const int ns = (bmt + bn == 256) ? 2 : (bmt + bn == 192) ? 3 : 4;      // 64 / 72 / 64 KB of LDS: 2 workgroups per CU
+    const size_t lds = (size_t)ns * TBK * (bmt + bn) * 2;
+    dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * t1 * t2)), block(NTHREADS);
+#define MVLT_TN_LAUNCH(BMT_, BN_, NS_)                                                                                          \
+  do {                                                                                                                         \
+    if (a->b_map.mode == 0) hipLaunchKernelGGL((gemm_tn_dma_kernel<BMT_, BN_, 0, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits);      \
+    else if (a->b_map.mode == 1) hipLaunchKernelGGL((gemm_tn_dma_kernel<BMT_, BN_, 1, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits); \
+    else hipLaunchKernelGGL((gemm_tn_dma_kernel<BMT_, BN_, 2, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits);                         \
+  } while (0)
+    if (bmt == 128 && bn == 128) MVLT_TN_LAUNCH(128, 128, 2);
+    else if (bmt == 128) MVLT_TN_LAUNCH(128, 64, 3);
+    else if (bn == 128) MVLT_TN_LAUNCH(64, 128, 3);
+    else MVLT_TN_LAUNCH(64, 64, 4);
+#undef MVLT_TN_LAUNCH
+    return mvlt_check_launch("mvlt_gemm_tn");
+  }
   const bool narrow = a->N2 <= 64;
   const int bn = narrow ? 64 : 128;
   const int t1 = (a->N1 + BM - 1) / BM, t2 = (a->N2 + bn - 1) / bn;
-  const int mtiles = (a->M + TBK - 1) / TBK;
   int splits = a->splits;
   if (splits <= 0) {
     splits = (1024 + t1 * t2 - 1) / (t1 * t2);       // ~4 workgroups per CU in total
