@@ -55,6 +55,140 @@ __device__ __forceinline__ float load_out(const void* base, long idx, int out_fp
   return out_fp32 ? ((const float*)base)[idx] : (float)((const bf16*)base)[idx];
 }
 
+// ---------------- NT epilogue (shared by the register-staged and the LDS-DMA main loops).  Must be entered after a
+// workgroup barrier that follows the last operand-tile read: the staging below reuses the tile LDS.
+template <typename T, int BN>
+__device__ __forceinline__ void nt_epilogue(const mvlt_gemm_nt_args& p, f32x4 (&acc)[4][BN / 32], char* smem, int m0, int n0,
+                                            int wave, int lane) {
+  constexpr int WN = BN / 2;
+  constexpr int TN_ = WN / 16;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  // ---------------- epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + 4*fg + r][n0 + wn*WN + j*16 + fr]
+  // The MFMA C layout gives each lane one column and 4 rows: stored directly that is 2-byte pieces, 32 B per row.
+  // Instead every wave parks its tile in the (now free) staging LDS, 32 rows at a time, and re-reads it row-major:
+  // each lane then owns 8 consecutive columns of one row, so bias / GELU / residual / H traffic and the C store are
+  // 16-byte accesses that cover a full 128-B (bf16) or 256-B (fp32) row segment per 8 lanes.
+  const RowMap cmap = to_rowmap(p.c_map);
+  const int ofp32 = p.out_dtype;
+  constexpr int LDW = WN + 4;                         // fp32 words per staged row (pad: <=2-way ds_write conflicts)
+  constexpr int CPR = WN / 8;                         // 8-column chunks per row
+  constexpr int RPI = 64 / CPR;                       // rows covered per wave iteration
+  float* stage = (float*)smem + wave * 32 * LDW;
+  const bool vec_ok = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.R || ((uintptr_t)p.R & 15) == 0) &&
+                      (!p.H || ((uintptr_t)p.H & 15) == 0);
+  // this lane's 8 output columns are the same in every iteration: fetch their bias once (two 16-B loads when aligned)
+  const int nc_lane = n0 + wn * WN + (lane % CPR) * 8;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  if (p.bias) {
+    if (nc_lane + 8 <= p.N && (((uintptr_t)p.bias & 15) == 0)) {
+      f32x4 b0 = *(const f32x4*)(p.bias + nc_lane), b1 = *(const f32x4*)(p.bias + nc_lane + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (nc_lane + e < p.N) bias8[e] = p.bias[nc_lane + e];
+    }
+  }
+#pragma unroll
+  // (the K loop ended with a workgroup barrier: nobody reads the operand tiles any more.  From here on every wave
+  //  touches only its own staging slice, so only wave-level ordering is needed and the waves drift apart freely.)
+  for (int half = 0; half < 2; ++half) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < TN_; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(ii * 16 + 4 * fg + r) * LDW + j * 16 + fr] = acc[half * 2 + ii][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int rl = it * RPI + lane / CPR;           // row inside this 32-row half
+      const int ch = lane % CPR;
+      const int m = m0 + wm * 64 + half * 32 + rl;
+      const int nc = n0 + wn * WN + ch * 8;           // first of this lane's 8 columns
+      if (m >= p.M || nc >= p.N) continue;
+      f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      int seg_rows = 0, ncol = nc;
+      if (cmap.mode == 1) {                           // scatter back through the patch map (dgrad of a kernel==stride conv)
+        int seg = nc / cmap.c_seg;
+        ncol = nc - seg * cmap.c_seg;
+        seg_rows = rowmap_seg(cmap, seg);
+      }
+      const long idx = (rowmap_base(cmap, m) + seg_rows) * p.ldc + ncol;
+      const bool full = vec_ok && (nc + 8 <= p.N);
+      const float rs = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+      if (full) {
+        auto load8 = [&](const void* base, float* o) {
+          if (ofp32) {
+            f32x4 a = *(const f32x4*)((const float*)base + idx), b = *(const f32x4*)((const float*)base + idx + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+          } else {
+            bf16x8 a = *(const bf16x8*)((const bf16*)base + idx);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (float)a[e];
+          }
+        };
+        auto store8 = [&](void* base, const float* o) {
+          if (ofp32) {
+            *(f32x4*)((float*)base + idx) = f32x4{o[0], o[1], o[2], o[3]};
+            *(f32x4*)((float*)base + idx + 4) = f32x4{o[4], o[5], o[6], o[7]};
+          } else {
+            bf16x8 a;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = (bf16)o[e];
+            *(bf16x8*)((bf16*)base + idx) = a;
+          }
+        };
+        if (p.act == 1) {
+          if (p.H) store8(p.H, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        } else if (p.act == 2) {
+          float h8[8];
+          load8(p.H, h8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(h8[e]);
+        }
+        if (p.row_scale) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= rs;
+        }
+        if (p.R) {
+          float r8[8];
+          load8(p.R, r8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r8[e];
+        }
+        store8(p.C, v);
+      } else {                                        // ragged N (vocabulary tail, 2/48/122-way heads) or unaligned rows
+        for (int e = 0; e < 8; ++e) {
+          if (nc + e >= p.N) break;
+          float x = v[e];
+          if (p.act == 1) {
+            if (p.H) store_out<T>(p.H, idx + e, x, ofp32);
+            x = gelu_erf(x);
+          } else if (p.act == 2) {
+            x *= gelu_erf_grad(load_out(p.H, idx + e, ofp32));
+          }
+          x *= rs;
+          if (p.R) x += load_out(p.R, idx + e, ofp32);
+          store_out<T>(p.C, idx + e, x, ofp32);
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ NT
 template <typename T, int BN>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p, int nbuf) {
@@ -198,129 +332,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p, 
     __syncthreads();
   }
 
-  // ---------------- epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + 4*fg + r][n0 + wn*WN + j*16 + fr]
-  // The MFMA C layout gives each lane one column and 4 rows: stored directly that is 2-byte pieces, 32 B per row.
-  // Instead every wave parks its tile in the (now free) staging LDS, 32 rows at a time, and re-reads it row-major:
-  // each lane then owns 8 consecutive columns of one row, so bias / GELU / residual / H traffic and the C store are
-  // 16-byte accesses that cover a full 128-B (bf16) or 256-B (fp32) row segment per 8 lanes.
-  const RowMap cmap = to_rowmap(p.c_map);
-  const int ofp32 = p.out_dtype;
-  constexpr int LDW = WN + 4;                         // fp32 words per staged row (pad: <=2-way ds_write conflicts)
-  constexpr int CPR = WN / 8;                         // 8-column chunks per row
-  constexpr int RPI = 64 / CPR;                       // rows covered per wave iteration
-  float* stage = (float*)smem + wave * 32 * LDW;
-  const bool vec_ok = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.R || ((uintptr_t)p.R & 15) == 0) &&
-                      (!p.H || ((uintptr_t)p.H & 15) == 0);
-  // this lane's 8 output columns are the same in every iteration: fetch their bias once (two 16-B loads when aligned)
-  const int nc_lane = n0 + wn * WN + (lane % CPR) * 8;
-  float bias8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-  if (p.bias) {
-    if (nc_lane + 8 <= p.N && (((uintptr_t)p.bias & 15) == 0)) {
-      f32x4 b0 = *(const f32x4*)(p.bias + nc_lane), b1 = *(const f32x4*)(p.bias + nc_lane + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) if (nc_lane + e < p.N) bias8[e] = p.bias[nc_lane + e];
-    }
-  }
-#pragma unroll
-  // (the K loop ended with a workgroup barrier: nobody reads the operand tiles any more.  From here on every wave
-  //  touches only its own staging slice, so only wave-level ordering is needed and the waves drift apart freely.)
-  for (int half = 0; half < 2; ++half) {
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < TN_; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) stage[(ii * 16 + 4 * fg + r) * LDW + j * 16 + fr] = acc[half * 2 + ii][j][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
-      const int rl = it * RPI + lane / CPR;           // row inside this 32-row half
-      const int ch = lane % CPR;
-      const int m = m0 + wm * 64 + half * 32 + rl;
-      const int nc = n0 + wn * WN + ch * 8;           // first of this lane's 8 columns
-      if (m >= p.M || nc >= p.N) continue;
-      f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
-      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      int seg_rows = 0, ncol = nc;
-      if (cmap.mode == 1) {                           // scatter back through the patch map (dgrad of a kernel==stride conv)
-        int seg = nc / cmap.c_seg;
-        ncol = nc - seg * cmap.c_seg;
-        seg_rows = rowmap_seg(cmap, seg);
-      }
-      const long idx = (rowmap_base(cmap, m) + seg_rows) * p.ldc + ncol;
-      const bool full = vec_ok && (nc + 8 <= p.N);
-      const float rs = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.0f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-      if (full) {
-        auto load8 = [&](const void* base, float* o) {
-          if (ofp32) {
-            f32x4 a = *(const f32x4*)((const float*)base + idx), b = *(const f32x4*)((const float*)base + idx + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
-          } else {
-            bf16x8 a = *(const bf16x8*)((const bf16*)base + idx);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (float)a[e];
-          }
-        };
-        auto store8 = [&](void* base, const float* o) {
-          if (ofp32) {
-            *(f32x4*)((float*)base + idx) = f32x4{o[0], o[1], o[2], o[3]};
-            *(f32x4*)((float*)base + idx + 4) = f32x4{o[4], o[5], o[6], o[7]};
-          } else {
-            bf16x8 a;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = (bf16)o[e];
-            *(bf16x8*)((bf16*)base + idx) = a;
-          }
-        };
-        if (p.act == 1) {
-          if (p.H) store8(p.H, v);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-        } else if (p.act == 2) {
-          float h8[8];
-          load8(p.H, h8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(h8[e]);
-        }
-        if (p.row_scale) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= rs;
-        }
-        if (p.R) {
-          float r8[8];
-          load8(p.R, r8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += r8[e];
-        }
-        store8(p.C, v);
-      } else {                                        // ragged N (vocabulary tail, 2/48/122-way heads) or unaligned rows
-        for (int e = 0; e < 8; ++e) {
-          if (nc + e >= p.N) break;
-          float x = v[e];
-          if (p.act == 1) {
-            if (p.H) store_out<T>(p.H, idx + e, x, ofp32);
-            x = gelu_erf(x);
-          } else if (p.act == 2) {
-            x *= gelu_erf_grad(load_out(p.H, idx + e, ofp32));
-          }
-          x *= rs;
-          if (p.R) x += load_out(p.R, idx + e, ofp32);
-          store_out<T>(p.C, idx + e, x, ofp32);
-        }
-      }
-    }
-  }
+  nt_epilogue<T, BN>(p, acc, smem, m0, n0, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ TN (wgrad)
@@ -692,8 +704,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_dma_kernel(mvlt_gemm_tn_args
 #pragma unroll
   for (int j = 0; j < TB::IT; ++j) bit[j] = row_init(bmap, m_begin + j * TB::RPP + b_row0);
 
-  // tiles are issued in order m_begin, m_begin + 64, ... (the row iterators advance by one tile per call); calls past
-  // the last tile still issue their LPT DMAs (from the zero page, into a ring slot nobody reads) to keep vmcnt uniform
+  // tiles are issued in order m_begin, m_begin + 64, ... (the row iterators advance by one tile per call)
   auto issue = [&](int mt, int slot) {
 #pragma unroll
     for (int j = 0; j < TA::IT; ++j) {
@@ -734,15 +745,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_dma_kernel(mvlt_gemm_tn_args
   const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
   bf16* const nb = nullptr;
 
-  // NS-deep ring: tile t+NS-1 is issued while tile t is consumed; the wait leaves the NS-2 younger tiles in flight
+  // NS-deep ring: tile t+NS-1 is issued while tile t is consumed; the wait leaves the NS-2 younger tiles in flight.
+  // Near the end fewer tiles are in flight than the count assumes, so the wait falls back to vmcnt(0) there; nothing
+  // is issued past the last tile, so no DMA is outstanding when the epilogue reuses the LDS.
 #pragma unroll
-  for (int st = 0; st < NS - 1; ++st) issue(m_begin + st * TBK, st);
+  for (int st = 0; st < NS - 1; ++st)
+    if (m_begin + st * TBK < m_end) issue(m_begin + st * TBK, st);
   int slot = 0, islot = NS - 1;
   for (int mt = m_begin; mt < m_end; mt += TBK) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (NS - 2)) : "memory");
+    if (NS > 2 && mt + (NS - 2) * TBK < m_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (NS - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();    // tile `mt` has landed for every wave; everyone is done reading the slot refilled next
     asm volatile("" ::: "memory");
-    issue(mt + (NS - 1) * TBK, islot);
+    if (mt + (NS - 1) * TBK < m_end) issue(mt + (NS - 1) * TBK, islot);
     islot = islot + 1 == NS ? 0 : islot + 1;
     const char* sA = smem + slot * STAGE;
     const char* sB = sA + TA::BYTES;
@@ -809,6 +824,135 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_dma_kernel(mvlt_gemm_tn_args
       }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, bf16, LDS-DMA
+// gemm_nt_kernel<bf16,BN> with the operand tiles filled by global_load_lds_dwordx4 instead of load -> VGPR ->
+// ds_write_b128 (LDS stores run at ~80 B/clk/CU, a third of the read rate, and were as expensive as the MFMAs).  The
+// LDS image is the same (128-B rows of 64 k, 16-B chunks XOR-swizzled by row); because the DMA writes lane-linear the
+// swizzle is applied to the source chunk each lane fetches.  ns-deep ring with a counted vmcnt wait, as in the TN kernel.
+template <int BN, int AMODE>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args p, int ns) {
+  constexpr int BK = 64;
+  constexpr int WN = BN / 2, TN_ = WN / 16;
+  constexpr int A_ITERS = BM * CHUNKS / NTHREADS;   // 4
+  constexpr int B_ITERS = BN * CHUNKS / NTHREADS;   // 4 or 2
+  constexpr int LPT = A_ITERS + B_ITERS;
+  constexpr int STAGE = (BM + BN) * ROW_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, bslot = bid >> 3;
+  const int tile_m = (bslot / tiles_n) * 8 + xcd, tile_n = bslot % tiles_n;
+  if (tile_m >= tiles_m) return;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const RowMap amap = to_rowmap(p.a_map);
+  const unsigned smem_lds = (unsigned)(uintptr_t)smem;
+
+  const int row_in = tid >> 3;                                  // 0..31 (+32 i)
+  const int chunk = (tid & 7) ^ ((row_in >> 1) & 7);            // source chunk of this thread's LDS slot: swz is an involution
+  const char* zsrc = (const char*)g_zero_page + ((tid * 16 + (bid & 15) * 4096) & 65535);
+
+  const char* a_ptr[A_ITERS];
+  bool a_ok[A_ITERS];
+  int a_y[A_ITERS], a_x[A_ITERS];
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) {
+    int m = m0 + row_in + 32 * i;
+    a_ok[i] = m < p.M;
+    RowIt it = row_init(amap, a_ok[i] ? m : 0);
+    int phys;
+    if constexpr (AMODE == 0) phys = it.b * amap.batch_stride + amap.offset + it.x;
+    else if constexpr (AMODE == 1) phys = it.b * amap.tokens_in + (it.y * amap.r) * amap.w_in + it.x * amap.r;
+    else phys = it.b * amap.tokens_in + it.y * amap.w_in + it.x;                   // centre pixel
+    a_y[i] = it.y; a_x[i] = it.x;
+    a_ptr[i] = (const char*)p.A + (unsigned long long)(unsigned)phys * (2u * (unsigned)p.lda);
+  }
+  const char* b_ptr[B_ITERS];
+  bool b_ok[B_ITERS];
+#pragma unroll
+  for (int i = 0; i < B_ITERS; ++i) {
+    int n = n0 + row_in + 32 * i;
+    b_ok[i] = n < p.N;
+    b_ptr[i] = (const char*)p.B + (unsigned long long)(unsigned)(b_ok[i] ? n : 0) * (2u * (unsigned)p.ldb);
+  }
+
+  // K position of this thread's chunk, kept as (segment, offset in segment) for the gather maps; advanced per tile
+  int kpos = chunk * 8, seg = 0, kk = chunk * 8;
+  if constexpr (AMODE != 0) { seg = kk / amap.c_seg; kk -= seg * amap.c_seg; }
+  auto issue = [&](int slot) {                                  // tiles are issued in K order
+    const bool k_ok = kpos < p.K;
+    int off_bytes = (AMODE == 0 ? kpos : kk) * 2, tdy = 0, tdx = 0;
+    if constexpr (AMODE == 1) off_bytes += rowmap_seg(amap, seg) * (2 * p.lda);
+    if constexpr (AMODE == 2) {
+      const int dy = seg / 3;
+      tdy = dy - 1; tdx = seg - dy * 3 - 1;
+      off_bytes += (tdy * amap.w_in + tdx) * (2 * p.lda);
+    }
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      bool ok = a_ok[i] && k_ok;
+      if constexpr (AMODE == 2) ok = ok && (unsigned)(a_y[i] + tdy) < (unsigned)amap.h_in && (unsigned)(a_x[i] + tdx) < (unsigned)amap.w_in;
+      glds16(ok ? a_ptr[i] + off_bytes : zsrc, __builtin_amdgcn_readfirstlane(smem_lds + slot * STAGE + (i * NTHREADS + wave * 64) * 16));
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i)
+      glds16((b_ok[i] && k_ok) ? b_ptr[i] + kpos * 2 : zsrc,
+             __builtin_amdgcn_readfirstlane(smem_lds + slot * STAGE + BM * ROW_BYTES + (i * NTHREADS + wave * 64) * 16));
+    kpos += BK;
+    if constexpr (AMODE != 0) {
+      kk += BK;
+      while (kk >= amap.c_seg) { kk -= amap.c_seg; ++seg; }
+    }
+  };
+
+  f32x4 acc[4][TN_];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int st = 0; st < ns - 1 && st < nk; ++st) issue(st);
+  if (ns == 1) issue(0);
+  int slot = 0, islot = ns - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (ns == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    else if (ns == 4 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ns > 1 && kt + ns - 1 < nk) issue(islot);
+    islot = islot + 1 >= ns ? 0 : islot + 1;
+    const char* a_s = smem + slot * STAGE + (wm * 64) * ROW_BYTES;
+    const char* b_s = smem + slot * STAGE + BM * ROW_BYTES + (wn * WN) * ROW_BYTES;
+    slot = slot + 1 >= ns ? 0 : slot + 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 fa[4], fb[TN_];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int r = i * 16 + fr;
+        fa[i] = *(const u32x4*)(a_s + r * ROW_BYTES + swz(wm * 64 + r, ks * 4 + fg) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < TN_; ++j) {
+        int r = j * 16 + fr;
+        fb[j] = *(const u32x4*)(b_s + r * ROW_BYTES + swz(wn * WN + r, ks * 4 + fg) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) mma16(acc[i][j], fa[i], fa[i], fb[j], fb[j], (bf16*)nullptr);
+    }
+  }
+  __syncthreads();                   // last tile's reads are done before the epilogue reuses the LDS
+  nt_epilogue<bf16, BN>(p, acc, smem, m0, n0, wave, lane);
+}
+
 int check_rowmap(const mvlt_rowmap& m, const char* who) {
   if (m.mode == 0) {
     MVLT_REQUIRE(m.rows_per_batch >= 0, "%s: rows_per_batch < 0", who);
@@ -853,7 +997,21 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   const size_t stage = (size_t)4 * 32 * (bn / 2 + 4) * sizeof(float);      // epilogue staging (4 waves x 32 rows)
   if (lds < stage) lds = stage;
   dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n)), block(NTHREADS);
-  if (a->dtype == 0) {
+  if (a->dtype == 0 && !getenv("MVLT_NT_LEGACY")) {
+    const int nk = (a->K + 63) / 64;
+    int ns = nk < 2 ? nk : 2;                              // 2 x 32 KB: two workgroups per CU
+    if (const char* e = getenv("MVLT_NT_NS")) { ns = atoi(e); if (ns > nk) ns = nk; if (ns < 1) ns = 1; if (ns > 4) ns = 4; }
+    size_t lds2 = (size_t)ns * (BM + bn) * ROW_BYTES;
+    if (lds2 < stage) lds2 = stage;
+#define MVLT_NT_LAUNCH(BN_)                                                                                          \
+  do {                                                                                                               \
+    if (a->a_map.mode == 0) hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, 0>), grid, block, lds2, s, *a, ns);          \
+    else if (a->a_map.mode == 1) hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, 1>), grid, block, lds2, s, *a, ns);     \
+    else hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, 2>), grid, block, lds2, s, *a, ns);                             \
+  } while (0)
+    if (narrow) MVLT_NT_LAUNCH(64); else MVLT_NT_LAUNCH(128);
+#undef MVLT_NT_LAUNCH
+  } else if (a->dtype == 0) {
     if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 64>), grid, block, lds, s, *a, nbuf);
     else hipLaunchKernelGGL((gemm_nt_kernel<bf16, 128>), grid, block, lds, s, *a, nbuf);
   } else {
