@@ -152,12 +152,18 @@ __device__ __forceinline__ void nt_epilogue(const mvlt_gemm_nt_args& p, f32x4 (&
         if (p.act == 1) {
           if (p.H) store8(p.H, v);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+          for (int e = 0; e < 8; e += 2) {
+            const f32x2 gv = gelu_erf2(f32x2{v[e], v[e + 1]});
+            v[e] = gv[0]; v[e + 1] = gv[1];
+          }
         } else if (p.act == 2) {
           float h8[8];
           load8(p.H, h8);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(h8[e]);
+          for (int e = 0; e < 8; e += 2) {
+            const f32x2 dv = gelu_erf_grad2(f32x2{h8[e], h8[e + 1]});
+            v[e] *= dv[0]; v[e + 1] *= dv[1];
+          }
         }
         if (p.row_scale) {
 #pragma unroll
@@ -548,22 +554,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
 // 32-lane read group touches (m..m+3 and m+8..m+11) over the eight 32-B bank windows.  Rows past m_end / columns past
 // N / out-of-image 3x3 taps are zero-filled by the owning lane.  Two buffers, one barrier per 64-row tile.  Column sums
 // (bias gradients) are one extra MFMA against an all-ones fragment, shared between the two waves of a tile row.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4 tr_frag(const char* lds_addr, int rowb) {
-  typedef __attribute__((address_space(3))) s16x4* lptr;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_addr));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_addr + 4 * rowb));
-  unsigned long long l = __builtin_bit_cast(unsigned long long, lo), h = __builtin_bit_cast(unsigned long long, hi);
-  return u32x4{(unsigned)l, (unsigned)(l >> 32), (unsigned)h, (unsigned)(h >> 32)};
-}
-// LDS-DMA of 16 B per lane to lds_wave_base + 16*lane_id.  Inline asm on purpose: for the builtin hipcc orders every
-// later LDS read after the DMA with s_waitcnt vmcnt(0) (it cannot prove the two buffers disjoint), which serialises
-// the prefetch behind the MFMAs; the kernel waits vmcnt(0) itself, once per tile, in front of its barrier.
-__device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_base) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src), "s"(lds_wave_base) : "memory");
-}
 // Logical row m of a row map as (b, y, x) digits, advanced by a fixed stride with carries instead of divisions: the
 // loader of a thread visits rows m0, m0+64, m0+128, ... and one division per row would cost more than the MFMAs it
 // feeds.  plain rows: x = m; batch-strided rows: (b, x) base rows_per_batch; patch / 3x3 maps: (b, y, x) in the
@@ -633,10 +623,6 @@ template <int W> struct DmaTile {
     return frow * ROWB + ((window ^ h(frow)) << 5) + ((L & 3) << 3);
   }
 };
-
-// zero source for slots whose row / column / 3x3 tap does not exist: every thread issues the same number of DMAs per
-// tile (the pipeline below counts them with s_waitcnt vmcnt(N)); 64 KB so that the reads spread over L2 channels
-__device__ __attribute__((aligned(256))) unsigned char g_zero_page[65536];
 
 template <int BMT, int BN, int BMODE, int NS>
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_dma_kernel(mvlt_gemm_tn_args p, int m_per_split, int t1, int t2, int splits) {

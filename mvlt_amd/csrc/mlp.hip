@@ -47,6 +47,8 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
   bf16* sWb = sWa + 2 * JC * C;                              // [2][C][JC]   W2[:, chunk] (mode 0) / W1^T[:, chunk] (mode 1)
   bf16* sWc = sWb + 2 * C * JC;                              // [2][JC][C]   W2^T chunk   (mode 1 only)
   bf16* sG = sWc + (MODE == 1 ? 2 * JC * C : 0);             // [BM][JC]     each wave touches only its own WR rows
+  float* sB1 = (float*)(sG + BM * JC);                       // [hid]        fc1 bias: a global load inside the chunk loop would
+                                                             //              wait (vmcnt is in-order) for the weight prefetch too
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
   const bf16* Wc = (const bf16*)p.wc;        // [hid][C]
   const int hid = p.hid;
 
+  for (int u = tid; u < p.hid; u += NT) sB1[u] = p.b1[u];
   // ---- token tiles (x and, for the backward, dy) into LDS once
   for (int u = tid; u < BM * (C / 8); u += NT) {
     int r = u / (C / 8), ch = u % (C / 8);
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
         if (MODE == 1) cf[ks] = ldfrag(wc + toff<C>(jrow, ks * 32 + fg * 8));
       }
       const int jl = jt * 16 + 4 * fg;                 // the four hidden units this lane ends up with: jl + r
-      f32x4 b1v = *(const f32x4*)(p.b1 + jc * JC + jl);
+      f32x4 b1v = *(const f32x4*)(sB1 + jc * JC + jl);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int mrow = wave * WR + mt * 16 + fr;     // token (column fr of the tile)
@@ -148,10 +151,11 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
         }
         bf16x4 g4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float hv = h[r] + b1v[r];
-          g4[r] = (bf16)((MODE == 0) ? gelu_erf(hv) : dg[r] * gelu_erf_grad(hv));
-          h[r] = hv;
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 hv = f32x2{h[r], h[r + 1]} + f32x2{b1v[r], b1v[r + 1]};
+          const f32x2 gv = (MODE == 0) ? gelu_fast2(hv) : f32x2{dg[r], dg[r + 1]} * gelu_fast_grad2(hv);
+          g4[r] = (bf16)gv[0]; g4[r + 1] = (bf16)gv[1];
+          h[r] = hv[0]; h[r + 1] = hv[1];
         }
         *(bf16x4*)(sG + toff<JC>(mrow, jl)) = g4;
         if (MODE == 0 && p.h_out && m0 + mrow < p.M) {
@@ -229,31 +233,72 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
 
 // ------------------------------------------------------------------------------------------------ weight gradients
 // dW1[j][c] += sum_m dh[m][j] x[m][c]      db1[j] += sum_m dh[m][j]
-// dW2[c][j] += sum_m dy[m][c] g[m][j]      db2[c] += sum_m dy[m][c]          (dy already multiplied by the DropPath scale)
-// A workgroup owns 128 hidden units (blockIdx.y) and a range of tokens (blockIdx.x); W1 / W2^T rows of its hidden range stay
-// in LDS.  Per 64-token tile it recomputes h and dg for its hidden units (MFMA, rows = tokens), turns them into g and dh
-// in registers and feeds those straight back as MFMA operands of the two weight-gradient products (k = tokens): the C
-// layout (4 consecutive tokens per lane) IS the operand layout once two 16-token tiles are paired.  The other operands are
-// x^T / dy^T tiles in LDS.  Nothing of size (tokens x hidden) is ever written.
-constexpr int TS = 72;                       // row stride (elements) of the transposed [C][64] tiles: 144 B
-__device__ __forceinline__ int tsw2(int c, int pair) { return pair ^ (((c >> 3) & 7) << 2); }
+// dW2[c][j] += sum_m dy[m][c] g[m][j]      db2[c] += sum_m dy[m][c]          (dy scaled by the per-sample DropPath factor)
+// A workgroup owns 128 hidden units and a range of tokens; W1 / W2^T rows of its hidden range stay in LDS.  Per 64-token
+// tile it recomputes h and dg for its hidden units (MFMA, rows = tokens), turns them into g and dh in registers and
+// feeds those straight back as MFMA operands of the two weight-gradient products (k = tokens): the C layout (4
+// consecutive tokens per lane) IS the operand layout once two 16-token tiles are paired.  The other operands, x^T / dy^T
+// fragments, are transposed reads (ds_read_b64_tr_b16) of the same natural-layout [token][C] tiles the producers read
+// row-wise; those tiles arrive by LDS-DMA in a 2-deep ring (the kernel runs one or two waves per SIMD: without the
+// prefetch every tile paid a full HBM/L2 round trip).  Nothing of size (tokens x hidden) is ever written.
+//
+// Tile layout: row = token, 16-B chunks XOR-swizzled by hs(token) << 1 on the DMA source side; hs is chosen so that
+// both access patterns are bank-conflict free: the b128 row reads (16 tokens x 4 chunks per instruction) and the
+// transposed reads (8 consecutive tokens x one 32-B window per 32-lane group).
+template <int C> __device__ __forceinline__ int wg_hs(int row) { return C == 64 ? ((row >> 1) & 3) : (row & 7); }
+
+__device__ __forceinline__ float sload_f32(const float* ptr) {      // scalar load: must not touch vmcnt (the DMA ring counts it)
+  float v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+  return v;
+}
 
 template <int C>
-__global__ __launch_bounds__(NT) void mlp_wgrad_kernel(mvlt_mlp_args p, int m_per_split) {
+__global__ __launch_bounds__(NT, C == 64 ? 2 : 1) void mlp_wgrad_kernel(mvlt_mlp_args p, int m_per_split, int splits, int ny) {
   constexpr int KS_C = C / 32, CT16 = C / 16;
+  constexpr int ROWB = 2 * C;                  // bytes per token row
+  constexpr int CH = C / 8;                    // 16-B slots per row
+  constexpr int RPP = NT / CH;                 // rows per 256-thread pass
+  constexpr int IT = 64 / RPP;                 // passes per tile
+  constexpr int TILE = 64 * ROWB;
+  constexpr int STAGE = 2 * TILE;              // x tile | dy tile
+  constexpr int LPT = 2 * IT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* sX = (bf16*)smem;                    // [64][C]
-  bf16* sDY = sX + 64 * C;                   // [64][C]
-  bf16* sXt = sDY + 64 * C;                  // [C][TS]
-  bf16* sDYt = sXt + C * TS;                 // [C][TS]
-  bf16* sW1 = sDYt + C * TS;                 // [128][C]
-  bf16* sW2T = sW1 + 128 * C;                // [128][C]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bf16* sW1 = (bf16*)smem;                     // [128][C]
+  bf16* sW2T = sW1 + 128 * C;                  // [128][C]
+  char* sT = smem + 2 * 128 * C * 2;           // [2][x tile | dy tile]
+  const unsigned sT_lds = (unsigned)(uintptr_t)sT;
+
+  // one token split (all its ny hidden blocks) per XCD: x / dy rows come through that L2 once
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int zq = kq / ny, by = kq - zq * ny;
+  const int bz = zq * 8 + xcd;
+  if (bz >= splits) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int j0 = blockIdx.y * 128;
-  const int m_begin = blockIdx.x * m_per_split, m_end = min(p.M, m_begin + m_per_split);
-  const bf16* X = (const bf16*)p.x;
-  const bf16* DY = (const bf16*)p.dy;
+  const int j0 = by * 128;
+  const int m_begin = bz * m_per_split, m_end = min(p.M, m_begin + m_per_split);
+
+  // ---- DMA geometry
+  const int l_row0 = tid / CH;
+  const int l_chunk = (tid % CH) ^ (wg_hs<C>(l_row0) << 1);
+  const char* xsrc = (const char*)p.x + l_chunk * 16;
+  const char* ysrc = (const char*)p.dy + l_chunk * 16;
+  const char* zsrc = (const char*)g_zero_page + ((tid * 16 + (blockIdx.x & 15) * 4096) & 65535);
+  auto issue = [&](int mt, int slot) {
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int m = mt + j * RPP + l_row0;
+      const bool ok = m < m_end;
+      const unsigned long long off = (unsigned long long)(unsigned)m * ROWB;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(sT_lds + slot * STAGE + (j * NT + wave * 64) * 16);
+      glds16(ok ? xsrc + off : zsrc, dst);
+      glds16(ok ? ysrc + off : zsrc, dst + TILE);
+    }
+  };
+  issue(m_begin, 0);
+
   for (int u = tid; u < 128 * (C / 8); u += NT) {
     int r = u / (C / 8), ch = u % (C / 8);
     *(u32x4*)(sW1 + toff<C>(r, ch * 8)) = *(const u32x4*)((const bf16*)p.w1 + (long)(j0 + r) * C + ch * 8);
@@ -262,6 +307,20 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(mvlt_mlp_args p, int m_pe
   float b1v[2];
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt) b1v[jt] = p.b1[j0 + wave * 32 + jt * 16 + fr];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                             // weights visible (and tile 0 has landed)
+
+  // ---- fragment geometry
+  const int hs_row = wg_hs<C>(fr);                                   // producers: token row 16 mt + fr
+  int xoff[KS_C];
+#pragma unroll
+  for (int ks = 0; ks < KS_C; ++ks) xoff[ks] = fr * ROWB + (((ks * 4 + fg) ^ (hs_row << 1)) << 4);
+  const int L = lane & 15;
+  const int trow = 4 * fg + (L >> 2);                                // transposed reads: token row 32 pair + trow (+16)
+  const int hs_t = wg_hs<C>(trow);
+  int toffs[CT16];
+#pragma unroll
+  for (int ct = 0; ct < CT16; ++ct) toffs[ct] = trow * ROWB + ((ct ^ hs_t) << 5) + ((L & 3) << 3);
 
   f32x4 dw1[2][CT16], dw2[CT16][2];
 #pragma unroll
@@ -269,73 +328,77 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(mvlt_mlp_args p, int m_pe
 #pragma unroll
     for (int b = 0; b < CT16; ++b) { dw1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; dw2[b][a] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   float db1acc[2] = {0.f, 0.f};
-  float db2acc[CT16];
+  float db2acc[CT16 / 4];
 #pragma unroll
-  for (int b = 0; b < CT16; ++b) db2acc[b] = 0.f;
-  const bool do_db2 = (blockIdx.y == 0) && (wave == 0);
+  for (int b = 0; b < CT16 / 4; ++b) db2acc[b] = 0.f;
+  const bool do_db2 = by == 0;                 // column sums of dy: the four waves take every fourth 16-channel tile each
+  const bool scaled = p.row_scale != nullptr;
 
-  constexpr int UNITS = 32 * (C / 8);        // (token pair, 8-channel chunk)
-  for (int mt0 = m_begin; mt0 < m_end; mt0 += 64) {
-    __syncthreads();                         // previous tile fully consumed
-    for (int u = tid; u < UNITS; u += NT) {
-      int ch = u % (C / 8), pr = u / (C / 8);
-      bf16x8 x0, x1, y0, y1;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { x0[e] = (bf16)0.f; x1[e] = (bf16)0.f; y0[e] = (bf16)0.f; y1[e] = (bf16)0.f; }
-      const int ma = mt0 + 2 * pr, mb = ma + 1;
-      if (ma < m_end) {
-        x0 = *(const bf16x8*)(X + (long)ma * C + ch * 8);
-        y0 = *(const bf16x8*)(DY + (long)ma * C + ch * 8);
-        if (p.row_scale) { float s0 = p.row_scale[ma / p.rows_per_scale];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) y0[e] = (bf16)((float)y0[e] * s0); }
-      }
-      if (mb < m_end) {
-        x1 = *(const bf16x8*)(X + (long)mb * C + ch * 8);
-        y1 = *(const bf16x8*)(DY + (long)mb * C + ch * 8);
-        if (p.row_scale) { float s1 = p.row_scale[mb / p.rows_per_scale];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) y1[e] = (bf16)((float)y1[e] * s1); }
-      }
-      *(bf16x8*)(sX + toff<C>(2 * pr, ch * 8)) = x0;
-      *(bf16x8*)(sX + toff<C>(2 * pr + 1, ch * 8)) = x1;
-      *(bf16x8*)(sDY + toff<C>(2 * pr, ch * 8)) = y0;
-      *(bf16x8*)(sDY + toff<C>(2 * pr + 1, ch * 8)) = y1;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = ch * 8 + e;
-        *(bf16x2*)(sXt + c * TS + tsw2(c, pr) * 2) = bf16x2{x0[e], x1[e]};
-        *(bf16x2*)(sDYt + c * TS + tsw2(c, pr) * 2) = bf16x2{y0[e], y1[e]};
-      }
+  int slot = 0;
+  for (int mt0 = m_begin; mt0 < m_end; mt0 += 64, slot ^= 1) {
+    if (mt0 != m_begin) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // tile mt0 landed for every wave; the other slot is free again
+      asm volatile("" ::: "memory");
     }
-    __syncthreads();
-    // ---- producers: h, dg for this wave's 32 hidden units x 64 tokens; rows = tokens (4 fg + r), cols = hidden (fr)
-    bf16x8 gfrag[2][2], dhfrag[2][2];        // [hidden tile][token-tile pair]: k-slot (fg, jj) <-> token 32 pair + 16 (jj>>2) + 4 fg + (jj&3)
+    if (mt0 + 64 < m_end) issue(mt0 + 64, slot ^ 1);
+    const char* tX = sT + slot * STAGE;
+    const char* tY = tX + TILE;
+
+    // per-sample DropPath factor of this lane's 16 token rows (16 mt + 4 fg + r): a tile spans at most two samples
+    float sc[4][4];
+    if (scaled) {
+      const int b0 = __builtin_amdgcn_readfirstlane(mt0 / p.rows_per_scale);
+      const int bound = (b0 + 1) * p.rows_per_scale;
+      const int b1i = __builtin_amdgcn_readfirstlane(min(b0 + 1, (p.M - 1) / p.rows_per_scale));
+      const float sA = sload_f32(p.row_scale + b0), sB = sload_f32(p.row_scale + b1i);
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-      bf16x8 w1f[KS_C], w2f[KS_C];
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[mt][r] = (mt0 + mt * 16 + 4 * fg + r < bound) ? sA : sB;
+    }
+
+    // ---- producers: h, dg for this wave's 32 hidden units x 64 tokens; rows = tokens (4 fg + r), cols = hidden (fr)
+    bf16x8 gfrag[2][2], dhfrag[2][2];          // [hidden tile][token-tile pair]: k-slot (fg, jj) <-> token 32 pair + 16 (jj>>2) + 4 fg + (jj&3)
+    bf16x8 w1f[2][KS_C], w2f[2][KS_C];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
       for (int ks = 0; ks < KS_C; ++ks) {
-        w1f[ks] = ldfrag(sW1 + toff<C>(wave * 32 + jt * 16 + fr, ks * 32 + fg * 8));
-        w2f[ks] = ldfrag(sW2T + toff<C>(wave * 32 + jt * 16 + fr, ks * 32 + fg * 8));
+        w1f[jt][ks] = ldfrag(sW1 + toff<C>(wave * 32 + jt * 16 + fr, ks * 32 + fg * 8));
+        w2f[jt][ks] = ldfrag(sW2T + toff<C>(wave * 32 + jt * 16 + fr, ks * 32 + fg * 8));
       }
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < 4; ++mt) {
+      bf16x8 xf[KS_C], yf[KS_C];
+#pragma unroll
+      for (int ks = 0; ks < KS_C; ++ks) {
+        xf[ks] = *(const bf16x8*)(tX + mt * 16 * ROWB + xoff[ks]);
+        yf[ks] = *(const bf16x8*)(tY + mt * 16 * ROWB + xoff[ks]);
+      }
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
         f32x4 h = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS_C; ++ks) {
-          bf16x8 xf = ldfrag(sX + toff<C>(mt * 16 + fr, ks * 32 + fg * 8));
-          bf16x8 yf = ldfrag(sDY + toff<C>(mt * 16 + fr, ks * 32 + fg * 8));
-          h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, w1f[ks], h, 0, 0, 0);
-          dg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, w2f[ks], dg, 0, 0, 0);
+          h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ks], w1f[jt][ks], h, 0, 0, 0);
+          dg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[ks], w2f[jt][ks], dg, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float hv = h[r] + b1v[jt];
-          const float dhv = dg[r] * gelu_erf_grad(hv);
-          db1acc[jt] += dhv;
-          gfrag[jt][mt >> 1][(mt & 1) * 4 + r] = (bf16)gelu_erf(hv);
-          dhfrag[jt][mt >> 1][(mt & 1) * 4 + r] = (bf16)dhv;
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 hv = f32x2{h[r], h[r + 1]} + b1v[jt];
+          f32x2 gv, dgv;
+          gelu_fast_both2(hv, gv, dgv);
+          f32x2 dhv = f32x2{dg[r], dg[r + 1]} * dgv;
+          if (scaled) {                        // dy's factor moves onto the two products it enters linearly
+            const f32x2 s2 = {sc[mt][r], sc[mt][r + 1]};
+            dhv *= s2; gv *= s2;
+          }
+          db1acc[jt] += dhv[0] + dhv[1];
+          gfrag[jt][mt >> 1][(mt & 1) * 4 + r] = (bf16)gv[0];
+          gfrag[jt][mt >> 1][(mt & 1) * 4 + r + 1] = (bf16)gv[1];
+          dhfrag[jt][mt >> 1][(mt & 1) * 4 + r] = (bf16)dhv[0];
+          dhfrag[jt][mt >> 1][(mt & 1) * 4 + r + 1] = (bf16)dhv[1];
         }
       }
     }
@@ -344,15 +407,21 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(mvlt_mlp_args p, int m_pe
     for (int pair = 0; pair < 2; ++pair) {
 #pragma unroll
       for (int ct = 0; ct < CT16; ++ct) {
-        const int c = ct * 16 + fr;
-        const int pA = tsw2(c, 16 * pair + 2 * fg), pB = tsw2(c, 16 * pair + 8 + 2 * fg);
-        bf16x4 xa = *(const bf16x4*)(sXt + c * TS + pA * 2), xb = *(const bf16x4*)(sXt + c * TS + pB * 2);
-        bf16x4 ya = *(const bf16x4*)(sDYt + c * TS + pA * 2), yb = *(const bf16x4*)(sDYt + c * TS + pB * 2);
-        bf16x8 xt = {xa[0], xa[1], xa[2], xa[3], xb[0], xb[1], xb[2], xb[3]};
-        bf16x8 yt = {ya[0], ya[1], ya[2], ya[3], yb[0], yb[1], yb[2], yb[3]};
-        if (do_db2) {
+        typedef __attribute__((address_space(3))) s16x4* lptr;
+        const char* ax = tX + pair * 32 * ROWB + toffs[ct];
+        const char* ay = tY + pair * 32 * ROWB + toffs[ct];
+        s16x4 xa = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)ax), xb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(ax + 16 * ROWB));
+        s16x4 ya = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)ay), yb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(ay + 16 * ROWB));
+        const unsigned long long xl = __builtin_bit_cast(unsigned long long, xa), xh = __builtin_bit_cast(unsigned long long, xb);
+        const unsigned long long yl = __builtin_bit_cast(unsigned long long, ya), yh = __builtin_bit_cast(unsigned long long, yb);
+        const bf16x8 xt = __builtin_bit_cast(bf16x8, u32x4{(unsigned)xl, (unsigned)(xl >> 32), (unsigned)xh, (unsigned)(xh >> 32)});
+        const bf16x8 yt = __builtin_bit_cast(bf16x8, u32x4{(unsigned)yl, (unsigned)(yl >> 32), (unsigned)yh, (unsigned)(yh >> 32)});
+        if (do_db2 && (ct & 3) == wave) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) db2acc[ct] += (float)yt[e];
+          for (int e = 0; e < 8; ++e) {
+            const float sv = scaled ? sc[2 * pair + (e >> 2)][e & 3] : 1.0f;
+            db2acc[ct >> 2] += (float)yt[e] * sv;
+          }
         }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
@@ -380,32 +449,34 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(mvlt_mlp_args p, int m_pe
   }
   if (do_db2) {
 #pragma unroll
-    for (int ct = 0; ct < CT16; ++ct) {
-      float v = db2acc[ct];
+    for (int q = 0; q < CT16 / 4; ++q) {
+      float v = db2acc[q];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      if (fg == 0) atomicAdd(&p.db2[ct * 16 + fr], v);
+      if (fg == 0) atomicAdd(&p.db2[(q * 4 + wave) * 16 + fr], v);
     }
   }
 }
 
 template <int C> int launch_wgrad(const mvlt_mlp_args& a, hipStream_t s) {
-  const size_t lds = (size_t)(2 * 64 * C + 2 * C * TS + 2 * 128 * C) * 2;
+  const size_t lds = (size_t)2 * 128 * C * 2 + (size_t)2 * 2 * 64 * 2 * C;      // weights + 2 x (x tile | dy tile)
   const int ny = a.hid / 128;
-  int splits = (1024 + ny - 1) / ny;
+  // one round of workgroups (2 per CU at C = 64, 1 per CU at C = 128): every extra split costs hid*C*2 fp32 atomics
+  int splits = ((C == 64 ? 512 : 256) + ny - 1) / ny;
+  splits = (splits + 7) / 8 * 8;
   const int mtiles = (a.M + 63) / 64;
   if (splits > mtiles) splits = mtiles;
   if (splits < 1) splits = 1;
   const int m_per_split = ((mtiles + splits - 1) / splits) * 64;
   splits = (a.M + m_per_split - 1) / m_per_split;
   hipFuncSetAttribute((const void*)mlp_wgrad_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((mlp_wgrad_kernel<C>), dim3(splits, ny), dim3(NT), lds, s, a, m_per_split);
+  hipLaunchKernelGGL((mlp_wgrad_kernel<C>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NT), lds, s, a, m_per_split, splits, ny);
   return mvlt_check_launch("mvlt_mlp_bwd_dw");
 }
 
 template <int C, int MODE> int launch(const mvlt_mlp_args& a, hipStream_t s) {
   constexpr int BM = (C == 64) ? 128 : 64;
-  size_t lds = (size_t)(BM * C * (MODE == 1 ? 2 : 1) + 2 * JC * C * (MODE == 1 ? 2 : 1) + 2 * C * JC + BM * JC) * 2;
+  size_t lds = (size_t)(BM * C * (MODE == 1 ? 2 : 1) + 2 * JC * C * (MODE == 1 ? 2 : 1) + 2 * C * JC + BM * JC) * 2 + (size_t)a.hid * 4;
   const size_t stage = (size_t)BM * (C + 4) * 4;
   if (lds < stage) lds = stage;
   hipFuncSetAttribute((const void*)mlp_fused_kernel<C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
