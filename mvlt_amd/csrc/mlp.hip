@@ -21,13 +21,13 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int JC = 64;                       // hidden units per chunk
+template <int C> struct MlpGeo { static constexpr int JC = (C == 64) ? 64 : 32; };   // hidden units per chunk: C*JC = 4096 MACs per token either way
 
 // element offset inside a [rows][K] bf16 tile with 16-B chunks XOR-swizzled by row (conflict-free fragment reads)
 template <int K> __device__ __forceinline__ int toff(int row, int k) {
-  constexpr int NCH = K / 8;                 // 16-B chunks per row: 8 (K=64) or 16 (K=128)
+  constexpr int NCH = K / 8;                 // 16-B chunks per row: 4 (K=32), 8 (K=64) or 16 (K=128)
   int ch = k >> 3;
-  int sw = (NCH == 8) ? (ch ^ ((row >> 1) & 7)) : (ch ^ (row & 15));
+  int sw = (NCH == 4) ? (ch ^ ((row >> 2) & 3)) : (NCH == 8) ? (ch ^ ((row >> 1) & 7)) : (ch ^ (row & 15));
   return row * K + sw * 8 + (k & 7);
 }
 
@@ -35,21 +35,18 @@ __device__ __forceinline__ bf16x8 ldfrag(const bf16* tile_base_elem) { return *(
 
 template <int C, int MODE>
 __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
-  constexpr int BM = (C == 64) ? 128 : 64;   // token rows per workgroup
+  constexpr int JC = MlpGeo<C>::JC;
+  constexpr int BM = 128;                    // token rows per workgroup
   constexpr int WR = BM / 4;                 // token rows per wave: each wave is self-contained (producer AND consumer of its rows)
-  constexpr int MT = WR / 16;                // 16-token tiles per wave: 2 (C=64) / 1 (C=128)
+  constexpr int MT = WR / 16;                // 16-token tiles per wave
   constexpr int CT = C / 16;                 // 16-col output tiles (all of C)
   constexpr int KS_C = C / 32;               // k32 steps over C
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* sX = (bf16*)smem;                                    // [BM][C]
-  bf16* sDY = sX + BM * C;                                   // [BM][C]      (mode 1 only)
-  bf16* sWa = sDY + (MODE == 1 ? BM * C : 0);                // [2][JC][C]   W1 chunk
+  bf16* sWa = (bf16*)smem;                                   // [2][JC][C]   W1 chunk
   bf16* sWb = sWa + 2 * JC * C;                              // [2][C][JC]   W2[:, chunk] (mode 0) / W1^T[:, chunk] (mode 1)
   bf16* sWc = sWb + 2 * C * JC;                              // [2][JC][C]   W2^T chunk   (mode 1 only)
-  bf16* sG = sWc + (MODE == 1 ? 2 * JC * C : 0);             // [BM][JC]     each wave touches only its own WR rows
-  float* sB1 = (float*)(sG + BM * JC);                       // [hid]        fc1 bias: a global load inside the chunk loop would
+  float* sB1 = (float*)(sWc + (MODE == 1 ? 2 * JC * C : 0)); // [hid]        fc1 bias: a global load inside the chunk loop would
                                                              //              wait (vmcnt is in-order) for the weight prefetch too
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int m0 = blockIdx.x * BM;
@@ -61,17 +58,22 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
   const int hid = p.hid;
 
   for (int u = tid; u < p.hid; u += NT) sB1[u] = p.b1[u];
-  // ---- token tiles (x and, for the backward, dy) into LDS once
-  for (int u = tid; u < BM * (C / 8); u += NT) {
-    int r = u / (C / 8), ch = u % (C / 8);
-    u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
-    if (m0 + r < p.M) {
-      v = *(const u32x4*)(X + (long)(m0 + r) * C + ch * 8);
-      if (MODE == 1) w = *(const u32x4*)(DY + (long)(m0 + r) * C + ch * 8);
+  // ---- B-operand fragments of this wave's tokens (x, and dy for the backward): 8 consecutive channels of token fr per
+  // lane, straight from global memory (used by every hidden chunk, never re-read: no LDS copy)
+  bf16x8 xfr[MT][KS_C], yfr[MODE == 1 ? MT : 1][KS_C];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < KS_C; ++ks) {
+      const int m = m0 + wave * WR + mt * 16 + fr;
+      u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
+      if (m < p.M) {
+        v = *(const u32x4*)(X + (long)m * C + ks * 32 + fg * 8);
+        if (MODE == 1) w = *(const u32x4*)(DY + (long)m * C + ks * 32 + fg * 8);
+      }
+      xfr[mt][ks] = __builtin_bit_cast(bf16x8, v);
+      if (MODE == 1) yfr[mt][ks] = __builtin_bit_cast(bf16x8, w);
     }
-    *(u32x4*)(sX + toff<C>(r, ch * 8)) = v;
-    if (MODE == 1) *(u32x4*)(sDY + toff<C>(r, ch * 8)) = w;
-  }
   // ---- weight-chunk staging (global -> registers -> LDS), double buffered
   constexpr int WA_IT = JC * (C / 8) / NT;   // 2 (C=64) / 4 (C=128)
   constexpr int WB_IT = C * (JC / 8) / NT;   // 2 / 4
@@ -106,16 +108,6 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
   wstore(0);
   __syncthreads();
 
-  // B-operand fragments of this wave's tokens (x, and dy for the backward) do not change across hidden chunks
-  bf16x8 xfr[MT][KS_C], yfr[MODE == 1 ? MT : 1][KS_C];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int ks = 0; ks < KS_C; ++ks) {
-      const int mrow = wave * WR + mt * 16 + fr;
-      xfr[mt][ks] = ldfrag(sX + toff<C>(mrow, ks * 32 + fg * 8));
-      if (MODE == 1) yfr[mt][ks] = ldfrag(sDY + toff<C>(mrow, ks * 32 + fg * 8));
-    }
   f32x4 oacc[MT][CT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -127,8 +119,13 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
     const int buf = jc & 1;
     if (jc + 1 < nchunks) wload(jc + 1);
     // ---- producers, transposed: tile (jt, mt): rows = hidden units 16 jt.. of the chunk, cols = this wave's tokens 16 mt..
+    // A lane ends up with hidden units 16 jt + 4 fg + r of token fr.  Two hidden tiles (jt = 2 pair, 2 pair + 1) give it 8
+    // values of one token = one A-operand fragment of the consumer MFMA, with k-slot (fg, jj) <-> hidden unit
+    // 32 pair + 16 (jj >> 2) + 4 fg + (jj & 3); the consumer's B operand is read from the W chunk in the same order
+    // (two 8-byte LDS reads), so the activation goes from accumulator to operand without touching LDS.
     const bf16* wa = sWa + buf * JC * C;
     const bf16* wc = sWc + buf * JC * C;
+    bf16x8 gfrag[JC / 32][MT];
 #pragma unroll
     for (int jt = 0; jt < JC / 16; ++jt) {
       const int jrow = jt * 16 + fr;                   // A-operand row (hidden unit inside the chunk)
@@ -149,37 +146,31 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
           h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], xfr[mt][ks], h, 0, 0, 0);
           if (MODE == 1) dg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[ks], yfr[mt][ks], dg, 0, 0, 0);
         }
-        bf16x4 g4;
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
           const f32x2 hv = f32x2{h[r], h[r + 1]} + f32x2{b1v[r], b1v[r + 1]};
           const f32x2 gv = (MODE == 0) ? gelu_fast2(hv) : f32x2{dg[r], dg[r + 1]} * gelu_fast_grad2(hv);
-          g4[r] = (bf16)gv[0]; g4[r + 1] = (bf16)gv[1];
+          gfrag[jt >> 1][mt][(jt & 1) * 4 + r] = (bf16)gv[0];
+          gfrag[jt >> 1][mt][(jt & 1) * 4 + r + 1] = (bf16)gv[1];
           h[r] = hv[0]; h[r + 1] = hv[1];
         }
-        *(bf16x4*)(sG + toff<JC>(mrow, jl)) = g4;
         if (MODE == 0 && p.h_out && m0 + mrow < p.M) {
           bf16x4 h4 = {(bf16)h[0], (bf16)h[1], (bf16)h[2], (bf16)h[3]};
           *(bf16x4*)((bf16*)p.h_out + (long)(m0 + mrow) * hid + jc * JC + jl) = h4;
         }
       }
     }
-    // the G rows written above are read back only by this wave: wave-level ordering, no workgroup barrier
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- consumer: out[this wave's tokens][C] += G[tokens][64] . Wb[C][64]^T
     const bf16* wb = sWb + buf * C * JC;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 gf[MT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) gf[i] = ldfrag(sG + toff<JC>(wave * WR + i * 16 + fr, ks * 32 + fg * 8));
+    for (int pair = 0; pair < JC / 32; ++pair) {
 #pragma unroll
       for (int j = 0; j < CT; ++j) {
-        bf16x8 bfr = ldfrag(wb + toff<JC>(j * 16 + fr, ks * 32 + fg * 8));
+        const bf16x4 b0 = *(const bf16x4*)(wb + toff<JC>(j * 16 + fr, pair * 32 + 4 * fg));
+        const bf16x4 b1 = *(const bf16x4*)(wb + toff<JC>(j * 16 + fr, pair * 32 + 16 + 4 * fg));
+        const bf16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
 #pragma unroll
-        for (int i = 0; i < MT; ++i) oacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], bfr, oacc[i][j], 0, 0, 0);
+        for (int i = 0; i < MT; ++i) oacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfrag[pair][i], bfr, oacc[i][j], 0, 0, 0);
       }
     }
     if (jc + 1 < nchunks) wstore(buf ^ 1);
@@ -188,45 +179,49 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
 
   // ---- epilogue: oacc[i][j][r] = out[token wave*WR + 16 i + 4 fg + r][c = 16 j + fr]
   // staged per wave through LDS (the operand tiles are dead) so that global traffic is 16-byte, row-contiguous
+  // (one 16-token tile at a time: 4 waves x 16 rows x (C+4) floats)
   constexpr int LDW = C + 4, CPR = C / 8, RPI = 64 / CPR;
-  float* stage = (float*)smem + wave * WR * LDW;
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) stage[(i * 16 + 4 * fg + r) * LDW + j * 16 + fr] = oacc[i][j][r];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float* stage = (float*)smem + wave * 16 * LDW;
   const int ch = lane % CPR;
   const int nc = ch * 8;
   float b2v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) b2v[e] = (MODE == 0) ? p.b2[nc + e] : 0.f;
 #pragma unroll
-  for (int it = 0; it < WR / RPI; ++it) {
-    const int rl = it * RPI + lane / CPR;
-    const int m = m0 + wave * WR + rl;
-    if (m >= p.M) continue;
-    f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
-    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    const float rs = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.0f;
-    const long idx = (long)m * C + nc;
-    if (MODE == 0) {
-      const float* R = (const float*)p.residual + idx;
-      f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
-      float rr[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+  for (int i = 0; i < MT; ++i) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();               // previous tile's reads are done before it is overwritten
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (v[e] + b2v[e]) * rs + rr[e];
-      float* O = (float*)p.out + idx;
-      *(f32x4*)O = f32x4{v[0], v[1], v[2], v[3]};
-      *(f32x4*)(O + 4) = f32x4{v[4], v[5], v[6], v[7]};
-    } else {
-      bf16x8 o;
+    for (int j = 0; j < CT; ++j)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16)(v[e] * rs);
-      *(bf16x8*)((bf16*)p.out + idx) = o;
+      for (int r = 0; r < 4; ++r) stage[(4 * fg + r) * LDW + j * 16 + fr] = oacc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 16 / RPI; ++it) {
+      const int rl = it * RPI + lane / CPR;
+      const int m = m0 + wave * WR + i * 16 + rl;
+      if (m >= p.M) continue;
+      f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      const float rs = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+      const long idx = (long)m * C + nc;
+      if (MODE == 0) {
+        const float* R = (const float*)p.residual + idx;
+        f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
+        float rr[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + b2v[e]) * rs + rr[e];
+        float* O = (float*)p.out + idx;
+        *(f32x4*)O = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(O + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)(v[e] * rs);
+        *(bf16x8*)((bf16*)p.out + idx) = o;
+      }
     }
   }
 }
@@ -475,9 +470,9 @@ template <int C> int launch_wgrad(const mvlt_mlp_args& a, hipStream_t s) {
 }
 
 template <int C, int MODE> int launch(const mvlt_mlp_args& a, hipStream_t s) {
-  constexpr int BM = (C == 64) ? 128 : 64;
-  size_t lds = (size_t)(BM * C * (MODE == 1 ? 2 : 1) + 2 * JC * C * (MODE == 1 ? 2 : 1) + 2 * C * JC + BM * JC) * 2 + (size_t)a.hid * 4;
-  const size_t stage = (size_t)BM * (C + 4) * 4;
+  constexpr int BM = 128, JC = MlpGeo<C>::JC;
+  size_t lds = (size_t)(2 * JC * C * (MODE == 1 ? 2 : 1) + 2 * C * JC) * 2 + (size_t)a.hid * 4;
+  const size_t stage = (size_t)4 * 16 * (C + 4) * 4;       // epilogue staging (4 waves x 16 rows) reuses the weight buffers
   if (lds < stage) lds = stage;
   hipFuncSetAttribute((const void*)mlp_fused_kernel<C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((mlp_fused_kernel<C, MODE>), dim3((a.M + BM - 1) / BM), dim3(NT), lds, s, a);
