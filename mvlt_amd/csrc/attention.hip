@@ -445,8 +445,251 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_kernel(mvlt
       for (int r = 0; r < 4; ++r) {
         int key = (wave * TPW + t) * 16 + 4 * fg + r;
         if (key < p.M) {
-          atomicAdd(&dKg[(long)key * p.lddkv + dt * 16 + fr], dKacc[t][dt][r]);
-          atomicAdd(&dVg[(long)key * p.lddkv + dt * 16 + fr], dVacc[t][dt][r]);
+          if (nq_chunks == 1) {        // this workgroup saw every query of its (batch, head): the sums are final
+            dKg[(long)key * p.lddkv + dt * 16 + fr] = dKacc[t][dt][r];
+            dVg[(long)key * p.lddkv + dt * 16 + fr] = dVacc[t][dt][r];
+          } else {
+            atomicAdd(&dKg[(long)key * p.lddkv + dt * 16 + fr], dKacc[t][dt][r]);
+            atomicAdd(&dVg[(long)key * p.lddkv + dt * 16 + fr], dVacc[t][dt][r]);
+          }
+        }
+      }
+}
+
+// ------------------------------------------------------------------------------------------------ backward, bf16, LDS-DMA
+// Same algorithm and work split as attn_bwd_kernel; what changes is how the per-tile operands reach the MFMAs.  The Q, dO
+// and O rows of a 32-query tile arrive by LDS-DMA into a 2-deep ring of natural-layout [query][64] tiles, one tile ahead
+// of the math (the kernel above paid a full global round trip per tile: load -> transposing 2-byte LDS stores -> barrier).
+// Row fragments (A operands of S / dP) are 16-byte reads of those tiles, the transposed fragments (B operands of dV / dK,
+// k = queries) are ds_read_b64_tr_b16 of the same tiles; D = rowsum(dO * O) is computed by every wave for itself from
+// LDS (no workgroup barrier), dQ leaves through an LDS tile as 16-byte row stores one iteration later.
+template <int NW, int TPW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(mvlt_attn_bwd_args p, int nq_chunks, int q_per_wg) {
+  typedef bf16 T;
+  constexpr int NTH = NW * 64;
+  constexpr int MP = NW * TPW * 16;           // padded keys (multiple of 32)
+  constexpr int KS = MP + 8;                  // row stride of sKt and sdS (elements; 16 B of padding)
+  constexpr int TILE = 32 * 128;              // bytes of one [32 q][64 d] tile
+  constexpr int STAGE = 3 * TILE;             // Q | dO | O
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sKt = (T*)smem;                          // [64 d][KS]   K^T
+  T* sdS = sKt + HD * KS;                     // [32 q][KS]
+  char* ring = (char*)(sdS + 32 * KS);        // [2][Q | dO | O]
+  T* sdQ = (T*)(ring + 2 * STAGE);            // [32 q][64 d]
+  float* sDw = (float*)(sdQ + 32 * HD);       // [NW][32]
+  float* sLw = sDw + NW * 32;                 // [NW][32]
+  const unsigned ring_lds = (unsigned)(uintptr_t)ring;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, jb = bid >> 3;
+  const int gidx = xcd + 8 * (jb / nq_chunks);
+  const int chunk_id = jb % nq_chunks;
+  if (gidx >= p.B * p.H) return;
+  const int b = gidx / p.H, h = gidx % p.H;
+
+  const T* Qg = (const T*)p.Q + (long)b * p.N * p.ldq + h * HD;
+  const T* Og = (const T*)p.O + (long)b * p.N * p.ldo + h * HD;
+  const T* dOg = (const T*)p.dO + (long)b * p.N * p.ldo + h * HD;
+  const T* Kg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.k_off + h * HD;
+  const T* Vg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.v_off + h * HD;
+  T* dQg = (T*)p.dQ + (long)b * p.N * p.ldq + h * HD;
+  float* dKg = p.dKV + (long)b * p.M * p.lddkv + p.k_off + h * HD;
+  float* dVg = p.dKV + (long)b * p.M * p.lddkv + p.v_off + h * HD;
+  const float* Lg = p.lse + ((long)b * p.H + h) * p.N;
+  const int q_begin = chunk_id * q_per_wg;
+  const int q_end = min(p.N, q_begin + q_per_wg);
+
+  // ---- DMA geometry: thread (row = tid >> 3, slot = tid & 7) of the first 256 threads fills one 16-B slot per tensor
+  const int l_row = (tid >> 3) & 31;
+  const int l_chunk = (tid & 7) ^ (((l_row >> 1) & 3) << 1);
+  const char* zsrc = (const char*)g_zero_page + ((tid * 16 + (bid & 15) * 4096) & 65535);
+  auto issue = [&](int q0, int slot) {
+    if (NW > 4 && wave >= 4) return;
+    const int q = q0 + l_row;
+    const bool ok = q < q_end;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + slot * STAGE + wave * 1024);
+    glds16(ok ? (const void*)(Qg + (long)q * p.ldq + l_chunk * 8) : (const void*)zsrc, dst);
+    glds16(ok ? (const void*)(dOg + (long)q * p.ldo + l_chunk * 8) : (const void*)zsrc, dst + TILE);
+    glds16(ok ? (const void*)(Og + (long)q * p.ldo + l_chunk * 8) : (const void*)zsrc, dst + 2 * TILE);
+  };
+  issue(q_begin, 0);
+  float lse_cur = (lane < 32 && q_begin + lane < q_end) ? Lg[q_begin + lane] : 0.f;
+
+  // K^T into LDS (all keys), zero beyond M
+  for (int u = tid; u < MP * 8; u += NTH) {
+    int r = u >> 3, c = u & 7;
+    u32x4 kv = {0u, 0u, 0u, 0u};
+    if (r < p.M) kv = *(const u32x4*)(Kg + (long)r * p.ldkv + c * 8);
+    T ke[8];
+    *(u32x4*)ke = kv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sKt[(c * 8 + e) * KS + r] = ke[e];
+  }
+  // this wave's K / V fragments (B operands: n = key = fr, k = d)
+  Frag<T> kreg[TPW][2], vreg[TPW][2];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    int key = (wave * TPW + t) * 16 + fr;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (key < p.M) {
+        kreg[t][s] = load_frag8<T>(Kg + (long)key * p.ldkv + 32 * s + 8 * fg);
+        vreg[t][s] = load_frag8<T>(Vg + (long)key * p.ldkv + 32 * s + 8 * fg);
+      } else {
+        kreg[t][s] = zero_frag<T>();
+        vreg[t][s] = zero_frag<T>();
+      }
+    }
+  }
+  f32x4 dKacc[TPW][4], dVacc[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dKacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dVacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const float sl2 = p.scale * 1.44269504088896340736f;
+  const float l2e = 1.44269504088896340736f;
+
+  // ---- fragment geometry inside a tile (byte offsets)
+  const int hs_r = (fr >> 1) & 3;                                           // rows 16 qs + fr
+  int roff[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) roff[s] = fr * 128 + (((s * 4 + fg) ^ (hs_r << 1)) << 4);
+  const int trow = 4 * fg + (fr >> 2);                                      // transposed reads: rows trow, trow + 16
+  const int hs_t = (trow >> 1) & 3;
+  int toffs[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) toffs[dt] = trow * 128 + ((dt ^ hs_t) << 5) + ((fr & 3) << 3);
+  const int dq_row = lane >> 1, dq_half = lane & 1;                         // per-wave D: lane = (query, half of d)
+  const int hs_d = (dq_row >> 1) & 3;
+  float* myD = sDw + wave * 32;
+  float* myL = sLw + wave * 32;
+
+  int slot = 0;
+  int q_prev = -1;
+  for (int q0 = q_begin; q0 < q_end; q0 += 32, slot ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // (A) tile q0 landed; previous tile's dS / dQ tiles are complete
+    if (q_prev >= 0 && tid < 256) {                    // deferred dQ store of the previous tile: 16 B per thread
+      const int r = tid >> 3, c = tid & 7;
+      if (q_prev + r < q_end) *(u32x4*)(dQg + (long)(q_prev + r) * p.ldq + c * 8) = *(const u32x4*)(sdQ + r * HD + c * 8);
+    }
+    const float lse_now = lse_cur;
+    if (q0 + 32 < q_end) {
+      lse_cur = (lane < 32 && q0 + 32 + lane < q_end) ? Lg[q0 + 32 + lane] : 0.f;
+      issue(q0 + 32, slot ^ 1);
+    }
+    const char* tQ = ring + slot * STAGE;
+    const char* tdO = tQ + TILE;
+    const char* tO = tQ + 2 * TILE;
+
+    // ---- per-wave D = rowsum(dO * O) and lse into this wave's scratch
+    {
+      float dsum = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int off = dq_row * 128 + (((dq_half * 4 + c) ^ (hs_d << 1)) << 4);
+        const bf16x8 a = *(const bf16x8*)(tdO + off), o = *(const bf16x8*)(tO + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += (float)a[e] * (float)o[e];
+      }
+      dsum += __shfl_xor(dsum, 1);
+      if (dq_half == 0) myD[dq_row] = dsum;
+      if (lane < 32) myL[lane] = lse_now * l2e;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    f32x4 dv[2], lv[2];                                // D and lse*log2e of this lane's 8 query rows (16 qs + 4 fg + r)
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      dv[qs] = *(const f32x4*)(myD + qs * 16 + 4 * fg);
+      lv[qs] = *(const f32x4*)(myL + qs * 16 + 4 * fg);
+    }
+    // A-operand fragments of Q and dO (rows = queries)
+    Frag<T> qf[2][2], dof[2][2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        qf[qs][s].v = *(const bf16x8*)(tQ + qs * 16 * 128 + roff[s]);
+        dof[qs][s].v = *(const bf16x8*)(tdO + qs * 16 * 128 + roff[s]);
+      }
+
+    // ---- per owned key tile: S, dP -> P, dS ; dV += P^T dO ; dK += dS^T Q ; park dS in LDS
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int key = (wave * TPW + t) * 16 + fr;
+      const bool key_ok = key < p.M;
+      Frag<T> pfrag, dsfrag;
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          mma16(sacc, qf[qs][s], kreg[t][s]);          // S[q = 16 qs + 4 fg + r][key]
+          mma16(pacc, dof[qs][s], vreg[t][s]);         // dP
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = qs * 16 + 4 * fg + r;
+          float pv = key_ok ? __builtin_amdgcn_exp2f(sacc[r] * sl2 - lv[qs][r]) : 0.f;
+          float dsv = pv * (pacc[r] - dv[qs][r]) * p.scale;
+          pfrag.v[qs * 4 + r] = (T)pv;
+          dsfrag.v[qs * 4 + r] = (T)dsv;
+          sdS[ql * KS + key] = (T)dsv;
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        // B operands (n = d): k-slot (fg, j) <-> q = 16 (j>>2) + 4 fg + (j&3): two transposed 8-byte reads, 16 rows apart
+        Frag<T> dotf, qtf;
+        dotf.v = __builtin_bit_cast(bf16x8, tr_frag16(tdO + toffs[dt]));
+        qtf.v = __builtin_bit_cast(bf16x8, tr_frag16(tQ + toffs[dt]));
+        mma16(dVacc[t][dt], pfrag, dotf);              // dV[key = tile*16 + 4 fg + r][d = 16 dt + fr]
+        mma16(dKacc[t][dt], dsfrag, qtf);
+      }
+    }
+    __syncthreads();                                   // (C) every wave's dS columns are parked
+
+    // ---- dQ[32 x 64] = dS[32 x MP] K[MP x 64]: 8 output tiles (16 x 16) dealt round-robin to the waves -> sdQ
+    for (int tile = wave; tile < 8; tile += NW) {
+      const int qs = tile >> 2, dt = tile & 3;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int ks = 0; ks < MP / 32; ++ks) {
+        Frag<T> a = load_frag8<T>(sdS + (qs * 16 + fr) * KS + 32 * ks + 8 * fg);
+        Frag<T> bb = load_frag8<T>(sKt + (dt * 16 + fr) * KS + 32 * ks + 8 * fg);
+        mma16(acc, a, bb);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sdQ[(qs * 16 + 4 * fg + r) * HD + dt * 16 + fr] = (T)acc[r];
+    }
+    q_prev = q0;
+  }
+  __syncthreads();
+  if (q_prev >= 0 && tid < 256) {
+    const int r = tid >> 3, c = tid & 7;
+    if (q_prev + r < q_end) *(u32x4*)(dQg + (long)(q_prev + r) * p.ldq + c * 8) = *(const u32x4*)(sdQ + r * HD + c * 8);
+  }
+  // ---- flush dK / dV
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = (wave * TPW + t) * 16 + 4 * fg + r;
+        if (key < p.M) {
+          if (nq_chunks == 1) {
+            dKg[(long)key * p.lddkv + dt * 16 + fr] = dKacc[t][dt][r];
+            dVg[(long)key * p.lddkv + dt * 16 + fr] = dVacc[t][dt][r];
+          } else {
+            atomicAdd(&dKg[(long)key * p.lddkv + dt * 16 + fr], dKacc[t][dt][r]);
+            atomicAdd(&dVg[(long)key * p.lddkv + dt * 16 + fr], dVacc[t][dt][r]);
+          }
         }
       }
 }
@@ -456,15 +699,25 @@ template <typename T, int NW, int TPW> int launch_bwd_n(const mvlt_attn_bwd_args
   constexpr int PAD = 16 / sizeof(T);
   const size_t lds = (size_t)(HD * (MP + PAD) + 32 * (MP + PAD) + 2 * HD * (32 + PAD)) * sizeof(T) + 64 * sizeof(float);
   MVLT_REQUIRE(lds <= 160 * 1024, "mvlt_sr_attention_bwd: LDS %zu B > 160 KB", lds);
-  // split the queries of one (batch, head) so that the grid has >= ~1024 workgroups, at most N/64 chunks
+  // split the queries of one (batch, head) only as far as needed to fill the chip once (2 workgroups per CU): every
+  // extra chunk flushes another M x 64 x 2 fp32 atomics per (batch, head), and with one chunk the flush is a plain store
   const int groups = a.B * a.H;
-  int nq = (1024 + groups - 1) / groups;
+  int nq = (512 + groups - 1) / groups;
   int maxq = (a.N + 63) / 64;
   if (nq > maxq) nq = maxq;
   if (nq < 1) nq = 1;
   int q_per_wg = ((a.N + nq - 1) / nq + 31) / 32 * 32;
   nq = (a.N + q_per_wg - 1) / q_per_wg;
   const int grid = 8 * ((groups + 7) / 8) * nq;
+  if constexpr (sizeof(T) == 2) {
+    if (!getenv("MVLT_ATTN_BWD_LEGACY")) {
+      const size_t lds2 = (size_t)(HD * (MP + 8) + 32 * (MP + 8)) * 2 + 2 * 3 * 4096 + 4096 + 2 * NW * 32 * sizeof(float);
+      MVLT_REQUIRE(lds2 <= 160 * 1024, "mvlt_sr_attention_bwd: LDS %zu B > 160 KB", lds2);
+      hipFuncSetAttribute((const void*)attn_bwd_dma_kernel<NW, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipLaunchKernelGGL((attn_bwd_dma_kernel<NW, TPW>), dim3(grid), dim3(NW * 64), lds2, s, a, nq, q_per_wg);
+      return mvlt_check_launch("mvlt_sr_attention_bwd");
+    }
+  }
   hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NW, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((attn_bwd_kernel<T, NW, TPW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
   return mvlt_check_launch("mvlt_sr_attention_bwd");

@@ -128,6 +128,14 @@ __device__ __forceinline__ u32x4 tr_frag(const char* lds_addr, int rowb) {
 // LDS-DMA of 16 B per lane to lds_wave_base + 16*lane_id.  Inline asm on purpose: for the builtin hipcc orders every
 // later LDS read after the DMA with s_waitcnt vmcnt(0) (it cannot prove the two buffers disjoint), which serialises
 // the prefetch behind the MFMAs; the kernel waits vmcnt(0) itself, once per tile, in front of its barrier.
+// same, second read 16 rows of 128 B below (the k-slot order of accumulator-born MFMA operands: two 16-row tiles paired)
+__device__ __forceinline__ u32x4 tr_frag16(const char* lds_addr) {
+  typedef __attribute__((address_space(3))) s16x4* lptr;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_addr));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_addr + 16 * 128));
+  unsigned long long l = __builtin_bit_cast(unsigned long long, lo), h = __builtin_bit_cast(unsigned long long, hi);
+  return u32x4{(unsigned)l, (unsigned)(l >> 32), (unsigned)h, (unsigned)(h >> 32)};
+}
 __device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_base) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
