@@ -60,6 +60,12 @@ typedef struct mvlt_gemm_nt_args {
   const float* row_scale;    /* [ceil(M / rows_per_scale)] fp32 or NULL (DropPath keep/(1-p) per sample) */
   int rows_per_scale;
   const void* R;
+  float* col_sum;            /* optional [N] += sum over rows of the stored C values, and */
+  float* col_sumsq;          /* [N] += sum of their squares (fp32 atomics into caller-zeroed buffers): the batch statistics
+                                of BatchNorm2d behind a conv (reference libs/vl_heads.py:107-120 BasicConv2d) without a
+                                second pass over the conv output */
+  int col_copies;            /* 0 / 1: one accumulator; k > 1: col_sum / col_sumsq are [k][N] and row tile t adds into copy
+                                t % k (spreads the same-address atomics; mvlt_bn_finalize sums the copies) */
 } mvlt_gemm_nt_args;
 int mvlt_gemm_nt(const mvlt_gemm_nt_args* args, void* stream);
 
@@ -211,7 +217,7 @@ int mvlt_mlp_bwd_dw(const mvlt_mlp_args* args, void* stream);
  * align_corners=True bilinear resizes and the feature products of reference libs/vl_heads.py:136-165.  The conv3x3
  * themselves are mvlt_gemm_nt / mvlt_gemm_tn with the mode-2 row map. --------------------------------------------- */
 int mvlt_col_stats(const float* z, int ldz, long M, int C, float* sum, float* sumsq, void* stream);         /* += */
-int mvlt_bn_finalize(const float* sum, const float* sumsq, long M, int C, float eps, float momentum, float* mean, float* rstd,
+int mvlt_bn_finalize(const float* sum, const float* sumsq, int copies /* accumulators [copies][C], summed here */, long M, int C, float eps, float momentum, float* mean, float* rstd,
                      float* running_mean, float* running_var /* nullable pair: updated like nn.BatchNorm2d */, void* stream);
 int mvlt_bn_norm(const float* z, int ldz, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
                  float* y32, int ld32, void* y_op, int ld_op, int op_dtype /* dtype of y_op: the MFMA-operand copy */, void* stream);

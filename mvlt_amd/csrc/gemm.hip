@@ -92,6 +92,10 @@ __device__ __forceinline__ void nt_epilogue(const mvlt_gemm_nt_args& p, f32x4 (&
       for (int e = 0; e < 8; ++e) if (nc_lane + e < p.N) bias8[e] = p.bias[nc_lane + e];
     }
   }
+  // optional per-column sum / sum of squares of the stored values (BatchNorm batch statistics of a conv output)
+  float cs8[8], cq8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { cs8[e] = 0.f; cq8[e] = 0.f; }
 #pragma unroll
   // (the K loop ended with a workgroup barrier: nobody reads the operand tiles any more.  From here on every wave
   //  touches only its own staging slice, so only wave-level ordering is needed and the waves drift apart freely.)
@@ -175,6 +179,10 @@ __device__ __forceinline__ void nt_epilogue(const mvlt_gemm_nt_args& p, f32x4 (&
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += r8[e];
         }
+        if (p.col_sum) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { cs8[e] += v[e]; cq8[e] += v[e] * v[e]; }
+        }
         store8(p.C, v);
       } else {                                        // ragged N (vocabulary tail, 2/48/122-way heads) or unaligned rows
         for (int e = 0; e < 8; ++e) {
@@ -188,9 +196,35 @@ __device__ __forceinline__ void nt_epilogue(const mvlt_gemm_nt_args& p, f32x4 (&
           }
           x *= rs;
           if (p.R) x += load_out(p.R, idx + e, ofp32);
+          if (p.col_sum) { cs8[e] += x; cq8[e] += x * x; }
           store_out<T>(p.C, idx + e, x, ofp32);
         }
       }
+    }
+  }
+  if (p.col_sum) {
+    // lanes with equal lane % CPR own the same 8 columns: fold them, then turn the CPR x 8 totals of this wave into one
+    // 64-lane (32 for the narrow tile) atomic per statistic through the wave's staging slice
+#pragma unroll
+    for (int off = CPR; off < 64; off <<= 1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { cs8[e] += __shfl_xor(cs8[e], off); cq8[e] += __shfl_xor(cq8[e], off); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { stage[lane * 8 + e] = cs8[e]; stage[WN + lane * 8 + e] = cq8[e]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // every row tile of the launch adds into the same N floats; same-line atomics serialise at the memory side, so the
+    // caller provides col_copies interleaved accumulators ([copy][N]) and sums them when it finalises the statistics
+    const int col = n0 + wn * WN + lane;
+    const long cpy = p.col_copies > 1 ? (long)((m0 / BM) % p.col_copies) * p.N : 0;
+    if (lane < WN && col < p.N) {
+      atomicAdd(&p.col_sum[cpy + col], stage[lane]);
+      atomicAdd(&p.col_sumsq[cpy + col], stage[WN + lane]);
     }
   }
 }
@@ -966,6 +1000,8 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   MVLT_REQUIRE(a->act >= 0 && a->act <= 2, "mvlt_gemm_nt: bad act");
   MVLT_REQUIRE(a->act != 2 || a->H, "mvlt_gemm_nt: act=2 (gelu') needs H");
   MVLT_REQUIRE(!a->row_scale || a->rows_per_scale > 0, "mvlt_gemm_nt: row_scale needs rows_per_scale");
+  MVLT_REQUIRE((a->col_sum == nullptr) == (a->col_sumsq == nullptr), "mvlt_gemm_nt: col_sum and col_sumsq come together");
+  MVLT_REQUIRE(a->col_copies >= 0, "mvlt_gemm_nt: col_copies < 0");
   if (int e = check_rowmap(a->a_map, "mvlt_gemm_nt a_map")) return e;
   if (int e = check_rowmap(a->c_map, "mvlt_gemm_nt c_map")) return e;
   MVLT_REQUIRE(a->a_map.mode == 0 || a->K == a->a_map.r * a->a_map.r * a->a_map.c_seg, "mvlt_gemm_nt: gather K != r*r*c_seg");

@@ -54,12 +54,14 @@ __global__ __launch_bounds__(NT) void col_reduce_kernel(const float* z, int ldz,
 }
 
 // mean / rstd from (sum, sumsq) and the running-stat update of nn.BatchNorm2d (momentum 0.1, unbiased running var)
-__global__ void bn_finalize_kernel(const float* sum, const float* sumsq, int M, int C, float eps, float momentum,
+__global__ void bn_finalize_kernel(const float* sum, const float* sumsq, int copies, int M, int C, float eps, float momentum,
                                    float* mean, float* rstd, float* running_mean, float* running_var) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float m = sum[c] / M;
-  float var = fmaxf(sumsq[c] / M - m * m, 0.f);
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < copies; ++k) { s1 += sum[(long)k * C + c]; s2 += sumsq[(long)k * C + c]; }
+  float m = s1 / M;
+  float var = fmaxf(s2 / M - m * m, 0.f);
   mean[c] = m;
   rstd[c] = rsqrtf(var + eps);
   if (running_mean) {
@@ -202,11 +204,11 @@ extern "C" int mvlt_col_stats(const float* z, int ldz, long M, int C, float* sum
   return mvlt_check_launch("mvlt_col_stats");
 }
 
-extern "C" int mvlt_bn_finalize(const float* sum, const float* sumsq, long M, int C, float eps, float momentum, float* mean, float* rstd,
+extern "C" int mvlt_bn_finalize(const float* sum, const float* sumsq, int copies, long M, int C, float eps, float momentum, float* mean, float* rstd,
                                 float* running_mean, float* running_var, void* stream) {
-  MVLT_REQUIRE(sum && sumsq && mean && rstd && M > 0 && C > 0, "mvlt_bn_finalize: bad arguments");
+  MVLT_REQUIRE(sum && sumsq && mean && rstd && M > 0 && C > 0 && copies >= 1, "mvlt_bn_finalize: bad arguments");
   MVLT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mvlt_bn_finalize: running_mean and running_var go together");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sum, sumsq, (int)M, C, eps, momentum, mean, rstd, running_mean, running_var);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sum, sumsq, copies, (int)M, C, eps, momentum, mean, rstd, running_mean, running_var);
   return mvlt_check_launch("mvlt_bn_finalize");
 }
 

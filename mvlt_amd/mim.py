@@ -13,6 +13,8 @@ from . import ops
 from ._lib import conv3map, rowmap
 
 BN_EPS, BN_MOM = 1e-5, 0.1
+_SEPARATE_STATS = bool(__import__('os').environ.get('MVLT_MIM_SEPARATE_STATS'))   # A/B switch: statistics by a second pass over z
+STAT_COPIES = 16           # interleaved batch-statistic accumulators of the conv epilogue (see mvlt_gemm_nt_args.col_copies)
 CONVS = ("reduction1", "reduction2", "reduction3", "conv_upsample1", "conv_upsample2", "conv_upsample3", "conv_upsample4",
          "conv_upsample5", "conv_concat2", "conv_concat3", "conv4")
 
@@ -44,13 +46,17 @@ class MimStep:
         p = f"t2i_head.{name}"
         amap = conv3map(side, side, tokens_in, cin)
         z = _e((M, cout), dev)
-        ops.gemm_nt(xin, S.extra[p + ".0.weight::K"], z, M, cout, 9 * cin, ld_in, 9 * cin, cout, a_map=amap)
         bn = getattr(self.m.t2i_head, name)[1]
+        st = _z((2, STAT_COPIES, cout), dev) if self.training else (None, None)   # batch statistics ride on the conv's epilogue
+        if _SEPARATE_STATS and self.training:
+            ops.gemm_nt(xin, S.extra[p + ".0.weight::K"], z, M, cout, 9 * cin, ld_in, 9 * cin, cout, a_map=amap)
+            ops.col_stats(z, cout, M, cout, st[0][0], st[1][0])
+        else:
+            ops.gemm_nt(xin, S.extra[p + ".0.weight::K"], z, M, cout, 9 * cin, ld_in, 9 * cin, cout, a_map=amap, col_sum=st[0], col_sumsq=st[1],
+                        col_copies=STAT_COPIES)
         if self.training:
-            st = _z((2, cout), dev)
-            ops.col_stats(z, cout, M, cout, st[0], st[1])
             mean, rstd = _e((cout,), dev), _e((cout,), dev)
-            ops.bn_finalize(st[0], st[1], M, cout, BN_EPS, BN_MOM, mean, rstd, bn.running_mean, bn.running_var)
+            ops.bn_finalize(st[0], st[1], M, cout, BN_EPS, BN_MOM, mean, rstd, bn.running_mean, bn.running_var, copies=STAT_COPIES)
             bn.num_batches_tracked += 1
         else:
             mean = bn.running_mean

@@ -12,7 +12,7 @@ _ID = rowmap()
 
 
 def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias=None, act=0, H=None,
-            row_scale=None, rows_per_scale=0, R=None):
+            row_scale=None, rows_per_scale=0, R=None, col_sum=None, col_sumsq=None, col_copies=0):
     """C[M,N] = epi(A[M,K] @ B[N,K]^T); see mvlt_gemm_nt in include/mvlt_hip.h."""
     assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype in DT
     if bias is not None:
@@ -23,8 +23,11 @@ def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias
         assert R.dtype == C_out.dtype
     if H is not None:
         assert H.dtype == C_out.dtype
+    if col_sum is not None:
+        assert col_sum.dtype == torch.float32 and col_sumsq is not None and col_sumsq.dtype == torch.float32
     a = L.GemmNTArgs(ptr(A), ptr(B), ptr(C_out), M, N, K, lda, ldb, ldc, DT[A.dtype], DT[C_out.dtype],
-                     a_map or _ID, c_map or _ID, ptr(bias), act, ptr(H), ptr(row_scale), rows_per_scale, ptr(R))
+                     a_map or _ID, c_map or _ID, ptr(bias), act, ptr(H), ptr(row_scale), rows_per_scale, ptr(R),
+                     ptr(col_sum), ptr(col_sumsq), col_copies)
     check(L.lib.mvlt_gemm_nt(C.byref(a), stream_ptr()), "mvlt_gemm_nt")
     return C_out
 
@@ -191,7 +194,7 @@ def transpose_cast(w, out, R, Ccols, ld_out):
 
 # ------------------------------------------------------------------ MIM decoder helpers (csrc/mim.hip)
 L.lib.mvlt_col_stats.argtypes = [_vp, _i, _l, _i, _vp, _vp, _vp]
-L.lib.mvlt_bn_finalize.argtypes = [_vp, _vp, _l, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]
+L.lib.mvlt_bn_finalize.argtypes = [_vp, _vp, _i, _l, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]
 L.lib.mvlt_bn_norm.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _i, _i, _vp]
 L.lib.mvlt_bn_bwd_reduce.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _l, _i, _vp, _vp, _vp]
 L.lib.mvlt_bn_bwd_apply.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _i, _vp]
@@ -205,8 +208,8 @@ def col_stats(z, ldz, M, Cdim, s, ss):
     check(L.lib.mvlt_col_stats(_p(z), ldz, M, Cdim, _p(s), _p(ss), stream_ptr()), "mvlt_col_stats")
 
 
-def bn_finalize(s, ss, M, Cdim, eps, momentum, mean, rstd, running_mean=None, running_var=None):
-    check(L.lib.mvlt_bn_finalize(_p(s), _p(ss), M, Cdim, eps, momentum, _p(mean), _p(rstd), _p(running_mean), _p(running_var), stream_ptr()),
+def bn_finalize(s, ss, M, Cdim, eps, momentum, mean, rstd, running_mean=None, running_var=None, copies=1):
+    check(L.lib.mvlt_bn_finalize(_p(s), _p(ss), copies, M, Cdim, eps, momentum, _p(mean), _p(rstd), _p(running_mean), _p(running_var), stream_ptr()),
           "mvlt_bn_finalize")
 
 

@@ -84,6 +84,23 @@ def test_gemm_nt_epilogues(ops, dtype, N):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(1000, 192, 576), (300, 64, 64), (129, 24, 128)])
+def test_gemm_nt_column_statistics(ops, dtype, M, N, K):
+    """BatchNorm batch statistics on the conv epilogue: per-column sum and sum of squares of the stored fp32 output."""
+    A, W = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.2)
+    out = torch.empty(M, N, device=dev(), dtype=torch.float32)
+    cs, cq = torch.zeros(N, device=dev()), torch.zeros(N, device=dev())
+    ops.gemm_nt(A, W, out, M, N, K, K, K, N, col_sum=cs, col_sumsq=cq)
+    assert maxrel(cs, out.sum(0)) < 1e-4
+    assert maxrel(cq, (out * out).sum(0)) < 1e-4
+    cs4, cq4 = torch.zeros(4, N, device=dev()), torch.zeros(4, N, device=dev())       # interleaved accumulators
+    ops.gemm_nt(A, W, out, M, N, K, K, K, N, col_sum=cs4, col_sumsq=cq4, col_copies=4)
+    assert maxrel(cs4.sum(0), out.sum(0)) < 1e-4 and maxrel(cq4.sum(0), (out * out).sum(0)) < 1e-4
+    if M > 128 * 4:
+        assert (cs4.abs().sum(1) > 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_nt_token_subrange(ops, dtype):
     """A = text tokens [HW, HW+T) of a (B, N, C) buffer; C written into another buffer's text range."""
     from mvlt_amd._lib import rowmap
