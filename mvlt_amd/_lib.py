@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvlt_hip.so")
+LIB_PATH = os.environ.get("MVLT_HIP_LIB") or os.path.join(_HERE, "libmvlt_hip.so")      # override: A/B runs of two builds
 
 
 class MVLTError(RuntimeError):
