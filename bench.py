@@ -124,7 +124,7 @@ def roofline_cases(B, device):
 
 
 def time_dominant_kernel(model, B, device):
-    """Roofline of the dominant kernel of the step, `gemm_nt_kernel<bf16,128>` (~21 % of GPU time in profiles/): its
+    """Roofline of the dominant kernel family of the step, `gemm_nt_dma_kernel` (~30 % of GPU time in profiles/): its
     largest in-step launch is the MIM decoder's 192->192 conv3x3 at 32x32 (conv4 / conv_concat3 forward and their
     input gradients) = a gathered-row GEMM with M = B*1024, N = 192, K = 9*192, MFMA-bound (AI ~ 575 F/B).  Timed
     with HIP events on torch's current stream, which is the stream mvlt_gemm_nt launches on.  `traffic` = HBM bytes
@@ -139,10 +139,10 @@ def time_dominant_kernel(model, B, device):
     if tj:
         t = json.load(open(os.path.join(ROOT, "profiles", tj[-1])))
         traffic, traffic2 = t.get("conv192", {}).get("hbm_bytes"), t.get("proj64", {}).get("hbm_bytes")
-    return dict(kernel="gemm_nt_kernel<bf16,128>: MIM conv3x3 192->192 @32x32 as 3x3-gather GEMM (M=B*1024, N=192, K=1728)",
+    return dict(kernel="gemm_nt_dma_kernel<128, 2> (bf16, 128x128 tile, 3x3-gather A): MIM conv3x3 192->192 @32x32 as GEMM (M=B*1024, N=192, K=1728)",
                 bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_BF16_TFLOPS, 4),
                 traffic=traffic, ms_per_launch=round(ms, 4), algorithmic_flops=flops,
-                hbm_bound_sibling=dict(kernel="gemm_nt_kernel<bf16,64>: K=64 N=64 projection, M=B*4224", bound="hbm",
+                hbm_bound_sibling=dict(kernel="gemm_nt_dma_kernel<64, 0> (bf16, 128x64 tile): K=64 N=64 projection, M=B*4224", bound="hbm",
                                        achieved=round(bytes2 / (ms2 * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                        frac=round(bytes2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), ms_per_launch=round(ms2, 4),
                                        algorithmic_bytes=bytes2, traffic=traffic2))

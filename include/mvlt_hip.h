@@ -66,6 +66,10 @@ typedef struct mvlt_gemm_nt_args {
                                 second pass over the conv output */
   int col_copies;            /* 0 / 1: one accumulator; k > 1: col_sum / col_sumsq are [k][N] and row tile t adds into copy
                                 t % k (spreads the same-address atomics; mvlt_bn_finalize sums the copies) */
+  int split_k;               /* 0 / 1: off; s > 1: K is cut into s ranges handled by separate workgroups that add their partial
+                                tiles into the fp32, caller-zeroed C with atomics (few output tiles, long K: the input
+                                gradient of the tied 30522-word MLM decoder, reference libs/vl_heads.py:31-36).  bf16
+                                operands, plain epilogue (bias allowed), identity row maps */
 } mvlt_gemm_nt_args;
 int mvlt_gemm_nt(const mvlt_gemm_nt_args* args, void* stream);
 

@@ -36,7 +36,7 @@ class GemmNTArgs(C.Structure):
                 ("a_map", RowMap), ("c_map", RowMap),
                 ("bias", c_void_p), ("act", c_int), ("H", c_void_p),
                 ("row_scale", c_void_p), ("rows_per_scale", c_int), ("R", c_void_p),
-                ("col_sum", c_void_p), ("col_sumsq", c_void_p), ("col_copies", c_int)]
+                ("col_sum", c_void_p), ("col_sumsq", c_void_p), ("col_copies", c_int), ("split_k", c_int)]
 
 
 class GemmTNArgs(C.Structure):

@@ -82,7 +82,7 @@ __device__ __forceinline__ void nt_epilogue(const mvlt_gemm_nt_args& p, f32x4 (&
   float bias8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-  if (p.bias) {
+  if (p.bias && p.split_k <= 1) {
     if (nc_lane + 8 <= p.N && (((uintptr_t)p.bias & 15) == 0)) {
       f32x4 b0 = *(const f32x4*)(p.bias + nc_lane), b1 = *(const f32x4*)(p.bias + nc_lane + 4);
 #pragma unroll
@@ -110,6 +110,20 @@ __device__ __forceinline__ void nt_epilogue(const mvlt_gemm_nt_args& p, f32x4 (&
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (p.split_k > 1) {
+      // partial tile of a K split: fp32 atomics into the caller-zeroed C, one staged row per instruction so that the
+      // lanes of a wave hit consecutive floats (whole 64-B atomic requests; the row-major 8-columns-per-lane layout
+      // below would touch every request eight times)
+      const int col = n0 + wn * WN + lane;
+      if (lane < WN && col < p.N) {
+        const float bv = (p.bias && blockIdx.y == 0) ? p.bias[col] : 0.f;
+        for (int r = 0; r < 32; ++r) {
+          const int m = m0 + wm * 64 + half * 32 + r;
+          if (m < p.M) atomicAdd((float*)p.C + (long)m * p.ldc + col, stage[r * LDW + lane] + bv);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int it = 0; it < 32 / RPI; ++it) {
       const int rl = it * RPI + lane / CPR;           // row inside this 32-row half
@@ -900,7 +914,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
   }
 
   // K position of this thread's chunk, kept as (segment, offset in segment) for the gather maps; advanced per tile
-  int kpos = chunk * 8, seg = 0, kk = chunk * 8;
+  // K split (blockIdx.y): this workgroup reduces k-tiles [kt0, kt0 + nk) and adds its partial tile atomically
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int nsplit = p.split_k > 1 ? p.split_k : 1;
+  const int kt_per = (nk_all + nsplit - 1) / nsplit;
+  const int kt0 = blockIdx.y * kt_per;
+  int kpos = kt0 * BK + chunk * 8, seg = 0, kk = chunk * 8;
   if constexpr (AMODE != 0) { seg = kk / amap.c_seg; kk -= seg * amap.c_seg; }
   auto issue = [&](int slot) {                                  // tiles are issued in K order
     const bool k_ok = kpos < p.K;
@@ -934,7 +953,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
 #pragma unroll
     for (int j = 0; j < TN_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
+  const int nk = min(kt_per, nk_all - kt0);
+  if (nk <= 0) return;
   const int fr = lane & 15, fg = lane >> 4;
   for (int st = 0; st < ns - 1 && st < nk; ++st) issue(st);
   if (ns == 1) issue(0);
@@ -1001,6 +1021,9 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   MVLT_REQUIRE(a->act != 2 || a->H, "mvlt_gemm_nt: act=2 (gelu') needs H");
   MVLT_REQUIRE(!a->row_scale || a->rows_per_scale > 0, "mvlt_gemm_nt: row_scale needs rows_per_scale");
   MVLT_REQUIRE((a->col_sum == nullptr) == (a->col_sumsq == nullptr), "mvlt_gemm_nt: col_sum and col_sumsq come together");
+  MVLT_REQUIRE(a->split_k <= 1 || (a->dtype == 0 && a->out_dtype == 1 && a->act == 0 && !a->H && !a->R && !a->row_scale && !a->col_sum &&
+                                   a->a_map.mode == 0 && a->c_map.mode == 0 && a->split_k <= 64),
+               "mvlt_gemm_nt: split_k needs bf16 operands, fp32 C (zeroed by the caller) and a plain epilogue");
   MVLT_REQUIRE(a->col_copies >= 0, "mvlt_gemm_nt: col_copies < 0");
   if (int e = check_rowmap(a->a_map, "mvlt_gemm_nt a_map")) return e;
   if (int e = check_rowmap(a->c_map, "mvlt_gemm_nt c_map")) return e;
@@ -1018,9 +1041,9 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   size_t lds = (size_t)nbuf * (BM + bn) * ROW_BYTES;
   const size_t stage = (size_t)4 * 32 * (bn / 2 + 4) * sizeof(float);      // epilogue staging (4 waves x 32 rows)
   if (lds < stage) lds = stage;
-  dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n)), block(NTHREADS);
-  if (a->dtype == 0 && !getenv("MVLT_NT_LEGACY")) {
-    const int nk = (a->K + 63) / 64;
+  dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n), (unsigned)(a->split_k > 1 ? a->split_k : 1)), block(NTHREADS);
+  if (a->dtype == 0 && (a->split_k > 1 || !getenv("MVLT_NT_LEGACY"))) {
+    const int nk = ((a->K + 63) / 64 + (a->split_k > 1 ? a->split_k : 1) - 1) / (a->split_k > 1 ? a->split_k : 1);
     int ns = nk < 2 ? nk : 2;                              // 2 x 32 KB: two workgroups per CU
     if (const char* e = getenv("MVLT_NT_NS")) { ns = atoi(e); if (ns > nk) ns = nk; if (ns < 1) ns = 1; if (ns > 4) ns = 4; }
     size_t lds2 = (size_t)ns * (BM + bn) * ROW_BYTES;

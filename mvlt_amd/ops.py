@@ -12,7 +12,7 @@ _ID = rowmap()
 
 
 def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias=None, act=0, H=None,
-            row_scale=None, rows_per_scale=0, R=None, col_sum=None, col_sumsq=None, col_copies=0):
+            row_scale=None, rows_per_scale=0, R=None, col_sum=None, col_sumsq=None, col_copies=0, split_k=0):
     """C[M,N] = epi(A[M,K] @ B[N,K]^T); see mvlt_gemm_nt in include/mvlt_hip.h."""
     assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype in DT
     if bias is not None:
@@ -27,7 +27,7 @@ def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias
         assert col_sum.dtype == torch.float32 and col_sumsq is not None and col_sumsq.dtype == torch.float32
     a = L.GemmNTArgs(ptr(A), ptr(B), ptr(C_out), M, N, K, lda, ldb, ldc, DT[A.dtype], DT[C_out.dtype],
                      a_map or _ID, c_map or _ID, ptr(bias), act, ptr(H), ptr(row_scale), rows_per_scale, ptr(R),
-                     ptr(col_sum), ptr(col_sumsq), col_copies)
+                     ptr(col_sum), ptr(col_sumsq), col_copies, split_k)
     check(L.lib.mvlt_gemm_nt(C.byref(a), stream_ptr()), "mvlt_gemm_nt")
     return C_out
 

@@ -595,9 +595,15 @@ def _mlm_decoder_bwd(model, dl, t, sv_t, e, sv_e, A, a_map, R, lda, dA, c_map=No
     Hd = model.hidden
     wname = "text_embeddings.word_embeddings.weight"
     ops.gemm_tn(dl, t, S.grad(wname), R, VOCAB, Hd, VOCAB_LD, Hd, Hd, colsum=S.grad("mlm_head.bias"))
-    dtr = _empty((R, Hd), dt, dev)
     wT = S.extra[wname + "::T"]                                   # [768, VOCAB_LD], zero padded
-    ops.gemm_nt(dl, wT, dtr, R, Hd, VOCAB_LD, VOCAB_LD, VOCAB_LD, Hd)
+    if dt == torch.bfloat16:
+        # few output tiles (R x 768), K = 30528: cut K over 4 workgroups per tile, partial sums meet in an fp32 buffer
+        dtr32 = torch.zeros(R, Hd, device=dev, dtype=torch.float32)
+        ops.gemm_nt(dl, wT, dtr32, R, Hd, VOCAB_LD, VOCAB_LD, VOCAB_LD, Hd, split_k=4)
+        dtr = dtr32.to(dt)
+    else:
+        dtr = _empty((R, Hd), dt, dev)
+        ops.gemm_nt(dl, wT, dtr, R, Hd, VOCAB_LD, VOCAB_LD, VOCAB_LD, Hd)
     de = _mlm_transform_bwd(model, dtr, sv_t, e, R)
     _embed_ln_bwd(model, "mlm_head_embed", de, sv_e, A, a_map, R, lda, dA, c_map if c_map is not None else a_map, False)
 

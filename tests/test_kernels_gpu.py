@@ -83,6 +83,16 @@ def test_gemm_nt_epilogues(ops, dtype, N):
     assert maxrel(out4, ref_pre) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,N,K,S", [(1490, 768, 30528, 16), (130, 100, 1000, 4), (64, 64, 64, 8)])
+def test_gemm_nt_split_k(ops, M, N, K, S):
+    """K cut over S workgroups per tile, fp32 atomics into a zeroed C (input gradient of the tied MLM decoder)."""
+    A, W = rnd(M, K, dtype=torch.bfloat16), rnd(N, K, dtype=torch.bfloat16, seed=1, scale=0.05)
+    bias = rnd(N, dtype=torch.float32, seed=2)
+    out = torch.zeros(M, N, device=dev(), dtype=torch.float32)
+    ops.gemm_nt(A, W, out, M, N, K, K, K, N, bias=bias, split_k=S)
+    assert maxrel(out, A.float() @ W.float().t() + bias) < TOL[torch.bfloat16]
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(1000, 192, 576), (300, 64, 64), (129, 24, 128)])
 def test_gemm_nt_column_statistics(ops, dtype, M, N, K):
