@@ -193,6 +193,23 @@ int mvlt_cast_bf16(const float* src, void* dst, long n, void* stream);
 /* out[c*ld_out + r] = in[r*C + c] (fp32 master weight -> transposed compute-dtype operand for the dgrad GEMMs) */
 int mvlt_transpose_cast(const float* in, void* out, int R, int C, int ld_out, int dtype, void* stream);
 
+/* All per-step derived weight copies in ONE launch (they used to be ~150 small transposes / permutes / casts per step):
+ * a device table of descriptors, each either a 2-D transpose-cast (fp32 [R][C] -> compute dtype [C][ld_out], the W^T dgrad
+ * operands) or a 3-D strided gather-cast (dst[i0*ds0 + i1*ds1 + i2*ds2] = src[src_off + i0*ss0 + i1*ss1 + i2*ss2]: the
+ * [out][kh][kw][cin] / flipped-tap re-orderings of the conv weights of reference libs/pvlt.py:104,168 and
+ * libs/vl_heads.py:107-165).  blk_start[ndesc + 1] = prefix sums of the workgroups each descriptor needs
+ * (kind 0: ceil(R/32)*ceil(C/32), kind 1: ceil(d0*d1*d2 / 256)). */
+typedef struct mvlt_prep_desc {
+  const float* src; void* dst;
+  int kind;                 /* 0 = transpose, 1 = gather */
+  int R, C, ld_out;         /* kind 0 */
+  int d0, d1, d2;           /* kind 1: loop extents (i2 fastest) */
+  int src_off, ss0, ss1, ss2;
+  int ds0, ds1, ds2;
+} mvlt_prep_desc;
+int mvlt_weight_prep(const mvlt_prep_desc* descs /* device */, const int* blk_start /* device, [ndesc + 1] */, int ndesc,
+                     int total_blocks, int dtype /* of every dst */, void* stream);
+
 /* ---- fused MLP for the narrow stages (mvlt_amd/csrc/mlp.hip), bf16 operands, C = 64 or 128 ------------------------
  * Replaces fc1 -> nn.GELU -> fc2 (+ DropPath + residual) of reference libs/pvlt.py:65-71,142 and their autograd: the
  * (tokens x hidden) activation stays in LDS / registers.

@@ -39,6 +39,12 @@ class GemmNTArgs(C.Structure):
                 ("col_sum", c_void_p), ("col_sumsq", c_void_p), ("col_copies", c_int), ("split_k", c_int)]
 
 
+class PrepDesc(C.Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("kind", c_int), ("R", c_int), ("C", c_int), ("ld_out", c_int),
+                ("d0", c_int), ("d1", c_int), ("d2", c_int), ("src_off", c_int), ("ss0", c_int), ("ss1", c_int), ("ss2", c_int),
+                ("ds0", c_int), ("ds1", c_int), ("ds2", c_int)]
+
+
 class GemmTNArgs(C.Structure):
     _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
                 ("M", c_int), ("N1", c_int), ("N2", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int),
@@ -86,7 +92,7 @@ class MlpArgs(C.Structure):
 
 lib.mvlt_last_error.restype = C.c_char_p
 lib.mvlt_sizeof.argtypes = [C.c_char_p]
-for _name, _cls in (("mvlt_rowmap", RowMap), ("mvlt_gemm_nt_args", GemmNTArgs), ("mvlt_gemm_tn_args", GemmTNArgs),
+for _name, _cls in (("mvlt_rowmap", RowMap), ("mvlt_prep_desc", PrepDesc), ("mvlt_gemm_nt_args", GemmNTArgs), ("mvlt_gemm_tn_args", GemmTNArgs),
                     ("mvlt_layernorm_args", LayerNormArgs), ("mvlt_layernorm_bwd_args", LayerNormBwdArgs),
                     ("mvlt_attn_args", AttnArgs), ("mvlt_attn_bwd_args", AttnBwdArgs), ("mvlt_mlp_args", MlpArgs)):
     _n = lib.mvlt_sizeof(_name.encode())
@@ -97,7 +103,7 @@ EXPORTS = ["mvlt_last_error", "mvlt_abi_version", "mvlt_sizeof", "mvlt_gemm_nt",
            "mvlt_layernorm_fwd", "mvlt_layernorm_bwd", "mvlt_batch_sum", "mvlt_sr_attention_fwd", "mvlt_sr_attention_bwd",
            "mvlt_bert_embed_fwd", "mvlt_bert_embed_bwd", "mvlt_patchify", "mvlt_masked_select", "mvlt_gather_rows",
            "mvlt_scatter_rows", "mvlt_cross_entropy_fwd", "mvlt_cross_entropy_bwd", "mvlt_adamw_step", "mvlt_cast_bf16",
-           "mvlt_transpose_cast", "mvlt_col_stats", "mvlt_bn_finalize", "mvlt_bn_norm", "mvlt_bn_bwd_reduce", "mvlt_bn_bwd_apply",
+           "mvlt_transpose_cast", "mvlt_weight_prep", "mvlt_col_stats", "mvlt_bn_finalize", "mvlt_bn_norm", "mvlt_bn_bwd_reduce", "mvlt_bn_bwd_apply",
            "mvlt_ew_mul", "mvlt_upsample_fwd", "mvlt_upsample_bwd", "mvlt_mlp_fwd", "mvlt_mlp_bwd_dx", "mvlt_mlp_bwd_dw"]
 
 DT = {torch.bfloat16: 0, torch.float32: 1}

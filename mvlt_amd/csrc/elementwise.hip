@@ -289,6 +289,45 @@ __global__ __launch_bounds__(NT) void transpose_cast_kernel(const float* in, T* 
   }
 }
 
+// table-driven version of the above plus a strided 3-D gather: one workgroup = one 32x32 tile or 256 gathered elements
+template <typename T>
+__global__ __launch_bounds__(NT) void weight_prep_kernel(const mvlt_prep_desc* descs, const int* blk_start, int ndesc) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  int lo = 0, hi = ndesc - 1;                         // last descriptor whose first block is <= b
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (blk_start[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const mvlt_prep_desc d = descs[lo];
+  const int lb = b - blk_start[lo];
+  T* out = (T*)d.dst;
+  if (d.kind == 0) {
+    const int tiles_c = (d.C + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int c0 = (lb % tiles_c) * 32, r0 = (lb / tiles_c) * 32;
+    for (int j = ty; j < 32; j += 8) {
+      int r = r0 + j, c = c0 + tx;
+      tile[j][tx] = (r < d.R && c < d.C) ? d.src[(long)r * d.C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+      int c = c0 + j, r = r0 + tx;
+      if (c < d.C && r < d.R) out[(long)c * d.ld_out + r] = (T)tile[tx][j];
+    }
+  } else {
+    const long i = (long)lb * NT + threadIdx.x;
+    const long n = (long)d.d0 * d.d1 * d.d2;
+    if (i < n) {
+      const int i2 = (int)(i % d.d2);
+      const long t = i / d.d2;
+      const int i1 = (int)(t % d.d1), i0 = (int)(t / d.d1);
+      out[(long)i0 * d.ds0 + (long)i1 * d.ds1 + (long)i2 * d.ds2] =
+          (T)d.src[(long)d.src_off + (long)i0 * d.ss0 + (long)i1 * d.ss1 + (long)i2 * d.ss2];
+    }
+  }
+}
+
 RowMap host_rowmap(const mvlt_rowmap* m) {
   RowMap r{};
   if (m) { r.mode = m->mode; r.rows_per_batch = m->rows_per_batch; r.batch_stride = m->batch_stride; r.offset = m->offset; }
@@ -408,6 +447,13 @@ extern "C" int mvlt_cast_bf16(const float* src, void* dst, long n, void* stream)
   if (n == 0) return MVLT_OK;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, src, (bf16*)dst, n);
   return mvlt_check_launch("mvlt_cast_bf16");
+}
+
+extern "C" int mvlt_weight_prep(const mvlt_prep_desc* descs, const int* blk_start, int ndesc, int total_blocks, int dtype, void* stream) {
+  MVLT_REQUIRE(descs && blk_start && ndesc > 0 && total_blocks > 0, "mvlt_weight_prep: bad arguments");
+  if (dtype == 0) hipLaunchKernelGGL((weight_prep_kernel<bf16>), dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, descs, blk_start, ndesc);
+  else hipLaunchKernelGGL((weight_prep_kernel<float>), dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, descs, blk_start, ndesc);
+  return mvlt_check_launch("mvlt_weight_prep");
 }
 
 extern "C" int mvlt_transpose_cast(const float* in, void* out, int R, int Ccols, int ld_out, int dtype, void* stream) {

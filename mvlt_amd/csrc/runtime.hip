@@ -27,7 +27,7 @@ extern "C" int mvlt_abi_version(void) { return 1; }
 // sizeof() of every argument struct, so a foreign-language binding can verify its mirror of include/mvlt_hip.h
 extern "C" int mvlt_sizeof(const char* name) {
 #define S(T) if (strcmp(name, #T) == 0) return (int)sizeof(T);
-  S(mvlt_rowmap) S(mvlt_gemm_nt_args) S(mvlt_gemm_tn_args) S(mvlt_layernorm_args) S(mvlt_layernorm_bwd_args)
+  S(mvlt_rowmap) S(mvlt_prep_desc) S(mvlt_gemm_nt_args) S(mvlt_gemm_tn_args) S(mvlt_layernorm_args) S(mvlt_layernorm_bwd_args)
   S(mvlt_attn_args) S(mvlt_attn_bwd_args) S(mvlt_mlp_args)
 #undef S
   return -1;

@@ -32,6 +32,12 @@ def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias
     return C_out
 
 
+def weight_prep(desc_dev, blk_dev, ndesc, total_blocks, dtype):
+    """desc_dev: uint8 device tensor holding ndesc packed mvlt_prep_desc; blk_dev: int32 device tensor [ndesc + 1]."""
+    check(L.lib.mvlt_weight_prep(C.c_void_p(desc_dev.data_ptr()), C.c_void_p(blk_dev.data_ptr()), ndesc, total_blocks, DT[dtype], stream_ptr()),
+          "mvlt_weight_prep")
+
+
 def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, colsum=None, splits=0):
     """C[N1,N2] += A[M,N1]^T @ B[M,N2] (fp32 atomics); colsum[N1] += A.sum(0)."""
     assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype == torch.float32

@@ -148,31 +148,73 @@ class FlatStore:
             return
         if self.C is not None:
             ops.cast_bf16(self.P, self.C, self.total)
-        dt = self.compute_dtype
-        for name in transposed:
-            w = self.master(name)
-            key = name + "::T"
-            if key not in self.extra:
-                ld = (w.shape[0] + 7) // 8 * 8               # rows of W^T padded to 16 B (vocab 30522 -> 30528)
-                self.extra[key] = torch.zeros(w.shape[1], ld, device=self.device, dtype=dt)
-            ops.transpose_cast(w, self.extra[key], w.shape[0], w.shape[1], ld_out=self.extra[key].shape[1])
-        for name in conv_perm:
-            w = self.master(name)                            # [out, cin, kh, kw]
-            wk = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)   # [out][kh][kw][cin]
-            self.extra[name + "::K"] = wk.to(dt).contiguous()
-            self.extra[name + "::KT"] = wk.t().to(dt).contiguous()
-        for name in conv3:
-            w = self.master(name)                            # [out, cin, 3, 3]
-            self.extra[name + "::K"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()       # [out][dy][dx][cin]
-            self.extra[name + "::F"] = w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(dt).contiguous()  # [cin][2-dy][2-dx][out]
-        if "t2i_head.score.0.weight" in self.offsets and conv3:
-            w = self.master("t2i_head.score.0.weight").view(3, -1)
-            self.extra["t2i_head.score.0.weight::W"] = w.to(dt).contiguous()
-            wt = torch.zeros(w.shape[1], 8, device=self.device, dtype=dt)
-            wt[:, :3] = w.t().to(dt)
-            self.extra["t2i_head.score.0.weight::T"] = wt
+        key = (tuple(transposed), tuple(conv_perm), tuple(conv3), self.compute_dtype, self.P.data_ptr())
+        if getattr(self, "_prep_key", None) != key:
+            self._build_prep(transposed, conv_perm, conv3)
+            self._prep_key = key
+        if self._prep_n:
+            ops.weight_prep(self._prep_desc, self._prep_blk, self._prep_n, self._prep_blocks, self.compute_dtype)
         self._cast_version = self.P._version
         self.force_dirty = False
+
+    def _build_prep(self, transposed, conv_perm, conv3):
+        """Descriptor table of every derived weight copy (one mvlt_weight_prep launch per step refreshes them all).
+        The destination tensors are allocated once here; their addresses are baked into the table."""
+        import ctypes
+        from ._lib import PrepDesc
+        dt, dev = self.compute_dtype, self.device
+        descs, blocks = [], []
+
+        def src_ptr(name):
+            return self.master(name).data_ptr()
+
+        def transpose(name):
+            w = self.master(name)
+            R, Ccols = w.shape
+            ld = (R + 7) // 8 * 8                            # rows of W^T padded to 16 B (vocab 30522 -> 30528)
+            k = name + "::T"
+            if k not in self.extra or self.extra[k].dtype != dt:
+                self.extra[k] = torch.zeros(Ccols, ld, device=dev, dtype=dt)
+            descs.append(PrepDesc(src_ptr(name), self.extra[k].data_ptr(), 0, R, Ccols, ld, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+            blocks.append(((R + 31) // 32) * ((Ccols + 31) // 32))
+
+        def gather(name, suffix, shape, dims, src_off, ss, ds):
+            k = name + suffix
+            if k not in self.extra or self.extra[k].dtype != dt or tuple(self.extra[k].shape) != tuple(shape):
+                self.extra[k] = torch.zeros(*shape, device=dev, dtype=dt)
+            descs.append(PrepDesc(src_ptr(name), self.extra[k].data_ptr(), 1, 0, 0, 0, dims[0], dims[1], dims[2], src_off,
+                                  ss[0], ss[1], ss[2], ds[0], ds[1], ds[2]))
+            blocks.append((dims[0] * dims[1] * dims[2] + 255) // 256)
+
+        for name in transposed:
+            transpose(name)
+        for name in list(conv_perm) + list(conv3):
+            out, cin, kh, kw = self.master(name).shape
+            t = kh * kw
+            # [out][kh][kw][cin]: dst (out, t, cin) <- src[out][cin][t]
+            gather(name, "::K", (out, t * cin), (out, t, cin), 0, (cin * t, 1, t), (t * cin, cin, 1))
+            if name in conv_perm:
+                # transpose of ::K: dst (t, cin, out) <- src[out][cin][t]
+                gather(name, "::KT", (t * cin, out), (t, cin, out), 0, (1, t, cin * t), (cin * out, out, 1))
+            else:
+                # dgrad taps: dst (cin, 8 - t, out) <- src[out][cin][t]   ([cin][2-dy][2-dx][out])
+                gather(name, "::F", (cin, t * out), (cin, t, out), t - 1, (t, -1, cin * t), (t * out, out, 1))
+        if "t2i_head.score.0.weight" in self.offsets and conv3:
+            name = "t2i_head.score.0.weight"
+            K = self.master(name).numel() // 3
+            gather(name, "::W", (3, K), (1, 1, 3 * K), 0, (0, 0, 1), (0, 0, 1))
+            gather(name, "::T", (K, 8), (K, 3, 1), 0, (1, K, 0), (8, 1, 0))            # W^T, rows padded to 8 (zeros stay)
+        self._prep_n = len(descs)
+        if not descs:
+            return
+        arr = (PrepDesc * len(descs))(*descs)
+        raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr))), dtype=torch.uint8)
+        self._prep_desc = raw.to(dev)
+        starts = [0]
+        for b in blocks:
+            starts.append(starts[-1] + b)
+        self._prep_blk = torch.tensor(starts, dtype=torch.int32, device=dev)
+        self._prep_blocks = starts[-1]
 
     # ------------------------------------------------------------------ gradients
     def begin_step(self):
