@@ -10,6 +10,7 @@ concatenated buffers.  MFMA operands are the only tensors in the compute dtype.
 import torch
 
 from . import ops
+from .params import pool_zeros
 from ._lib import conv3map, rowmap
 
 BN_EPS, BN_MOM = 1e-5, 0.1
@@ -20,7 +21,7 @@ CONVS = ("reduction1", "reduction2", "reduction3", "conv_upsample1", "conv_upsam
 
 
 def _z(shape, dev, dtype=torch.float32):
-    return torch.zeros(shape, device=dev, dtype=dtype)
+    return pool_zeros(shape, dtype, dev)                          # step-scoped scratch (params.ZeroPool)
 
 
 def _e(shape, dev, dtype=torch.float32):

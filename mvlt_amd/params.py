@@ -52,6 +52,49 @@ def conv_default_init_(w, b):
         nn.init.uniform_(b, -bound, bound)
 
 
+class ZeroPool:
+    """Per-step scratch that must start at zero (atomic accumulation targets: weight-gradient tiles, BN statistics, dK/dV,
+    split-K partial sums ...).  One `zero_()` of a pooled buffer at the start of a step replaces ~50 tiny fill launches;
+    a request that does not fit falls back to torch.zeros and grows the pool for the next step.  Tensors taken from the
+    pool are valid until the next `reset()` (= next training/eval step): only use it for schedule-internal scratch."""
+    _pools = {}
+
+    def __init__(self, device):
+        self.device, self.buf, self.used, self.need = device, None, 0, 0
+
+    @classmethod
+    def of(cls, device):
+        key = (device.type, device.index)
+        if key not in cls._pools:
+            cls._pools[key] = cls(device)
+        return cls._pools[key]
+
+    def reset(self):
+        want = max(self.need, self.used)
+        if self.buf is None or want > self.buf.numel():
+            self.buf = torch.empty(int(want * 1.25) + (1 << 20), dtype=torch.uint8, device=self.device)
+            want = self.buf.numel()                              # a fresh buffer is zeroed in full
+        if want:
+            self.buf[:want].zero_()
+        self.used, self.need = 0, 0
+
+    def take(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = (n * torch.empty((), dtype=dtype).element_size() + 255) // 256 * 256
+        self.need += nbytes
+        if self.buf is None or self.used + nbytes > self.buf.numel():
+            return torch.zeros(shape, dtype=dtype, device=self.device)
+        t = self.buf[self.used:self.used + nbytes].view(dtype)[:n].view(shape)
+        self.used += nbytes
+        return t
+
+
+def pool_zeros(shape, dtype, device):
+    return ZeroPool.of(torch.device(device) if not isinstance(device, torch.device) else device).take(tuple(shape) if not isinstance(shape, int) else (shape,), dtype)
+
+
 class FlatStore:
     """Flat fp32 master/grad buffers behind a module's parameters, plus compute-dtype operand copies."""
 
