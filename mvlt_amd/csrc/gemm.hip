@@ -243,6 +243,173 @@ __device__ __forceinline__ void nt_epilogue(const mvlt_gemm_nt_args& p, f32x4 (&
   }
 }
 
+// ---------------- lean NT epilogues (bf16 LDS-DMA kernels).  The generic epilogue above decides every feature at run time
+// inside the per-row loop and recomputes row / column addressing per 8 outputs: ~100 instructions per 8 outputs, 55 % of
+// the stage-3 fc1 GEMM's time.  The call sites use five shapes of epilogue; each gets a compile-time variant in which the
+// column side (bias, chunk index) is fixed per lane, the row side is a multiply, and the operands a variant needs (R, H,
+// DropPath factor) are requested for a whole 32-row half before it is processed.  Preconditions (checked by the host
+// dispatch): identity or batch-strided c_map, N % 8 == 0, ldc % 8 == 0, 16-byte aligned C / R / H, no split-K.
+//   EPI 1: C = AB^T (+bias)                      EPI 2: C = (AB^T + bias) * row_scale + R
+//   EPI 3: H = AB^T + bias ; C = gelu(H)         EPI 4: C = AB^T * gelu'(H)          EPI 5: EPI 1 + column sum / sum of squares
+__device__ __forceinline__ int fdiv24(int m, int d, float inv) {      // exact m / d for 0 <= m < 2^24, inv = 1.0f / d
+  int q = (int)((float)m * inv);
+  int r = m - q * d;
+  return q + (r >= d) - (r < 0);
+}
+template <int BN, int EPI>
+__device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32x4 (&acc)[4][BN / 32], char* smem, int m0, int n0,
+                                                 int wave, int lane) {
+  constexpr int WN = BN / 2;
+  constexpr int TN_ = WN / 16;
+  constexpr int LDW = WN + 4;
+  constexpr int CPR = WN / 8;
+  constexpr int RPI = 64 / CPR;
+  constexpr int NIT = 32 / RPI;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ofp32 = p.out_dtype;
+  float* stage = (float*)smem + wave * 32 * LDW;
+  const int ch = lane % CPR;
+  const int nc = n0 + wn * WN + ch * 8;
+  const bool col_ok = nc < p.N;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  if (p.bias && col_ok) {
+    if (((uintptr_t)p.bias & 15) == 0) {
+      f32x4 b0 = *(const f32x4*)(p.bias + nc), b1 = *(const f32x4*)(p.bias + nc + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias8[e] = p.bias[nc + e];
+    }
+  }
+  const int m_first = m0 + wm * 64 + lane / CPR;
+  const int rpb = p.c_map.rows_per_batch;
+  const float inv_rpb = rpb > 0 ? 1.0f / (float)rpb : 0.f;
+  const float inv_rps = (EPI == 2 && p.rows_per_scale > 0) ? 1.0f / (float)p.rows_per_scale : 0.f;
+  float cs8[8], cq8[8];
+  if (EPI == 5) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { cs8[e] = 0.f; cq8[e] = 0.f; }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < TN_; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(ii * 16 + 4 * fg + r) * LDW + j * 16 + fr] = acc[half * 2 + ii][j][r];
+    long idx[NIT];
+    bool ok[NIT];
+    float rs[NIT];
+    u32x4 raw[NIT][2];                                // R (EPI 2) or H (EPI 4) of this half, all requested up front
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m_first + half * 32 + it * RPI;
+      ok[it] = m < p.M && col_ok;
+      const int mm = ok[it] ? m : 0;
+      long phys = mm;
+      if (rpb > 0) {
+        const int b = fdiv24(mm, rpb, inv_rpb);
+        phys = (long)b * p.c_map.batch_stride + p.c_map.offset + (mm - b * rpb);
+      }
+      idx[it] = phys * p.ldc + nc;
+      rs[it] = 1.0f;
+      if (EPI == 2 && p.row_scale) rs[it] = p.row_scale[fdiv24(mm, p.rows_per_scale, inv_rps)];
+      if ((EPI == 2 || EPI == 4) && ok[it]) {
+        const void* src = (EPI == 2) ? p.R : p.H;
+        if (ofp32) { raw[it][0] = *(const u32x4*)((const float*)src + idx[it]); raw[it][1] = *(const u32x4*)((const float*)src + idx[it] + 4); }
+        else raw[it][0] = *(const u32x4*)((const bf16*)src + idx[it]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (!ok[it]) continue;
+      const int rl = it * RPI + lane / CPR;
+      const f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+      const long ix = idx[it];
+      auto store8 = [&](void* base, const float* o) {
+        if (ofp32) {
+          *(f32x4*)((float*)base + ix) = f32x4{o[0], o[1], o[2], o[3]};
+          *(f32x4*)((float*)base + ix + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        } else {
+          bf16x8 a;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = (bf16)o[e];
+          *(bf16x8*)((bf16*)base + ix) = a;
+        }
+      };
+      float o8[8];
+      if (EPI == 2 || EPI == 4) {
+        if (ofp32) {
+          const f32x4 a = __builtin_bit_cast(f32x4, raw[it][0]), b = __builtin_bit_cast(f32x4, raw[it][1]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o8[e] = a[e]; o8[4 + e] = b[e]; }
+        } else {
+          const bf16x8 a = __builtin_bit_cast(bf16x8, raw[it][0]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = (float)a[e];
+        }
+      }
+      if (EPI == 3) {
+        if (p.H) store8(p.H, v);
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const f32x2 gv = gelu_erf2(f32x2{v[e], v[e + 1]});
+          v[e] = gv[0]; v[e + 1] = gv[1];
+        }
+      }
+      if (EPI == 4) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const f32x2 dv = gelu_erf_grad2(f32x2{o8[e], o8[e + 1]});
+          v[e] *= dv[0]; v[e + 1] *= dv[1];
+        }
+      }
+      if (EPI == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[it] + o8[e];
+      }
+      if (EPI == 5) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { cs8[e] += v[e]; cq8[e] += v[e] * v[e]; }
+      }
+      store8(p.C, v);
+    }
+  }
+  if (EPI == 5) {
+#pragma unroll
+    for (int off = CPR; off < 64; off <<= 1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { cs8[e] += __shfl_xor(cs8[e], off); cq8[e] += __shfl_xor(cq8[e], off); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { stage[lane * 8 + e] = cs8[e]; stage[WN + lane * 8 + e] = cq8[e]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int col = n0 + wn * WN + lane;
+    const long cpy = p.col_copies > 1 ? (long)((m0 / BM) % p.col_copies) * p.N : 0;
+    if (lane < WN && col < p.N) {
+      atomicAdd(&p.col_sum[cpy + col], stage[lane]);
+      atomicAdd(&p.col_sumsq[cpy + col], stage[WN + lane]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ NT
 template <typename T, int BN>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p, int nbuf) {
@@ -863,7 +1030,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_dma_kernel(mvlt_gemm_tn_args
 // ds_write_b128 (LDS stores run at ~80 B/clk/CU, a third of the read rate, and were as expensive as the MFMAs).  The
 // LDS image is the same (128-B rows of 64 k, 16-B chunks XOR-swizzled by row); because the DMA writes lane-linear the
 // swizzle is applied to the source chunk each lane fetches.  ns-deep ring with a counted vmcnt wait, as in the TN kernel.
-template <int BN, int AMODE>
+template <int BN, int AMODE, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args p, int ns) {
   constexpr int BK = 64;
   constexpr int WN = BN / 2, TN_ = WN / 16;
@@ -990,7 +1157,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
     }
   }
   __syncthreads();                   // last tile's reads are done before the epilogue reuses the LDS
-  nt_epilogue<bf16, BN>(p, acc, smem, m0, n0, wave, lane);
+  if constexpr (EPI == 0) nt_epilogue<bf16, BN>(p, acc, smem, m0, n0, wave, lane);
+  else nt_epilogue_lean<BN, EPI>(p, acc, smem, m0, n0, wave, lane);
 }
 
 int check_rowmap(const mvlt_rowmap& m, const char* who) {
@@ -1048,13 +1216,37 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     if (const char* e = getenv("MVLT_NT_NS")) { ns = atoi(e); if (ns > nk) ns = nk; if (ns < 1) ns = 1; if (ns > 4) ns = 4; }
     size_t lds2 = (size_t)ns * (BM + bn) * ROW_BYTES;
     if (lds2 < stage) lds2 = stage;
+    // compile-time epilogue variant (see nt_epilogue_lean); 0 = generic
+    int epi = 0;
+    const bool lean_ok = a->c_map.mode == 0 && a->split_k <= 1 && a->N % 8 == 0 && a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 &&
+                         (!a->R || ((uintptr_t)a->R & 15) == 0) && (!a->H || ((uintptr_t)a->H & 15) == 0) && a->M < (1 << 24) &&
+                         !getenv("MVLT_NT_GENERIC_EPI");
+    if (lean_ok) {
+      if (a->act == 1 && !a->R && !a->row_scale && !a->col_sum) epi = 3;
+      else if (a->act == 2 && !a->R && !a->row_scale && !a->col_sum) epi = 4;
+      else if (a->act == 0 && a->R && !a->col_sum) epi = 2;
+      else if (a->act == 0 && !a->R && !a->row_scale && a->col_sum) epi = 5;
+      else if (a->act == 0 && !a->R && !a->row_scale && !a->col_sum) epi = 1;
+    }
+#define MVLT_NT_LAUNCH_E(BN_, AM_)                                                                                   \
+  do {                                                                                                               \
+    switch (epi) {                                                                                                   \
+      case 1: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 1>), grid, block, lds2, s, *a, ns); break;            \
+      case 2: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 2>), grid, block, lds2, s, *a, ns); break;            \
+      case 3: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 3>), grid, block, lds2, s, *a, ns); break;            \
+      case 4: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 4>), grid, block, lds2, s, *a, ns); break;            \
+      case 5: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 5>), grid, block, lds2, s, *a, ns); break;            \
+      default: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 0>), grid, block, lds2, s, *a, ns);                  \
+    }                                                                                                                \
+  } while (0)
 #define MVLT_NT_LAUNCH(BN_)                                                                                          \
   do {                                                                                                               \
-    if (a->a_map.mode == 0) hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, 0>), grid, block, lds2, s, *a, ns);          \
-    else if (a->a_map.mode == 1) hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, 1>), grid, block, lds2, s, *a, ns);     \
-    else hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, 2>), grid, block, lds2, s, *a, ns);                             \
+    if (a->a_map.mode == 0) MVLT_NT_LAUNCH_E(BN_, 0);                                                                \
+    else if (a->a_map.mode == 1) MVLT_NT_LAUNCH_E(BN_, 1);                                                           \
+    else MVLT_NT_LAUNCH_E(BN_, 2);                                                                                   \
   } while (0)
     if (narrow) MVLT_NT_LAUNCH(64); else MVLT_NT_LAUNCH(128);
+#undef MVLT_NT_LAUNCH_E
 #undef MVLT_NT_LAUNCH
   } else if (a->dtype == 0) {
     if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 64>), grid, block, lds, s, *a, nbuf);

@@ -12,6 +12,6 @@ def timeit(fn, reps=20):
 for M, N, K in [(98304, 1280, 320), (49152, 2048, 512), (262144, 128, 1152)]:
     A = torch.randn(M, K, device=dev).to(bf); W = (torch.randn(N, K, device=dev) * K ** -0.5).to(bf)
     out = torch.empty(M, N, device=dev, dtype=bf)
-    for name, cc in [('normal', 0), ('no C store', 0x10000), ('1 k-tile only', 0x20000), ('1 k-tile, no store', 0x30000)]:
+    for name, cc in [('normal', 0), ('no C store', 0x10000), ('no epilogue', 0x40000), ('1 k-tile only', 0x20000), ('1 k-tile, no store', 0x30000), ('1 k-tile, no epilogue', 0x60000)]:
         t = timeit(lambda: ops.gemm_nt(A, W, out, M, N, K, K, K, N, col_copies=cc))
         print('nt M=%d N=%d K=%d %-20s %.1f us' % (M, N, K, name, t * 1e3))
