@@ -840,7 +840,7 @@ template <int W> struct DmaTile {
 };
 
 template <int BMT, int BN, int BMODE, int NS>
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_dma_kernel(mvlt_gemm_tn_args p, int m_per_split, int t1, int t2, int splits) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_args p, int m_per_split, int t1, int t2, int splits) {
   using TA = DmaTile<BMT>;
   using TB = DmaTile<BN>;
   constexpr int WM = BMT / 2, TM_ = WM / 16;             // wave tile rows: 64 (4 fragments) or 32 (2)
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_dma_kernel(mvlt_gemm_tn_args
   const int b_colg = n2_0 + ((((tid % TB::CH)) ^ (TB::h(b_row0) << 1)) << 3);
   const bool b_col_ok = b_colg < p.N2;
   int b_col = b_colg, b_seg_rows = 0, tap_dy = 0, tap_dx = 0;
-  if constexpr (BMODE != 0) {
+  if constexpr (BMODE == 1 || BMODE == 2) {
     const int b_seg = b_colg / bmap.c_seg;
     b_col = b_colg - b_seg * bmap.c_seg;
     if constexpr (BMODE == 1) b_seg_rows = rowmap_seg(bmap, b_seg);
@@ -905,8 +905,38 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_dma_kernel(mvlt_gemm_tn_args
 #pragma unroll
   for (int j = 0; j < TB::IT; ++j) bit[j] = row_init(bmap, m_begin + j * TB::RPP + b_row0);
 
+  // BMODE 3 = both operands with identity rows (most weight gradients): the source of a slot is a pointer that advances
+  // by 64 rows per tile, and only the last (partial) tile of a split looks at row indices at all
+  constexpr bool PLAIN = (BMODE == 3);
+  const char* a_ptr[TA::IT];
+  const char* b_ptr[TB::IT];
+  const long a_adv = a_col_ok ? (long)TBK * a_rowb : 0, b_adv = b_col_ok ? (long)TBK * b_rowb : 0;
+  if constexpr (PLAIN) {
+#pragma unroll
+    for (int j = 0; j < TA::IT; ++j) a_ptr[j] = a_col_ok ? a_src + (unsigned long long)(unsigned)(m_begin + j * TA::RPP + a_row0) * a_rowb : zsrc;
+#pragma unroll
+    for (int j = 0; j < TB::IT; ++j) b_ptr[j] = b_col_ok ? b_src + (unsigned long long)(unsigned)(m_begin + j * TB::RPP + b_row0) * b_rowb : zsrc;
+  }
   // tiles are issued in order m_begin, m_begin + 64, ... (the row iterators advance by one tile per call)
   auto issue = [&](int mt, int slot) {
+    if constexpr (PLAIN) {
+      const bool whole = mt + TBK <= m_end;               // uniform
+#pragma unroll
+      for (int j = 0; j < TA::IT; ++j) {
+        const int woff = slot * STAGE + (j * NTHREADS + wave * 64) * 16;
+        const char* src = (whole || mt + j * TA::RPP + a_row0 < m_end) ? a_ptr[j] : zsrc;
+        glds16(src, __builtin_amdgcn_readfirstlane(smem_lds + woff));
+        a_ptr[j] += a_adv;
+      }
+#pragma unroll
+      for (int j = 0; j < TB::IT; ++j) {
+        const int woff = slot * STAGE + TA::BYTES + (j * NTHREADS + wave * 64) * 16;
+        const char* src = (whole || mt + j * TB::RPP + b_row0 < m_end) ? b_ptr[j] : zsrc;
+        glds16(src, __builtin_amdgcn_readfirstlane(smem_lds + woff));
+        b_ptr[j] += b_adv;
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < TA::IT; ++j) {
       int m = mt + j * TA::RPP + a_row0;
@@ -920,7 +950,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_dma_kernel(mvlt_gemm_tn_args
     for (int j = 0; j < TB::IT; ++j) {
       int m = mt + j * TB::RPP + b_row0;
       int phys;
-      bool ok = row_phys<BMODE>(bmap, bit[j], tap_dy, tap_dx, b_seg_rows, phys) && m < m_end && b_col_ok;
+      bool ok = row_phys<(BMODE == 3 ? 0 : BMODE)>(bmap, bit[j], tap_dy, tap_dx, b_seg_rows, phys) && m < m_end && b_col_ok;
       row_advance(bit[j], bstep);
       const int woff = slot * STAGE + TA::BYTES + (j * NTHREADS + wave * 64) * 16;
       glds16(ok ? b_src + (unsigned long long)(unsigned)phys * b_rowb : zsrc, __builtin_amdgcn_readfirstlane(smem_lds + woff));
@@ -1296,7 +1326,9 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
     dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * t1 * t2)), block(NTHREADS);
 #define MVLT_TN_LAUNCH(BMT_, BN_, NS_)                                                                                          \
   do {                                                                                                                         \
-    if (a->b_map.mode == 0) hipLaunchKernelGGL((gemm_tn_dma_kernel<BMT_, BN_, 0, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits);      \
+    if (a->b_map.mode == 0 && a->b_map.rows_per_batch == 0 && a->a_map.rows_per_batch == 0)                                                        \
+      hipLaunchKernelGGL((gemm_tn_dma_kernel<BMT_, BN_, 3, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits);                           \
+    else if (a->b_map.mode == 0) hipLaunchKernelGGL((gemm_tn_dma_kernel<BMT_, BN_, 0, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits); \
     else if (a->b_map.mode == 1) hipLaunchKernelGGL((gemm_tn_dma_kernel<BMT_, BN_, 1, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits); \
     else hipLaunchKernelGGL((gemm_tn_dma_kernel<BMT_, BN_, 2, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits);                         \
   } while (0)
