@@ -1157,6 +1157,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
   if (ns == 1) issue(0);
   int slot = 0, islot = ns - 1;
   for (int kt = 0; kt < nk; ++kt) {
+    if (ns == 1 && kt > 0) {           // single stage (many workgroups per CU hide the latency instead of a ring)
+      __builtin_amdgcn_s_barrier();    // everyone is done reading the stage
+      asm volatile("" ::: "memory");
+      issue(0);
+    }
     if (ns == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
     else if (ns == 4 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1242,10 +1247,6 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n), (unsigned)(a->split_k > 1 ? a->split_k : 1)), block(NTHREADS);
   if (a->dtype == 0 && (a->split_k > 1 || !getenv("MVLT_NT_LEGACY"))) {
     const int nk = ((a->K + 63) / 64 + (a->split_k > 1 ? a->split_k : 1) - 1) / (a->split_k > 1 ? a->split_k : 1);
-    int ns = nk < 2 ? nk : 2;                              // 2 x 32 KB: two workgroups per CU
-    if (const char* e = getenv("MVLT_NT_NS")) { ns = atoi(e); if (ns > nk) ns = nk; if (ns < 1) ns = 1; if (ns > 4) ns = 4; }
-    size_t lds2 = (size_t)ns * (BM + bn) * ROW_BYTES;
-    if (lds2 < stage) lds2 = stage;
     // compile-time epilogue variant (see nt_epilogue_lean); 0 = generic
     int epi = 0;
     const bool lean_ok = a->c_map.mode == 0 && a->split_k <= 1 && a->N % 8 == 0 && a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 &&
@@ -1258,6 +1259,12 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
       else if (a->act == 0 && !a->R && !a->row_scale && a->col_sum) epi = 5;
       else if (a->act == 0 && !a->R && !a->row_scale && !a->col_sum) epi = 1;
     }
+    // ring depth: 2 stages (64 KB, two workgroups per CU).  One stage (32 KB, four per CU, the other workgroups hiding the
+    // load latency) times the same in isolation for the write-only epilogues and the same in the step: MVLT_NT_NS=1 keeps it testable
+    int ns = nk < 2 ? nk : 2;
+    if (const char* e = getenv("MVLT_NT_NS")) { ns = atoi(e); if (ns > nk) ns = nk; if (ns < 1) ns = 1; if (ns > 4) ns = 4; }
+    size_t lds2 = (size_t)ns * (BM + bn) * ROW_BYTES;
+    if (lds2 < stage) lds2 = stage;
 #define MVLT_NT_LAUNCH_E(BN_, AM_)                                                                                   \
   do {                                                                                                               \
     switch (epi) {                                                                                                   \
