@@ -187,6 +187,124 @@ __global__ __launch_bounds__(NT) void upsample_bwd_kernel(const float* dy, int l
   }
 }
 
+// ---- row-per-workgroup versions of the two kernels above (the generic ones spend ~4 64-bit divisions per element on
+// index decomposition).  A workgroup = one output row (b, oy) [forward] / input row (b, iy) [backward]; threads cover
+// (pixel, 4-channel group) pairs with float4 accesses (pixel-major layout, C % 4 == 0), or pixels of one channel plane
+// (NCHW side of the final x8 upsample, C = 3).  Row interpolation weights are uniform per workgroup.
+template <typename TO>
+__global__ __launch_bounds__(NT) void upsample_fwd_row_kernel(const float* x, int ldx, int H, int W, int C, int s, TO* out, int ldo, int chunks) {
+  const int Ho = H * s, Wo = W * s;
+  const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
+  const int b = row / Ho, oy = row - b * Ho;
+  const int C4 = C >> 2;
+  const int idx = chunk * NT + threadIdx.x;
+  if (idx >= Wo * C4) return;
+  const int ox = idx / C4, c = (idx - ox * C4) << 2;
+  const float fy = oy * ry, fx = ox * rx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float wy = fy - y0, wx = fx - x0;
+  const float* xb = x + (long)b * H * W * ldx + c;
+  const f32x4 v00 = *(const f32x4*)(xb + ((long)y0 * W + x0) * ldx), v01 = *(const f32x4*)(xb + ((long)y0 * W + x1) * ldx);
+  const f32x4 v10 = *(const f32x4*)(xb + ((long)y1 * W + x0) * ldx), v11 = *(const f32x4*)(xb + ((long)y1 * W + x1) * ldx);
+  const f32x4 v = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+  TO* o = out + (((long)b * Ho + oy) * Wo + ox) * ldo + c;
+  if constexpr (sizeof(TO) == 4) *(f32x4*)o = v;
+  else *(bf16x4*)o = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+}
+// NCHW fp32 output: workgroup = (b, c, oy) plane row, threads = ox
+__global__ __launch_bounds__(NT) void upsample_fwd_nchw_kernel(const float* x, int ldx, int H, int W, int C, int s, float* out) {
+  const int Ho = H * s, Wo = W * s;
+  const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const int row = blockIdx.x;                      // (b * C + c) * Ho + oy
+  const int oy = row % Ho, bc = row / Ho;
+  const int c = bc % C, b = bc / C;
+  const float fy = oy * ry;
+  const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+  const float wy = fy - y0;
+  const float* xb = x + (long)b * H * W * ldx + c;
+  for (int ox = threadIdx.x; ox < Wo; ox += NT) {
+    const float fx = ox * rx;
+    const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+    const float wx = fx - x0;
+    const float v00 = xb[((long)y0 * W + x0) * ldx], v01 = xb[((long)y0 * W + x1) * ldx];
+    const float v10 = xb[((long)y1 * W + x0) * ldx], v11 = xb[((long)y1 * W + x1) * ldx];
+    out[(long)row * Wo + ox] = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+  }
+}
+// backward, pixel-major dy: workgroup = input row (b, iy), threads = (ix, 4-channel group)
+__global__ __launch_bounds__(NT) void upsample_bwd_row_kernel(const float* dy, int lddy, int H, int W, int C, int s, float* dx, int lddx, int accumulate, int chunks) {
+  const int Ho = H * s, Wo = W * s;
+  const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
+  const int b = row / H, iy = row - b * H;
+  const int C4 = C >> 2;
+  const int idx = chunk * NT + threadIdx.x;
+  if (idx >= W * C4) return;
+  const int ix = idx / C4, c = (idx - ix * C4) << 2;
+  const int oy_lo = ry > 0.f ? max(0, (int)floorf((iy - 1) / ry)) : 0, oy_hi = ry > 0.f ? min(Ho - 1, (int)ceilf((iy + 1) / ry)) : Ho - 1;
+  const int ox_lo = rx > 0.f ? max(0, (int)floorf((ix - 1) / rx)) : 0, ox_hi = rx > 0.f ? min(Wo - 1, (int)ceilf((ix + 1) / rx)) : Wo - 1;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    const float fy = oy * ry;
+    const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+    const float wy = fy - y0;
+    const float wyi = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+    if (wyi == 0.f) continue;
+    const float* drow = dy + ((long)b * Ho + oy) * Wo * lddy + c;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      const float fx = ox * rx;
+      const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+      const float wx = fx - x0;
+      const float wxi = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
+      if (wxi == 0.f) continue;
+      acc += (wyi * wxi) * *(const f32x4*)(drow + (long)ox * lddy);
+    }
+  }
+  float* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
+  if (accumulate) acc += *(const f32x4*)d;
+  *(f32x4*)d = acc;
+}
+// backward, NCHW dy (final x8 upsample, C = 3): workgroup = (b, c, iy); the threads split the (2s+1)^2 footprint of each
+// input pixel: thread = (ix, slice of the output rows), partial sums through LDS
+__global__ __launch_bounds__(NT) void upsample_bwd_nchw_kernel(const float* dy, int H, int W, int C, int s, float* dx, int lddx, int accumulate) {
+  __shared__ float part[NT];
+  const int Ho = H * s, Wo = W * s;
+  const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const int row = blockIdx.x;                      // (b * C + c) * H + iy
+  const int iy = row % H, bc = row / H;
+  const int c = bc % C, b = bc / C;
+  const int slices = NT / W;                       // W <= NT, NT % W == 0 (checked by the host)
+  const int ix = threadIdx.x % W, sl = threadIdx.x / W;
+  const int oy_lo = ry > 0.f ? max(0, (int)floorf((iy - 1) / ry)) : 0, oy_hi = ry > 0.f ? min(Ho - 1, (int)ceilf((iy + 1) / ry)) : Ho - 1;
+  const int ox_lo = rx > 0.f ? max(0, (int)floorf((ix - 1) / rx)) : 0, ox_hi = rx > 0.f ? min(Wo - 1, (int)ceilf((ix + 1) / rx)) : Wo - 1;
+  const float* plane = dy + (long)bc * Ho * Wo;
+  float acc = 0.f;
+  for (int oy = oy_lo + sl; oy <= oy_hi; oy += slices) {
+    const float fy = oy * ry;
+    const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+    const float wy = fy - y0;
+    const float wyi = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+    if (wyi == 0.f) continue;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      const float fx = ox * rx;
+      const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+      const float wx = fx - x0;
+      const float wxi = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
+      if (wxi != 0.f) acc += wyi * wxi * plane[(long)oy * Wo + ox];
+    }
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl == 0) {
+    float t = 0.f;
+    for (int k = 0; k < slices; ++k) t += part[k * W + ix];
+    float* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
+    *d = accumulate ? *d + t : t;
+  }
+}
+
 inline int grid_for(long work, int cap = 8192) {
   long g = (work + NT - 1) / NT;
   if (g > cap) g = cap;
@@ -256,6 +374,17 @@ extern "C" int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, i
   MVLT_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1, "mvlt_upsample_fwd: bad arguments");
   MVLT_REQUIRE(!nchw || out_dtype == 1, "mvlt_upsample_fwd: NCHW output is fp32");
   long total = (long)B * H * scale * W * scale * C;
+  if (nchw && (long)B * C * H * scale < (1L << 31)) {
+    hipLaunchKernelGGL(upsample_fwd_nchw_kernel, dim3((unsigned)(B * C * H * scale)), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (float*)out);
+    return mvlt_check_launch("mvlt_upsample_fwd");
+  }
+  if (!nchw && C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 7) == 0) {
+    const int chunks = (W * scale * (C / 4) + NT - 1) / NT;
+    const unsigned grid = (unsigned)((long)B * H * scale * chunks);
+    if (out_dtype == 0) hipLaunchKernelGGL((upsample_fwd_row_kernel<bf16>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (bf16*)out, ldo, chunks);
+    else hipLaunchKernelGGL((upsample_fwd_row_kernel<float>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (float*)out, ldo, chunks);
+    return mvlt_check_launch("mvlt_upsample_fwd");
+  }
   if (out_dtype == 0) hipLaunchKernelGGL((upsample_fwd_kernel<bf16>), dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, x, ldx, B, H, W, C, scale, (bf16*)out, ldo, nchw);
   else hipLaunchKernelGGL((upsample_fwd_kernel<float>), dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, x, ldx, B, H, W, C, scale, (float*)out, ldo, nchw);
   return mvlt_check_launch("mvlt_upsample_fwd");
@@ -264,6 +393,16 @@ extern "C" int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, i
 extern "C" int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int H, int W, int C, int scale, float* dx, int lddx, int accumulate, void* stream) {
   MVLT_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1, "mvlt_upsample_bwd: bad arguments");
   long total = (long)B * H * W * C;
+  if (nchw && W <= NT && NT % W == 0) {
+    hipLaunchKernelGGL(upsample_bwd_nchw_kernel, dim3((unsigned)(B * C * H)), dim3(NT), 0, (hipStream_t)stream, dy, H, W, C, scale, dx, lddx, accumulate);
+    return mvlt_check_launch("mvlt_upsample_bwd");
+  }
+  if (!nchw && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0) {
+    const int chunks = (W * (C / 4) + NT - 1) / NT;
+    hipLaunchKernelGGL(upsample_bwd_row_kernel, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, H, W, C, scale, dx, lddx,
+                       accumulate, chunks);
+    return mvlt_check_launch("mvlt_upsample_bwd");
+  }
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, nchw, B, H, W, C, scale, dx, lddx, accumulate);
   return mvlt_check_launch("mvlt_upsample_bwd");
 }

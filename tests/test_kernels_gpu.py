@@ -478,3 +478,31 @@ def test_fused_mlp(ops, Cdim, hid, M, Bsz):
     ops.mlp_bwd_dw(x, dy, w1, w2.t().contiguous(), b1, dw1, db1, dw2, db2, M, Cdim, hid, row_scale=scale, rows_per_scale=rps)
     for a, r, nm in ((dw1, w1r.grad, "dw1"), (db1, b1r.grad, "db1"), (dw2, w2r.grad, "dw2"), (db2, b2r.grad, "db2")):
         assert maxrel(a, r) < 3e-2, nm
+
+
+# ------------------------------------------------------------------ bilinear upsample (align_corners=True) and its adjoint
+@pytest.mark.parametrize("B,H,C,s,nchw,out_dtype", [(2, 8, 64, 2, False, torch.float32), (3, 6, 192, 2, False, torch.bfloat16),
+                                                    (2, 8, 3, 8, True, torch.float32), (1, 5, 6, 3, False, torch.float32)])
+def test_upsample_fwd_bwd(ops, B, H, C, s, nchw, out_dtype):
+    """reference libs/vl_heads.py:128-134 (nn.Upsample(scale_factor, 'bilinear', align_corners=True)) on pixel-major tensors."""
+    x = rnd(B * H * H, C, dtype=torch.float32)
+    xt = x.view(B, H, H, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = F.interpolate(xt, scale_factor=s, mode="bilinear", align_corners=True)
+    Ho = H * s
+    if nchw:
+        out = torch.empty(B, C, Ho, Ho, device=dev(), dtype=torch.float32)
+        ops.upsample_fwd(x, C, B, H, H, C, s, out, 0, nchw=True)
+        got = out
+    else:
+        out = torch.empty(B * Ho * Ho, C, device=dev(), dtype=out_dtype)
+        ops.upsample_fwd(x, C, B, H, H, C, s, out, C)
+        got = out.float().view(B, Ho, Ho, C).permute(0, 3, 1, 2)
+    assert maxrel(got, ref.detach()) < (1e-5 if out_dtype == torch.float32 else TOL[torch.bfloat16])
+    g = rnd(B, C, Ho, Ho, dtype=torch.float32, seed=3)
+    ref.backward(g)
+    dy = g.contiguous() if nchw else g.permute(0, 2, 3, 1).reshape(B * Ho * Ho, C).contiguous()
+    base = rnd(B * H * H, C, dtype=torch.float32, seed=5)
+    dx = base.clone()
+    ops.upsample_bwd(dy, 0 if nchw else C, nchw, B, H, H, C, s, dx, C, accumulate=True)
+    want = base + xt.grad.permute(0, 2, 3, 1).reshape(B * H * H, C)
+    assert maxrel(dx, want) < 1e-5
