@@ -60,18 +60,9 @@ __global__ __launch_bounds__(NT) void bert_embed_bwd_kernel(const T* dy, const l
   float ag[PER], ab[PER], at[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) { ag[i] = 0.f; ab[i] = 0.f; at[i] = 0.f; }
-  // a wave owns ONE position t and a slice of the batch: the position-embedding gradient of its rows accumulates in
-  // registers and is added once at the end (it used to be 768 atomics per row onto a 128-row table: 256-way contention)
-  const int wave_id = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-  const int nsl = (gridDim.x * (NT / 64)) / Tlen;          // the host launches a multiple of Tlen waves
-  const int t = wave_id % Tlen, sl = wave_id / Tlen;
-  const int nb = rows / Tlen;
-  float apos[PER];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) apos[i] = 0.f;
-  for (int b = sl; b < nb && sl < nsl; b += nsl) {
-    const int row = b * Tlen + t;
+  for (int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6); row < rows; row += gridDim.x * (NT / 64)) {
     const long id = ids[row];
+    const int t = row % Tlen;
     const float mean = mean_in[row], rstd = rstd_in[row];
     float g[PER], xh[PER];
     float s1 = 0.f, s2 = 0.f;
@@ -94,13 +85,9 @@ __global__ __launch_bounds__(NT) void bert_embed_bwd_kernel(const T* dy, const l
       int c = lane + 64 * i;
       float dx = rstd * (g[i] - s1 - xh[i] * s2);
       if (id != 0) atomicAdd(&dword[id * HID + c], dx);
-      apos[i] += dx;
+      atomicAdd(&dpos[(long)t * HID + c], dx);
       at[i] += dx;
     }
-  }
-  if (sl < nsl) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) atomicAdd(&dpos[(long)t * HID + lane + 64 * i], apos[i]);
   }
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
@@ -378,10 +365,8 @@ extern "C" int mvlt_bert_embed_bwd(const void* dy, const long* ids, const float*
   MVLT_REQUIRE(hidden == 768, "mvlt_bert_embed_bwd: hidden must be 768");
   if (rows <= 0) return MVLT_OK;
   const float inv_keep = 1.0f / (1.0f - drop_p);
-  MVLT_REQUIRE(T > 0 && rows % T == 0, "mvlt_bert_embed_bwd: rows must be a multiple of T");
-  int nsl = 1024 / T; if (nsl < 1) nsl = 1; if (nsl > rows / T) nsl = rows / T;      // ~1024 waves: T positions x nsl batch slices
-  while ((T * nsl) % 4 != 0) ++nsl;
-  dim3 grid(T * nsl / 4), block(NT);
+  int g = (rows + 3) / 4; if (g > 2048) g = 2048;
+  dim3 grid(g), block(NT);
   if (dtype == 0) hipLaunchKernelGGL((bert_embed_bwd_kernel<bf16, 768>), grid, block, 0, (hipStream_t)stream, (const bf16*)dy, ids, word, pos, type0, gamma, keep, inv_keep, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T);
   else hipLaunchKernelGGL((bert_embed_bwd_kernel<float, 768>), grid, block, 0, (hipStream_t)stream, (const float*)dy, ids, word, pos, type0, gamma, keep, inv_keep, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T);
   return mvlt_check_launch("mvlt_bert_embed_bwd");

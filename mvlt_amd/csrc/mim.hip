@@ -214,23 +214,26 @@ __global__ __launch_bounds__(NT) void upsample_fwd_row_kernel(const float* x, in
   else *(bf16x4*)o = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 }
 // NCHW fp32 output: workgroup = (b, c, oy) plane row, threads = ox
-__global__ __launch_bounds__(NT) void upsample_fwd_nchw_kernel(const float* x, int ldx, int H, int W, int C, int s, float* out) {
+__global__ __launch_bounds__(NT) void upsample_fwd_nchw_kernel(const float* x, int ldx, int H, int W, int C, int s, float* out, int nrows) {
   const int Ho = H * s, Wo = W * s;
   const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
-  const int row = blockIdx.x;                      // (b * C + c) * Ho + oy
-  const int oy = row % Ho, bc = row / Ho;
-  const int c = bc % C, b = bc / C;
-  const float fy = oy * ry;
-  const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
-  const float wy = fy - y0;
-  const float* xb = x + (long)b * H * W * ldx + c;
-  for (int ox = threadIdx.x; ox < Wo; ox += NT) {
-    const float fx = ox * rx;
-    const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
-    const float wx = fx - x0;
-    const float v00 = xb[((long)y0 * W + x0) * ldx], v01 = xb[((long)y0 * W + x1) * ldx];
-    const float v10 = xb[((long)y1 * W + x0) * ldx], v11 = xb[((long)y1 * W + x1) * ldx];
-    out[(long)row * Wo + ox] = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+  for (int rr = 0; rr < 8; ++rr) {                 // 8 plane rows per workgroup (a row alone is too little work per launch slot)
+    const int row = blockIdx.x * 8 + rr;           // (b * C + c) * Ho + oy
+    if (row >= nrows) return;
+    const int oy = row % Ho, bc = row / Ho;
+    const int c = bc % C, b = bc / C;
+    const float fy = oy * ry;
+    const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+    const float wy = fy - y0;
+    const float* xb = x + (long)b * H * W * ldx + c;
+    for (int ox = threadIdx.x; ox < Wo; ox += NT) {
+      const float fx = ox * rx;
+      const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+      const float wx = fx - x0;
+      const float v00 = xb[((long)y0 * W + x0) * ldx], v01 = xb[((long)y0 * W + x1) * ldx];
+      const float v10 = xb[((long)y1 * W + x0) * ldx], v11 = xb[((long)y1 * W + x1) * ldx];
+      out[(long)row * Wo + ox] = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+    }
   }
 }
 // backward, pixel-major dy: workgroup = input row (b, iy), threads = (ix, 4-channel group)
@@ -266,40 +269,39 @@ __global__ __launch_bounds__(NT) void upsample_bwd_row_kernel(const float* dy, i
   if (accumulate) acc += *(const f32x4*)d;
   *(f32x4*)d = acc;
 }
-// backward, NCHW dy (final x8 upsample, C = 3): workgroup = (b, c, iy); the threads split the (2s+1)^2 footprint of each
-// input pixel: thread = (ix, slice of the output rows), partial sums through LDS
+// backward, NCHW dy (final x8 upsample, C = 3): workgroup = (b, c, iy).  Pass 1: thread ox folds its output column over
+// the rows that touch iy (coalesced plane-row reads) into LDS; pass 2: thread ix folds the <= 2s+1 columns that touch it.
 __global__ __launch_bounds__(NT) void upsample_bwd_nchw_kernel(const float* dy, int H, int W, int C, int s, float* dx, int lddx, int accumulate) {
-  __shared__ float part[NT];
+  extern __shared__ float colsum[];                // [Wo]
   const int Ho = H * s, Wo = W * s;
   const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
   const int row = blockIdx.x;                      // (b * C + c) * H + iy
   const int iy = row % H, bc = row / H;
   const int c = bc % C, b = bc / C;
-  const int slices = NT / W;                       // W <= NT, NT % W == 0 (checked by the host)
-  const int ix = threadIdx.x % W, sl = threadIdx.x / W;
   const int oy_lo = ry > 0.f ? max(0, (int)floorf((iy - 1) / ry)) : 0, oy_hi = ry > 0.f ? min(Ho - 1, (int)ceilf((iy + 1) / ry)) : Ho - 1;
-  const int ox_lo = rx > 0.f ? max(0, (int)floorf((ix - 1) / rx)) : 0, ox_hi = rx > 0.f ? min(Wo - 1, (int)ceilf((ix + 1) / rx)) : Wo - 1;
   const float* plane = dy + (long)bc * Ho * Wo;
-  float acc = 0.f;
-  for (int oy = oy_lo + sl; oy <= oy_hi; oy += slices) {
-    const float fy = oy * ry;
-    const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
-    const float wy = fy - y0;
-    const float wyi = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
-    if (wyi == 0.f) continue;
+  for (int ox = threadIdx.x; ox < Wo; ox += NT) {
+    float t = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const float fy = oy * ry;
+      const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+      const float wy = fy - y0;
+      const float wyi = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+      t += wyi * plane[(long)oy * Wo + ox];
+    }
+    colsum[ox] = t;
+  }
+  __syncthreads();
+  for (int ix = threadIdx.x; ix < W; ix += NT) {
+    const int ox_lo = rx > 0.f ? max(0, (int)floorf((ix - 1) / rx)) : 0, ox_hi = rx > 0.f ? min(Wo - 1, (int)ceilf((ix + 1) / rx)) : Wo - 1;
+    float t = 0.f;
     for (int ox = ox_lo; ox <= ox_hi; ++ox) {
       const float fx = ox * rx;
       const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
       const float wx = fx - x0;
       const float wxi = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
-      if (wxi != 0.f) acc += wyi * wxi * plane[(long)oy * Wo + ox];
+      t += wxi * colsum[ox];
     }
-  }
-  part[threadIdx.x] = acc;
-  __syncthreads();
-  if (sl == 0) {
-    float t = 0.f;
-    for (int k = 0; k < slices; ++k) t += part[k * W + ix];
     float* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
     *d = accumulate ? *d + t : t;
   }
@@ -375,7 +377,8 @@ extern "C" int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, i
   MVLT_REQUIRE(!nchw || out_dtype == 1, "mvlt_upsample_fwd: NCHW output is fp32");
   long total = (long)B * H * scale * W * scale * C;
   if (nchw && (long)B * C * H * scale < (1L << 31)) {
-    hipLaunchKernelGGL(upsample_fwd_nchw_kernel, dim3((unsigned)(B * C * H * scale)), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (float*)out);
+    hipLaunchKernelGGL(upsample_fwd_nchw_kernel, dim3((unsigned)((B * C * H * scale + 7) / 8)), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (float*)out,
+                       B * C * H * scale);
     return mvlt_check_launch("mvlt_upsample_fwd");
   }
   if (!nchw && C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 7) == 0) {
@@ -393,8 +396,9 @@ extern "C" int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, i
 extern "C" int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int H, int W, int C, int scale, float* dx, int lddx, int accumulate, void* stream) {
   MVLT_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1, "mvlt_upsample_bwd: bad arguments");
   long total = (long)B * H * W * C;
-  if (nchw && W <= NT && NT % W == 0) {
-    hipLaunchKernelGGL(upsample_bwd_nchw_kernel, dim3((unsigned)(B * C * H)), dim3(NT), 0, (hipStream_t)stream, dy, H, W, C, scale, dx, lddx, accumulate);
+  if (nchw && (size_t)W * scale * sizeof(float) <= 64 * 1024) {
+    hipLaunchKernelGGL(upsample_bwd_nchw_kernel, dim3((unsigned)(B * C * H)), dim3(NT), (size_t)W * scale * sizeof(float), (hipStream_t)stream, dy, H, W, C,
+                       scale, dx, lddx, accumulate);
     return mvlt_check_launch("mvlt_upsample_bwd");
   }
   if (!nchw && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0) {
