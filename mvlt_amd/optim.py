@@ -61,8 +61,10 @@ class FusedAdamW(torch.optim.Optimizer):
         row = [g0["lr"], b1, b2, g0["eps"], g1["weight_decay"], 1 - b1 ** self._step, 1 - b2 ** self._step, 1.0]
         self._hp.copy_(torch.tensor(row, dtype=torch.float32), non_blocking=True)
         ops.adamw_step(S.P, S.G, self._m, self._v, S.C, S.total, self._hp, self._wd_mask)
-        # W^T / permuted conv operand copies are refreshed by the next forward
+        # W^T / permuted conv operand copies are refreshed by the next forward; the plain bf16 copy S.C is already current
+        # (valid as long as nothing else writes P before that forward: any torch in-place op bumps P._version)
         S.force_dirty = True
+        S._c_fresh_version = S.P._version if S.C is not None else None
         return loss
 
     def zero_grad(self, set_to_none=True):

@@ -189,8 +189,9 @@ class FlatStore:
         GEMMs; conv3: names of the MIM decoder's 3x3 conv weights (forward taps + flipped/transposed dgrad taps)."""
         if not self.force_dirty and self._cast_version == self.P._version:
             return
-        if self.C is not None:
-            ops.cast_bf16(self.P, self.C, self.total)
+        if self.C is not None and getattr(self, "_c_fresh_version", None) != self.P._version:
+            ops.cast_bf16(self.P, self.C, self.total)        # (the fused AdamW step writes the bf16 copy itself: skipped then)
+        self._c_fresh_version = None
         key = (tuple(transposed), tuple(conv_perm), tuple(conv3), self.compute_dtype, self.P.data_ptr())
         if getattr(self, "_prep_key", None) != key:
             self._build_prep(transposed, conv_perm, conv3)
