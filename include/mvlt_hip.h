@@ -117,12 +117,6 @@ typedef struct mvlt_layernorm_bwd_args {
   int dx_accumulate;
   int dtype;                          /* of dy */
   int x_dtype, dx_dtype;
-  void* dx2;                          /* optional second output, dtype of dy, identity rows, row stride lddx2:
-                                         dx2[r] = dx_final[r] * dx2_scale[r / dx2_rows_per_scale]  (dx2_scale NULL = 1) -- the
-                                         DropPath-scaled gradient of the NEXT branch (reference libs/pvlt.py:146: x + drop_path(f(x))),
-                                         written while dx is in registers instead of by a separate scaling pass */
-  const float* dx2_scale;
-  int dx2_rows_per_scale, lddx2;
 } mvlt_layernorm_bwd_args;
 int mvlt_layernorm_bwd(const mvlt_layernorm_bwd_args* args, void* stream);
 

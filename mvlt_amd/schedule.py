@@ -13,9 +13,7 @@ import torch.nn.functional as F
 
 from . import ops
 from ._lib import patchmap, rowmap
-import os as _os
 from .params import ZeroPool, pool_zeros
-_NO_DX2 = bool(_os.environ.get("MVLT_NO_DX2"))       # A/B switch: DropPath-scaled gradient by a separate pass
 from .pvlt import BERT_DROP, EPS_BERT, EPS_BLOCK, EPS_DEFAULT, VOCAB, VOCAB_LD
 
 
@@ -386,16 +384,11 @@ class TrunkStep:
             ops.gemm_tn(dh, bs["xn2"], self.g(p + "mlp.fc1.weight"), M, hid, C, hid, C, C, colsum=self.g(p + "mlp.fc1.bias"))
             ops.gemm_nt(dh, self.wT(p + "mlp.fc1.weight"), dxn2, M, C, hid, hid, hid, C)
             del dh
-        # LN2 backward finishes d(x_mid) in dx and, while it has it in registers, also writes the DropPath-scaled copy
-        # that the attention branch consumes (dy1 = s1 * dx)
-        dy1 = _empty((M, C), dt, dev) if (bs["s1"] is not None and dx.dtype == dt and not _NO_DX2) else None
         ops.layernorm_bwd(dxn2, bs["xm"], dx, self.f32(p + "norm2.weight"), bs["m2"], bs["r2"], M, C, C, C, C,
-                          dgamma=self.g(p + "norm2.weight"), dbeta=self.g(p + "norm2.bias"), accumulate=True,
-                          dx2=dy1, dx2_scale=bs["s1"] if dy1 is not None else None, dx2_rows_per_scale=N, lddx2=C)
+                          dgamma=self.g(p + "norm2.weight"), dbeta=self.g(p + "norm2.bias"), accumulate=True)
         # dx now holds d(x_mid)
         # ---- attention branch: x_mid = x + s1 * proj(attn(LN1(x)))
-        if dy1 is None:
-            dy1 = self._scaled(dx, bs["s1"], N)
+        dy1 = self._scaled(dx, bs["s1"], N)
         ops.gemm_tn(dy1, bs["ao"], self.g(p + "attn.proj.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.proj.bias"))
         dao = dxn2          # reuse
         ops.gemm_nt(dy1, self.wT(p + "attn.proj.weight"), dao, M, C, C, C, C, C)
