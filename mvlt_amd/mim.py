@@ -157,10 +157,11 @@ class MimStep:
         # score head
         dsc = _e((M1, 3), dev)
         ops.upsample_bwd(dout, 0, True, B, s1, s1, 3, 8, dsc, 3)
-        S.grad("t2i_head.score.0.bias").add_(dsc.sum(0))
         dsc_p = _z((M1, 8), dev, dt)
         dsc_p[:, :3] = dsc.to(dt)
-        ops.gemm_tn(dsc_p, k["e16"], S.grad("t2i_head.score.0.weight").view(3, 3 * ch), M1, 3, 3 * ch, 8, 3 * ch, 3 * ch)
+        # weight gradient and, as the GEMM's column sum, the bias gradient (a torch sum over a [262144, 3] matrix took 92 us)
+        ops.gemm_tn(dsc_p, k["e16"], S.grad("t2i_head.score.0.weight").view(3, 3 * ch), M1, 3, 3 * ch, 8, 3 * ch, 3 * ch,
+                    colsum=S.grad("t2i_head.score.0.bias"))
         de = _e((M1, 3 * ch), dev)
         ops.gemm_nt(dsc_p, S.extra["t2i_head.score.0.weight::T"], de, M1, 3 * ch, 8, 8, 8, 3 * ch)
         dd = self.bn_conv_bwd("conv4", de, 3 * ch)
