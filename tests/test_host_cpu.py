@@ -139,3 +139,25 @@ def test_reference_import_surface():
 def test_masked_positions_definition():
     lab = torch.tensor([[-1, 5, -1], [7, -1, 0]])
     assert O.masked_positions(lab).tolist() == [1, 3, 5]
+
+
+def test_zero_pool_hands_out_zeroed_disjoint_scratch():
+    """params.ZeroPool: step-scoped zero-initialised scratch (one fill per step instead of one per buffer)."""
+    import torch
+    from mvlt_amd.params import ZeroPool
+    pool = ZeroPool(torch.device("cpu"))
+    pool.reset()
+    a = pool.take((3, 5), torch.float32)          # first step: nothing pooled yet -> plain zeros, need recorded
+    a += 1.0
+    pool.reset()                                  # second step: buffer sized from the recorded need
+    b = pool.take((3, 5), torch.float32)
+    c = pool.take((7,), torch.bfloat16)
+    assert b.abs().sum() == 0 and c.float().abs().sum() == 0
+    b += 2.0
+    c += 1.0
+    assert b.data_ptr() != c.data_ptr() and float(c.float().sum()) == 7.0 and float(b.sum()) == 30.0
+    pool.reset()
+    d = pool.take((3, 5), torch.float32)
+    assert d.abs().sum() == 0                     # re-zeroed
+    big = pool.take((1 << 22,), torch.float32)    # does not fit: falls back to torch.zeros, pool grows next step
+    assert big.numel() == 1 << 22 and big.abs().sum() == 0
