@@ -138,7 +138,9 @@ typedef struct mvlt_attn_args {
 } mvlt_attn_args;
 int mvlt_sr_attention_fwd(const mvlt_attn_args* args, void* stream);
 
-/* Backward of the above: dQ (like Q) and dKV (B,M,ldkv fp32, atomically accumulated, caller-zeroed). */
+/* Backward of the above: dQ (like Q) and dKV (B,M,ldkv fp32).  With B*H < 512 the queries of a (batch, head) are split over
+ * workgroups that accumulate dKV atomically (caller-zeroed buffer); from B*H >= 512 on one workgroup sees all queries and
+ * stores every dKV element exactly once (no zero fill needed). */
 typedef struct mvlt_attn_bwd_args {
   const void* Q; const void* KV; const void* O; const void* dO; const float* lse;
   void* dQ; float* dKV;

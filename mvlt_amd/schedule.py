@@ -394,7 +394,9 @@ class TrunkStep:
         ops.gemm_nt(dy1, self.wT(p + "attn.proj.weight"), dao, M, C, C, C, C, C)
         Mk = bs["Mk"]
         dq = _empty((B, N, C), dt, dev)
-        dkv32 = pool_zeros((B, Mk, 2 * C), f32, dev)
+        # dK/dV: one query chunk per (batch, head) from B*heads >= 512 on (mvlt_sr_attention_bwd then stores plainly, every
+        # element once); only the split case accumulates with atomics and needs the zero fill
+        dkv32 = _empty((B, Mk, 2 * C), f32, dev) if (B * h >= 512 and dt == torch.bfloat16) else pool_zeros((B, Mk, 2 * C), f32, dev)
         ops.sr_attention_bwd(bs["q"], bs["kv"], bs["ao"], dao, bs["lse"], dq, dkv32, B, h, N, Mk, C, 2 * C, C, 2 * C, 0, C, 64 ** -0.5)
         dkv = dkv32.to(dt)
         del dkv32
