@@ -194,7 +194,8 @@ class MimStep:
         # reductions: gradients w.r.t. the image tokens of the stage outputs (text rows stay zero)
         grads = []
         for name, dy, x, side in (("reduction1", dlow, self.x[0], s1), ("reduction2", dmid, self.x[1], s2), ("reduction3", dhigh, self.x[2], s3)):
-            dxs = torch.zeros_like(x)
+            dxs = torch.empty_like(x)                      # image rows are all written by the conv dgrad below;
+            dxs[:, side * side:].zero_()                   # only the text rows need the explicit zeros
             self.bn_conv_bwd(name, dy, ch, dx=dxs, lddx=x.shape[2], dx_map=rowmap(side * side, x.shape[1], 0))
             grads.append(dxs)
         self.rec, self.keep = {}, {}
