@@ -217,14 +217,14 @@ class FlatStore:
             R, Ccols = w.shape
             ld = (R + 7) // 8 * 8                            # rows of W^T padded to 16 B (vocab 30522 -> 30528)
             k = name + "::T"
-            if k not in self.extra or self.extra[k].dtype != dt:
+            if k not in self.extra or self.extra[k].dtype != dt or self.extra[k].device != dev:
                 self.extra[k] = torch.zeros(Ccols, ld, device=dev, dtype=dt)
             descs.append(PrepDesc(src_ptr(name), self.extra[k].data_ptr(), 0, R, Ccols, ld, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
             blocks.append(((R + 31) // 32) * ((Ccols + 31) // 32))
 
         def gather(name, suffix, shape, dims, src_off, ss, ds):
             k = name + suffix
-            if k not in self.extra or self.extra[k].dtype != dt or tuple(self.extra[k].shape) != tuple(shape):
+            if k not in self.extra or self.extra[k].dtype != dt or tuple(self.extra[k].shape) != tuple(shape) or self.extra[k].device != dev:
                 self.extra[k] = torch.zeros(*shape, device=dev, dtype=dt)
             descs.append(PrepDesc(src_ptr(name), self.extra[k].data_ptr(), 1, 0, 0, 0, dims[0], dims[1], dims[2], src_off,
                                   ss[0], ss[1], ss[2], ds[0], ds[1], ds[2]))
