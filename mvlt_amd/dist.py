@@ -47,9 +47,15 @@ class DataParallel(nn.Module):
             if not self._synced_init:
                 self._sync_init()
             if self.broadcast_buffers and self.module.training:
-                for b in self.module.buffers():           # BatchNorm running stats of the MIM decoder
-                    if b.is_floating_point():
-                        dist.broadcast(b, 0, group=self.pg)
+                # BatchNorm running stats of the MIM decoder: one coalesced broadcast (DDP's broadcast_buffers does the
+                # same), not one small collective per buffer
+                bufs = [b for b in self.module.buffers() if b.is_floating_point()]
+                if bufs:
+                    try:
+                        dist._broadcast_coalesced(self.pg if self.pg is not None else dist.group.WORLD, bufs, 64 << 20, 0)
+                    except (AttributeError, RuntimeError):
+                        for b in bufs:
+                            dist.broadcast(b, 0, group=self.pg)
         return self.module(*a, **k)
 
     def _range_ready(self, store, lo, hi):
