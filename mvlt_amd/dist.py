@@ -47,16 +47,20 @@ class DataParallel(nn.Module):
             if not self._synced_init:
                 self._sync_init()
             if self.broadcast_buffers and self.module.training:
-                # BatchNorm running stats of the MIM decoder: one coalesced broadcast (DDP's broadcast_buffers does the
-                # same), not one small collective per buffer
-                bufs = [b for b in self.module.buffers() if b.is_floating_point()]
-                if bufs:
-                    try:
-                        dist._broadcast_coalesced(self.pg if self.pg is not None else dist.group.WORLD, bufs, 64 << 20, 0)
-                    except (AttributeError, RuntimeError):
-                        for b in bufs:
-                            dist.broadcast(b, 0, group=self.pg)
+                self._sync_buffers()
         return self.module(*a, **k)
+
+    def _sync_buffers(self):
+        """BatchNorm running stats of the MIM decoder follow rank 0 (DDP's broadcast_buffers=True): one coalesced broadcast,
+        not one small collective per buffer."""
+        bufs = [b for b in self.module.buffers() if b.is_floating_point()]
+        if not bufs or self.world <= 1:
+            return
+        try:
+            dist._broadcast_coalesced(self.pg if self.pg is not None else dist.group.WORLD, bufs, 64 << 20, 0)
+        except (AttributeError, RuntimeError):
+            for b in bufs:
+                dist.broadcast(b, 0, group=self.pg)
 
     def _range_ready(self, store, lo, hi):
         """called by the backward schedule when G[lo:hi] is final on the compute stream"""

@@ -49,8 +49,13 @@ def _worker(rank, world, port, q):
             p.data.normal_()
         S = m.store
         S.materialize(torch.device("cpu"))
+        m.register_buffer("running_mean", torch.full((5,), float(rank + 1)))
+        m.register_buffer("running_var", torch.full((3, 2), 10.0 * (rank + 1)))
+        m.register_buffer("num_batches_tracked", torch.tensor(rank + 7))           # integer buffers stay per rank
         dp = DataParallel(m, broadcast_buffers=False)
         dp._sync_init()
+        dp._sync_buffers()
+        ok_buf = bool((m.running_mean == 1.0).all() and (m.running_var == 10.0).all() and int(m.num_batches_tracked) == rank + 7)
         p0 = S.P.clone()
         # emulate one backward: every rank writes rank-dependent gradients, stages complete 4 -> 1
         S.G.copy_(torch.arange(S.total, dtype=torch.float32) * (rank + 1))
@@ -62,7 +67,7 @@ def _worker(rank, world, port, q):
         lo, hi = S.stage_range(2)
         names = [n for n, (o, k, _) in S.offsets.items() if lo <= o < hi]
         cnt, tot = allreduce_meter(3, 1.5 * (rank + 1), "cpu")
-        q.put((rank, ok_grad, p0.sum().item(), names, cnt, tot))
+        q.put((rank, ok_grad and ok_buf, p0.sum().item(), names, cnt, tot))
     finally:
         dist.destroy_process_group()
 
