@@ -248,17 +248,20 @@ __device__ __forceinline__ void nt_epilogue(const mvlt_gemm_nt_args& p, f32x4 (&
 // the stage-3 fc1 GEMM's time.  The call sites use five shapes of epilogue; each gets a compile-time variant in which the
 // column side (bias, chunk index) is fixed per lane, the row side is a multiply, and the operands a variant needs (R, H,
 // DropPath factor) are requested for a whole 32-row half before it is processed.  Preconditions (checked by the host
-// dispatch): identity or batch-strided c_map, N % 8 == 0, ldc % 8 == 0, 16-byte aligned C / R / H, no split-K.
+// dispatch): identity, batch-strided or patch-scatter c_map, N % 8 == 0, ldc % 8 == 0, 16-byte aligned C / R / H, no split-K.
 //   EPI 1: C = AB^T (+bias)                      EPI 2: C = (AB^T + bias) * row_scale + R
 //   EPI 3: H = AB^T + bias ; C = gelu(H)         EPI 4: C = AB^T * gelu'(H)          EPI 5: EPI 1 + column sum / sum of squares
+//   EPI 6 / 7: EPI 1 / 2 written through a patch-scatter c_map (dgrad of the kernel==stride convs)
 __device__ __forceinline__ int fdiv24(int m, int d, float inv) {      // exact m / d for 0 <= m < 2^24, inv = 1.0f / d
   int q = (int)((float)m * inv);
   int r = m - q * d;
   return q + (r >= d) - (r < 0);
 }
-template <int BN, int EPI>
+template <int BN, int EPIX>
 __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32x4 (&acc)[4][BN / 32], char* smem, int m0, int n0,
                                                  int wave, int lane) {
+  constexpr bool SCAT = (EPIX == 6 || EPIX == 7);     // EPI 6 / 7 = EPI 1 / 2 with a patch-scatter c_map (mode 1)
+  constexpr int EPI = EPIX == 6 ? 1 : EPIX == 7 ? 2 : EPIX;
   constexpr int WN = BN / 2;
   constexpr int TN_ = WN / 16;
   constexpr int LDW = WN + 4;
@@ -288,6 +291,17 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
   const int m_first = m0 + wm * 64 + lane / CPR;
   const int rpb = p.c_map.rows_per_batch;
   const float inv_rpb = rpb > 0 ? 1.0f / (float)rpb : 0.f;
+  // patch scatter (c_map mode 1, dgrad of a kernel==stride conv): this lane's 8 columns lie in one (di, dj) segment
+  int seg_rows = 0, ncol = nc;
+  float inv_hw = 0.f, inv_w = 0.f;
+  if constexpr (SCAT) {
+    const int seg = nc / p.c_map.c_seg;
+    ncol = nc - seg * p.c_map.c_seg;
+    const int di = seg / p.c_map.r;
+    seg_rows = di * p.c_map.w_in + (seg - di * p.c_map.r);
+    inv_hw = 1.0f / (float)p.c_map.hw_out;
+    inv_w = 1.0f / (float)p.c_map.w_out;
+  }
   const float inv_rps = (EPI == 2 && p.rows_per_scale > 0) ? 1.0f / (float)p.rows_per_scale : 0.f;
   float cs8[8], cq8[8];
   if (EPI == 5) {
@@ -313,11 +327,16 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       ok[it] = m < p.M && col_ok;
       const int mm = ok[it] ? m : 0;
       long phys = mm;
-      if (rpb > 0) {
+      if constexpr (SCAT) {
+        const int b = fdiv24(mm, p.c_map.hw_out, inv_hw);
+        const int rem = mm - b * p.c_map.hw_out;
+        const int oi = fdiv24(rem, p.c_map.w_out, inv_w), oj = rem - oi * p.c_map.w_out;
+        phys = (long)b * p.c_map.tokens_in + (long)(oi * p.c_map.r) * p.c_map.w_in + oj * p.c_map.r + seg_rows;
+      } else if (rpb > 0) {
         const int b = fdiv24(mm, rpb, inv_rpb);
         phys = (long)b * p.c_map.batch_stride + p.c_map.offset + (mm - b * rpb);
       }
-      idx[it] = phys * p.ldc + nc;
+      idx[it] = phys * p.ldc + ncol;
       rs[it] = 1.0f;
       if (EPI == 2 && p.row_scale) rs[it] = p.row_scale[fdiv24(mm, p.rows_per_scale, inv_rps)];
       if ((EPI == 2 || EPI == 4) && ok[it]) {
@@ -1157,11 +1176,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
   if (ns == 1) issue(0);
   int slot = 0, islot = ns - 1;
   for (int kt = 0; kt < nk; ++kt) {
-    if (ns == 1 && kt > 0) {           // single stage (many workgroups per CU hide the latency instead of a ring)
-      __builtin_amdgcn_s_barrier();    // everyone is done reading the stage
-      asm volatile("" ::: "memory");
-      issue(0);
-    }
     if (ns == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
     else if (ns == 4 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1249,20 +1263,23 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     const int nk = ((a->K + 63) / 64 + (a->split_k > 1 ? a->split_k : 1) - 1) / (a->split_k > 1 ? a->split_k : 1);
     // compile-time epilogue variant (see nt_epilogue_lean); 0 = generic
     int epi = 0;
-    const bool lean_ok = a->c_map.mode == 0 && a->split_k <= 1 && a->N % 8 == 0 && a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 &&
+    const bool lean_ok = (a->c_map.mode == 0 || (a->c_map.mode == 1 && a->c_map.c_seg % 8 == 0)) && a->split_k <= 1 && a->N % 8 == 0 && a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 &&
                          (!a->R || ((uintptr_t)a->R & 15) == 0) && (!a->H || ((uintptr_t)a->H & 15) == 0) && a->M < (1 << 24) &&
                          !getenv("MVLT_NT_GENERIC_EPI");
-    if (lean_ok) {
+    if (lean_ok && a->c_map.mode == 1) {
+      if (a->act == 0 && !a->col_sum && !a->R && !a->row_scale) epi = 6;
+      else if (a->act == 0 && !a->col_sum && a->R) epi = 7;
+    } else if (lean_ok) {
       if (a->act == 1 && !a->R && !a->row_scale && !a->col_sum) epi = 3;
       else if (a->act == 2 && !a->R && !a->row_scale && !a->col_sum) epi = 4;
       else if (a->act == 0 && a->R && !a->col_sum) epi = 2;
       else if (a->act == 0 && !a->R && !a->row_scale && a->col_sum) epi = 5;
       else if (a->act == 0 && !a->R && !a->row_scale && !a->col_sum) epi = 1;
     }
-    // ring depth: 2 stages (64 KB, two workgroups per CU).  One stage (32 KB, four per CU, the other workgroups hiding the
-    // load latency) times the same in isolation for the write-only epilogues and the same in the step: MVLT_NT_NS=1 keeps it testable
+    // ring depth: 2 stages (64 KB, two workgroups per CU).  A single stage at four workgroups per CU was tried: same time in
+    // the step, and its extra in-loop issue path cost 34 VGPRs (a wave per SIMD on the K <= 64 launches)
     int ns = nk < 2 ? nk : 2;
-    if (const char* e = getenv("MVLT_NT_NS")) { ns = atoi(e); if (ns > nk) ns = nk; if (ns < 1) ns = 1; if (ns > 4) ns = 4; }
+    if (const char* e = getenv("MVLT_NT_NS")) { ns = atoi(e); if (ns > nk) ns = nk; if (ns < 2) ns = nk < 2 ? nk : 2; if (ns > 4) ns = 4; }
     size_t lds2 = (size_t)ns * (BM + bn) * ROW_BYTES;
     if (lds2 < stage) lds2 = stage;
 #define MVLT_NT_LAUNCH_E(BN_, AM_)                                                                                   \
@@ -1273,6 +1290,8 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
       case 3: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 3>), grid, block, lds2, s, *a, ns); break;            \
       case 4: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 4>), grid, block, lds2, s, *a, ns); break;            \
       case 5: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 5>), grid, block, lds2, s, *a, ns); break;            \
+      case 6: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 6>), grid, block, lds2, s, *a, ns); break;            \
+      case 7: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 7>), grid, block, lds2, s, *a, ns); break;            \
       default: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 0>), grid, block, lds2, s, *a, ns);                  \
     }                                                                                                                \
   } while (0)
