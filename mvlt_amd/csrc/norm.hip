@@ -117,7 +117,9 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(mvlt_layernorm_args p) {
   }
 }
 
-template <typename T, typename TX, typename TDX, int G>
+// ITS = chunks per lane (1 when the lane group covers the row: C <= 8 G; the second slot of the arrays would only hold
+// registers: 126 -> ~90 VGPRs, 4 -> 5 waves per SIMD on an HBM-bound kernel)
+template <typename T, typename TX, typename TDX, int G, int ITS>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
   constexpr int GROUPS = NT / G;
   extern __shared__ __attribute__((aligned(16))) float s_part[];               // [2][C] block partials of dgamma / dbeta
@@ -127,9 +129,9 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
   const float inv_c = 1.0f / (float)p.C;
   for (int i = threadIdx.x; i < 2 * p.C; i += NT) s_part[i] = 0.f;
   __syncthreads();
-  float dg[MAXIT][VN], db[MAXIT][VN], gam[MAXIT][VN];
+  float dg[ITS][VN], db[ITS][VN], gam[ITS][VN];
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
+  for (int it = 0; it < ITS; ++it) {
     int c = gl + it * G;
 #pragma unroll
     for (int e = 0; e < VN; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; gam[it][e] = c < nchunk ? p.gamma[c * VN + e] : 0.f; }
@@ -140,10 +142,10 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
     const TX* xr = (const TX*)p.x + rowmap_base(xm, row) * p.ldx;
     TDX* dxr = (TDX*)p.dx + rowmap_base(dxm, row) * p.lddx;
     const float mean = p.mean[row], rstd = p.rstd[row];
-    float g[MAXIT][VN], xh[MAXIT][VN];
+    float g[ITS][VN], xh[ITS][VN];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < ITS; ++it) {
       int c = gl + it * G;
       if (c < nchunk) {
         float dyv[VN], xv[VN];
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
     s1 = group_sum<G>(s1) * inv_c;
     s2 = group_sum<G>(s2) * inv_c;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < ITS; ++it) {
       int c = gl + it * G;
       if (c < nchunk) {
         float o[VN];
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
   }
   if (p.dgamma) {
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < ITS; ++it) {
       int c = gl + it * G;
       if (c < nchunk) {
 #pragma unroll
@@ -267,12 +269,19 @@ template <typename T, typename TX, typename TDX> int launch_bwd(const mvlt_layer
   int grid = (a.rows + groups - 1) / groups;
   if (grid > 1024) grid = 1024;                 // each block ends with 2*C global atomics
   size_t lds = 2 * a.C * sizeof(float);
+  const bool one = g * VN >= a.C;               // one chunk per lane covers the row
+#define MVLT_LN_BWD(G_)                                                                                              \
+  do {                                                                                                               \
+    if (one) hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, G_, 1>), dim3(grid), dim3(NT), lds, s, a);                \
+    else hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, G_, MAXIT>), dim3(grid), dim3(NT), lds, s, a);                \
+  } while (0)
   switch (g) {
-    case 8: hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, 8>), dim3(grid), dim3(NT), lds, s, a); break;
-    case 16: hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, 16>), dim3(grid), dim3(NT), lds, s, a); break;
-    case 32: hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, 32>), dim3(grid), dim3(NT), lds, s, a); break;
-    default: hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, 64>), dim3(grid), dim3(NT), lds, s, a); break;
+    case 8: MVLT_LN_BWD(8); break;
+    case 16: MVLT_LN_BWD(16); break;
+    case 32: MVLT_LN_BWD(32); break;
+    default: MVLT_LN_BWD(64); break;
   }
+#undef MVLT_LN_BWD
   return mvlt_check_launch("mvlt_layernorm_bwd");
 }
 
