@@ -192,6 +192,9 @@ int mvlt_cross_entropy_bwd(const void* logits, const long* labels, long ignore_i
 int mvlt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* hp,
                     const uint8_t* decay_mask /* [n] 1 = apply weight decay (NULL = all), timm's no-decay split */, void* stream);
 int mvlt_cast_bf16(const float* src, void* dst, long n, void* stream);
+/* out[row,:] = x[row,:] * scale[row / rows_per_scale] over contiguous [M, C]: the per-sample DropPath factor applied to a
+ * block's incoming gradient before its branch GEMMs (timm drop_path backward, reference libs/pvlt.py:133-134). */
+int mvlt_row_scale(const void* x, const float* scale, int rows_per_scale, long M, int C, void* out, int dtype, void* stream);
 /* out[c*ld_out + r] = in[r*C + c] (fp32 master weight -> transposed compute-dtype operand for the dgrad GEMMs) */
 int mvlt_transpose_cast(const float* in, void* out, int R, int C, int ld_out, int dtype, void* stream);
 
@@ -247,7 +250,9 @@ int mvlt_bn_norm(const float* z, int ldz, const float* mean, const float* rstd, 
 int mvlt_bn_bwd_reduce(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, long M, int C,
                        float* s1 /* += sum dy = dbeta */, float* s2 /* += sum dy*xhat = dgamma */, void* stream);
 int mvlt_bn_bwd_apply(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, const float* gamma,
-                      const float* s1, const float* s2, long M, int C, void* dz_op, int lddz, int op_dtype, void* stream);
+                      const float* s1, const float* s2, long M, int C, void* dz_op, int lddz,
+                      float* g_beta, float* g_gamma /* nullable pair: += s1, += s2 (the BatchNorm parameter gradients) */,
+                      int op_dtype, void* stream);
 /* out (+)= a*b(*c) elementwise over [M, C] fp32 with row strides; optional operand-dtype copy of the result */
 int mvlt_ew_mul(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c, int ldc, long M, int C,
                 int accumulate, void* out_op, int ld_op, int op_dtype, void* stream);

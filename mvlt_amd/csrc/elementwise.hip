@@ -272,6 +272,24 @@ __global__ __launch_bounds__(NT) void cast_f32_bf16_kernel(const float* src, bf1
   }
 }
 
+// out[row, :] = x[row, :] * scale[row / rows_per_scale]   (DropPath factor of the sample a row belongs to; contiguous [M, C])
+template <typename T>
+__global__ __launch_bounds__(NT) void row_scale_kernel(const T* x, const float* scale, long per_scale, long n, T* out) {
+  constexpr int V = 16 / sizeof(T);
+  for (long i = ((long)blockIdx.x * NT + threadIdx.x) * V; i < n; i += (long)gridDim.x * NT * V) {
+    const float s = scale[i / per_scale];
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 v = *(const bf16x8*)(x + i), o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)v[e] * s);
+      *(bf16x8*)(out + i) = o;
+    } else {
+      f32x4 v = *(const f32x4*)(x + i);
+      *(f32x4*)(out + i) = f32x4{v[0] * s, v[1] * s, v[2] * s, v[3] * s};
+    }
+  }
+}
+
 // out[c][r] = (T) in[r][c]   (fp32 master weight [R,C] -> transposed compute copy for the dgrad GEMMs)
 template <typename T>
 __global__ __launch_bounds__(NT) void transpose_cast_kernel(const float* in, T* out, int R, int Ccols, int ld_out) {
@@ -447,6 +465,16 @@ extern "C" int mvlt_cast_bf16(const float* src, void* dst, long n, void* stream)
   if (n == 0) return MVLT_OK;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, src, (bf16*)dst, n);
   return mvlt_check_launch("mvlt_cast_bf16");
+}
+
+extern "C" int mvlt_row_scale(const void* x, const float* scale, int rows_per_scale, long M, int C, void* out, int dtype, void* stream) {
+  MVLT_REQUIRE(x && scale && out && rows_per_scale > 0 && M >= 0 && C > 0 && C % 8 == 0, "mvlt_row_scale: bad arguments (C must be a multiple of 8)");
+  MVLT_REQUIRE(dtype == 0 || dtype == 1, "mvlt_row_scale: bad dtype");
+  if (M == 0) return MVLT_OK;
+  const long n = M * C, per = (long)rows_per_scale * C;
+  if (dtype == 0) hipLaunchKernelGGL((row_scale_kernel<bf16>), dim3(grid_for(n / 8, 8192)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, scale, per, n, (bf16*)out);
+  else hipLaunchKernelGGL((row_scale_kernel<float>), dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, (const float*)x, scale, per, n, (float*)out);
+  return mvlt_check_launch("mvlt_row_scale");
 }
 
 extern "C" int mvlt_weight_prep(const mvlt_prep_desc* descs, const int* blk_start, int ndesc, int total_blocks, int dtype, void* stream) {

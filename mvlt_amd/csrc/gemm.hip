@@ -308,24 +308,18 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
 #pragma unroll
     for (int e = 0; e < 8; ++e) { cs8[e] = 0.f; cq8[e] = 0.f; }
   }
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < TN_; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) stage[(ii * 16 + 4 * fg + r) * LDW + j * 16 + fr] = acc[half * 2 + ii][j][r];
-    long idx[NIT];
-    bool ok[NIT];
-    float rs[NIT];
-    u32x4 raw[NIT][2];                                // R (EPI 2) or H (EPI 4) of this half, all requested up front
+  // R (EPI 2) / H (EPI 4) are requested for BOTH 32-row halves before the first one is staged: their HBM latency is paid once,
+  // behind the LDS staging, instead of once per half
+  long idx[2][NIT];
+  bool ok[2][NIT];
+  float rs[2][NIT];
+  u32x4 raw[2][NIT][2];
+  auto request = [&](int half) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int m = m_first + half * 32 + it * RPI;
-      ok[it] = m < p.M && col_ok;
-      const int mm = ok[it] ? m : 0;
+      ok[half][it] = m < p.M && col_ok;
+      const int mm = ok[half][it] ? m : 0;
       long phys = mm;
       if constexpr (SCAT) {
         const int b = fdiv24(mm, p.c_map.hw_out, inv_hw);
@@ -336,27 +330,40 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
         const int b = fdiv24(mm, rpb, inv_rpb);
         phys = (long)b * p.c_map.batch_stride + p.c_map.offset + (mm - b * rpb);
       }
-      idx[it] = phys * p.ldc + ncol;
-      rs[it] = 1.0f;
-      if (EPI == 2 && p.row_scale) rs[it] = p.row_scale[fdiv24(mm, p.rows_per_scale, inv_rps)];
-      if ((EPI == 2 || EPI == 4) && ok[it]) {
+      idx[half][it] = phys * p.ldc + ncol;
+      rs[half][it] = 1.0f;
+      if (EPI == 2 && p.row_scale) rs[half][it] = p.row_scale[fdiv24(mm, p.rows_per_scale, inv_rps)];
+      if ((EPI == 2 || EPI == 4) && ok[half][it]) {
         const void* src = (EPI == 2) ? p.R : p.H;
-        if (ofp32) { raw[it][0] = *(const u32x4*)((const float*)src + idx[it]); raw[it][1] = *(const u32x4*)((const float*)src + idx[it] + 4); }
-        else raw[it][0] = *(const u32x4*)((const bf16*)src + idx[it]);
+        if (ofp32) { raw[half][it][0] = *(const u32x4*)((const float*)src + idx[half][it]); raw[half][it][1] = *(const u32x4*)((const float*)src + idx[half][it] + 4); }
+        else raw[half][it][0] = *(const u32x4*)((const bf16*)src + idx[half][it]);
       }
     }
+  };
+  constexpr bool PREFETCH = (EPI == 2 || EPI == 4);
+  if (PREFETCH) { request(0); request(1); }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < TN_; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(ii * 16 + 4 * fg + r) * LDW + j * 16 + fr] = acc[half * 2 + ii][j][r];
+    if (!PREFETCH) request(half);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      if (!ok[it]) continue;
+      if (!ok[half][it]) continue;
       const int rl = it * RPI + lane / CPR;
       const f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-      const long ix = idx[it];
+      const long ix = idx[half][it];
       auto store8 = [&](void* base, const float* o) {
         if (ofp32) {
           *(f32x4*)((float*)base + ix) = f32x4{o[0], o[1], o[2], o[3]};
@@ -371,11 +378,11 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       float o8[8];
       if (EPI == 2 || EPI == 4) {
         if (ofp32) {
-          const f32x4 a = __builtin_bit_cast(f32x4, raw[it][0]), b = __builtin_bit_cast(f32x4, raw[it][1]);
+          const f32x4 a = __builtin_bit_cast(f32x4, raw[half][it][0]), b = __builtin_bit_cast(f32x4, raw[half][it][1]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { o8[e] = a[e]; o8[4 + e] = b[e]; }
         } else {
-          const bf16x8 a = __builtin_bit_cast(bf16x8, raw[it][0]);
+          const bf16x8 a = __builtin_bit_cast(bf16x8, raw[half][it][0]);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o8[e] = (float)a[e];
         }
@@ -384,20 +391,20 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
         if (p.H) store8(p.H, v);
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
-          const f32x2 gv = gelu_erf2(f32x2{v[e], v[e + 1]});
+          const f32x2 gv = gelu_fast2(f32x2{v[e], v[e + 1]});
           v[e] = gv[0]; v[e + 1] = gv[1];
         }
       }
       if (EPI == 4) {
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
-          const f32x2 dv = gelu_erf_grad2(f32x2{o8[e], o8[e + 1]});
+          const f32x2 dv = gelu_fast_grad2(f32x2{o8[e], o8[e + 1]});
           v[e] *= dv[0]; v[e + 1] *= dv[1];
         }
       }
       if (EPI == 2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[it] + o8[e];
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[half][it] + o8[e];
       }
       if (EPI == 5) {
 #pragma unroll
@@ -1079,14 +1086,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_a
 // ds_write_b128 (LDS stores run at ~80 B/clk/CU, a third of the read rate, and were as expensive as the MFMAs).  The
 // LDS image is the same (128-B rows of 64 k, 16-B chunks XOR-swizzled by row); because the DMA writes lane-linear the
 // swizzle is applied to the source chunk each lane fetches.  ns-deep ring with a counted vmcnt wait, as in the TN kernel.
-template <int BN, int AMODE, int EPI>
+template <int BN, int AMODE, int EPI, int BK>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args p, int ns) {
-  constexpr int BK = 64;
+  constexpr int ROWB = BK * 2;                      // LDS row: BK k-values of one tile row
+  constexpr int CH = BK / 8;                        // 16-B chunks per row (8 or 4)
+  constexpr int RPL = NTHREADS / CH;                // tile rows one DMA instruction of the workgroup covers
   constexpr int WN = BN / 2, TN_ = WN / 16;
-  constexpr int A_ITERS = BM * CHUNKS / NTHREADS;   // 4
-  constexpr int B_ITERS = BN * CHUNKS / NTHREADS;   // 4 or 2
+  constexpr int A_ITERS = BM * CH / NTHREADS;       // 4 (BK 64) or 2 (BK 32)
+  constexpr int B_ITERS = BN * CH / NTHREADS;
   constexpr int LPT = A_ITERS + B_ITERS;
-  constexpr int STAGE = (BM + BN) * ROW_BYTES;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  // chunk swizzle by row: 16 consecutive rows x one logical chunk must spread over all 64 banks
+  auto swzk = [](int row, int chunk) { return CH == 8 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3)); };
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1101,8 +1112,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
   const RowMap amap = to_rowmap(p.a_map);
   const unsigned smem_lds = (unsigned)(uintptr_t)smem;
 
-  const int row_in = tid >> 3;                                  // 0..31 (+32 i)
-  const int chunk = (tid & 7) ^ ((row_in >> 1) & 7);            // source chunk of this thread's LDS slot: swz is an involution
+  const int row_in = tid / CH;                                  // 0..RPL-1 (+RPL i)
+  const int chunk = swzk(row_in, tid % CH);                     // source chunk of this thread's LDS slot: swz is an involution
   const char* zsrc = (const char*)g_zero_page + ((tid * 16 + (bid & 15) * 4096) & 65535);
 
   const char* a_ptr[A_ITERS];
@@ -1110,7 +1121,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
   int a_y[A_ITERS], a_x[A_ITERS];
 #pragma unroll
   for (int i = 0; i < A_ITERS; ++i) {
-    int m = m0 + row_in + 32 * i;
+    int m = m0 + row_in + RPL * i;
     a_ok[i] = m < p.M;
     RowIt it = row_init(amap, a_ok[i] ? m : 0);
     int phys;
@@ -1124,7 +1135,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
   bool b_ok[B_ITERS];
 #pragma unroll
   for (int i = 0; i < B_ITERS; ++i) {
-    int n = n0 + row_in + 32 * i;
+    int n = n0 + row_in + RPL * i;
     b_ok[i] = n < p.N;
     b_ptr[i] = (const char*)p.B + (unsigned long long)(unsigned)(b_ok[i] ? n : 0) * (2u * (unsigned)p.ldb);
   }
@@ -1155,7 +1166,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i)
       glds16((b_ok[i] && k_ok) ? b_ptr[i] + kpos * 2 : zsrc,
-             __builtin_amdgcn_readfirstlane(smem_lds + slot * STAGE + BM * ROW_BYTES + (i * NTHREADS + wave * 64) * 16));
+             __builtin_amdgcn_readfirstlane(smem_lds + slot * STAGE + BM * ROWB + (i * NTHREADS + wave * 64) * 16));
     kpos += BK;
     if constexpr (AMODE != 0) {
       kk += BK;
@@ -1176,28 +1187,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
   if (ns == 1) issue(0);
   int slot = 0, islot = ns - 1;
   for (int kt = 0; kt < nk; ++kt) {
-    if (ns == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-    else if (ns == 4 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    // tile kt must have landed; up to ns - 2 later tiles may still be in flight (none near the tail)
+    const int ahead = min(nk - 1 - kt, ns - 2);
+    if (ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT) : "memory");
+    else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (ns > 1 && kt + ns - 1 < nk) issue(islot);
     islot = islot + 1 >= ns ? 0 : islot + 1;
-    const char* a_s = smem + slot * STAGE + (wm * 64) * ROW_BYTES;
-    const char* b_s = smem + slot * STAGE + BM * ROW_BYTES + (wn * WN) * ROW_BYTES;
+    const char* a_s = smem + slot * STAGE + (wm * 64) * ROWB;
+    const char* b_s = smem + slot * STAGE + BM * ROWB + (wn * WN) * ROWB;
     slot = slot + 1 >= ns ? 0 : slot + 1;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 32; ++ks) {
       u32x4 fa[4], fb[TN_];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int r = i * 16 + fr;
-        fa[i] = *(const u32x4*)(a_s + r * ROW_BYTES + swz(wm * 64 + r, ks * 4 + fg) * 16);
+        fa[i] = *(const u32x4*)(a_s + r * ROWB + swzk(wm * 64 + r, ks * 4 + fg) * 16);
       }
 #pragma unroll
       for (int j = 0; j < TN_; ++j) {
         int r = j * 16 + fr;
-        fb[j] = *(const u32x4*)(b_s + r * ROW_BYTES + swz(wn * WN + r, ks * 4 + fg) * 16);
+        fb[j] = *(const u32x4*)(b_s + r * ROWB + swzk(wn * WN + r, ks * 4 + fg) * 16);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1278,30 +1293,38 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     }
     // ring depth: 2 stages (64 KB, two workgroups per CU).  A single stage at four workgroups per CU was tried: same time in
     // the step, and its extra in-loop issue path cost 34 VGPRs (a wave per SIMD on the K <= 64 launches)
-    int ns = nk < 2 ? nk : 2;
-    if (const char* e = getenv("MVLT_NT_NS")) { ns = atoi(e); if (ns > nk) ns = nk; if (ns < 2) ns = nk < 2 ? nk : 2; if (ns > 4) ns = 4; }
-    size_t lds2 = (size_t)ns * (BM + bn) * ROW_BYTES;
+    // The GELU epilogue (EPI 3) on the short-K fc1 GEMMs is epilogue-bound: 32-wide K stages halve the ring (32 KB) so a third
+    // workgroup fits per CU and covers it (98304x1280x320: 240 -> 220 us, 49152x2048x512: 234 -> 201 us).  Long K loses to the
+    // doubled barrier count (K = 2048: 103 -> 125 us), other epilogues are neutral; EPI 4 prefers its two-half H prefetch,
+    // whose registers allow two workgroups per CU either way (220 / 213 us against 227 / 217 us).
+    const int bkd = (!narrow && a->a_map.mode == 0 && epi == 3 && a->K <= 512 && !getenv("MVLT_NT_BK64")) ? 32 : 64;
+    const int nkd = bkd == 32 ? (a->K + 31) / 32 : nk;
+    int ns = nkd < 2 ? nkd : 2;
+    if (const char* e = getenv("MVLT_NT_NS")) { ns = atoi(e); if (ns > nkd) ns = nkd; if (ns < 2) ns = nkd < 2 ? nkd : 2; if (ns > 6) ns = 6; }
+    size_t lds2 = (size_t)ns * (BM + bn) * (bkd * 2);
     if (lds2 < stage) lds2 = stage;
-#define MVLT_NT_LAUNCH_E(BN_, AM_)                                                                                   \
+#define MVLT_NT_LAUNCH_E(BN_, AM_, BK_)                                                                                 \
   do {                                                                                                               \
     switch (epi) {                                                                                                   \
-      case 1: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 1>), grid, block, lds2, s, *a, ns); break;            \
-      case 2: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 2>), grid, block, lds2, s, *a, ns); break;            \
-      case 3: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 3>), grid, block, lds2, s, *a, ns); break;            \
-      case 4: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 4>), grid, block, lds2, s, *a, ns); break;            \
-      case 5: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 5>), grid, block, lds2, s, *a, ns); break;            \
-      case 6: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 6>), grid, block, lds2, s, *a, ns); break;            \
-      case 7: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 7>), grid, block, lds2, s, *a, ns); break;            \
-      default: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 0>), grid, block, lds2, s, *a, ns);                  \
+      case 1: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 1, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      case 2: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 2, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      case 3: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 3, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      case 4: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 4, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      case 5: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 5, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      case 6: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 6, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      case 7: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 7, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      default: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 0, BK_>), grid, block, lds2, s, *a, ns);                  \
     }                                                                                                                \
   } while (0)
-#define MVLT_NT_LAUNCH(BN_)                                                                                          \
+#define MVLT_NT_LAUNCH(BN_, BK_)                                                                                     \
   do {                                                                                                               \
-    if (a->a_map.mode == 0) MVLT_NT_LAUNCH_E(BN_, 0);                                                                \
-    else if (a->a_map.mode == 1) MVLT_NT_LAUNCH_E(BN_, 1);                                                           \
-    else MVLT_NT_LAUNCH_E(BN_, 2);                                                                                   \
+    if (a->a_map.mode == 0) MVLT_NT_LAUNCH_E(BN_, 0, BK_);                                                           \
+    else if (a->a_map.mode == 1) MVLT_NT_LAUNCH_E(BN_, 1, BK_);                                                      \
+    else MVLT_NT_LAUNCH_E(BN_, 2, BK_);                                                                              \
   } while (0)
-    if (narrow) MVLT_NT_LAUNCH(64); else MVLT_NT_LAUNCH(128);
+    if (narrow) MVLT_NT_LAUNCH(64, 64);
+    else if (bkd == 32) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 0, 3, 32>), grid, block, lds2, s, *a, ns);
+    else MVLT_NT_LAUNCH(128, 64);
 #undef MVLT_NT_LAUNCH_E
 #undef MVLT_NT_LAUNCH
   } else if (a->dtype == 0) {

@@ -53,6 +53,54 @@ __global__ __launch_bounds__(NT) void col_reduce_kernel(const float* z, int ldz,
   for (int i = threadIdx.x; i < C; i += NT) { atomicAdd(&s1[i], sm[i]); atomicAdd(&s2[i], sm[C + i]); }
 }
 
+// The same two reductions with 16-byte loads: C/4 lanes span a row, NT/(C/4) rows per pass, four passes in flight per thread
+// (the 4-byte form above keeps too few bytes in flight to reach HBM speed at C = 64).  C % 4 == 0, ld % 4 == 0, 16-byte aligned.
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void col_reduce4_kernel(const float* z, int ldz, const float* dy, int lddy, const float* mean, const float* rstd,
+                                                         long M, int C, float* s1, float* s2, int rows_per_wg) {
+  extern __shared__ float sm[];             // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += NT) sm[i] = 0.f;
+  __syncthreads();
+  const int cq = C >> 2, rpp = NT / cq;
+  const int tr = threadIdx.x / cq, tc = (threadIdx.x - tr * cq) * 4;
+  if (tr < rpp) {
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, mu = a1, rs = a1;
+    if (MODE == 1) { mu = *(const f32x4*)(mean + tc); rs = *(const f32x4*)(rstd + tc); }
+    const long r0 = (long)blockIdx.x * rows_per_wg;
+    const long r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
+    long r = r0 + tr;
+    constexpr int U = 4;
+    for (; r + (long)(U - 1) * rpp < r1; r += (long)U * rpp) {
+      f32x4 zv[U], dv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        zv[u] = *(const f32x4*)(z + (r + (long)u * rpp) * ldz + tc);
+        if (MODE == 1) dv[u] = *(const f32x4*)(dy + (r + (long)u * rpp) * lddy + tc);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (MODE == 0) { a1[e] += zv[u][e]; a2[e] += zv[u][e] * zv[u][e]; }
+          else { a1[e] += dv[u][e]; a2[e] += dv[u][e] * (zv[u][e] - mu[e]) * rs[e]; }
+        }
+    }
+    for (; r < r1; r += rpp) {
+      f32x4 zv = *(const f32x4*)(z + r * ldz + tc), dv = zv;
+      if (MODE == 1) dv = *(const f32x4*)(dy + r * lddy + tc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (MODE == 0) { a1[e] += zv[e]; a2[e] += zv[e] * zv[e]; }
+        else { a1[e] += dv[e]; a2[e] += dv[e] * (zv[e] - mu[e]) * rs[e]; }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { atomicAdd(&sm[tc + e], a1[e]); atomicAdd(&sm[C + tc + e], a2[e]); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += NT) { atomicAdd(&s1[i], sm[i]); atomicAdd(&s2[i], sm[C + i]); }
+}
+
 // mean / rstd from (sum, sumsq) and the running-stat update of nn.BatchNorm2d (momentum 0.1, unbiased running var)
 __global__ void bn_finalize_kernel(const float* sum, const float* sumsq, int copies, int M, int C, float eps, float momentum,
                                    float* mean, float* rstd, float* running_mean, float* running_var) {
@@ -90,9 +138,12 @@ __global__ __launch_bounds__(NT) void bn_norm_kernel(const float* z, int ldz, co
 // dz = gamma * rstd * (dy - s1/M - xhat * s2/M)   (bf16: it is the A operand of the conv dgrad / wgrad GEMMs)
 template <typename TO>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd,
-                                                          const float* gamma, const float* s1, const float* s2, long M, int C, TO* dz, int lddz) {
+                                                          const float* gamma, const float* s1, const float* s2, long M, int C, TO* dz, int lddz,
+                                                          float* g_beta, float* g_gamma) {
   const int cq = C / 4;
   const float invM = 1.0f / (float)M;
+  if (g_beta && blockIdx.x == 0)             // BatchNorm parameter gradients: d beta += s1, d gamma += s2 (one writer)
+    for (int c = threadIdx.x; c < C; c += NT) { g_beta[c] += s1[c]; g_gamma[c] += s2[c]; }
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
     long r = i / cq; int c = (int)(i - r * cq) * 4;
     f32x4 d = *(const f32x4*)(dy + r * lddy + c), zv = *(const f32x4*)(z + r * ldz + c);
@@ -314,11 +365,27 @@ inline int grid_for(long work, int cap = 8192) {
   return (int)g;
 }
 
+constexpr int RNT = 1024, RWGS = 256;     // the vectorised reductions: one workgroup per CU (every extra one adds 2C same-line atomics)
+inline bool vec4_ok(const float* p, int ld, int C) { return C % 4 == 0 && C <= 256 && ld % 4 == 0 && ((uintptr_t)p & 15) == 0; }
+// about 1024 workgroups, each a whole number of four-pass iterations
+inline int reduce_rows_per_wg(long M, int C, int nt, int wgs) {
+  const int step = 4 * (nt / (C / 4));
+  long rows = (M + wgs - 1) / wgs;
+  rows = (rows + step - 1) / step * step;
+  return (int)rows;
+}
+
 }  // namespace
 
 extern "C" int mvlt_col_stats(const float* z, int ldz, long M, int C, float* sum, float* sumsq, void* stream) {
   MVLT_REQUIRE(z && sum && sumsq && C > 0 && C <= 256 && ldz >= C, "mvlt_col_stats: bad arguments (C <= 256)");
   if (M <= 0) return MVLT_OK;
+  if (vec4_ok(z, ldz, C)) {
+    int rows_per_wg = reduce_rows_per_wg(M, C, RNT, RWGS);
+    int grid = (int)((M + rows_per_wg - 1) / rows_per_wg);
+    hipLaunchKernelGGL((col_reduce4_kernel<0, RNT>), dim3(grid), dim3(RNT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, nullptr, 0, nullptr, nullptr, M, C, sum, sumsq, rows_per_wg);
+    return mvlt_check_launch("mvlt_col_stats");
+  }
   int grid = (int)((M + 63) / 64); if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(grid), dim3(NT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, nullptr, 0, nullptr, nullptr, (int)M, C, sum, sumsq);
   return mvlt_check_launch("mvlt_col_stats");
@@ -346,18 +413,29 @@ extern "C" int mvlt_bn_bwd_reduce(const float* dy, int lddy, const float* z, int
                                   float* s1, float* s2, void* stream) {
   MVLT_REQUIRE(dy && z && mean && rstd && s1 && s2 && C > 0 && C <= 256, "mvlt_bn_bwd_reduce: bad arguments (C <= 256)");
   if (M <= 0) return MVLT_OK;
+  if (vec4_ok(z, ldz, C) && vec4_ok(dy, lddy, C) && (((uintptr_t)mean | (uintptr_t)rstd) & 15) == 0) {
+    // measured at M = 262144: C = 64 34.7 -> 30.6 us with 512 threads, C = 192 98.8 -> 80.0 us with 1024 (5.0 TB/s)
+    const int nt = C <= 64 ? 512 : 1024;
+    int rows_per_wg = reduce_rows_per_wg(M, C, nt, RWGS);
+    int grid = (int)((M + rows_per_wg - 1) / rows_per_wg);
+    if (nt == 512) hipLaunchKernelGGL((col_reduce4_kernel<1, 512>), dim3(grid), dim3(512), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, M, C, s1, s2, rows_per_wg);
+    else hipLaunchKernelGGL((col_reduce4_kernel<1, 1024>), dim3(grid), dim3(1024), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, M, C, s1, s2, rows_per_wg);
+    return mvlt_check_launch("mvlt_bn_bwd_reduce");
+  }
   int grid = (int)((M + 63) / 64); if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(grid), dim3(NT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, (int)M, C, s1, s2);
   return mvlt_check_launch("mvlt_bn_bwd_reduce");
 }
 
 extern "C" int mvlt_bn_bwd_apply(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, const float* gamma,
-                                 const float* s1, const float* s2, long M, int C, void* dz_bf16, int lddz, int op_dtype, void* stream) {
+                                 const float* s1, const float* s2, long M, int C, void* dz_bf16, int lddz, float* g_beta, float* g_gamma,
+                                 int op_dtype, void* stream) {
   MVLT_REQUIRE(dy && z && mean && rstd && gamma && s1 && s2 && dz_bf16 && C % 4 == 0 && lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0,
                "mvlt_bn_bwd_apply: bad arguments");
+  MVLT_REQUIRE((g_beta == nullptr) == (g_gamma == nullptr), "mvlt_bn_bwd_apply: g_beta and g_gamma go together");
   if (M <= 0) return MVLT_OK;
-  if (op_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz);
-  else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (float*)dz_bf16, lddz);
+  if (op_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (float*)dz_bf16, lddz, g_beta, g_gamma);
   return mvlt_check_launch("mvlt_bn_bwd_apply");
 }
 

@@ -132,10 +132,9 @@ class MimStep:
         p, M, cin, cout = r["p"], r["M"], r["cin"], r["cout"]
         red = _z((2, cout), dev)
         ops.bn_bwd_reduce(dy, lddy, r["z"], cout, r["mean"], r["rstd"], M, cout, red[0], red[1])
-        S.grad(p + ".1.bias").add_(red[0])
-        S.grad(p + ".1.weight").add_(red[1])
         dz = _e((M, cout), dev, dt)
-        ops.bn_bwd_apply(dy, lddy, r["z"], cout, r["mean"], r["rstd"], S.master(p + ".1.weight"), red[0], red[1], M, cout, dz, cout)
+        ops.bn_bwd_apply(dy, lddy, r["z"], cout, r["mean"], r["rstd"], S.master(p + ".1.weight"), red[0], red[1], M, cout, dz, cout,
+                         g_beta=S.grad(p + ".1.bias"), g_gamma=S.grad(p + ".1.weight"))
         # wgrad in [out][dy][dx][cin] order, folded back to nn.Conv2d's [out][cin][3][3]
         dWk = _z((cout, 9 * cin), dev)
         ops.gemm_tn(dz, r["xin"], dWk, M, cout, 9 * cin, cout, r["ld_in"], 9 * cin, b_map=r["amap"])

@@ -192,6 +192,15 @@ def cast_bf16(src, dst, n):
     check(L.lib.mvlt_cast_bf16(_p(src), _p(dst), n, stream_ptr()), "mvlt_cast_bf16")
 
 
+L.lib.mvlt_row_scale.argtypes = [_vp, _vp, _i, _l, _i, _vp, _i, _vp]
+
+
+def row_scale(x, scale, rows_per_scale, M, Cdim, out):
+    _need_cuda(x, scale, out)
+    assert x.is_contiguous() and out.is_contiguous() and scale.dtype == torch.float32 and x.dtype == out.dtype
+    check(L.lib.mvlt_row_scale(_p(x), _p(scale), rows_per_scale, M, Cdim, _p(out), DT[x.dtype], stream_ptr()), "mvlt_row_scale")
+
+
 def transpose_cast(w, out, R, Ccols, ld_out):
     _need_cuda(w, out)
     assert w.dtype == torch.float32 and w.is_contiguous()
@@ -203,7 +212,7 @@ L.lib.mvlt_col_stats.argtypes = [_vp, _i, _l, _i, _vp, _vp, _vp]
 L.lib.mvlt_bn_finalize.argtypes = [_vp, _vp, _i, _l, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]
 L.lib.mvlt_bn_norm.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _i, _i, _vp]
 L.lib.mvlt_bn_bwd_reduce.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _l, _i, _vp, _vp, _vp]
-L.lib.mvlt_bn_bwd_apply.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _i, _vp]
+L.lib.mvlt_bn_bwd_apply.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _vp, _i, _vp]
 L.lib.mvlt_ew_mul.argtypes = [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _l, _i, _i, _vp, _i, _i, _vp]
 L.lib.mvlt_upsample_fwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]
 L.lib.mvlt_upsample_bwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]
@@ -228,9 +237,9 @@ def bn_bwd_reduce(dy, lddy, z, ldz, mean, rstd, M, Cdim, s1, s2):
     check(L.lib.mvlt_bn_bwd_reduce(_p(dy), lddy, _p(z), ldz, _p(mean), _p(rstd), M, Cdim, _p(s1), _p(s2), stream_ptr()), "mvlt_bn_bwd_reduce")
 
 
-def bn_bwd_apply(dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, Cdim, dz16, lddz):
-    check(L.lib.mvlt_bn_bwd_apply(_p(dy), lddy, _p(z), ldz, _p(mean), _p(rstd), _p(gamma), _p(s1), _p(s2), M, Cdim, _p(dz16), lddz, DT[dz16.dtype], stream_ptr()),
-          "mvlt_bn_bwd_apply")
+def bn_bwd_apply(dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, Cdim, dz16, lddz, g_beta=None, g_gamma=None):
+    check(L.lib.mvlt_bn_bwd_apply(_p(dy), lddy, _p(z), ldz, _p(mean), _p(rstd), _p(gamma), _p(s1), _p(s2), M, Cdim, _p(dz16), lddz,
+                                  _p(g_beta), _p(g_gamma), DT[dz16.dtype], stream_ptr()), "mvlt_bn_bwd_apply")
 
 
 def ew_mul(out, ldo, a, lda, b, ldb, c=None, ldc=0, *, M, Cdim, accumulate=False, out16=None, ld16=0):

@@ -274,7 +274,9 @@ class TrunkStep:
         """dy * scale[b] per sample (DropPath); identity when scale is None."""
         if scale is None:
             return dy
-        return (dy.view(self.B, N, -1) * scale.view(self.B, 1, 1).to(dy.dtype)).view_as(dy)
+        out = torch.empty_like(dy)
+        ops.row_scale(dy, scale, N, self.B * N, dy.shape[-1], out)
+        return out
 
     def backward(self, dxs):
         """dxs: gradients w.r.t. the four stage outputs (None allowed).  Fills the flat gradient buffer."""

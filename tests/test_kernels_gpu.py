@@ -506,3 +506,48 @@ def test_upsample_fwd_bwd(ops, B, H, C, s, nchw, out_dtype):
     ops.upsample_bwd(dy, 0 if nchw else C, nchw, B, H, H, C, s, dx, C, accumulate=True)
     want = base + xt.grad.permute(0, 2, 3, 1).reshape(B * H * H, C)
     assert maxrel(dx, want) < 1e-5
+
+
+# ------------------------------------------------------------------ train-mode BatchNorm over pixel-major matrices
+@pytest.mark.parametrize("M,C,lddy,off", [(5000, 64, 192, 0), (3001, 192, 192, 0), (2048, 128, 192, 64), (777, 6, 6, 0)])
+def test_batchnorm_fwd_bwd(ops, M, C, lddy, off):
+    """reference libs/vl_heads.py:113-125 (BasicConv2d's nn.BatchNorm2d in train mode) on [pixels, channels] fp32; dy may be a
+    column range of a wider matrix (the concat gradients)."""
+    z = rnd(M, C, dtype=torch.float32, scale=2.0) + 0.5
+    gamma, beta = rnd(C, dtype=torch.float32, seed=1) + 1.0, rnd(C, dtype=torch.float32, seed=2)
+    dyw = rnd(M, lddy, dtype=torch.float32, seed=3)
+    dy = dyw[:, off:off + C]
+    # fp64 autograd of the defining formulas (MIOpen's own batch-norm backward is not accurate enough to be the reference here)
+    zr = z.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = (zr - zr.mean(0)) * (zr.var(0, unbiased=False) + 1e-5).rsqrt() * gr + br
+    ref.backward(dy.double())
+    s = torch.zeros(2, C, device=dev())
+    ops.col_stats(z, C, M, C, s[0], s[1])
+    mean, rstd = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+    ops.bn_finalize(s[0], s[1], M, C, 1e-5, 0.1, mean, rstd)
+    assert maxrel(mean, z.mean(0)) < 1e-5 and maxrel(rstd, (z.var(0, unbiased=False) + 1e-5).rsqrt()) < 1e-4
+    if C % 4 == 0:
+        y = torch.empty(M, C, device=dev())
+        ops.bn_norm(z, C, mean, rstd, gamma, beta, M, C, y32=y, ld32=C)
+        assert maxrel(y, ref.detach()) < 1e-4
+    red = torch.zeros(2, C, device=dev())
+    ops.bn_bwd_reduce(dy, lddy, z, C, mean, rstd, M, C, red[0], red[1])
+    assert maxrel(red[0], br.grad) < 1e-4 and maxrel(red[1], gr.grad) < 1e-4
+    if C % 4 == 0:
+        gb, gg = torch.ones(C, device=dev()), torch.full((C,), 2.0, device=dev())
+        dz = torch.empty(M, C, device=dev())
+        ops.bn_bwd_apply(dy, lddy, z, C, mean, rstd, gamma, red[0], red[1], M, C, dz, C, g_beta=gb, g_gamma=gg)
+        assert maxrel(dz, zr.grad) < 1e-3
+        assert maxrel(gb - 1.0, br.grad) < 1e-4 and maxrel(gg - 2.0, gr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_row_scale(ops, dtype):
+    B, N, C = 5, 37, 64
+    x = rnd(B * N, C, dtype=dtype)
+    sc = torch.tensor([0.0, 1.25, 1.0, 0.0, 1.111], device=dev())
+    out = torch.empty_like(x)
+    ops.row_scale(x, sc, N, B * N, C, out)
+    want = (x.float().view(B, N, C) * sc.view(B, 1, 1)).view(B * N, C).to(dtype)
+    assert torch.equal(out, want)

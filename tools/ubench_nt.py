@@ -11,7 +11,7 @@ def timeit(fn):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for M, N, K in [(98304, 1280, 320), (49152, 2048, 512), (98304, 320, 1280)]:
+for M, N, K in [(98304, 1280, 320), (49152, 2048, 512), (98304, 320, 1280), (49152, 512, 2048), (262144, 256, 1728)]:
     A = torch.randn(M, K, device=dev).to(bf); W = (torch.randn(N, K, device=dev) * K ** -0.5).to(bf)
     b = torch.randn(N, device=dev); out = torch.empty(M, N, device=dev, dtype=bf); H = torch.empty_like(out)
     for name, kw in [('plain', {}), ('bias+gelu', dict(bias=b, act=1)), ('bias+gelu+H', dict(bias=b, act=1, H=H)), ("gelu'(H)", dict(act=2, H=H))]:

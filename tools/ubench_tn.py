@@ -14,7 +14,7 @@ def timeit(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 SHAPES = [(49152, 2048, 512, None), (98304, 1280, 320, None), (262144, 192, 1728, 'conv'), (1081344, 64, 64, None), (294912, 128, 128, None),
-          (49152, 512, 512, None)]
+          (49152, 512, 512, None), (98304, 320, 1280, None), (98304, 320, 320, None), (98304, 640, 320, None)]
 for M, N1, N2, kind in SHAPES:
     A = torch.randn(M, N1, device=dev).to(bf)
     if kind == 'conv':
