@@ -436,6 +436,107 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
   }
 }
 
+// BN = 192 (wave tile 64 x 96, for N % 192 == 0 outputs that the 128-wide tile would pad to the next 256): the wave's 96 columns
+// leave as three 32-column groups, 4 lanes x 8 columns per row and 16 rows per instruction.  Only the two epilogues the
+// 192-channel convolutions use: EPI 1 (plain (+bias)) and EPI 5 (the same + column sum / sum of squares).
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue_192(const mvlt_gemm_nt_args& p, f32x4 (&acc)[4][6], char* smem, int m0, int n0, int wave,
+                                                int lane) {
+  static_assert(EPI == 1 || EPI == 5, "192-wide tiles carry the plain and the column-statistics epilogue only");
+  constexpr int WN = 96, TN_ = 6, LDW = WN + 4, NG = 3;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ofp32 = p.out_dtype;
+  float* stage = (float*)smem + wave * 32 * LDW;
+  const int ch = lane & 3, rl0 = lane >> 2;
+  const int nbase = n0 + wn * WN + ch * 8;
+  const int rpb = p.c_map.rows_per_batch;
+  const float inv_rpb = rpb > 0 ? 1.0f / (float)rpb : 0.f;
+  float cs[NG][8], cq[NG][8];
+  if (EPI == 5) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { cs[g][e] = 0.f; cq[g][e] = 0.f; }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < TN_; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(ii * 16 + 4 * fg + r) * LDW + j * 16 + fr] = acc[half * 2 + ii][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int rl = it * 16 + rl0;
+      const int m = m0 + wm * 64 + half * 32 + rl;
+      if (m >= p.M) continue;
+      long phys = m;
+      if (rpb > 0) {
+        const int b = fdiv24(m, rpb, inv_rpb);
+        phys = (long)b * p.c_map.batch_stride + p.c_map.offset + (m - b * rpb);
+      }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int nc = nbase + g * 32;
+        if (nc >= p.N) continue;
+        const f32x4 v0 = *(const f32x4*)(stage + rl * LDW + g * 32 + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + g * 32 + ch * 8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += p.bias[nc + e];
+        }
+        if (EPI == 5) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { cs[g][e] += v[e]; cq[g][e] += v[e] * v[e]; }
+        }
+        const long ix = phys * p.ldc + nc;
+        if (ofp32) {
+          *(f32x4*)((float*)p.C + ix) = f32x4{v[0], v[1], v[2], v[3]};
+          *(f32x4*)((float*)p.C + ix + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+          *(bf16x8*)((bf16*)p.C + ix) = o;
+        }
+      }
+    }
+  }
+  if (EPI == 5) {
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1)
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { cs[g][e] += __shfl_xor(cs[g][e], off); cq[g][e] += __shfl_xor(cq[g][e], off); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 4) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { stage[g * 32 + lane * 8 + e] = cs[g][e]; stage[WN + g * 32 + lane * 8 + e] = cq[g][e]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const long cpy = p.col_copies > 1 ? (long)((m0 / BM) % p.col_copies) * p.N : 0;
+    for (int c = lane; c < WN; c += 64) {
+      const int col = n0 + wn * WN + c;
+      if (col < p.N) {
+        atomicAdd(&p.col_sum[cpy + col], stage[c]);
+        atomicAdd(&p.col_sumsq[cpy + col], stage[WN + c]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ NT
 template <typename T, int BN>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mvlt_gemm_nt_args p, int nbuf) {
@@ -1221,7 +1322,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
     }
   }
   __syncthreads();                   // last tile's reads are done before the epilogue reuses the LDS
-  if constexpr (EPI == 0) nt_epilogue<bf16, BN>(p, acc, smem, m0, n0, wave, lane);
+  if constexpr (BN == 192) nt_epilogue_192<EPI>(p, acc, smem, m0, n0, wave, lane);
+  else if constexpr (EPI == 0) nt_epilogue<bf16, BN>(p, acc, smem, m0, n0, wave, lane);
   else nt_epilogue_lean<BN, EPI>(p, acc, smem, m0, n0, wave, lane);
 }
 
@@ -1322,7 +1424,20 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     else if (a->a_map.mode == 1) MVLT_NT_LAUNCH_E(BN_, 1, BK_);                                                      \
     else MVLT_NT_LAUNCH_E(BN_, 2, BK_);                                                                              \
   } while (0)
-    if (narrow) MVLT_NT_LAUNCH(64, 64);
+    // N % 192 == 0 (the 192-channel convolutions): one 192-wide tile instead of 128 + a half-empty 128
+    const bool wide = !narrow && a->N % 192 == 0 && a->N % 128 != 0 && (epi == 1 || epi == 5) && a->c_map.mode == 0 && a->a_map.mode != 1 &&
+                      a->K >= 128 && !getenv("MVLT_NT_NO192");
+    if (wide) {
+      const int tn192 = a->N / 192;
+      dim3 grid192((unsigned)(8 * ((tiles_m + 7) / 8) * tn192), 1);
+      size_t lds3 = (size_t)ns * (BM + 192) * ROW_BYTES;
+      const size_t stage192 = (size_t)4 * 32 * 100 * sizeof(float);
+      if (lds3 < stage192) lds3 = stage192;
+      if (a->a_map.mode == 0 && epi == 1) hipLaunchKernelGGL((gemm_nt_dma_kernel<192, 0, 1, 64>), grid192, block, lds3, s, *a, ns);
+      else if (a->a_map.mode == 0) hipLaunchKernelGGL((gemm_nt_dma_kernel<192, 0, 5, 64>), grid192, block, lds3, s, *a, ns);
+      else if (epi == 1) hipLaunchKernelGGL((gemm_nt_dma_kernel<192, 2, 1, 64>), grid192, block, lds3, s, *a, ns);
+      else hipLaunchKernelGGL((gemm_nt_dma_kernel<192, 2, 5, 64>), grid192, block, lds3, s, *a, ns);
+    } else if (narrow) MVLT_NT_LAUNCH(64, 64);
     else if (bkd == 32) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 0, 3, 32>), grid, block, lds2, s, *a, ns);
     else MVLT_NT_LAUNCH(128, 64);
 #undef MVLT_NT_LAUNCH_E

@@ -40,7 +40,7 @@ def ops():
 # ------------------------------------------------------------------ gemm_nt
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(300, 64, 64), (1000, 512, 64), (257, 320, 1280), (130, 30522, 768), (64, 2, 768),
-                                   (129, 48, 48), (4224 * 2, 64, 512), (5, 122, 768)])
+                                   (129, 48, 48), (4224 * 2, 64, 512), (5, 122, 768), (1000, 384, 256), (777, 192, 1728)])
 def test_gemm_nt_plain(ops, dtype, M, N, K):
     A, B = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1)
     bias = rnd(N, dtype=torch.float32, seed=2)

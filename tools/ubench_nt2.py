@@ -11,7 +11,7 @@ def timeit(fn):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for M, N, K in [(98304, 320, 320), (49152, 512, 512), (49152, 1024, 512), (294912, 128, 128), (294912, 256, 128), (98304, 640, 320), (262144, 192, 576), (262144, 128, 1152)]:
+for M, N, K in [(262144, 192, 1728), (98304, 320, 320), (49152, 512, 512), (49152, 1024, 512), (294912, 128, 128), (294912, 256, 128), (98304, 640, 320), (262144, 192, 576), (262144, 128, 1152)]:
     A = torch.randn(M, K, device=dev).to(bf); W = (torch.randn(N, K, device=dev) * K ** -0.5).to(bf)
     b = torch.randn(N, device=dev); out = torch.empty(M, N, device=dev, dtype=bf); R = torch.randn(M, N, device=dev); o32 = torch.empty_like(R)
     rs = torch.ones(M // 64, device=dev)
