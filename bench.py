@@ -139,10 +139,10 @@ def time_dominant_kernel(model, B, device):
     if tj:
         t = json.load(open(os.path.join(ROOT, "profiles", tj[-1])))
         traffic, traffic2 = t.get("conv192", {}).get("hbm_bytes"), t.get("proj64", {}).get("hbm_bytes")
-    return dict(kernel="gemm_nt_dma_kernel<192, 2, 1, 64> (bf16, 128x192 tile, 3x3-gather A, plain epilogue): MIM conv3x3 192->192 @32x32 as GEMM (M=B*1024, N=192, K=1728)",
+    return dict(kernel="gemm_nt_dma_kernel<192, 2, 1, 64, 128> (bf16, 128x192 tile, 3x3-gather A, plain epilogue): MIM conv3x3 192->192 @32x32 as GEMM (M=B*1024, N=192, K=1728)",
                 bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_BF16_TFLOPS, 4),
                 traffic=traffic, ms_per_launch=round(ms, 4), algorithmic_flops=flops,
-                hbm_bound_sibling=dict(kernel="gemm_nt_dma_kernel<64, 0, 1, 64> (bf16, 128x64 tile): K=64 N=64 projection, M=B*4224", bound="hbm",
+                hbm_bound_sibling=dict(kernel="gemm_nt_dma_kernel<64, 0, 1, 64, 128> (bf16, 128x64 tile): K=64 N=64 projection, M=B*4224", bound="hbm",
                                        achieved=round(bytes2 / (ms2 * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                        frac=round(bytes2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), ms_per_launch=round(ms2, 4),
                                        algorithmic_bytes=bytes2, traffic=traffic2))

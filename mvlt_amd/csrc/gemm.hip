@@ -257,8 +257,8 @@ __device__ __forceinline__ int fdiv24(int m, int d, float inv) {      // exact m
   int r = m - q * d;
   return q + (r >= d) - (r < 0);
 }
-template <int BN, int EPIX>
-__device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32x4 (&acc)[4][BN / 32], char* smem, int m0, int n0,
+template <int BN, int EPIX, int TM = 4>
+__device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32x4 (&acc)[TM][BN / 32], char* smem, int m0, int n0,
                                                  int wave, int lane) {
   constexpr bool SCAT = (EPIX == 6 || EPIX == 7);     // EPI 6 / 7 = EPI 1 / 2 with a patch-scatter c_map (mode 1)
   constexpr int EPI = EPIX == 6 ? 1 : EPIX == 7 ? 2 : EPIX;
@@ -288,7 +288,8 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       for (int e = 0; e < 8; ++e) bias8[e] = p.bias[nc + e];
     }
   }
-  const int m_first = m0 + wm * 64 + lane / CPR;
+  constexpr int NH = TM / 2;                          // 32-row halves of the wave tile (2, or 4 under the 256-row tile)
+  const int m_first = m0 + wm * (TM * 16) + lane / CPR;
   const int rpb = p.c_map.rows_per_batch;
   const float inv_rpb = rpb > 0 ? 1.0f / (float)rpb : 0.f;
   // patch scatter (c_map mode 1, dgrad of a kernel==stride conv): this lane's 8 columns lie in one (di, dj) segment
@@ -308,18 +309,19 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
 #pragma unroll
     for (int e = 0; e < 8; ++e) { cs8[e] = 0.f; cq8[e] = 0.f; }
   }
-  // R (EPI 2) / H (EPI 4) are requested for BOTH 32-row halves before the first one is staged: their HBM latency is paid once,
-  // behind the LDS staging, instead of once per half
+  // R (EPI 2) / H (EPI 4) of two 32-row halves are requested before the first one is staged (two rotating slots): their HBM
+  // latency hides behind the LDS staging and the previous half instead of being paid once per half
   long idx[2][NIT];
   bool ok[2][NIT];
   float rs[2][NIT];
   u32x4 raw[2][NIT][2];
   auto request = [&](int half) {
+    const int sl = half & 1;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int m = m_first + half * 32 + it * RPI;
-      ok[half][it] = m < p.M && col_ok;
-      const int mm = ok[half][it] ? m : 0;
+      ok[sl][it] = m < p.M && col_ok;
+      const int mm = ok[sl][it] ? m : 0;
       long phys = mm;
       if constexpr (SCAT) {
         const int b = fdiv24(mm, p.c_map.hw_out, inv_hw);
@@ -330,20 +332,21 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
         const int b = fdiv24(mm, rpb, inv_rpb);
         phys = (long)b * p.c_map.batch_stride + p.c_map.offset + (mm - b * rpb);
       }
-      idx[half][it] = phys * p.ldc + ncol;
-      rs[half][it] = 1.0f;
-      if (EPI == 2 && p.row_scale) rs[half][it] = p.row_scale[fdiv24(mm, p.rows_per_scale, inv_rps)];
-      if ((EPI == 2 || EPI == 4) && ok[half][it]) {
+      idx[sl][it] = phys * p.ldc + ncol;
+      rs[sl][it] = 1.0f;
+      if (EPI == 2 && p.row_scale) rs[sl][it] = p.row_scale[fdiv24(mm, p.rows_per_scale, inv_rps)];
+      if ((EPI == 2 || EPI == 4) && ok[sl][it]) {
         const void* src = (EPI == 2) ? p.R : p.H;
-        if (ofp32) { raw[half][it][0] = *(const u32x4*)((const float*)src + idx[half][it]); raw[half][it][1] = *(const u32x4*)((const float*)src + idx[half][it] + 4); }
-        else raw[half][it][0] = *(const u32x4*)((const bf16*)src + idx[half][it]);
+        if (ofp32) { raw[sl][it][0] = *(const u32x4*)((const float*)src + idx[sl][it]); raw[sl][it][1] = *(const u32x4*)((const float*)src + idx[sl][it] + 4); }
+        else raw[sl][it][0] = *(const u32x4*)((const bf16*)src + idx[sl][it]);
       }
     }
   };
   constexpr bool PREFETCH = (EPI == 2 || EPI == 4);
   if (PREFETCH) { request(0); request(1); }
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < NH; ++half) {
+    const int sl = half & 1;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
@@ -357,13 +360,13 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      if (!ok[half][it]) continue;
+      if (!ok[sl][it]) continue;
       const int rl = it * RPI + lane / CPR;
       const f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-      const long ix = idx[half][it];
+      const long ix = idx[sl][it];
       auto store8 = [&](void* base, const float* o) {
         if (ofp32) {
           *(f32x4*)((float*)base + ix) = f32x4{o[0], o[1], o[2], o[3]};
@@ -378,11 +381,11 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       float o8[8];
       if (EPI == 2 || EPI == 4) {
         if (ofp32) {
-          const f32x4 a = __builtin_bit_cast(f32x4, raw[half][it][0]), b = __builtin_bit_cast(f32x4, raw[half][it][1]);
+          const f32x4 a = __builtin_bit_cast(f32x4, raw[sl][it][0]), b = __builtin_bit_cast(f32x4, raw[sl][it][1]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { o8[e] = a[e]; o8[4 + e] = b[e]; }
         } else {
-          const bf16x8 a = __builtin_bit_cast(bf16x8, raw[half][it][0]);
+          const bf16x8 a = __builtin_bit_cast(bf16x8, raw[sl][it][0]);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o8[e] = (float)a[e];
         }
@@ -404,7 +407,7 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       }
       if (EPI == 2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[half][it] + o8[e];
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[sl][it] + o8[e];
       }
       if (EPI == 5) {
 #pragma unroll
@@ -412,6 +415,7 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       }
       store8(p.C, v);
     }
+    if (PREFETCH && half + 2 < NH) request(half + 2);
   }
   if (EPI == 5) {
 #pragma unroll
@@ -1187,29 +1191,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_a
 // ds_write_b128 (LDS stores run at ~80 B/clk/CU, a third of the read rate, and were as expensive as the MFMAs).  The
 // LDS image is the same (128-B rows of 64 k, 16-B chunks XOR-swizzled by row); because the DMA writes lane-linear the
 // swizzle is applied to the source chunk each lane fetches.  ns-deep ring with a counted vmcnt wait, as in the TN kernel.
-template <int BN, int AMODE, int EPI, int BK>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args p, int ns) {
+template <int BN, int AMODE, int EPI, int BK, int BMT = BM>
+__global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kernel(mvlt_gemm_nt_args p, int ns) {
   constexpr int ROWB = BK * 2;                      // LDS row: BK k-values of one tile row
   constexpr int CH = BK / 8;                        // 16-B chunks per row (8 or 4)
   constexpr int RPL = NTHREADS / CH;                // tile rows one DMA instruction of the workgroup covers
   constexpr int WN = BN / 2, TN_ = WN / 16;
-  constexpr int A_ITERS = BM * CH / NTHREADS;       // 4 (BK 64) or 2 (BK 32)
+  // BMT = 256 (wave tile 128 x 64 with 32-wide K stages, a quarter less operand traffic per MFMA) was measured and is not
+  // dispatched: -5 % on 49152x2048x512 and the 256-channel conv shape, +13 % on 98304x320x1280, worse under every R / H epilogue
+  constexpr int WM = BMT / 2, TM_ = WM / 16;        // wave tile rows: 64
+  constexpr int A_ITERS = BMT * CH / NTHREADS;      // 4 (BK 64) or 2 (BK 32) at 128 rows
   constexpr int B_ITERS = BN * CH / NTHREADS;
   constexpr int LPT = A_ITERS + B_ITERS;
-  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int STAGE = (BMT + BN) * ROWB;
   // chunk swizzle by row: 16 consecutive rows x one logical chunk must spread over all 64 banks
   auto swzk = [](int row, int chunk) { return CH == 8 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3)); };
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_m = (p.M + BMT - 1) / BMT;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, bslot = bid >> 3;
   const int tile_m = (bslot / tiles_n) * 8 + xcd, tile_n = bslot % tiles_n;
   if (tile_m >= tiles_m) return;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BMT, n0 = tile_n * BN;
   const RowMap amap = to_rowmap(p.a_map);
   const unsigned smem_lds = (unsigned)(uintptr_t)smem;
 
@@ -1267,7 +1274,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i)
       glds16((b_ok[i] && k_ok) ? b_ptr[i] + kpos * 2 : zsrc,
-             __builtin_amdgcn_readfirstlane(smem_lds + slot * STAGE + BM * ROWB + (i * NTHREADS + wave * 64) * 16));
+             __builtin_amdgcn_readfirstlane(smem_lds + slot * STAGE + BMT * ROWB + (i * NTHREADS + wave * 64) * 16));
     kpos += BK;
     if constexpr (AMODE != 0) {
       kk += BK;
@@ -1275,9 +1282,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
     }
   };
 
-  f32x4 acc[4][TN_];
+  f32x4 acc[TM_][TN_];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM_; ++i)
 #pragma unroll
     for (int j = 0; j < TN_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -1299,32 +1306,40 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_dma_kernel(mvlt_gemm_nt_args
     asm volatile("" ::: "memory");
     if (ns > 1 && kt + ns - 1 < nk) issue(islot);
     islot = islot + 1 >= ns ? 0 : islot + 1;
-    const char* a_s = smem + slot * STAGE + (wm * 64) * ROWB;
-    const char* b_s = smem + slot * STAGE + BM * ROWB + (wn * WN) * ROWB;
+    const char* a_s = smem + slot * STAGE + (wm * WM) * ROWB;
+    const char* b_s = smem + slot * STAGE + BMT * ROWB + (wn * WN) * ROWB;
     slot = slot + 1 >= ns ? 0 : slot + 1;
+    // every fragment of the tile is requested before the first MFMA (both 32-k halves): the compiler otherwise recycles one
+    // fragment set and waits out the LDS latency three times per half
+    constexpr int KS = BK / 32;
+    u32x4 fa[KS][TM_], fb[KS][TN_];
 #pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      u32x4 fa[4], fb[TN_];
+    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < TM_; ++i) {
         int r = i * 16 + fr;
-        fa[i] = *(const u32x4*)(a_s + r * ROWB + swzk(wm * 64 + r, ks * 4 + fg) * 16);
+        fa[ks][i] = *(const u32x4*)(a_s + r * ROWB + swzk(wm * WM + r, ks * 4 + fg) * 16);
       }
 #pragma unroll
       for (int j = 0; j < TN_; ++j) {
         int r = j * 16 + fr;
-        fb[j] = *(const u32x4*)(b_s + r * ROWB + swzk(wn * WN + r, ks * 4 + fg) * 16);
+        fb[ks][j] = *(const u32x4*)(b_s + r * ROWB + swzk(wn * WN + r, ks * 4 + fg) * 16);
       }
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int ks = 0; ks < KS; ++ks) {
+      __builtin_amdgcn_sched_barrier(0);             // keeps every ds_read ahead of the MFMAs (one wait per tile)
 #pragma unroll
-        for (int j = 0; j < TN_; ++j) mma16(acc[i][j], fa[i], fa[i], fb[j], fb[j], (bf16*)nullptr);
+      for (int i = 0; i < TM_; ++i)
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) mma16(acc[i][j], fa[ks][i], fa[ks][i], fb[ks][j], fb[ks][j], (bf16*)nullptr);
     }
   }
   __syncthreads();                   // last tile's reads are done before the epilogue reuses the LDS
+  static_assert(BMT == BM || (BN != 192 && EPI != 0), "the 256-row tile carries the lean epilogues only");
   if constexpr (BN == 192) nt_epilogue_192<EPI>(p, acc, smem, m0, n0, wave, lane);
   else if constexpr (EPI == 0) nt_epilogue<bf16, BN>(p, acc, smem, m0, n0, wave, lane);
-  else nt_epilogue_lean<BN, EPI>(p, acc, smem, m0, n0, wave, lane);
+  else nt_epilogue_lean<BN, EPI, TM_>(p, acc, smem, m0, n0, wave, lane);
 }
 
 int check_rowmap(const mvlt_rowmap& m, const char* who) {
