@@ -117,6 +117,88 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(mvlt_layernorm_args p) {
   }
 }
 
+// The same forward with the row geometry fixed at compile time: G lanes x ITS chunks of 8 columns cover the row exactly
+// (C == 8 G ITS: no idle lanes at C = 320 = 8 x 5 x 8, where the power-of-two group of 64 lanes left 24 idle), RU rows of a
+// lane group are loaded before the first is reduced (twice the bytes in flight per lane), gamma / beta sit in LDS when ITS > 2,
+// and the grid is sized for a few row passes per workgroup so that the per-workgroup prologue is paid once per several rows
+// (one pass per workgroup at C = 512 spent as long fetching gamma / beta as normalising).
+template <typename T, typename TY, int G, int ITS, int RU>
+__global__ __launch_bounds__(NT) void ln_fwd_fixed_kernel(mvlt_layernorm_args p) {
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G;
+  constexpr int GROUPS = NT / G;
+  constexpr bool KEEP = ITS <= 2;                  // gamma / beta in registers
+  const RowMap xm = rm0(p.x_map), ym = rm0(p.y_map);
+  const float inv_c = 1.0f / (float)p.C;
+  float gam[KEEP ? ITS : 1][VN], bet[KEEP ? ITS : 1][VN];
+  __shared__ __attribute__((aligned(16))) float s_gb[KEEP ? 8 : 2 * G * ITS * VN];      // [gamma | beta] when they do not stay in registers
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int it = 0; it < ITS; ++it)
+#pragma unroll
+      for (int e = 0; e < VN; ++e) { gam[it][e] = p.gamma[(gl + it * G) * VN + e]; bet[it][e] = p.beta[(gl + it * G) * VN + e]; }
+  } else {
+    for (int i = threadIdx.x; i < G * ITS * VN; i += NT) { s_gb[i] = p.gamma[i]; s_gb[G * ITS * VN + i] = p.beta[i]; }
+    __syncthreads();
+  }
+  const int stride = gridDim.x * GROUPS;
+  for (int row0 = blockIdx.x * GROUPS + grp; row0 < p.rows; row0 += stride * RU) {
+    float v[RU][ITS][VN];
+    float s[RU];
+    bool live[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int row = row0 + u * stride;
+      live[u] = row < p.rows;
+      s[u] = 0.f;
+      if (live[u]) {
+        const T* xr = (const T*)p.x + rowmap_base(xm, row) * p.ldx;
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) Vec<T>::load(xr + (gl + it * G) * VN, v[u][it]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (!live[u]) continue;                        // uniform over the lane group
+      const int row = row0 + u * stride;
+#pragma unroll
+      for (int it = 0; it < ITS; ++it)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) s[u] += v[u][it][e];
+      const float mean = group_sum<G>(s[u]) * inv_c;
+      float q = 0.f;
+#pragma unroll
+      for (int it = 0; it < ITS; ++it)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { float d = v[u][it][e] - mean; q += d * d; }
+      const float rstd = rsqrtf(group_sum<G>(q) * inv_c + p.eps);
+      if (gl == 0) {
+        if (p.mean) p.mean[row] = mean;
+        if (p.rstd) p.rstd[row] = rstd;
+      }
+      const float* addr = p.add ? p.add + (long)(row % p.add_rows) * p.C : nullptr;
+      TY* yr = (TY*)p.y + rowmap_base(ym, row) * p.ldy;
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        const int c0 = (gl + it * G) * VN;
+        float o[VN], ga[VN], be[VN];
+        if constexpr (KEEP) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) { ga[e] = gam[KEEP ? it : 0][e]; be[e] = bet[KEEP ? it : 0][e]; }
+        } else {
+          Vec<float>::load(s_gb + c0, ga);
+          Vec<float>::load(s_gb + G * ITS * VN + c0, be);
+        }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+          o[e] = (v[u][it][e] - mean) * rstd * ga[e] + be[e];
+          if (addr) o[e] += addr[c0 + e];
+        }
+        Vec<TY>::store(yr + c0, o);
+      }
+    }
+  }
+}
+
 // ITS = chunks per lane (1 when the lane group covers the row: C <= 8 G; the second slot of the arrays would only hold
 // registers: 126 -> ~90 VGPRs, 4 -> 5 waves per SIMD on an HBM-bound kernel)
 template <typename T, typename TX, typename TDX, int G, int ITS>
@@ -247,7 +329,27 @@ int pick_group(int C) {
   return g;
 }
 
+template <typename T, typename TY, int G, int ITS, int RU> void launch_fwd_fixed(const mvlt_layernorm_args& a, hipStream_t s) {
+  constexpr int GROUPS = NT / G;
+  static const int cap = getenv("MVLT_LN_GRID") ? atoi(getenv("MVLT_LN_GRID")) : 8192;
+  long grid = ((long)a.rows + GROUPS * RU - 1) / (GROUPS * RU);
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL((ln_fwd_fixed_kernel<T, TY, G, ITS, RU>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+}
+
 template <typename T, typename TY> int launch_fwd(const mvlt_layernorm_args& a, hipStream_t s) {
+  // the widths of this model get an exact (lanes, chunks) split; everything else takes the power-of-two group kernel
+  static const bool fixed_ok = !getenv("MVLT_LN_GENERIC");
+  if (fixed_ok) {
+    switch (a.C) {
+      case 64: launch_fwd_fixed<T, TY, 8, 1, 2>(a, s); return mvlt_check_launch("mvlt_layernorm_fwd");
+      case 128: launch_fwd_fixed<T, TY, 16, 1, 2>(a, s); return mvlt_check_launch("mvlt_layernorm_fwd");
+      case 320: launch_fwd_fixed<T, TY, 8, 5, 1>(a, s); return mvlt_check_launch("mvlt_layernorm_fwd");
+      case 512: launch_fwd_fixed<T, TY, 16, 4, 1>(a, s); return mvlt_check_launch("mvlt_layernorm_fwd");
+      case 768: launch_fwd_fixed<T, TY, 32, 3, 1>(a, s); return mvlt_check_launch("mvlt_layernorm_fwd");
+      default: break;
+    }
+  }
   int g = pick_group(a.C);
   MVLT_REQUIRE(g * MAXIT * VN >= a.C, "mvlt_layernorm_fwd: C=%d too large", a.C);
   int groups = NT / g;
@@ -267,7 +369,8 @@ template <typename T, typename TX, typename TDX> int launch_bwd(const mvlt_layer
   MVLT_REQUIRE(g * MAXIT * VN >= a.C, "mvlt_layernorm_bwd: C=%d too large", a.C);
   int groups = NT / g;
   int grid = (a.rows + groups - 1) / groups;
-  if (grid > 1024) grid = 1024;                 // each block ends with 2*C global atomics
+  static const int bcap = getenv("MVLT_LN_BWD_GRID") ? atoi(getenv("MVLT_LN_BWD_GRID")) : 1024;
+  if (grid > bcap) grid = bcap;                 // each block ends with 2*C global atomics
   size_t lds = 2 * a.C * sizeof(float);
   const bool one = g * VN >= a.C;               // one chunk per lane covers the row
 #define MVLT_LN_BWD(G_)                                                                                              \
