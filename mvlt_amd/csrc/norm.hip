@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_fixed_kernel(mvlt_layernorm_args p)
 
 // ITS = chunks per lane (1 when the lane group covers the row: C <= 8 G; the second slot of the arrays would only hold
 // registers: 126 -> ~90 VGPRs, 4 -> 5 waves per SIMD on an HBM-bound kernel)
-template <typename T, typename TX, typename TDX, int G, int ITS>
+template <typename T, typename TX, typename TDX, int G, int ITS, int NT>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
   constexpr int GROUPS = NT / G;
   extern __shared__ __attribute__((aligned(16))) float s_part[];               // [2][C] block partials of dgamma / dbeta
@@ -367,16 +367,25 @@ template <typename T, typename TY> int launch_fwd(const mvlt_layernorm_args& a, 
 template <typename T, typename TX, typename TDX> int launch_bwd(const mvlt_layernorm_bwd_args& a, hipStream_t s) {
   int g = pick_group(a.C);
   MVLT_REQUIRE(g * MAXIT * VN >= a.C, "mvlt_layernorm_bwd: C=%d too large", a.C);
-  int groups = NT / g;
+  // every workgroup ends with 2*C atomics on the same few cache lines, and those serialise at the memory side: the rows are
+  // spread over few, large workgroups (1024 threads, one per CU) instead of many small ones.  Same time as 1024 x 256 threads
+  // on most shapes, 123 -> 96 us at 98304 x 320 (fp32 x, dx +=); more workgroups of either size are slower (1536 x 256: +10 %)
+  static const int nt = getenv("MVLT_LN_BWD_NT") ? atoi(getenv("MVLT_LN_BWD_NT")) : 1024;
+  static const int bcap = getenv("MVLT_LN_BWD_GRID") ? atoi(getenv("MVLT_LN_BWD_GRID")) : 256;
+  int groups = nt / g;
   int grid = (a.rows + groups - 1) / groups;
-  static const int bcap = getenv("MVLT_LN_BWD_GRID") ? atoi(getenv("MVLT_LN_BWD_GRID")) : 1024;
-  if (grid > bcap) grid = bcap;                 // each block ends with 2*C global atomics
+  if (grid > bcap) grid = bcap;
   size_t lds = 2 * a.C * sizeof(float);
   const bool one = g * VN >= a.C;               // one chunk per lane covers the row
+#define MVLT_LN_BWD_N(G_, NT_)                                                                                       \
+  do {                                                                                                               \
+    if (one) hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, G_, 1, NT_>), dim3(grid), dim3(NT_), lds, s, a);          \
+    else hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, G_, MAXIT, NT_>), dim3(grid), dim3(NT_), lds, s, a);          \
+  } while (0)
 #define MVLT_LN_BWD(G_)                                                                                              \
   do {                                                                                                               \
-    if (one) hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, G_, 1>), dim3(grid), dim3(NT), lds, s, a);                \
-    else hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, G_, MAXIT>), dim3(grid), dim3(NT), lds, s, a);                \
+    if (nt == 256) MVLT_LN_BWD_N(G_, 256);                                                                           \
+    else MVLT_LN_BWD_N(G_, 1024);                                                                                    \
   } while (0)
   switch (g) {
     case 8: MVLT_LN_BWD(8); break;
@@ -385,6 +394,7 @@ template <typename T, typename TX, typename TDX> int launch_bwd(const mvlt_layer
     default: MVLT_LN_BWD(64); break;
   }
 #undef MVLT_LN_BWD
+#undef MVLT_LN_BWD_N
   return mvlt_check_launch("mvlt_layernorm_bwd");
 }
 
