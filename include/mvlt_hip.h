@@ -117,6 +117,10 @@ typedef struct mvlt_layernorm_bwd_args {
   int dx_accumulate;
   int dtype;                          /* of dy */
   int x_dtype, dx_dtype;
+  /* optional second output: dx2[row,:] = (final dx)[row,:] * dx2_scale[row / dx2_rows_per_scale], dtype of dy, plain rows with
+   * stride lddx2.  It is the DropPath-scaled gradient the next branch's GEMMs read (timm drop_path backward), written while
+   * the row is still in registers instead of by a separate pass over dx. */
+  void* dx2; const float* dx2_scale; int dx2_rows_per_scale; int lddx2;
 } mvlt_layernorm_bwd_args;
 int mvlt_layernorm_bwd(const mvlt_layernorm_bwd_args* args, void* stream);
 

@@ -65,7 +65,8 @@ class LayerNormBwdArgs(C.Structure):
                 ("dgamma", c_void_p), ("dbeta", c_void_p),
                 ("rows", c_int), ("C", c_int), ("lddy", c_int), ("ldx", c_int), ("lddx", c_int),
                 ("dy_map", RowMap), ("x_map", RowMap), ("dx_map", RowMap),
-                ("dx_accumulate", c_int), ("dtype", c_int), ("x_dtype", c_int), ("dx_dtype", c_int)]
+                ("dx_accumulate", c_int), ("dtype", c_int), ("x_dtype", c_int), ("dx_dtype", c_int),
+                ("dx2", c_void_p), ("dx2_scale", c_void_p), ("dx2_rows_per_scale", c_int), ("lddx2", c_int)]
 
 
 class AttnArgs(C.Structure):

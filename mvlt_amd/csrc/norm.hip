@@ -224,6 +224,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
     const TX* xr = (const TX*)p.x + rowmap_base(xm, row) * p.ldx;
     TDX* dxr = (TDX*)p.dx + rowmap_base(dxm, row) * p.lddx;
     const float mean = p.mean[row], rstd = p.rstd[row];
+    const float sc2 = p.dx2 ? p.dx2_scale[row / p.dx2_rows_per_scale] : 0.f;
     float g[ITS][VN], xh[ITS][VN];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -260,6 +261,11 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
           for (int e = 0; e < VN; ++e) o[e] += old[e];
         }
         Vec<TDX>::store(dxr + c * VN, o);
+        if (p.dx2) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) o[e] *= sc2;
+          Vec<T>::store((T*)p.dx2 + (long)row * p.lddx2 + c * VN, o);
+        }
       }
     }
   }
@@ -419,6 +425,8 @@ extern "C" int mvlt_layernorm_bwd(const mvlt_layernorm_bwd_args* a, void* stream
                "mvlt_layernorm_bwd: bad dtype");
   MVLT_REQUIRE(a->C > 0 && a->C % 8 == 0 && a->ldx % 8 == 0 && a->lddy % 8 == 0 && a->lddx % 8 == 0, "mvlt_layernorm_bwd: C/ld* must be multiples of 8");
   MVLT_REQUIRE(a->x_map.mode == 0 && a->dy_map.mode == 0 && a->dx_map.mode == 0, "mvlt_layernorm_bwd: only mode-0 row maps");
+  MVLT_REQUIRE(!a->dx2 || (a->dx2_scale && a->dx2_rows_per_scale > 0 && a->lddx2 % 8 == 0 && a->lddx2 >= a->C),
+               "mvlt_layernorm_bwd: dx2 needs dx2_scale, dx2_rows_per_scale > 0 and lddx2 (multiple of 8) >= C");
   if (a->rows <= 0) return MVLT_OK;
   hipStream_t s = (hipStream_t)stream;
   const int key = a->dtype * 4 + a->x_dtype * 2 + a->dx_dtype;

@@ -64,11 +64,13 @@ def layernorm_fwd(x, y, gamma, beta, rows, Cdim, ldx, ldy, eps, *, mean=None, rs
 
 
 def layernorm_bwd(dy, x, dx, gamma, mean, rstd, rows, Cdim, lddy, ldx, lddx, *, dgamma=None, dbeta=None,
-                  dy_map=None, x_map=None, dx_map=None, accumulate=False):
+                  dy_map=None, x_map=None, dx_map=None, accumulate=False, dx2=None, dx2_scale=None, dx2_rows_per_scale=0, lddx2=0):
     assert dy.dtype in DT and x.dtype in DT and dx.dtype in DT
+    assert dx2 is None or (dx2.dtype == dy.dtype and dx2_scale is not None and dx2_scale.dtype == torch.float32 and dx2_rows_per_scale > 0)
     a = L.LayerNormBwdArgs(ptr(dy), ptr(x), ptr(dx), ptr(gamma), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta),
                            rows, Cdim, lddy, ldx, lddx, dy_map or _ID, x_map or _ID, dx_map or _ID,
-                           1 if accumulate else 0, DT[dy.dtype], DT[x.dtype], DT[dx.dtype])
+                           1 if accumulate else 0, DT[dy.dtype], DT[x.dtype], DT[dx.dtype],
+                           ptr(dx2), ptr(dx2_scale), dx2_rows_per_scale, lddx2)
     check(L.lib.mvlt_layernorm_bwd(C.byref(a), stream_ptr()), "mvlt_layernorm_bwd")
     return dx
 

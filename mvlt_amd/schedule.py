@@ -8,6 +8,8 @@ Data layout: one token-major activation buffer (B, HW+T, C) per stage in the com
 Backward is scheduled by hand: every weight gradient is accumulated by the wgrad GEMM directly into the flat fp32
 gradient buffer (no autograd accumulate pass), input gradients reuse buffers in place.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -19,6 +21,9 @@ from .pvlt import BERT_DROP, EPS_BERT, EPS_BLOCK, EPS_DEFAULT, VOCAB, VOCAB_LD
 
 def _empty(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
+
+
+_NO_DX2 = bool(os.environ.get("MVLT_NO_DX2"))      # A/B switch: DropPath-scaled gradient copy by a separate pass
 
 
 class Names:
@@ -386,11 +391,15 @@ class TrunkStep:
             ops.gemm_tn(dh, bs["xn2"], self.g(p + "mlp.fc1.weight"), M, hid, C, hid, C, C, colsum=self.g(p + "mlp.fc1.bias"))
             ops.gemm_nt(dh, self.wT(p + "mlp.fc1.weight"), dxn2, M, C, hid, hid, hid, C)
             del dh
+        # dx += LN2 backward = d(x_mid); the same kernel writes its DropPath-scaled copy, the gradient of the attention branch
+        # x_mid = x + s1 * proj(attn(LN1(x)))
+        fuse = bs["s1"] is not None and not _NO_DX2
+        dy1 = _empty((M, C), dx.dtype, dev) if fuse else dx
         ops.layernorm_bwd(dxn2, bs["xm"], dx, self.f32(p + "norm2.weight"), bs["m2"], bs["r2"], M, C, C, C, C,
-                          dgamma=self.g(p + "norm2.weight"), dbeta=self.g(p + "norm2.bias"), accumulate=True)
-        # dx now holds d(x_mid)
-        # ---- attention branch: x_mid = x + s1 * proj(attn(LN1(x)))
-        dy1 = self._scaled(dx, bs["s1"], N)
+                          dgamma=self.g(p + "norm2.weight"), dbeta=self.g(p + "norm2.bias"), accumulate=True,
+                          dx2=dy1 if fuse else None, dx2_scale=bs["s1"], dx2_rows_per_scale=N, lddx2=C)
+        if not fuse:
+            dy1 = self._scaled(dx, bs["s1"], N)
         ops.gemm_tn(dy1, bs["ao"], self.g(p + "attn.proj.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.proj.bias"))
         dao = dxn2          # reuse
         ops.gemm_nt(dy1, self.wT(p + "attn.proj.weight"), dao, M, C, C, C, C, C)

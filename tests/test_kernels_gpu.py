@@ -296,6 +296,31 @@ def test_sr_attention_bwd(ops, dtype, B, H, N, M):
 
 
 # ------------------------------------------------------------------ mixed-dtype LayerNorm (fp32 residual stream, bf16 operands)
+def test_layernorm_bwd_scaled_copy(ops):
+    """dx2 = (dx after accumulation) * scale[sample]: the DropPath-scaled gradient written by the same kernel."""
+    B, N, Cd = 3, 50, 128
+    rows = B * N
+    for dtype in (torch.bfloat16, torch.float32):
+        x = rnd(rows, Cd, dtype=torch.float32)
+        dy = rnd(rows, Cd, dtype=dtype, seed=1)
+        gamma = rnd(Cd, dtype=torch.float32, seed=2) + 1.0
+        mean, var = x.mean(1), x.var(1, unbiased=False)
+        rstd = (var + 1e-6).rsqrt()
+        base = rnd(rows, Cd, dtype=dtype, seed=3)
+        dx = base.clone()
+        dx2 = torch.empty_like(dx)
+        sc = torch.tensor([0.0, 1.25, 1.0], device=dev())
+        dg, db = torch.zeros(Cd, device=dev()), torch.zeros(Cd, device=dev())
+        ops.layernorm_bwd(dy, x, dx, gamma, mean, rstd, rows, Cd, Cd, Cd, Cd, dgamma=dg, dbeta=db, accumulate=True,
+                          dx2=dx2, dx2_scale=sc, dx2_rows_per_scale=N, lddx2=Cd)
+        xr = x.clone().requires_grad_(True)
+        F.layer_norm(xr, (Cd,), gamma, torch.zeros_like(gamma), 1e-6).backward(dy.float())
+        want = base.float() + xr.grad
+        assert maxrel(dx.float(), want) < TOL[dtype]
+        assert maxrel(dx2.float(), want * sc.repeat_interleave(N)[:, None]) < TOL[dtype]
+        assert dx2[:N].abs().max().item() == 0
+
+
 def test_layernorm_mixed_dtypes(ops):
     rows, Cdim, eps = 777, 320, 1e-6
     x = rnd(rows, Cdim, dtype=torch.float32, scale=2.0) + 0.5
