@@ -270,14 +270,24 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
     }
   }
   if (p.dgamma) {
+    // the 64 / G row groups of a wave hold partial sums of the same columns: combine them in registers first, so that only
+    // G lanes per wave go to the LDS atomics (at G = 8 that is 8x fewer, and no two lanes of an instruction share an address)
 #pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-      int c = gl + it * G;
-      if (c < nchunk) {
+    for (int off = G; off < 64; off <<= 1)
 #pragma unroll
-        for (int e = 0; e < VN; ++e) {
-          atomicAdd(&s_part[c * VN + e], dg[it][e]);
-          atomicAdd(&s_part[p.C + c * VN + e], db[it][e]);
+      for (int it = 0; it < ITS; ++it)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { dg[it][e] += __shfl_xor(dg[it][e], off); db[it][e] += __shfl_xor(db[it][e], off); }
+    if ((threadIdx.x & 63) < G) {
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        int c = gl + it * G;
+        if (c < nchunk) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) {
+            atomicAdd(&s_part[c * VN + e], dg[it][e]);
+            atomicAdd(&s_part[p.C + c * VN + e], db[it][e]);
+          }
         }
       }
     }
@@ -370,11 +380,12 @@ template <typename T, typename TY> int launch_fwd(const mvlt_layernorm_args& a, 
   return mvlt_check_launch("mvlt_layernorm_fwd");
 }
 
-template <typename T, typename TX, typename TDX> int launch_bwd(const mvlt_layernorm_bwd_args& a, hipStream_t s) {
+template <typename T, typename TX, typename TDX> int launch_bwd(const mvlt_layernorm_bwd_args& a_in, hipStream_t s) {
+  const mvlt_layernorm_bwd_args& a = a_in;
   int g = pick_group(a.C);
   MVLT_REQUIRE(g * MAXIT * VN >= a.C, "mvlt_layernorm_bwd: C=%d too large", a.C);
-  // every workgroup ends with 2*C atomics on the same few cache lines, and those serialise at the memory side: the rows are
-  // spread over few, large workgroups (1024 threads, one per CU) instead of many small ones.  Same time as 1024 x 256 threads
+  // every workgroup ends with 2*C atomics on the same few cache lines: the rows are spread over few, large workgroups (1024
+  // threads, one per CU).  (Storing the partial rows plainly and adding them in a second launch was measured: same time.)  Same time as 1024 x 256 threads
   // on most shapes, 123 -> 96 us at 98304 x 320 (fp32 x, dx +=); more workgroups of either size are slower (1536 x 256: +10 %)
   static const int nt = getenv("MVLT_LN_BWD_NT") ? atoi(getenv("MVLT_LN_BWD_NT")) : 1024;
   static const int bcap = getenv("MVLT_LN_BWD_GRID") ? atoi(getenv("MVLT_LN_BWD_GRID")) : 256;
