@@ -147,12 +147,14 @@ int mvlt_sr_attention_fwd(const mvlt_attn_args* args, void* stream);
  * stores every dKV element exactly once (no zero fill needed). */
 typedef struct mvlt_attn_bwd_args {
   const void* Q; const void* KV; const void* O; const void* dO; const float* lse;
-  void* dQ; float* dKV;
+  void* dQ; void* dKV;
   int B, H, N, M;
   int ldq, ldkv, ldo, lddkv;
   int k_off, v_off;
   float scale;
   int dtype;
+  int dkv_dtype;   /* 1 (default use): dKV is fp32.  0: dKV is bf16 [B, M, lddkv] and takes the plain stores of the one-chunk case
+                      directly (allowed only when B*H >= 512 and dtype == 0: no atomics, so no fp32 staging buffer and no cast) */
 } mvlt_attn_bwd_args;
 int mvlt_sr_attention_bwd(const mvlt_attn_bwd_args* args, void* stream);
 
@@ -207,7 +209,7 @@ int mvlt_transpose_cast(const float* in, void* out, int R, int C, int ld_out, in
  * operands) or a 3-D strided gather-cast (dst[i0*ds0 + i1*ds1 + i2*ds2] = src[src_off + i0*ss0 + i1*ss1 + i2*ss2]: the
  * [out][kh][kw][cin] / flipped-tap re-orderings of the conv weights of reference libs/pvlt.py:104,168 and
  * libs/vl_heads.py:107-165).  blk_start[ndesc + 1] = prefix sums of the workgroups each descriptor needs
- * (kind 0: ceil(R/32)*ceil(C/32), kind 1: ceil(d0*d1*d2 / 256)). */
+ * (kind 0: ceil(R/64)*ceil(C/64), kind 1: ceil(d0*d1*d2 / 256)). */
 typedef struct mvlt_prep_desc {
   const float* src; void* dst;
   int kind;                 /* 0 = transpose, 1 = gather */

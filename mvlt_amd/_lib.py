@@ -81,7 +81,7 @@ class AttnBwdArgs(C.Structure):
                 ("dQ", c_void_p), ("dKV", c_void_p),
                 ("B", c_int), ("H", c_int), ("N", c_int), ("M", c_int),
                 ("ldq", c_int), ("ldkv", c_int), ("ldo", c_int), ("lddkv", c_int),
-                ("k_off", c_int), ("v_off", c_int), ("scale", c_float), ("dtype", c_int)]
+                ("k_off", c_int), ("v_off", c_int), ("scale", c_float), ("dtype", c_int), ("dkv_dtype", c_int)]
 
 
 class MlpArgs(C.Structure):

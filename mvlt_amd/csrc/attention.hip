@@ -297,8 +297,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_kernel(mvlt
   const T* Kg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.k_off + h * HD;
   const T* Vg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.v_off + h * HD;
   T* dQg = (T*)p.dQ + (long)b * p.N * p.ldq + h * HD;
-  float* dKg = p.dKV + (long)b * p.M * p.lddkv + p.k_off + h * HD;
-  float* dVg = p.dKV + (long)b * p.M * p.lddkv + p.v_off + h * HD;
+  float* dKg = (float*)p.dKV + (long)b * p.M * p.lddkv + p.k_off + h * HD;
+  float* dVg = (float*)p.dKV + (long)b * p.M * p.lddkv + p.v_off + h * HD;
   const float* Lg = p.lse + ((long)b * p.H + h) * p.N;
 
   // K^T into LDS (all keys), zero beyond M
@@ -495,8 +495,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
   const T* Kg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.k_off + h * HD;
   const T* Vg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.v_off + h * HD;
   T* dQg = (T*)p.dQ + (long)b * p.N * p.ldq + h * HD;
-  float* dKg = p.dKV + (long)b * p.M * p.lddkv + p.k_off + h * HD;
-  float* dVg = p.dKV + (long)b * p.M * p.lddkv + p.v_off + h * HD;
+  float* dKg = (float*)p.dKV + (long)b * p.M * p.lddkv + p.k_off + h * HD;
+  float* dVg = (float*)p.dKV + (long)b * p.M * p.lddkv + p.v_off + h * HD;
   const float* Lg = p.lse + ((long)b * p.H + h) * p.N;
   const int q_begin = chunk_id * q_per_wg;
   const int q_end = min(p.N, q_begin + q_per_wg);
@@ -683,7 +683,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
       for (int r = 0; r < 4; ++r) {
         int key = (wave * TPW + t) * 16 + 4 * fg + r;
         if (key < p.M) {
-          if (nq_chunks == 1) {
+          if (nq_chunks == 1 && p.dkv_dtype == 0) {       // bf16 dKV: the operand of the kv-projection gradients, no cast pass
+            ((bf16*)p.dKV)[((long)b * p.M + key) * p.lddkv + p.k_off + h * HD + dt * 16 + fr] = (bf16)dKacc[t][dt][r];
+            ((bf16*)p.dKV)[((long)b * p.M + key) * p.lddkv + p.v_off + h * HD + dt * 16 + fr] = (bf16)dVacc[t][dt][r];
+          } else if (nq_chunks == 1) {
             dKg[(long)key * p.lddkv + dt * 16 + fr] = dKacc[t][dt][r];
             dVg[(long)key * p.lddkv + dt * 16 + fr] = dVacc[t][dt][r];
           } else {
@@ -749,6 +752,8 @@ extern "C" int mvlt_sr_attention_fwd(const mvlt_attn_args* a, void* stream) {
 
 extern "C" int mvlt_sr_attention_bwd(const mvlt_attn_bwd_args* a, void* stream) {
   MVLT_REQUIRE(a && a->Q && a->KV && a->O && a->dO && a->lse && a->dQ && a->dKV, "mvlt_sr_attention_bwd: null pointer");
+  MVLT_REQUIRE(a->dkv_dtype == 1 || (a->dkv_dtype == 0 && a->dtype == 0 && (long)a->B * a->H >= 512 && !getenv("MVLT_ATTN_BWD_LEGACY")),
+               "mvlt_sr_attention_bwd: bf16 dKV needs bf16 operands and B*H >= 512 (one query chunk per (batch, head), plain stores)");
   MVLT_REQUIRE(a->B > 0 && a->H > 0 && a->N > 0 && a->M > 0, "mvlt_sr_attention_bwd: bad shape");
   MVLT_REQUIRE(a->dtype == 0 || a->dtype == 1, "mvlt_sr_attention_bwd: bad dtype");
   const int pc = a->dtype == 0 ? 8 : 4;

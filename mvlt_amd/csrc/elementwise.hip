@@ -184,10 +184,24 @@ __global__ __launch_bounds__(NT) void ce_fwd_kernel(const T* logits, const long*
   const int row = blockIdx.x;
   const T* lr = logits + (long)row * ld;
   float m = -INFINITY, s = 0.f;
-  for (int c = threadIdx.x; c < V; c += NT) {
+  int c_first = 0;
+  if constexpr (sizeof(T) == 4) {
+    // fp32 rows on 16-byte boundaries (the 30522-wide MLM logits, ld = 30528): four columns per load, one rescale per four
+    if ((ld & 3) == 0 && (((uintptr_t)logits) & 15) == 0) {
+      const int V4 = V & ~3;
+      for (int c = threadIdx.x * 4; c < V4; c += NT * 4) {
+        const f32x4 x = *(const f32x4*)((const float*)lr + c);
+        const float nm = fmaxf(m, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+        s = s * __expf(m - nm) + (__expf(x[0] - nm) + __expf(x[1] - nm)) + (__expf(x[2] - nm) + __expf(x[3] - nm));
+        m = nm;
+      }
+      c_first = V4;
+    }
+  }
+  for (int c = c_first + threadIdx.x; c < V; c += NT) {
     float x = (float)lr[c];
     float nm = fmaxf(m, x);
-    s = s * __expf(m - nm) + __expf(x - nm);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - nm)) + __expf(x - nm);
     m = nm;
   }
   // combine (m, s) pairs: wave, then block
@@ -227,7 +241,22 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* logits, const long*
   const long lab = labels[row];
   const float l = lse[row];
   const float sc = (lab == ignore) ? 0.f : gscale[0] / fmaxf(count[0], 1.0f);
-  for (int c = threadIdx.x; c < ldd; c += NT) {
+  int c_first = 0;
+  if constexpr (sizeof(T) == 4) {
+    if ((ld & 3) == 0 && (ldd & 3) == 0 && (((uintptr_t)logits) & 15) == 0 && (((uintptr_t)dlogits) & 15) == 0) {
+      const int V4 = V & ~3;
+      for (int c = threadIdx.x * 4; c < V4; c += NT * 4) {
+        const f32x4 x = *(const f32x4*)((const float*)lr + c);
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = (__expf(x[e] - l) - (c + e == lab ? 1.f : 0.f)) * sc;
+        if constexpr (sizeof(TO) == 2) *(bf16x4*)((bf16*)dr + c) = bf16x4{(bf16)g[0], (bf16)g[1], (bf16)g[2], (bf16)g[3]};
+        else *(f32x4*)((float*)dr + c) = g;
+      }
+      c_first = V4;
+    }
+  }
+  for (int c = c_first + threadIdx.x; c < ldd; c += NT) {
     float g = 0.f;
     if (c < V) g = (__expf((float)lr[c] - l) - (c == lab ? 1.f : 0.f)) * sc;
     dr[c] = (TO)g;                        // padding columns [V, ldd) are zeroed
@@ -307,29 +336,40 @@ __global__ __launch_bounds__(NT) void transpose_cast_kernel(const float* in, T* 
   }
 }
 
-// table-driven version of the above plus a strided 3-D gather: one workgroup = one 32x32 tile or 256 gathered elements
+// table-driven version of the above plus a strided 3-D gather: one workgroup = one 64x64 tile or 256 gathered elements.
+// The block -> descriptor search runs on an LDS copy of blk_start (one coalesced load instead of log2(ndesc) dependent global
+// loads per workgroup: with 32x32 tiles and the search in global memory the launch spent most of its 115 us there).
 template <typename T>
 __global__ __launch_bounds__(NT) void weight_prep_kernel(const mvlt_prep_desc* descs, const int* blk_start, int ndesc) {
-  __shared__ float tile[32][33];
+  constexpr int TS = 64, MAXD = 1024;
+  __shared__ float tile[TS][TS + 1];
+  __shared__ int s_start[MAXD];
   const int b = blockIdx.x;
+  const bool in_lds = ndesc <= MAXD;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < ndesc; i += NT) s_start[i] = blk_start[i];
+    __syncthreads();
+  }
   int lo = 0, hi = ndesc - 1;                         // last descriptor whose first block is <= b
   while (lo < hi) {
     int mid = (lo + hi + 1) >> 1;
-    if (blk_start[mid] <= b) lo = mid; else hi = mid - 1;
+    if ((in_lds ? s_start[mid] : blk_start[mid]) <= b) lo = mid; else hi = mid - 1;
   }
   const mvlt_prep_desc d = descs[lo];
-  const int lb = b - blk_start[lo];
+  const int lb = b - (in_lds ? s_start[lo] : blk_start[lo]);
   T* out = (T*)d.dst;
   if (d.kind == 0) {
-    const int tiles_c = (d.C + 31) / 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const int c0 = (lb % tiles_c) * 32, r0 = (lb / tiles_c) * 32;
-    for (int j = ty; j < 32; j += 8) {
+    const int tiles_c = (d.C + TS - 1) / TS;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+    const int c0 = (lb % tiles_c) * TS, r0 = (lb / tiles_c) * TS;
+#pragma unroll 4
+    for (int j = ty; j < TS; j += 4) {
       int r = r0 + j, c = c0 + tx;
       tile[j][tx] = (r < d.R && c < d.C) ? d.src[(long)r * d.C + c] : 0.f;
     }
     __syncthreads();
-    for (int j = ty; j < 32; j += 8) {
+#pragma unroll 4
+    for (int j = ty; j < TS; j += 4) {
       int c = c0 + j, r = r0 + tx;
       if (c < d.C && r < d.R) out[(long)c * d.ld_out + r] = (T)tile[tx][j];
     }

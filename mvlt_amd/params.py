@@ -220,7 +220,7 @@ class FlatStore:
             if k not in self.extra or self.extra[k].dtype != dt or self.extra[k].device != dev:
                 self.extra[k] = torch.zeros(Ccols, ld, device=dev, dtype=dt)
             descs.append(PrepDesc(src_ptr(name), self.extra[k].data_ptr(), 0, R, Ccols, ld, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
-            blocks.append(((R + 31) // 32) * ((Ccols + 31) // 32))
+            blocks.append(((R + 63) // 64) * ((Ccols + 63) // 64))
 
         def gather(name, suffix, shape, dims, src_off, ss, ds):
             k = name + suffix

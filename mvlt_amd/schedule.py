@@ -407,10 +407,14 @@ class TrunkStep:
         dq = _empty((B, N, C), dt, dev)
         # dK/dV: one query chunk per (batch, head) from B*heads >= 512 on (mvlt_sr_attention_bwd then stores plainly, every
         # element once); only the split case accumulates with atomics and needs the zero fill
-        dkv32 = _empty((B, Mk, 2 * C), f32, dev) if (B * h >= 512 and dt == torch.bfloat16) else pool_zeros((B, Mk, 2 * C), f32, dev)
-        ops.sr_attention_bwd(bs["q"], bs["kv"], bs["ao"], dao, bs["lse"], dq, dkv32, B, h, N, Mk, C, 2 * C, C, 2 * C, 0, C, 64 ** -0.5)
-        dkv = dkv32.to(dt)
-        del dkv32
+        if B * h >= 512 and dt == torch.bfloat16:
+            dkv = _empty((B, Mk, 2 * C), dt, dev)              # written once, in the operand dtype
+            ops.sr_attention_bwd(bs["q"], bs["kv"], bs["ao"], dao, bs["lse"], dq, dkv, B, h, N, Mk, C, 2 * C, C, 2 * C, 0, C, 64 ** -0.5)
+        else:
+            dkv32 = pool_zeros((B, Mk, 2 * C), f32, dev)
+            ops.sr_attention_bwd(bs["q"], bs["kv"], bs["ao"], dao, bs["lse"], dq, dkv32, B, h, N, Mk, C, 2 * C, C, 2 * C, 0, C, 64 ** -0.5)
+            dkv = dkv32.to(dt)
+            del dkv32
         # q projection
         ops.gemm_tn(dq, bs["xn1"], self.g(p + "attn.q.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.q.bias"))
         dxn1 = dao          # reuse again: d(LN1 output), every row written by the q dgrad

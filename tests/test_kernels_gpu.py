@@ -295,6 +295,27 @@ def test_sr_attention_bwd(ops, dtype, B, H, N, M):
     assert maxrel(dkv, kvr.grad) < tol
 
 
+def test_sr_attention_bwd_bf16_dkv(ops):
+    """B*H >= 512: one query chunk per (batch, head), dK/dV stored once and directly in bf16."""
+    B, H, N, M = 128, 4, 96, 80
+    Cdim = 64 * H
+    dtype = torch.bfloat16
+    q = rnd(B, N, Cdim, dtype=dtype)
+    kv = rnd(B, M, 2 * Cdim, dtype=dtype, seed=1)
+    do = rnd(B, N, Cdim, dtype=dtype, seed=2)
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, N, device=dev())
+    ops.sr_attention_fwd(q, kv, o, lse, B, H, N, M, Cdim, 2 * Cdim, Cdim, 0, Cdim, 0.125)
+    dq = torch.empty_like(q)
+    dkv = torch.full((B, M, 2 * Cdim), float("nan"), device=dev(), dtype=dtype)       # every element must be written
+    ops.sr_attention_bwd(q, kv, o, do, lse, dq, dkv, B, H, N, M, Cdim, 2 * Cdim, Cdim, 2 * Cdim, 0, Cdim, 0.125)
+    qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    ref, _ = attn_ref(qr, kvr, H, 0.125)
+    ref.backward(do.float())
+    assert maxrel(dq.float(), qr.grad) < 3e-2
+    assert maxrel(dkv.float(), kvr.grad) < 3e-2
+
+
 # ------------------------------------------------------------------ mixed-dtype LayerNorm (fp32 residual stream, bf16 operands)
 def test_layernorm_bwd_scaled_copy(ops):
     """dx2 = (dx after accumulation) * scale[sample]: the DropPath-scaled gradient written by the same kernel."""
