@@ -192,6 +192,12 @@ int mvlt_cross_entropy_fwd(const void* logits, const long* labels, long ignore_i
 int mvlt_cross_entropy_bwd(const void* logits, const long* labels, long ignore_index, const float* lse, const float* gscale,
                            const float* count, void* dlogits, int rows, int V, int ld, int ldd, int dtype, int out_dtype, void* stream);
 
+/* SmoothL1 (beta = 1, mean reduction) between fp32 tensors of n elements: the T2I loss of reference
+ * engine_grid_masking.py:99 (F.smooth_l1_loss(t2i_logits, images)).  fwd: *loss_sum += sum of the element losses (caller
+ * zeroes it and divides by n); bwd: grad = clamp(pred - target, -1, 1) * gscale[0] / n. */
+int mvlt_smooth_l1_fwd(const float* pred, const float* target, long n, float* loss_sum, void* stream);
+int mvlt_smooth_l1_bwd(const float* pred, const float* target, long n, const float* gscale /* device scalar */, float* grad, void* stream);
+
 /* torch.optim.AdamW step over a flat fp32 buffer (+ optional bf16 re-cast of the updated parameters).
  * hp (device, fp32[8]) = {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, grad_scale}.
  * Replaces timm create_optimizer('adamw') stepping (reference main_vl.py:308, engine_grid_masking.py:126). */

@@ -263,6 +263,43 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* logits, const long*
   }
 }
 
+// ------------------------------------------------------------------ SmoothL1 (beta = 1) over fp32 tensors: sum, then gradient
+// loss_sum += sum_i l(p_i - t_i), l(d) = 0.5 d^2 for |d| < 1, |d| - 0.5 otherwise (torch.nn.functional.smooth_l1_loss, the
+// T2I loss of reference engine_grid_masking.py:99); no per-element loss tensor is written.
+__global__ __launch_bounds__(NT) void smooth_l1_sum_kernel(const float* pred, const float* target, long n, float* loss_sum) {
+  __shared__ float s_w[NT / 64];
+  float acc = 0.f;
+  for (long i = ((long)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += (long)gridDim.x * NT * 4) {
+    const f32x4 a = *(const f32x4*)(pred + i), b = *(const f32x4*)(target + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = fabsf(a[e] - b[e]);
+      acc += d < 1.0f ? 0.5f * d * d : d - 0.5f;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += s_w[w];
+    atomicAdd(loss_sum, t);
+  }
+}
+// grad_i = clamp(p_i - t_i, -1, 1) * gscale[0] * inv_n   (d/dp of mean-reduced SmoothL1 times the incoming scalar gradient)
+__global__ __launch_bounds__(NT) void smooth_l1_grad_kernel(const float* pred, const float* target, long n, const float* gscale, float inv_n,
+                                                            float* grad) {
+  const float sc = gscale[0] * inv_n;
+  for (long i = ((long)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += (long)gridDim.x * NT * 4) {
+    const f32x4 a = *(const f32x4*)(pred + i), b = *(const f32x4*)(target + i);
+    f32x4 g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = __builtin_amdgcn_fmed3f(a[e] - b[e], -1.0f, 1.0f) * sc;
+    *(f32x4*)(grad + i) = g;
+  }
+}
+
 // ------------------------------------------------------------------ fused AdamW over a flat fp32 buffer (+ bf16 re-cast)
 // torch.optim.AdamW semantics (reference main_vl.py:308 via timm create_optimizer): decoupled weight decay,
 // bias-corrected moments.  lr / step-dependent scalars come from a small device array so that a captured graph replays.
@@ -490,6 +527,20 @@ extern "C" int mvlt_cross_entropy_bwd(const void* logits, const long* labels, lo
   else if (dtype == 1 && out_dtype == 1) hipLaunchKernelGGL((ce_bwd_kernel<float, float>), grid, block, 0, s, (const float*)logits, labels, ignore_index, lse, gscale, count, (float*)dlogits, rows, V, ld, ldd);
   else hipLaunchKernelGGL((ce_bwd_kernel<bf16, float>), grid, block, 0, s, (const bf16*)logits, labels, ignore_index, lse, gscale, count, (float*)dlogits, rows, V, ld, ldd);
   return mvlt_check_launch("mvlt_cross_entropy_bwd");
+}
+
+extern "C" int mvlt_smooth_l1_fwd(const float* pred, const float* target, long n, float* loss_sum, void* stream) {
+  MVLT_REQUIRE(pred && target && loss_sum && n > 0 && n % 4 == 0 && (((uintptr_t)pred | (uintptr_t)target) & 15) == 0,
+               "mvlt_smooth_l1_fwd: bad arguments (n multiple of 4, 16-byte aligned)");
+  hipLaunchKernelGGL(smooth_l1_sum_kernel, dim3(grid_for(n / 4, 2048)), dim3(NT), 0, (hipStream_t)stream, pred, target, n, loss_sum);
+  return mvlt_check_launch("mvlt_smooth_l1_fwd");
+}
+
+extern "C" int mvlt_smooth_l1_bwd(const float* pred, const float* target, long n, const float* gscale, float* grad, void* stream) {
+  MVLT_REQUIRE(pred && target && gscale && grad && n > 0 && n % 4 == 0 && (((uintptr_t)pred | (uintptr_t)target | (uintptr_t)grad) & 15) == 0,
+               "mvlt_smooth_l1_bwd: bad arguments (n multiple of 4, 16-byte aligned)");
+  hipLaunchKernelGGL(smooth_l1_grad_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, pred, target, n, gscale, 1.0f / (float)n, grad);
+  return mvlt_check_launch("mvlt_smooth_l1_bwd");
 }
 
 extern "C" int mvlt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* hp,

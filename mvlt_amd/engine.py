@@ -26,6 +26,35 @@ def _core(model):
     return model.module if hasattr(model, "module") else model
 
 
+class _SmoothL1Fn(torch.autograd.Function):
+    """F.smooth_l1_loss(pred, target) (beta 1, mean) on fp32 device tensors as two HIP passes (sum; gradient): ATen writes and
+    re-reads the per-element loss tensor (201 MB at batch 256) before reducing it."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        from . import ops
+        pred, target = pred.contiguous(), target.contiguous()
+        acc = torch.zeros(1, device=pred.device, dtype=torch.float32)
+        ops.smooth_l1_fwd(pred, target, acc)
+        ctx.save_for_backward(pred, target)
+        return (acc / pred.numel()).reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import ops
+        pred, target = ctx.saved_tensors
+        grad = torch.empty_like(pred)
+        ops.smooth_l1_bwd(pred, target, gout.reshape(1).float().contiguous(), grad)
+        return grad, None
+
+
+def smooth_l1(pred, target):
+    """the T2I loss of reference engine_grid_masking.py:99; HIP on the GPU, ATen elsewhere (CPU oracle runs, odd shapes)"""
+    if pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.shape == target.shape and pred.numel() % 4 == 0:
+        return _SmoothL1Fn.apply(pred, target)
+    return F.smooth_l1_loss(pred, target)
+
+
 def compute_losses(outputs, images, mlm_labels, itm_labels, sup_cls_labels, sub_cls_labels):
     """Loss composition of reference engine_grid_masking.py:81-102.  Returns (total, dict of the five parts)."""
     dev = images.device
@@ -46,7 +75,7 @@ def compute_losses(outputs, images, mlm_labels, itm_labels, sup_cls_labels, sub_
         parts["loss_sub_cls"] = F.cross_entropy(outputs["sub_cls_logits"].view(-1, 122).float(), sub_cls_labels.view(-1))
         total = total + parts["loss_sup_cls"] + parts["loss_sub_cls"]
     if outputs["t2i_logits"] is not None:
-        parts["loss_t2i"] = T2I_LOSS_WEIGHT * F.smooth_l1_loss(outputs["t2i_logits"].float(), images)
+        parts["loss_t2i"] = T2I_LOSS_WEIGHT * smooth_l1(outputs["t2i_logits"].float(), images)
         total = total + parts["loss_t2i"]
     return total, parts
 

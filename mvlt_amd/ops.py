@@ -189,6 +189,21 @@ def adamw_step(p, g, m, v, p16, n, hp, decay_mask=None):
     check(L.lib.mvlt_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(p16), n, _p(hp), _p(decay_mask), stream_ptr()), "mvlt_adamw_step")
 
 
+L.lib.mvlt_smooth_l1_fwd.argtypes = [_vp, _vp, _l, _vp, _vp]
+L.lib.mvlt_smooth_l1_bwd.argtypes = [_vp, _vp, _l, _vp, _vp, _vp]
+
+
+def smooth_l1_fwd(pred, target, loss_sum):
+    _need_cuda(pred, target, loss_sum)
+    assert pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.is_contiguous() and target.is_contiguous()
+    check(L.lib.mvlt_smooth_l1_fwd(_p(pred), _p(target), pred.numel(), _p(loss_sum), stream_ptr()), "mvlt_smooth_l1_fwd")
+
+
+def smooth_l1_bwd(pred, target, gscale, grad):
+    _need_cuda(pred, target, gscale, grad)
+    check(L.lib.mvlt_smooth_l1_bwd(_p(pred), _p(target), pred.numel(), _p(gscale), _p(grad), stream_ptr()), "mvlt_smooth_l1_bwd")
+
+
 def cast_bf16(src, dst, n):
     _need_cuda(src, dst)
     check(L.lib.mvlt_cast_bf16(_p(src), _p(dst), n, stream_ptr()), "mvlt_cast_bf16")

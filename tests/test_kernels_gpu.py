@@ -597,3 +597,17 @@ def test_row_scale(ops, dtype):
     ops.row_scale(x, sc, N, B * N, C, out)
     want = (x.float().view(B, N, C) * sc.view(B, 1, 1)).view(B * N, C).to(dtype)
     assert torch.equal(out, want)
+
+
+def test_smooth_l1_matches_torch(ops):
+    """reference engine_grid_masking.py:99: F.smooth_l1_loss(t2i_logits, images), forward value and gradient."""
+    from mvlt_amd.engine import smooth_l1
+    pred = (rnd(3, 3, 64, 64, dtype=torch.float32) * 1.5).requires_grad_(True)
+    target = rnd(3, 3, 64, 64, dtype=torch.float32, seed=4)
+    loss = smooth_l1(pred, target)
+    (loss * 10).backward()
+    pr = pred.detach().clone().requires_grad_(True)
+    ref = F.smooth_l1_loss(pr, target)
+    (ref * 10).backward()
+    assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+    assert maxrel(pred.grad, pr.grad) < 1e-6
