@@ -287,6 +287,47 @@ __global__ __launch_bounds__(NT) void upsample_fwd_nchw_kernel(const float* x, i
     }
   }
 }
+// the same for W <= 64 and Wo % 4 == 0 (the x8 score upsampling to the image: W = 32, Wo = 256): the two source rows of each of
+// the workgroup's 8 plane rows go through LDS once, a thread interpolates four neighbouring outputs and stores 16 bytes
+// (4-byte stores, one per lane, held the first version at 2 TB/s of output)
+__global__ __launch_bounds__(NT) void upsample_fwd_nchw4_kernel(const float* x, int ldx, int H, int W, int C, int s, float* out, int nrows) {
+  __shared__ float src[8][2][64];
+  __shared__ float s_wy[8];
+  const int Ho = H * s, Wo = W * s;
+  const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const int row_base = blockIdx.x * 8;
+  for (int i = threadIdx.x; i < 8 * 2 * W; i += NT) {
+    const int rr = i / (2 * W), rem = i - rr * 2 * W, yy = rem / W, xx = rem - yy * W;
+    const int row = row_base + rr;
+    if (row < nrows) {
+      const int oy = row % Ho, bc = row / Ho;
+      const int c = bc % C, b = bc / C;
+      const float fy = oy * ry;
+      const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+      src[rr][yy][xx] = x[((long)b * H * W + (long)(yy ? y1 : y0) * W + xx) * ldx + c];
+      if (rem == 0) s_wy[rr] = fy - y0;
+    }
+  }
+  __syncthreads();
+  const int q = threadIdx.x & 63, rsub = threadIdx.x >> 6;
+  if (q * 4 >= Wo) return;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rr = pass * 4 + rsub, row = row_base + rr;
+    if (row >= nrows) continue;
+    const float wy = s_wy[rr];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ox = q * 4 + e;
+      const float fx = ox * rx;
+      const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+      const float wx = fx - x0;
+      o[e] = (1.f - wy) * ((1.f - wx) * src[rr][0][x0] + wx * src[rr][0][x1]) + wy * ((1.f - wx) * src[rr][1][x0] + wx * src[rr][1][x1]);
+    }
+    *(f32x4*)(out + (long)row * Wo + q * 4) = o;
+  }
+}
 // backward, pixel-major dy: workgroup = input row (b, iy), threads = (ix, 4-channel group)
 __global__ __launch_bounds__(NT) void upsample_bwd_row_kernel(const float* dy, int lddy, int H, int W, int C, int s, float* dx, int lddx, int accumulate, int chunks) {
   const int Ho = H * s, Wo = W * s;
@@ -355,6 +396,44 @@ __global__ __launch_bounds__(NT) void upsample_bwd_nchw_kernel(const float* dy, 
     }
     float* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
     *d = accumulate ? *d + t : t;
+  }
+}
+
+// the same for Wo % 4 == 0, Wo <= 256: 16-byte loads, the ~2s contributing output rows split over the four waves
+__global__ __launch_bounds__(NT) void upsample_bwd_nchw4_kernel(const float* dy, int H, int W, int C, int s, float* dx, int lddx, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float part[4][256];
+  const int Ho = H * s, Wo = W * s;
+  const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const int row = blockIdx.x;                      // (b * C + c) * H + iy
+  const int iy = row % H, bc = row / H;
+  const int c = bc % C, b = bc / C;
+  const int oy_lo = ry > 0.f ? max(0, (int)floorf((iy - 1) / ry)) : 0, oy_hi = ry > 0.f ? min(Ho - 1, (int)ceilf((iy + 1) / ry)) : Ho - 1;
+  const float* plane = dy + (long)bc * Ho * Wo;
+  const int q = threadIdx.x & 63, g = threadIdx.x >> 6;
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  if (q * 4 < Wo) {
+    for (int oy = oy_lo + g; oy <= oy_hi; oy += 4) {
+      const float fy = oy * ry;
+      const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+      const float wy = fy - y0;
+      const float wyi = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+      t += wyi * *(const f32x4*)(plane + (long)oy * Wo + q * 4);
+    }
+    *(f32x4*)(&part[g][q * 4]) = t;
+  }
+  __syncthreads();
+  for (int ix = threadIdx.x; ix < W; ix += NT) {
+    const int ox_lo = rx > 0.f ? max(0, (int)floorf((ix - 1) / rx)) : 0, ox_hi = rx > 0.f ? min(Wo - 1, (int)ceilf((ix + 1) / rx)) : Wo - 1;
+    float acc = 0.f;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      const float fx = ox * rx;
+      const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+      const float wx = fx - x0;
+      const float wxi = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
+      acc += wxi * (part[0][ox] + part[1][ox] + part[2][ox] + part[3][ox]);
+    }
+    float* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
+    *d = accumulate ? *d + acc : acc;
   }
 }
 
@@ -454,6 +533,11 @@ extern "C" int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, i
   MVLT_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1, "mvlt_upsample_fwd: bad arguments");
   MVLT_REQUIRE(!nchw || out_dtype == 1, "mvlt_upsample_fwd: NCHW output is fp32");
   long total = (long)B * H * scale * W * scale * C;
+  if (nchw && (long)B * C * H * scale < (1L << 31) && W <= 64 && (W * scale) % 4 == 0 && W * scale <= 256 && ((uintptr_t)out & 15) == 0) {
+    hipLaunchKernelGGL(upsample_fwd_nchw4_kernel, dim3((unsigned)((B * C * H * scale + 7) / 8)), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (float*)out,
+                       B * C * H * scale);
+    return mvlt_check_launch("mvlt_upsample_fwd");
+  }
   if (nchw && (long)B * C * H * scale < (1L << 31)) {
     hipLaunchKernelGGL(upsample_fwd_nchw_kernel, dim3((unsigned)((B * C * H * scale + 7) / 8)), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (float*)out,
                        B * C * H * scale);
@@ -475,8 +559,11 @@ extern "C" int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int
   MVLT_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1, "mvlt_upsample_bwd: bad arguments");
   long total = (long)B * H * W * C;
   if (nchw && (size_t)W * scale * sizeof(float) <= 64 * 1024) {
-    hipLaunchKernelGGL(upsample_bwd_nchw_kernel, dim3((unsigned)(B * C * H)), dim3(NT), (size_t)W * scale * sizeof(float), (hipStream_t)stream, dy, H, W, C,
-                       scale, dx, lddx, accumulate);
+    if ((W * scale) % 4 == 0 && W * scale <= 256 && ((uintptr_t)dy & 15) == 0)
+      hipLaunchKernelGGL(upsample_bwd_nchw4_kernel, dim3((unsigned)(B * C * H)), dim3(NT), 0, (hipStream_t)stream, dy, H, W, C, scale, dx, lddx, accumulate);
+    else
+      hipLaunchKernelGGL(upsample_bwd_nchw_kernel, dim3((unsigned)(B * C * H)), dim3(NT), (size_t)W * scale * sizeof(float), (hipStream_t)stream, dy, H, W, C,
+                         scale, dx, lddx, accumulate);
     return mvlt_check_launch("mvlt_upsample_bwd");
   }
   if (!nchw && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0) {

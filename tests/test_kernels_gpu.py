@@ -528,7 +528,8 @@ def test_fused_mlp(ops, Cdim, hid, M, Bsz):
 
 # ------------------------------------------------------------------ bilinear upsample (align_corners=True) and its adjoint
 @pytest.mark.parametrize("B,H,C,s,nchw,out_dtype", [(2, 8, 64, 2, False, torch.float32), (3, 6, 192, 2, False, torch.bfloat16),
-                                                    (2, 8, 3, 8, True, torch.float32), (1, 5, 6, 3, False, torch.float32)])
+                                                    (2, 8, 3, 8, True, torch.float32), (1, 5, 6, 3, False, torch.float32),
+                                                    (2, 32, 3, 8, True, torch.float32), (1, 5, 3, 3, True, torch.float32)])
 def test_upsample_fwd_bwd(ops, B, H, C, s, nchw, out_dtype):
     """reference libs/vl_heads.py:128-134 (nn.Upsample(scale_factor, 'bilinear', align_corners=True)) on pixel-major tensors."""
     x = rnd(B * H * H, C, dtype=torch.float32)
