@@ -1487,12 +1487,16 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
   const int mtiles = (a->M + TBK - 1) / TBK;
   if (a->dtype == 0 && a->M < (1 << 24) && !getenv("MVLT_TN_LEGACY")) {
     // LDS-DMA kernel: A tile 128 or 64 wide, B tile 128 or 64 wide; ~1024 workgroups, splits a multiple of the 8 XCDs
-    const int bmt = a->N1 <= 64 ? 64 : 128, bn = a->N2 <= 64 ? 64 : 128;
+    // outputs of at most 128 x 128 take 64 x 64 tiles: every output cache line receives one atomic request per m-split, those
+    // serialise at the memory side (~100 ns each), and four small tiles need a quarter of the splits of one big tile for the same
+    // number of workgroups (294912 x 128 x 128: 61 -> 35 us)
+    const bool small_out = a->N1 <= 128 && a->N2 <= 128 && !getenv("MVLT_TN_NO64");
+    const int bmt = (a->N1 <= 64 || small_out) ? 64 : 128, bn = (a->N2 <= 64 || small_out) ? 64 : 128;
     const int t1 = (a->N1 + bmt - 1) / bmt, t2 = (a->N2 + bn - 1) / bn;
     int splits = a->splits;
     if (splits <= 0) {
       // 2 workgroups per CU in one round: every extra split is another N1*N2 fp32 atomics through the fabric
-      splits = (512 + t1 * t2 - 1) / (t1 * t2);
+      splits = ((t1 * t2 == 1 ? 384 : 512) + t1 * t2 - 1) / (t1 * t2);     // a single output tile: 384 (1081344 x 64 x 64: 54.7 -> 48.9 us)
       if (splits >= 8) splits = (splits + 4) / 8 * 8;
       if (splits > 4096) splits = 4096;
     }
