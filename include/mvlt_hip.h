@@ -121,8 +121,15 @@ typedef struct mvlt_layernorm_bwd_args {
    * stride lddx2.  It is the DropPath-scaled gradient the next branch's GEMMs read (timm drop_path backward), written while
    * the row is still in registers instead of by a separate pass over dx. */
   void* dx2; const float* dx2_scale; int dx2_rows_per_scale; int lddx2;
+  /* dg_copies > 1: dgamma / dbeta are the first of dg_copies interleaved accumulators dg_copy_stride floats apart and workgroup
+   * b adds into copy b % dg_copies (mvlt_fold_copies sums them): every workgroup of a launch adds 2*C floats to the same few
+   * cache lines, and those requests serialise at the memory side at ~100 ns each (16-27 us per call with one copy). */
+  int dg_copies; long dg_copy_stride;
 } mvlt_layernorm_bwd_args;
 int mvlt_layernorm_bwd(const mvlt_layernorm_bwd_args* args, void* stream);
+/* dst[dst_index[j]] += sum_k arena[k * stride + j] for j in [j0, j1), and those arena elements are zeroed again: folds the
+ * interleaved LayerNorm parameter-gradient accumulators into the flat gradient buffer (one launch per backward stage). */
+int mvlt_fold_copies(float* arena, int copies, long stride, const int* dst_index, int j0, int j1, float* dst, void* stream);
 
 /* out[r,c] (fp32) = sum_b in[(b*batch_stride_rows + r) * ld + c]: gradient of the broadcast "+ pos_embed /
  * text_pos_embed" of reference libs/pvlt.py:346 (reduction over the batch). */

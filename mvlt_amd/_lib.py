@@ -66,7 +66,8 @@ class LayerNormBwdArgs(C.Structure):
                 ("rows", c_int), ("C", c_int), ("lddy", c_int), ("ldx", c_int), ("lddx", c_int),
                 ("dy_map", RowMap), ("x_map", RowMap), ("dx_map", RowMap),
                 ("dx_accumulate", c_int), ("dtype", c_int), ("x_dtype", c_int), ("dx_dtype", c_int),
-                ("dx2", c_void_p), ("dx2_scale", c_void_p), ("dx2_rows_per_scale", c_int), ("lddx2", c_int)]
+                ("dx2", c_void_p), ("dx2_scale", c_void_p), ("dx2_rows_per_scale", c_int), ("lddx2", c_int),
+                ("dg_copies", c_int), ("dg_copy_stride", C.c_long)]
 
 
 class AttnArgs(C.Structure):
@@ -101,7 +102,7 @@ for _name, _cls in (("mvlt_rowmap", RowMap), ("mvlt_prep_desc", PrepDesc), ("mvl
         raise ImportError(f"ABI mismatch for {_name}: library says {_n} bytes, binding has {C.sizeof(_cls)}")
 
 EXPORTS = ["mvlt_last_error", "mvlt_abi_version", "mvlt_sizeof", "mvlt_gemm_nt", "mvlt_gemm_tn",
-           "mvlt_layernorm_fwd", "mvlt_layernorm_bwd", "mvlt_batch_sum", "mvlt_sr_attention_fwd", "mvlt_sr_attention_bwd",
+           "mvlt_layernorm_fwd", "mvlt_layernorm_bwd", "mvlt_fold_copies", "mvlt_batch_sum", "mvlt_sr_attention_fwd", "mvlt_sr_attention_bwd",
            "mvlt_bert_embed_fwd", "mvlt_bert_embed_bwd", "mvlt_patchify", "mvlt_masked_select", "mvlt_gather_rows",
            "mvlt_scatter_rows", "mvlt_cross_entropy_fwd", "mvlt_cross_entropy_bwd", "mvlt_adamw_step", "mvlt_smooth_l1_fwd", "mvlt_smooth_l1_bwd", "mvlt_cast_bf16",
            "mvlt_transpose_cast", "mvlt_row_scale", "mvlt_weight_prep", "mvlt_col_stats", "mvlt_bn_finalize", "mvlt_bn_norm", "mvlt_bn_bwd_reduce", "mvlt_bn_bwd_apply",

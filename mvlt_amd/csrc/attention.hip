@@ -570,7 +570,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
   int slot = 0;
   int q_prev = -1;
   for (int q0 = q_begin; q0 < q_end; q0 += 32, slot ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // lgkmcnt(0) explicitly: hipcc emitted this barrier without draining the wave's own ds_write_b16 of the dQ tile issued just
+    // before the loop back-edge, and the deferred dQ store below then read two or four stale rows about once in 100 launches
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                   // (A) tile q0 landed; previous tile's dS / dQ tiles are complete
     if (q_prev >= 0 && tid < 256) {                    // deferred dQ store of the previous tile: 16 B per thread
       const int r = tid >> 3, c = tid & 7;

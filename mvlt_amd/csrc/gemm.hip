@@ -1115,8 +1115,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_a
     if (m_begin + st * TBK < m_end) issue(m_begin + st * TBK, st);
   int slot = 0, islot = NS - 1;
   for (int mt = m_begin; mt < m_end; mt += TBK) {
-    if (NS > 2 && mt + (NS - 2) * TBK < m_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (NS - 2)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NS > 2 && mt + (NS - 2) * TBK < m_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPT * (NS - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();    // tile `mt` has landed for every wave; everyone is done reading the slot refilled next
     asm volatile("" ::: "memory");
     if (mt + (NS - 1) * TBK < m_end) issue(mt + (NS - 1) * TBK, islot);
@@ -1297,11 +1297,11 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt must have landed; up to ns - 2 later tiles may still be in flight (none near the tail)
     const int ahead = min(nk - 1 - kt, ns - 2);
-    if (ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT) : "memory");
-    else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
-    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ahead >= 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * LPT) : "memory");
+    else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * LPT) : "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LPT) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (ns > 1 && kt + ns - 1 < nk) issue(islot);

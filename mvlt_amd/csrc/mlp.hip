@@ -302,7 +302,7 @@ __global__ __launch_bounds__(NT, C == 64 ? 2 : 1) void mlp_wgrad_kernel(mvlt_mlp
   float b1v[2];
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt) b1v[jt] = p.b1[j0 + wave * 32 + jt * 16 + fr];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();                             // weights visible (and tile 0 has landed)
 
   // ---- fragment geometry
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(NT, C == 64 ? 2 : 1) void mlp_wgrad_kernel(mvlt_mlp
   int slot = 0;
   for (int mt0 = m_begin; mt0 < m_end; mt0 += 64, slot ^= 1) {
     if (mt0 != m_begin) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();            // tile mt0 landed for every wave; the other slot is free again
       asm volatile("" ::: "memory");
     }

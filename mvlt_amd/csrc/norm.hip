@@ -292,11 +292,20 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
       }
     }
     __syncthreads();
+    const long cp = p.dg_copies > 1 ? (long)(blockIdx.x % p.dg_copies) * p.dg_copy_stride : 0;
     for (int i = threadIdx.x; i < p.C; i += NT) {
-      atomicAdd(&p.dgamma[i], s_part[i]);
-      atomicAdd(&p.dbeta[i], s_part[p.C + i]);
+      atomicAdd(&p.dgamma[cp + i], s_part[i]);
+      atomicAdd(&p.dbeta[cp + i], s_part[p.C + i]);
     }
   }
+}
+
+__global__ __launch_bounds__(NT) void fold_copies_kernel(float* arena, int copies, long stride, const int* dst_index, int j0, int j1, float* dst) {
+  const int j = j0 + blockIdx.x * NT + threadIdx.x;
+  if (j >= j1) return;
+  float t = 0.f;
+  for (int k = 0; k < copies; ++k) { t += arena[(long)k * stride + j]; arena[(long)k * stride + j] = 0.f; }
+  dst[dst_index[j]] += t;
 }
 
 // out[r, c] = sum_b in[b*batch_stride_rows + r][c]   (gradient of a broadcast "+ pos_embed"); fp32 out
@@ -429,6 +438,13 @@ extern "C" int mvlt_layernorm_fwd(const mvlt_layernorm_args* a, void* stream) {
   return a->y_dtype == 0 ? launch_fwd<float, bf16>(*a, s) : launch_fwd<float, float>(*a, s);
 }
 
+extern "C" int mvlt_fold_copies(float* arena, int copies, long stride, const int* dst_index, int j0, int j1, float* dst, void* stream) {
+  MVLT_REQUIRE(arena && dst_index && dst && copies >= 1 && j0 >= 0 && j1 >= j0 && stride >= j1, "mvlt_fold_copies: bad arguments");
+  if (j1 == j0) return MVLT_OK;
+  hipLaunchKernelGGL(fold_copies_kernel, dim3((j1 - j0 + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, arena, copies, stride, dst_index, j0, j1, dst);
+  return mvlt_check_launch("mvlt_fold_copies");
+}
+
 extern "C" int mvlt_layernorm_bwd(const mvlt_layernorm_bwd_args* a, void* stream) {
   MVLT_REQUIRE(a && a->dy && a->x && a->dx && a->gamma && a->mean && a->rstd, "mvlt_layernorm_bwd: null pointer");
   MVLT_REQUIRE((a->dgamma == nullptr) == (a->dbeta == nullptr), "mvlt_layernorm_bwd: dgamma and dbeta go together");
@@ -436,6 +452,7 @@ extern "C" int mvlt_layernorm_bwd(const mvlt_layernorm_bwd_args* a, void* stream
                "mvlt_layernorm_bwd: bad dtype");
   MVLT_REQUIRE(a->C > 0 && a->C % 8 == 0 && a->ldx % 8 == 0 && a->lddy % 8 == 0 && a->lddx % 8 == 0, "mvlt_layernorm_bwd: C/ld* must be multiples of 8");
   MVLT_REQUIRE(a->x_map.mode == 0 && a->dy_map.mode == 0 && a->dx_map.mode == 0, "mvlt_layernorm_bwd: only mode-0 row maps");
+  MVLT_REQUIRE(a->dg_copies <= 1 || (a->dgamma && a->dg_copy_stride >= a->C), "mvlt_layernorm_bwd: dg_copies needs dgamma / dbeta and dg_copy_stride >= C");
   MVLT_REQUIRE(!a->dx2 || (a->dx2_scale && a->dx2_rows_per_scale > 0 && a->lddx2 % 8 == 0 && a->lddx2 >= a->C),
                "mvlt_layernorm_bwd: dx2 needs dx2_scale, dx2_rows_per_scale > 0 and lddx2 (multiple of 8) >= C");
   if (a->rows <= 0) return MVLT_OK;

@@ -64,15 +64,24 @@ def layernorm_fwd(x, y, gamma, beta, rows, Cdim, ldx, ldy, eps, *, mean=None, rs
 
 
 def layernorm_bwd(dy, x, dx, gamma, mean, rstd, rows, Cdim, lddy, ldx, lddx, *, dgamma=None, dbeta=None,
-                  dy_map=None, x_map=None, dx_map=None, accumulate=False, dx2=None, dx2_scale=None, dx2_rows_per_scale=0, lddx2=0):
+                  dy_map=None, x_map=None, dx_map=None, accumulate=False, dx2=None, dx2_scale=None, dx2_rows_per_scale=0, lddx2=0,
+                  copies=1, copy_stride=0):
     assert dy.dtype in DT and x.dtype in DT and dx.dtype in DT
     assert dx2 is None or (dx2.dtype == dy.dtype and dx2_scale is not None and dx2_scale.dtype == torch.float32 and dx2_rows_per_scale > 0)
     a = L.LayerNormBwdArgs(ptr(dy), ptr(x), ptr(dx), ptr(gamma), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta),
                            rows, Cdim, lddy, ldx, lddx, dy_map or _ID, x_map or _ID, dx_map or _ID,
                            1 if accumulate else 0, DT[dy.dtype], DT[x.dtype], DT[dx.dtype],
-                           ptr(dx2), ptr(dx2_scale), dx2_rows_per_scale, lddx2)
+                           ptr(dx2), ptr(dx2_scale), dx2_rows_per_scale, lddx2, copies, copy_stride)
     check(L.lib.mvlt_layernorm_bwd(C.byref(a), stream_ptr()), "mvlt_layernorm_bwd")
     return dx
+
+
+L.lib.mvlt_fold_copies.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+
+
+def fold_copies(arena, copies, stride, dst_index, j0, j1, dst):
+    assert arena.dtype == torch.float32 and dst.dtype == torch.float32 and dst_index.dtype == torch.int32
+    check(L.lib.mvlt_fold_copies(ptr(arena), copies, stride, ptr(dst_index), j0, j1, ptr(dst), stream_ptr()), "mvlt_fold_copies")
 
 
 L.lib.mvlt_batch_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]

@@ -277,6 +277,7 @@ class FlatStore:
 
     def _finalize(self):
         self._finalize_queued = False
+        self.fold_copies()
         if self.on_backward_done is not None:
             self.on_backward_done(self)
 
@@ -287,9 +288,42 @@ class FlatStore:
         o, n, _ = self.offsets[names[-1]]
         return lo, o + (n + ALIGN - 1) // ALIGN * ALIGN
 
+    # ---- interleaved accumulators for the LayerNorm parameter gradients ------------------------------------------------
+    # Every workgroup of a LayerNorm backward adds its 2*C partial sums to the same few cache lines; those atomics serialise at
+    # the memory side (~100 ns each, 16-27 us per launch).  The launches therefore add into LN_COPIES copies (workgroup b ->
+    # copy b % LN_COPIES) inside a small arena, and one `mvlt_fold_copies` launch per backward stage sums the copies into G
+    # (and zeroes them again).  Arena slots are handed out in first-use order, so a stage's slots are one contiguous range.
+    LN_COPIES, LN_ARENA = 8, 32768
+
+    def grad_copies(self, name):
+        """arena view (copy 0) standing in for self.grad(name) in ops.layernorm_bwd(..., copies=LN_COPIES, copy_stride=LN_ARENA)"""
+        if getattr(self, "_ln_arena", None) is None or self._ln_arena.device != self.G.device:
+            self._ln_arena = torch.zeros(self.LN_COPIES, self.LN_ARENA, device=self.G.device, dtype=torch.float32)
+            self._ln_index = torch.zeros(self.LN_ARENA, device=self.G.device, dtype=torch.int32)
+            self._ln_slots, self._ln_next, self._ln_lo, self._ln_hi = {}, 0, None, None
+        goff, n, _ = self.offsets[name]
+        slot = self._ln_slots.get(name)
+        if slot is None:
+            assert self._ln_next + n <= self.LN_ARENA, "LayerNorm gradient arena too small"
+            slot = self._ln_slots[name] = self._ln_next
+            self._ln_index[slot:slot + n] = torch.arange(goff, goff + n, device=self.G.device, dtype=torch.int32)
+            self._ln_next += n
+        self._ln_lo = slot if self._ln_lo is None else min(self._ln_lo, slot)
+        self._ln_hi = slot + n if self._ln_hi is None else max(self._ln_hi, slot + n)
+        return self._ln_arena[0, slot:slot + n]
+
+    def fold_copies(self):
+        """sum the accumulator copies touched since the last fold into G"""
+        if getattr(self, "_ln_lo", None) is None:
+            return
+        from . import ops
+        ops.fold_copies(self._ln_arena, self.LN_COPIES, self.LN_ARENA, self._ln_index, self._ln_lo, self._ln_hi, self.G)
+        self._ln_lo = self._ln_hi = None
+
     def announce_stage(self, i):
         """backward of stage i finished: its parameter gradients are final -> let the data-parallel wrapper start
         reducing them while the earlier stages are still running."""
+        self.fold_copies()
         if self.on_range_ready is not None:
             lo, hi = self.stage_range(i)
             self._ranges_done.append((lo, hi))
