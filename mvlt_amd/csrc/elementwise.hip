@@ -46,7 +46,10 @@ __global__ __launch_bounds__(NT) void bert_embed_fwd_kernel(const long* ids, con
 
 // backward: recompute x = word+type+pos, LN backward, then scatter: word[id] (skipping padding_idx 0, as
 // nn.Embedding(padding_idx=0) does), pos[t], type[0], gamma, beta -- all fp32 atomics into zeroed grads.
-template <typename T, int HID>
+// 1024-thread workgroups, at most one per CU: every workgroup ends with 3 x 768 atomics on the same 72 cache lines (dgamma, dbeta,
+// dtype0), which the memory side serves one at a time at ~100 ns -- 2048 workgroups of 256 threads spent 0.2 of the kernel's
+// 0.26 ms there
+template <typename T, int HID, int NT>
 __global__ __launch_bounds__(NT) void bert_embed_bwd_kernel(const T* dy, const long* ids, const float* word, const float* pos, const float* type0,
                                                             const float* gamma, const uint8_t* keep, float inv_keep,
                                                             const float* mean_in, const float* rstd_in,
@@ -60,9 +63,14 @@ __global__ __launch_bounds__(NT) void bert_embed_bwd_kernel(const T* dy, const l
   float ag[PER], ab[PER], at[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) { ag[i] = 0.f; ab[i] = 0.f; at[i] = 0.f; }
-  for (int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6); row < rows; row += gridDim.x * (NT / 64)) {
+  // a workgroup owns ONE position t and a slice of the batch (its waves take every (NT/64)-th sample): the position-embedding
+  // gradient of that slice is summed in registers (at[] doubles as it: dtype0 = sum over all rows of the same dx) and leaves as one
+  // 768-float flush per workgroup instead of one per row
+  const int t = blockIdx.x % Tlen, split = blockIdx.x / Tlen, nsplit = gridDim.x / Tlen;
+  const int nb = rows / Tlen;
+  for (int bb = split * (NT / 64) + (threadIdx.x >> 6); bb < nb; bb += nsplit * (NT / 64)) {
+    const int row = bb * Tlen + t;
     const long id = ids[row];
-    const int t = row % Tlen;
     const float mean = mean_in[row], rstd = rstd_in[row];
     float g[PER], xh[PER];
     float s1 = 0.f, s2 = 0.f;
@@ -85,7 +93,6 @@ __global__ __launch_bounds__(NT) void bert_embed_bwd_kernel(const T* dy, const l
       int c = lane + 64 * i;
       float dx = rstd * (g[i] - s1 - xh[i] * s2);
       if (id != 0) atomicAdd(&dword[id * HID + c], dx);
-      atomicAdd(&dpos[(long)t * HID + c], dx);
       at[i] += dx;
     }
   }
@@ -97,6 +104,7 @@ __global__ __launch_bounds__(NT) void bert_embed_bwd_kernel(const T* dy, const l
   __syncthreads();
   for (int i = threadIdx.x; i < HID; i += NT) {
     atomicAdd(&dgamma[i], s_g[i]); atomicAdd(&dbeta[i], s_b[i]); atomicAdd(&dtype0[i], s_t[i]);
+    atomicAdd(&dpos[(long)t * HID + i], s_t[i]);
   }
 }
 
@@ -460,10 +468,13 @@ extern "C" int mvlt_bert_embed_bwd(const void* dy, const long* ids, const float*
   MVLT_REQUIRE(hidden == 768, "mvlt_bert_embed_bwd: hidden must be 768");
   if (rows <= 0) return MVLT_OK;
   const float inv_keep = 1.0f / (1.0f - drop_p);
-  int g = (rows + 3) / 4; if (g > 2048) g = 2048;
-  dim3 grid(g), block(NT);
-  if (dtype == 0) hipLaunchKernelGGL((bert_embed_bwd_kernel<bf16, 768>), grid, block, 0, (hipStream_t)stream, (const bf16*)dy, ids, word, pos, type0, gamma, keep, inv_keep, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T);
-  else hipLaunchKernelGGL((bert_embed_bwd_kernel<float, 768>), grid, block, 0, (hipStream_t)stream, (const float*)dy, ids, word, pos, type0, gamma, keep, inv_keep, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T);
+  MVLT_REQUIRE(rows % T == 0, "mvlt_bert_embed_bwd: rows must be a multiple of T");
+  int nsplit = 256 / T; if (nsplit < 1) nsplit = 1;
+  const int nbatch = rows / T;
+  if (nsplit > (nbatch + 15) / 16) nsplit = (nbatch + 15) / 16;
+  dim3 grid(T * nsplit), block(1024);
+  if (dtype == 0) hipLaunchKernelGGL((bert_embed_bwd_kernel<bf16, 768, 1024>), grid, block, 0, (hipStream_t)stream, (const bf16*)dy, ids, word, pos, type0, gamma, keep, inv_keep, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T);
+  else hipLaunchKernelGGL((bert_embed_bwd_kernel<float, 768, 1024>), grid, block, 0, (hipStream_t)stream, (const float*)dy, ids, word, pos, type0, gamma, keep, inv_keep, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T);
   return mvlt_check_launch("mvlt_bert_embed_bwd");
 }
 
