@@ -40,6 +40,7 @@ class MimStep:
         self.training = training
         self.need_grad = need_grad
         self.rec = {}                               # per conv: saved tensors for backward
+        self.nbt = []                               # num_batches_tracked buffers of the BatchNorms run in train mode
 
     # ---- one conv3x3 (no bias) + BatchNorm: returns the record; y is produced by `norm`
     def conv_bn(self, name, xin, ld_in, tokens_in, side, cin, cout, M):
@@ -58,7 +59,7 @@ class MimStep:
         if self.training:
             mean, rstd = _e((cout,), dev), _e((cout,), dev)
             ops.bn_finalize(st[0], st[1], M, cout, BN_EPS, BN_MOM, mean, rstd, bn.running_mean, bn.running_var, copies=STAT_COPIES)
-            bn.num_batches_tracked += 1
+            self.nbt.append(bn.num_batches_tracked)        # all eleven counters are bumped by one launch at the end of forward
         else:
             mean = bn.running_mean
             rstd = torch.rsqrt(bn.running_var + BN_EPS)
@@ -117,6 +118,9 @@ class MimStep:
         ops.gemm_nt(e16, S.extra["t2i_head.score.0.weight::W"], sc, M1, 3, 3 * ch, 3 * ch, 3 * ch, 3, bias=S.master("t2i_head.score.0.bias"))
         out = _e((B, 3, 8 * s1, 8 * s1), dev)
         ops.upsample_fwd(sc, 3, B, s1, s1, 3, 8, out, 0, nchw=True)
+        if self.nbt:
+            torch._foreach_add_(self.nbt, 1)
+            self.nbt = []
         if self.need_grad:
             self.keep = dict(low=low, mid=mid, cu1o=cu1o, cu2o=cu2o, cu3o=cu3o, e16=e16)
         else:

@@ -21,7 +21,8 @@ def step(i):
     opt.zero_grad(); scaler(total, opt, clip_grad=None, parameters=None)
 for i in range(3): step(i)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=False) as prof:
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=False,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     step(3)
 torch.cuda.synchronize()
 cnt = collections.Counter()
@@ -32,8 +33,8 @@ for ev in prof.events():
                                                            "aten::_local_scalar_dense", "aten::empty_like", "aten::narrow", "aten::unflatten", "aten::flatten", "aten::contiguous",
                                                            "aten::to", "aten::_to_copy", "aten::clone", "aten::zeros", "aten::zeros_like", "aten::result_type", "aten::lift_fresh", "aten::resolve_conj", "aten::resolve_neg"):
         continue
-    st = [f for f in (ev.stack or []) if "mvlt_amd" in f or "bench.py" in f]
-    where = st[0].split("/root/repo/")[-1] if st else (ev.stack[0] if ev.stack else "?")
+    st = [f for f in (ev.stack or []) if ("mvlt_amd/" in f or "bench.py" in f) and "_lib.py" not in f]
+    where = st[0].split("mvlt_amd/")[-1] if st else (ev.stack[0] if ev.stack else "?")
     cnt[(ev.name, where[:90])] += 1
 for (name, where), c in cnt.most_common(60):
     print(f"{c:4d}  {name:28s} {where}")
