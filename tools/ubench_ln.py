@@ -3,6 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvlt_amd import ops
 dev = torch.device('cuda:0'); bf = torch.bfloat16
+COPIES = int(os.environ.get('UB_COPIES', '1'))      # interleaved dgamma / dbeta accumulators (FlatStore.LN_COPIES in the model)
 def timeit(fn, reps=20):
     for _ in range(2): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -15,11 +16,12 @@ for rows, C in [(1081344, 64), (294912, 128), (98304, 320), (49152, 512)]:
     g = torch.ones(C, device=dev); b = torch.zeros(C, device=dev); mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
     t = timeit(lambda: ops.layernorm_fwd(x, y, g, b, rows, C, C, C, 1e-6, mean=mean, rstd=rstd))
     by = rows * C * 6 + rows * 8
-    dy = torch.randn(rows, C, device=dev).to(bf); dx = torch.zeros(rows, C, device=dev); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
-    t2 = timeit(lambda: ops.layernorm_bwd(dy, x, dx, g, mean, rstd, rows, C, C, C, C, dgamma=dg, dbeta=db, accumulate=True))
+    dy = torch.randn(rows, C, device=dev).to(bf); dx = torch.zeros(rows, C, device=dev); dgc = torch.zeros(COPIES, 1024, device=dev); dbc = torch.zeros(COPIES, 1024, device=dev); dg, db = dgc[0, :C], dbc[0, :C]
+    kw = dict(copies=COPIES, copy_stride=1024) if COPIES > 1 else {}
+    t2 = timeit(lambda: ops.layernorm_bwd(dy, x, dx, g, mean, rstd, rows, C, C, C, C, dgamma=dg, dbeta=db, accumulate=True, **kw))
     by2 = rows * C * (2 + 4 + 8) + rows * 8
     dxb = torch.empty(rows, C, device=dev, dtype=bf); xb = x.to(bf)
-    t3 = timeit(lambda: ops.layernorm_bwd(dy, xb, dxb, g, mean, rstd, rows, C, C, C, C, dgamma=dg, dbeta=db))
+    t3 = timeit(lambda: ops.layernorm_bwd(dy, xb, dxb, g, mean, rstd, rows, C, C, C, C, dgamma=dg, dbeta=db, **kw))
     by3 = rows * C * 6 + rows * 8
     print('ln rows=%d C=%d: fwd %.1f us %.2f TB/s | bwd(f32 x, dx+=) %.1f us %.2f TB/s | bwd(bf16) %.1f us %.2f TB/s' % (
         rows, C, t * 1e3, by / t / 1e9, t2 * 1e3, by2 / t2 / 1e9, t3 * 1e3, by3 / t3 / 1e9))
