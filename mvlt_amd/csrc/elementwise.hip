@@ -277,7 +277,21 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* logits, const long*
 __global__ __launch_bounds__(NT) void smooth_l1_sum_kernel(const float* pred, const float* target, long n, float* loss_sum) {
   __shared__ float s_w[NT / 64];
   float acc = 0.f;
-  for (long i = ((long)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += (long)gridDim.x * NT * 4) {
+  const long stride = (long)gridDim.x * NT * 4;
+  long i = ((long)blockIdx.x * NT + threadIdx.x) * 4;
+  for (; i + 3 * stride < n; i += 4 * stride) {                // four independent 16-byte loads per tensor in flight
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = *(const f32x4*)(pred + i + u * stride); b[u] = *(const f32x4*)(target + i + u * stride); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = fabsf(a[u][e] - b[u][e]);
+        acc += d < 1.0f ? 0.5f * d * d : d - 0.5f;
+      }
+  }
+  for (; i < n; i += stride) {
     const f32x4 a = *(const f32x4*)(pred + i), b = *(const f32x4*)(target + i);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -407,16 +421,19 @@ __global__ __launch_bounds__(NT) void weight_prep_kernel(const mvlt_prep_desc* d
     const int tiles_c = (d.C + TS - 1) / TS;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
     const int c0 = (lb % tiles_c) * TS, r0 = (lb / tiles_c) * TS;
-#pragma unroll 4
-    for (int j = ty; j < TS; j += 4) {
-      int r = r0 + j, c = c0 + tx;
-      tile[j][tx] = (r < d.R && c < d.C) ? d.src[(long)r * d.C + c] : 0.f;
+    float v[TS / 4];
+#pragma unroll
+    for (int jj = 0; jj < TS / 4; ++jj) {                       // all 16 loads of the thread in flight before the first LDS write
+      int r = r0 + ty + 4 * jj, c = c0 + tx;
+      v[jj] = (r < d.R && c < d.C) ? d.src[(long)r * d.C + c] : 0.f;
     }
+#pragma unroll
+    for (int jj = 0; jj < TS / 4; ++jj) tile[ty + 4 * jj][tx] = v[jj];
     __syncthreads();
-#pragma unroll 4
-    for (int j = ty; j < TS; j += 4) {
-      int c = c0 + j, r = r0 + tx;
-      if (c < d.C && r < d.R) out[(long)c * d.ld_out + r] = (T)tile[tx][j];
+#pragma unroll
+    for (int jj = 0; jj < TS / 4; ++jj) {
+      int c = c0 + ty + 4 * jj, r = r0 + tx;
+      if (c < d.C && r < d.R) out[(long)c * d.ld_out + r] = (T)tile[tx][ty + 4 * jj];
     }
   } else {
     const long i = (long)lb * NT + threadIdx.x;

@@ -189,9 +189,12 @@ __global__ __launch_bounds__(NT) void ln_fwd_fixed_kernel(mvlt_layernorm_args p)
           Vec<float>::load(s_gb + G * ITS * VN + c0, be);
         }
 #pragma unroll
-        for (int e = 0; e < VN; ++e) {
-          o[e] = (v[u][it][e] - mean) * rstd * ga[e] + be[e];
-          if (addr) o[e] += addr[c0 + e];
+        for (int e = 0; e < VN; ++e) o[e] = (v[u][it][e] - mean) * rstd * ga[e] + be[e];
+        if (addr) {                                  // "+ pos_embed": two 16-byte loads instead of eight scalar ones
+          float ad[VN];
+          Vec<float>::load(addr + c0, ad);
+#pragma unroll
+          for (int e = 0; e < VN; ++e) o[e] += ad[e];
         }
         Vec<TY>::store(yr + c0, o);
       }
