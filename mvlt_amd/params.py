@@ -292,19 +292,31 @@ class FlatStore:
     # Every workgroup of a LayerNorm backward adds its 2*C partial sums to the same few cache lines; those atomics serialise at
     # the memory side (~100 ns each, 16-27 us per launch).  The launches therefore add into LN_COPIES copies (workgroup b ->
     # copy b % LN_COPIES) inside a small arena, and one `mvlt_fold_copies` launch per backward stage sums the copies into G
-    # (and zeroes them again).  Arena slots are handed out in first-use order, so a stage's slots are one contiguous range.
-    LN_COPIES, LN_ARENA = 8, 32768
+    # (and zeroes them again).  Arena slots are handed out in first-use order, so a stage's slots are one contiguous range; a
+    # copy has room for every 1-D parameter of the model, whatever its depth.
+    LN_COPIES = 8
+
+    @property
+    def ln_stride(self):
+        """floats per accumulator copy: room for every 1-D parameter of the model (all LayerNorm weights / biases are among them)"""
+        if getattr(self, "_ln_stride", None) is None:
+            total = sum(n for _, n, shape in self.offsets.values() if len(shape) == 1)
+            self._ln_stride = (total + 63) // 64 * 64
+        return self._ln_stride
+
+    def ln_kwargs(self):
+        return dict(copies=self.LN_COPIES, copy_stride=self.ln_stride)
 
     def grad_copies(self, name):
-        """arena view (copy 0) standing in for self.grad(name) in ops.layernorm_bwd(..., copies=LN_COPIES, copy_stride=LN_ARENA)"""
+        """arena view (copy 0) standing in for self.grad(name) in ops.layernorm_bwd(..., **self.ln_kwargs())"""
         if getattr(self, "_ln_arena", None) is None or self._ln_arena.device != self.G.device:
-            self._ln_arena = torch.zeros(self.LN_COPIES, self.LN_ARENA, device=self.G.device, dtype=torch.float32)
-            self._ln_index = torch.zeros(self.LN_ARENA, device=self.G.device, dtype=torch.int32)
+            self._ln_arena = torch.zeros(self.LN_COPIES, self.ln_stride, device=self.G.device, dtype=torch.float32)
+            self._ln_index = torch.zeros(self.ln_stride, device=self.G.device, dtype=torch.int32)
             self._ln_slots, self._ln_next, self._ln_lo, self._ln_hi = {}, 0, None, None
         goff, n, _ = self.offsets[name]
         slot = self._ln_slots.get(name)
         if slot is None:
-            assert self._ln_next + n <= self.LN_ARENA, "LayerNorm gradient arena too small"
+            assert self._ln_next + n <= self.ln_stride, "LayerNorm gradient arena too small"
             slot = self._ln_slots[name] = self._ln_next
             self._ln_index[slot:slot + n] = torch.arange(goff, goff + n, device=self.G.device, dtype=torch.int32)
             self._ln_next += n
@@ -317,7 +329,7 @@ class FlatStore:
         if getattr(self, "_ln_lo", None) is None:
             return
         from . import ops
-        ops.fold_copies(self._ln_arena, self.LN_COPIES, self.LN_ARENA, self._ln_index, self._ln_lo, self._ln_hi, self.G)
+        ops.fold_copies(self._ln_arena, self.LN_COPIES, self.ln_stride, self._ln_index, self._ln_lo, self._ln_hi, self.G)
         self._ln_lo = self._ln_hi = None
 
     def announce_stage(self, i):

@@ -26,7 +26,6 @@ def _empty(shape, dtype, dev):
 _LN_COPIES = not os.environ.get("MVLT_LN_NO_COPIES")      # A/B switch: LayerNorm parameter gradients by plain atomics
 _NO_DX2 = bool(os.environ.get("MVLT_NO_DX2"))      # A/B switch: DropPath-scaled gradient copy by a separate pass
 
-_LNK = dict(copies=8, copy_stride=32768) if _LN_COPIES else {}      # = FlatStore.LN_COPIES, LN_ARENA
 
 
 class Names:
@@ -85,6 +84,9 @@ class TrunkStep:
     def gl(self, name):
         """LayerNorm weight / bias gradient: slot of the interleaved accumulators (FlatStore.grad_copies)"""
         return self.S.grad_copies(name) if _LN_COPIES else self.S.grad(name)
+
+    def lnk(self):
+        return self.S.ln_kwargs() if _LN_COPIES else {}
 
     # ---- pos embed (tiny, parameter-only: torch bilinear; its backward is taken with torch.autograd on demand)
     def _pos(self, i, param):
@@ -323,10 +325,10 @@ class TrunkStep:
         # patch-embed LN backward -> d(pe_pre)
         d_pe = _empty((B * HW, C), dt, dev)
         ops.layernorm_bwd(dx, sv["pe_pre"], d_pe, self.f32(pe + "norm.weight"), sv["pe_mean"], sv["pe_rstd"], B * HW, C, C, C, C,
-                          dgamma=self.gl(pe + "norm.weight"), dbeta=self.gl(pe + "norm.bias"), **_LNK, dy_map=rowmap(HW, N, 0))
+                          dgamma=self.gl(pe + "norm.weight"), dbeta=self.gl(pe + "norm.bias"), **self.lnk(), dy_map=rowmap(HW, N, 0))
         d_te = _empty((B * T, C), dt, dev)
         ops.layernorm_bwd(dx, sv["te_pre"], d_te, self.f32(ten + "1.weight"), sv["te_mean"], sv["te_rstd"], B * T, C, C, C, C,
-                          dgamma=self.gl(ten + "1.weight"), dbeta=self.gl(ten + "1.bias"), **_LNK, dy_map=rowmap(T, N, HW))
+                          dgamma=self.gl(ten + "1.weight"), dbeta=self.gl(ten + "1.bias"), **self.lnk(), dy_map=rowmap(T, N, HW))
         if i == 0:
             K = m.in_chans * m.patch_size ** 2
             ops.gemm_tn(d_pe, sv["P1"], self.g(pe + "proj.weight").view(C, K), B * HW, C, K, C, K, K, colsum=self.g(pe + "proj.bias"))
@@ -404,7 +406,7 @@ class TrunkStep:
         fuse = bs["s1"] is not None and not _NO_DX2
         dy1 = _empty((M, C), dx.dtype, dev) if fuse else dx
         ops.layernorm_bwd(dxn2, bs["xm"], dx, self.f32(p + "norm2.weight"), bs["m2"], bs["r2"], M, C, C, C, C,
-                          dgamma=self.gl(p + "norm2.weight"), dbeta=self.gl(p + "norm2.bias"), **_LNK, accumulate=True,
+                          dgamma=self.gl(p + "norm2.weight"), dbeta=self.gl(p + "norm2.bias"), **self.lnk(), accumulate=True,
                           dx2=dy1 if fuse else None, dx2_scale=bs["s1"], dx2_rows_per_scale=N, lddx2=C)
         if not fuse:
             dy1 = self._scaled(dx, bs["s1"], N)
@@ -440,7 +442,7 @@ class TrunkStep:
             ops.gemm_nt(dkv, wkvT, dkvin, B * HWr, C, 2 * C, 2 * C, 2 * C, C, a_map=rowmap(HWr, Mk, 0))
             dsr = _empty((B * HWr, C), dt, dev)
             ops.layernorm_bwd(dkvin, bs["sr_pre"], dsr, self.f32(p + "attn.norm.weight"), bs["msr"], bs["rsr"], B * HWr, C, C, C, C,
-                              dgamma=self.gl(p + "attn.norm.weight"), dbeta=self.gl(p + "attn.norm.bias"), **_LNK)
+                              dgamma=self.gl(p + "attn.norm.weight"), dbeta=self.gl(p + "attn.norm.bias"), **self.lnk())
             K = r * r * C
             dWk = pool_zeros((C, K), f32, dev)
             ops.gemm_tn(dsr, bs["xn1"], dWk, B * HWr, C, K, C, C, K, b_map=pm, colsum=self.g(p + "attn.sr.bias"))
@@ -450,7 +452,7 @@ class TrunkStep:
             ops.gemm_tn(dkv, bs["xn1"], gkvw, M, 2 * C, C, 2 * C, C, C, colsum=gkvb)
             ops.gemm_nt(dkv, wkvT, dxn1, M, C, 2 * C, 2 * C, 2 * C, C, R=dxn1)
         ops.layernorm_bwd(dxn1, bs["x"], dx, self.f32(p + "norm1.weight"), bs["m1"], bs["r1"], M, C, C, C, C,
-                          dgamma=self.gl(p + "norm1.weight"), dbeta=self.gl(p + "norm1.bias"), **_LNK, accumulate=True)
+                          dgamma=self.gl(p + "norm1.weight"), dbeta=self.gl(p + "norm1.bias"), **self.lnk(), accumulate=True)
         bs.clear()
         return dx
 

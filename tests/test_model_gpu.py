@@ -316,3 +316,32 @@ def test_mim_decoder_hip_vs_torch_twin(dtype, tol, img, B):
         if not e < 4 * tol:
             bad[k] = e
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+
+
+def test_deep_variant_train_step_runs():
+    """pvlt_medium (3/4/18/3 blocks): one bf16 train step end to end -- sizes that depend on the depth (the LayerNorm
+    gradient accumulator arena, the weight-prep table) must follow the model, not the tiny configuration."""
+    from mvlt_amd import pvlt
+    from mvlt_amd.engine import compute_losses
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = pvlt.pvlt_medium(pretrained=False, token_hidden_size=768, num_text_tokens=16, loss_type=dict(mlm=1, itm=1, t2i=1, cls=0),
+                             pretrained_pth=None, drop_path_rate=0.0, drop_rate=0.0, num_classes=1000, in_chans=3).cuda(dev)
+    model.train()
+    B = 2
+    img = torch.randn(B, 3, 256, 256, device=dev)
+    ids = torch.randint(1, 30000, (B, 16), device=dev)
+    labels = torch.full((B, 16), -1, device=dev, dtype=torch.long)
+    labels[:, 3] = 17
+    out = model(img, ids, mlm_labels=labels)
+    total, _ = compute_losses(out, img, labels, torch.zeros(B, dtype=torch.long, device=dev), None, None)
+    total.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(total).item()
+    n_ln = 0
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        if "norm" in k and p.dim() == 1:
+            n_ln += 1
+            assert p.grad.abs().sum().item() > 0, k          # every LayerNorm gradient went through the accumulator fold
+    assert n_ln > 100
