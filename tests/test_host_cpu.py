@@ -161,3 +161,16 @@ def test_zero_pool_hands_out_zeroed_disjoint_scratch():
     assert d.abs().sum() == 0                     # re-zeroed
     big = pool.take((1 << 22,), torch.float32)    # does not fit: falls back to torch.zeros, pool grows next step
     assert big.numel() == 1 << 22 and big.abs().sum() == 0
+
+
+def test_no_barrier_with_undrained_lds_writes():
+    """tools/isa_barrier_check.py over every kernel source (hipcc -S, no GPU): no s_barrier may be reached over a loop back-edge
+    while the wave's own LDS writes are still in flight (the attention-backward race of round 1)."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_barrier_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
