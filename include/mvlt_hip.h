@@ -275,6 +275,10 @@ int mvlt_bn_bwd_apply(const float* dy, int lddy, const float* z, int ldz, const 
 /* out (+)= a*b(*c) elementwise over [M, C] fp32 with row strides; optional operand-dtype copy of the result */
 int mvlt_ew_mul(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c, int ldc, long M, int C,
                 int accumulate, void* out_op, int ld_op, int op_dtype, void* stream);
+/* gradients of y = a*b*c (all [M, C] fp32, row stride ld; dy row stride lddy): da = dy*b*c, db = dy*a*c, dc = dy*a*b
+ * (the three-way feature product of reference libs/vl_heads.py:152) */
+int mvlt_ew_mul3_bwd(const float* dy, int lddy, const float* a, const float* b, const float* c, int ld, float* da, float* db, float* dc,
+                     long M, int C, void* stream);
 /* bilinear resize by an integer factor, align_corners=True.  x fp32 [B,H,W,C] (row stride ldx) -> [B,sH,sW,C] (bf16/fp32,
  * row stride ldo) or NCHW fp32 [B,C,sH,sW]; bwd is the exact adjoint in gather form (no atomics). */
 int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, int C, int scale, void* out, int ldo, int out_dtype, int nchw, void* stream);

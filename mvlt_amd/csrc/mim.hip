@@ -183,6 +183,24 @@ __global__ __launch_bounds__(NT) void ew_mul_kernel(float* out, int ldo, const f
   }
 }
 
+// gradients of the three-way product y = a * b * c (reference libs/vl_heads.py:152: conv_upsample2(..) * conv_upsample3(..) * low):
+// da = dy b c, db = dy a c, dc = dy a b in one pass (three ew_mul launches read dy and two of the factors each)
+__global__ __launch_bounds__(NT) void ew_mul3_bwd_kernel(const float* dy, int lddy, const float* a, const float* b, const float* c, int ld,
+                                                         float* da, float* db, float* dc, long M, int C) {
+  const int cq = C / 4;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
+    long r = i / cq; int col = (int)(i - r * cq) * 4;
+    const f32x4 g = *(const f32x4*)(dy + r * lddy + col);
+    const f32x4 va = *(const f32x4*)(a + r * ld + col), vb = *(const f32x4*)(b + r * ld + col), vc = *(const f32x4*)(c + r * ld + col);
+    f32x4 oa, ob, oc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { oa[e] = g[e] * vb[e] * vc[e]; ob[e] = g[e] * va[e] * vc[e]; oc[e] = g[e] * va[e] * vb[e]; }
+    *(f32x4*)(da + r * ld + col) = oa;
+    *(f32x4*)(db + r * ld + col) = ob;
+    *(f32x4*)(dc + r * ld + col) = oc;
+  }
+}
+
 // ---- bilinear resize by an integer factor, align_corners=True (nn.Upsample in reference libs/vl_heads.py:114,134)
 // forward: x fp32 pixel-major [B, H, W, C] (row stride ldx)  ->  out [B, sH, sW, C] (bf16 or fp32, row stride ldo)
 //          or NCHW fp32 [B, C, sH, sW] when nchw != 0
@@ -527,6 +545,14 @@ extern "C" int mvlt_ew_mul(float* out, int ldo, const float* a, int lda, const f
   if (op_dtype == 0) hipLaunchKernelGGL((ew_mul_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, c, ldc, M, C, accumulate, (bf16*)out_bf16, ld16);
   else hipLaunchKernelGGL((ew_mul_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, c, ldc, M, C, accumulate, (float*)out_bf16, ld16);
   return mvlt_check_launch("mvlt_ew_mul");
+}
+
+extern "C" int mvlt_ew_mul3_bwd(const float* dy, int lddy, const float* a, const float* b, const float* c, int ld, float* da, float* db, float* dc,
+                                long M, int C, void* stream) {
+  MVLT_REQUIRE(dy && a && b && c && da && db && dc && C % 4 == 0 && lddy % 4 == 0 && ld % 4 == 0 && ld >= C, "mvlt_ew_mul3_bwd: bad arguments");
+  if (M <= 0) return MVLT_OK;
+  hipLaunchKernelGGL(ew_mul3_bwd_kernel, dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy, lddy, a, b, c, ld, da, db, dc, M, C);
+  return mvlt_check_launch("mvlt_ew_mul3_bwd");
 }
 
 extern "C" int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, int C, int scale, void* out, int ldo, int out_dtype, int nchw, void* stream) {

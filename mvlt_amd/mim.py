@@ -175,9 +175,7 @@ class MimStep:
         # b = cu2o * cu3o * low
         db = dcat3                                                                  # columns [0, 64), row stride 192
         dcu2o, dcu3o, dlow = _e((M1, ch), dev), _e((M1, ch), dev), _e((M1, ch), dev)
-        ops.ew_mul(dcu2o, ch, db, 3 * ch, k["cu3o"], ch, k["low"], ch, M=M1, Cdim=ch)
-        ops.ew_mul(dcu3o, ch, db, 3 * ch, k["cu2o"], ch, k["low"], ch, M=M1, Cdim=ch)
-        ops.ew_mul(dlow, ch, db, 3 * ch, k["cu2o"], ch, k["cu3o"], ch, M=M1, Cdim=ch)
+        ops.ew_mul3_bwd(db, 3 * ch, k["cu2o"], k["cu3o"], k["low"], ch, dcu2o, dcu3o, dlow, M1, ch)
         # gradient of cat2 = [a | cu4 out]: starts with the path a -> up -> cu3
         dcat2 = _z((M2, 2 * ch), dev)
         dupa = self.bn_conv_bwd("conv_upsample3", dcu3o, ch)

@@ -268,6 +268,13 @@ def bn_bwd_apply(dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, Cdim, dz16, ldd
                                   _p(g_beta), _p(g_gamma), DT[dz16.dtype], stream_ptr()), "mvlt_bn_bwd_apply")
 
 
+L.lib.mvlt_ew_mul3_bwd.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _l, _i, _vp]
+
+
+def ew_mul3_bwd(dy, lddy, a, b, c, ld, da, db, dc, M, Cdim):
+    check(L.lib.mvlt_ew_mul3_bwd(_p(dy), lddy, _p(a), _p(b), _p(c), ld, _p(da), _p(db), _p(dc), M, Cdim, stream_ptr()), "mvlt_ew_mul3_bwd")
+
+
 def ew_mul(out, ldo, a, lda, b, ldb, c=None, ldc=0, *, M, Cdim, accumulate=False, out16=None, ld16=0):
     check(L.lib.mvlt_ew_mul(_p(out), ldo, _p(a), lda, _p(b), ldb, _p(c), ldc, M, Cdim, 1 if accumulate else 0, _p(out16), ld16,
                             DT[out16.dtype] if out16 is not None else 0, stream_ptr()), "mvlt_ew_mul")

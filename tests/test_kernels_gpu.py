@@ -636,3 +636,14 @@ def test_smooth_l1_matches_torch(ops):
     (ref * 10).backward()
     assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
     assert maxrel(pred.grad, pr.grad) < 1e-6
+
+
+def test_ew_mul3_bwd(ops):
+    """gradients of the three-way feature product (reference libs/vl_heads.py:152), dy read as a column range of a wider matrix"""
+    M, Cd = 3000, 64
+    a, b, c = (rnd(M, Cd, dtype=torch.float32, seed=s) for s in (1, 2, 3))
+    dyw = rnd(M, 3 * Cd, dtype=torch.float32, seed=4)
+    da, db, dc = (torch.empty(M, Cd, device=dev()) for _ in range(3))
+    ops.ew_mul3_bwd(dyw, 3 * Cd, a, b, c, Cd, da, db, dc, M, Cd)
+    dy = dyw[:, :Cd]
+    assert maxrel(da, dy * b * c) < 1e-6 and maxrel(db, dy * a * c) < 1e-6 and maxrel(dc, dy * a * b) < 1e-6
