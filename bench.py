@@ -15,9 +15,16 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
   roofline      the dominant kernel timed live with HIP events on its launch stream (see DESIGN.md for the
                 algorithmic FLOP count used)
   cpu_baseline  the CPU oracle (oracle/pvlt_oracle.py, kind "port") timed on this box's host cores at config #1
-                shapes (4 pairs), N=1 only
+                shapes (4 pairs), N=1 only: full train step (fwd+loss+bwd+AdamW) = `value`, forward+loss beside it
+  flops         reference-equivalent and EXECUTED FLOPs per pair, and the blocks-only (SRAttention + MLP) MFMA utilisation
+                north_star asks for: 3 x 8.003 GFLOP/pair over the GPU time between HIP events around the Block kernels
+
+The timed region is `engine_grid_masking.train_one_epoch_vl` itself (the reference's entry point, main_vl.py:431-437) over
+a loader of K batches that are already resident in HBM: masked-index selection, loss read-back, zero_grad, backward,
+gradient exchange, AdamW and the epoch-end meter reduction are all inside it.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -30,6 +37,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR_TRAIN = 50.38e9      # 3 x 16.793 GFLOP forward (reference-equivalent work)
+# SURVEY.md 8d, forward GFLOP per pair of pvlt_tiny @256/T128: blocks 8.003 (of which MLP 5.184: stage 1-4 blocks
+# 0.554/0.604/0.629/0.805 each), MLM head 6.253, everything else 16.793 - 6.253
+FWD_BLOCKS, FWD_MLM, FWD_ALL = 8.003e9, 6.253e9, 16.793e9
+FWD_FC1_RECOMPUTED = 2 * (0.554e9 + 0.604e9) / 2      # fc1 of the 2+2 fused-MLP blocks of stages 1-2 (half of each block's MLP FLOPs)
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
@@ -64,7 +75,9 @@ def synth_batch(B, S, T, device, seed):
 
 
 def cpu_baseline(seconds=20.0):
-    """The oracle's train step (forward + loss + backward) at BASELINE config #1 shapes on the host cores."""
+    """The oracle at BASELINE config #1 shapes (4 pairs, 256x256 + 128 tokens, fp32) on the host cores: forward+loss, and the
+    full train step the way the reference's loop runs it (forward, loss, zero_grad, backward, torch.optim.AdamW with timm's
+    parameter split -- engine_grid_masking.py:69-127, main_vl.py:308).  BASELINE.md section 5 asks for both."""
     from oracle import filler
     from oracle import pvlt_oracle as O
     from oracle.hostinfo import usable_cores
@@ -75,21 +88,32 @@ def cpu_baseline(seconds=20.0):
     sdg = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running_" not in k) else v) for k, v in sd.items() if k != O.TIED[0]}
     sdg[O.TIED[0]] = sdg[O.TIED[1]]
     batch = O.to_torch_batch(filler.make_batch(7, 4, 256, 128))
-    n, t0 = 0, None
-    while True:
-        ls, _ = O.step_loss(sdg, cfg, batch, n, train=True, masks=None, bn_out={})
+    opt = torch.optim.AdamW(O.adamw_param_groups([(k, v) for k, v in sdg.items() if k != O.TIED[0] and v.requires_grad], 0.01), lr=1e-5)
+
+    def timed(fn, budget, min_n):
+        fn(0)                             # warm-up
+        n, t0 = 0, time.time()
+        while time.time() - t0 < budget or n < min_n:
+            fn(n)
+            n += 1
+        return n, time.time() - t0
+
+    def fwd(i):
+        with torch.no_grad():
+            O.step_loss(sdg, cfg, batch, i, train=True, masks=None, bn_out={})
+
+    def step(i):
+        ls, _ = O.step_loss(sdg, cfg, batch, i, train=True, masks=None, bn_out={})
+        opt.zero_grad()
         ls["total_loss"].backward()
-        for v in sdg.values():
-            if v.is_floating_point() and v.grad is not None:
-                v.grad = None
-        n += 1
-        if t0 is None:                    # first iteration = warm-up
-            t0, n = time.time(), 0
-        elif time.time() - t0 > seconds and n >= 3:
-            break
-    dt = time.time() - t0
-    return dict(value=round(4 * n / dt, 3), unit="pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} train steps (fwd+loss+bwd, fp32) of 4 pairs 256x256+128 tok on the CPU oracle, {dt:.1f} s")
+        opt.step()
+
+    nf, tf = timed(fwd, seconds * 0.3, 3)
+    ns, ts = timed(step, seconds * 0.7, 3)
+    return dict(value=round(4 * ns / ts, 3), unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{ns} train steps (fwd+loss+bwd+AdamW, fp32) of 4 pairs 256x256+128 tok on the CPU oracle in {ts:.1f} s; "
+                       f"forward+loss alone: {nf} passes in {tf:.1f} s",
+                forward_loss_value=round(4 * nf / tf, 3))
 
 
 def _time_launch(fn, reps=20):
@@ -173,8 +197,9 @@ def main():
 
     from mvlt_amd import pvlt
     from mvlt_amd.dist import DataParallel
-    from mvlt_amd.engine import BF16Scaler, train_step
+    from mvlt_amd.engine import BF16Scaler
     from mvlt_amd.optim import FusedAdamW
+    import engine_grid_masking as E                        # the drop-in module path reference main_vl.py:198 imports
 
     torch.manual_seed(1234 + rank)
     loss_type = dict(mlm=1, itm=1, t2i=1, cls=0)
@@ -184,32 +209,25 @@ def main():
     core = model
     if world > 1:
         model = DataParallel(model)
-    model.train()
     B = args.batch
-    batch = synth_batch(B, args.img, 128, device, 1234 + rank)
-    batch["mlm_positions"] = torch.nonzero(batch["mlm_labels"].reshape(-1) != -1).flatten().to(torch.int32)
+    batch = synth_batch(B, args.img, 128, device, 1234 + rank)       # resident in HBM before the timed region starts
+    n_sel = int((batch["mlm_labels"] != -1).sum())
     lr = 2.5e-4 * B * world / 512.0                       # reference main_vl.py:306
-    with torch.no_grad():                                 # build the flat store before the optimizer looks at it
-        core.eval()
-        core(batch["image"][:2], batch["input_ids"][:2])
-        core.train()
-    opt = FusedAdamW(core, lr=lr, weight_decay=0.01)
+    opt = FusedAdamW(core, lr=lr, weight_decay=0.01)      # before any forward, like main_vl.py:308
     scaler = BF16Scaler()
+    eargs = argparse.Namespace(loss_type=loss_type)
 
-    def step(i):
-        total, parts = train_step(model, batch, i, True)
-        opt.zero_grad()
-        scaler(total, opt, clip_grad=None, parameters=None)
-        return total
+    def epoch(n_iter, ep):
+        with contextlib.redirect_stdout(sys.stderr):      # the loop's progress lines must not mix with the one JSON line
+            return E.train_one_epoch_vl(model, None, [batch] * n_iter, opt, device, ep, scaler, None, None, None, True, False, eargs)
 
-    for i in range(args.warmup):
-        step(i)
+    if args.warmup:
+        epoch(args.warmup, 0)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
-    for i in range(args.steps):
-        last = step(i)
+    stats = epoch(args.steps, 1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -218,22 +236,46 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    loss_val = float(last)
     pairs_s = B * world * args.steps / dt
 
+    # blocks-only GPU time (SRAttention + MLP Blocks incl. their LayerNorms): two more iterations with HIP events around the
+    # Block kernels of every stage, forward and backward, outside the timed region
+    core._block_events = []
+    epoch(2, 2)
+    torch.cuda.synchronize()
+    ev, core._block_events = core._block_events, None
+    blocks_ms = sum(a.elapsed_time(b) for a, b in zip(ev[0::2], ev[1::2])) / 2.0
+
     if rank == 0:
+        ms_step = 1e3 * dt / args.steps
         line = {
             "metric": "image-text pairs/sec/node, PVT-tiny MVLT pre-train step", "value": round(pairs_s, 2), "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model} MVLT pre-train (MLM+MIM+ITM), {args.img}x{args.img} RGB + 128 tokens, "
-                                   f"batch {B}/GPU (global {B * world}), fwd+loss+bwd+allreduce+AdamW",
+                                   f"batch {B}/GPU (global {B * world}), train_one_epoch_vl: fwd+loss+bwd+allreduce+AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "fused AdamW (fp32 master)",
-                       "final_loss": round(loss_val, 4)},
-            "step_tflops_reference_equivalent": round(pairs_s * FLOP_PER_PAIR_TRAIN / 1e12, 1),
-            "mfma_frac_reference_equivalent": round(pairs_s * FLOP_PER_PAIR_TRAIN / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+                       "entry": "engine_grid_masking.train_one_epoch_vl", "epoch_avg_loss": round(stats["total_loss"], 4)},
         }
-        if args.model == "pvlt_tiny":
+        if args.model == "pvlt_tiny" and args.img == 256:
+            executed = 3 * (FWD_ALL - FWD_MLM) + 3 * FWD_MLM * n_sel / (B * 128) + 2 * FWD_FC1_RECOMPUTED
+            per_gpu = pairs_s / world
+            line["flops"] = {
+                "reference_equivalent_gflop_per_pair": FLOP_PER_PAIR_TRAIN / 1e9,
+                "executed_gflop_per_pair": round(executed / 1e9, 2),
+                "executed_note": f"MLM head on the {n_sel} selected rows of {B * 128} only (reference-equivalent share 18.76 GFLOP/pair); "
+                                 "+2.32 GFLOP/pair fc1 recomputed by the fused-MLP backward passes of stages 1-2",
+                "step_tflops_reference_equivalent": round(per_gpu * FLOP_PER_PAIR_TRAIN / 1e12, 1),
+                "step_tflops_executed": round(per_gpu * executed / 1e12, 1),
+                "mfma_frac_reference_equivalent": round(per_gpu * FLOP_PER_PAIR_TRAIN / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "mfma_frac_executed": round(per_gpu * executed / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "blocks_only": {"what": "SRAttention + MLP Blocks (LN1, q, sr, kv, attention, proj, LN2, fc1, GELU, fc2; fwd + bwd): "
+                                        "3 x 8.003 GFLOP/pair over the GPU time between HIP events around the Block kernels",
+                                "ms_per_step": round(blocks_ms, 3),
+                                "tflops": round(3 * FWD_BLOCKS * B / (blocks_ms * 1e-3) / 1e12, 1),
+                                "mfma_frac": round(3 * FWD_BLOCKS * B / (blocks_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                "target": 0.40},
+            }
             line["roofline"] = time_dominant_kernel(core, B, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

@@ -82,7 +82,7 @@ class DataParallel(nn.Module):
             w.wait()
         self._works = []
         store._ranges_done = []
-        store.G.mul_(1.0 / self.world)
+        store.scale_grads(1.0 / self.world)          # DDP's mean; folded into the fused AdamW kernel when that is the optimizer
 
 
 def allreduce_meter(count, total, device):

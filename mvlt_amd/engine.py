@@ -7,8 +7,12 @@ main_vl.py:431-437 calls it unchanged.  What differs, on purpose:
     gradients, no (B, T, 30522) logits tensor.  Models without that keyword get the reference's full-logits path.
   * a forward runs on EVERY iteration (the shipped engine reuses stale outputs on odd iterations when t2i is off
     and crashes in backward -- SURVEY.md App. D #1)
-  * one device->host transfer per iteration for the six logged scalars instead of six `.item()` syncs
-  * no unconditional torch.cuda.synchronize(): the transfer above is the only sync
+  * the six logged scalars of an iteration travel to the host in ONE asynchronous copy into pinned memory that is read
+    only after the backward and the optimizer step of the same iteration have been queued: the host waits for the
+    forward alone while the GPU already holds the rest of the step (the reference's six `.item()` calls and its
+    torch.cuda.synchronize() each drain the queue, :104-129)
+  * the number of selected MLM positions is counted on the host when the loader hands over CPU labels (no device
+    round trip); device-resident labels go through the model's asynchronous count (schedule._HostCount)
 The compute dtype is a property of the model (bf16 by default, fp32 when `fp32=True`), not an autocast region.
 """
 import math
@@ -87,10 +91,46 @@ def train_step(model, batch, idx, t2i_on, fused=True):
     inp = batch["masked_images"] if use_masked else images
     core = _core(model)
     if fused and hasattr(core, "store") and core.loss_type.get("mlm"):
-        outputs = model(inp, batch["input_ids"], mlm_labels=batch["mlm_labels"], mlm_positions=batch.get("mlm_positions"))
+        outputs = model(inp, batch["input_ids"], mlm_labels=batch["mlm_labels"], mlm_positions=batch.get("mlm_positions"),
+                        mlm_count=batch.get("mlm_count"))
     else:
         outputs = model(inp, batch["input_ids"])
     return compute_losses(outputs, images, batch["mlm_labels"], batch["itm_labels"], batch["sup_cls_labels"], batch["sub_cls_labels"])
+
+
+LOSS_KEYS = ("total_loss", "loss_mlm", "loss_itm", "loss_sup_cls", "loss_sub_cls", "loss_t2i")
+
+
+class _LossReadback:
+    """the six loss scalars of one iteration: device -> pinned host memory, asynchronously, with an event behind the copy"""
+
+    def __init__(self):
+        self.pin = torch.empty(len(LOSS_KEYS), dtype=torch.float32).pin_memory()
+        self.ev = torch.cuda.Event()
+
+    def post(self, total, parts):
+        vals = torch.stack([total.detach().float()] + [parts[k].detach().float() for k in LOSS_KEYS[1:]])
+        self.pin.copy_(vals, non_blocking=True)
+        self.ev.record()
+
+    def get(self):
+        self.ev.synchronize()
+        return self.pin.tolist()
+
+
+def to_device_batch(samples, device):
+    """The reference's per-tensor `.to(device, non_blocking=True)` (engine_grid_masking.py:42-56) plus the host-side count of
+    the MLM selection when the labels arrive on the CPU."""
+    keys = ("image", "mlm_labels", "i2t_labels", "masked_images", "itm_labels", "sup_cls_labels", "sub_cls_labels")
+    batch = {k: samples[k].to(device, non_blocking=True) for k in keys if k in samples}
+    batch["input_ids"] = samples["ori_input_ids" if USE_ORI_INPUT_IDS else "input_ids"].to(device, non_blocking=True)
+    if "mlm_positions" in samples:
+        batch["mlm_positions"] = samples["mlm_positions"].to(device, non_blocking=True)
+    if "mlm_count" in samples:
+        batch["mlm_count"] = int(samples["mlm_count"])
+    elif "mlm_positions" not in samples and not samples["mlm_labels"].is_cuda:
+        batch["mlm_count"] = int((samples["mlm_labels"] != -1).sum())
+    return batch
 
 
 def train_one_epoch_vl(model, criterion, data_loader, optimizer, device, epoch, loss_scaler, max_norm=0,
@@ -104,24 +144,21 @@ def train_one_epoch_vl(model, criterion, data_loader, optimizer, device, epoch, 
     header = f"Epoch: [{epoch}]"
     loss_type = getattr(args, "loss_type", None) or core.loss_type
     t2i_on = loss_type.get("t2i", 0) == 1
-    keys = ("image", "mlm_labels", "i2t_labels", "masked_images", "itm_labels", "sup_cls_labels", "sub_cls_labels")
+    readback = _LossReadback()
     for idx, samples in enumerate(logger.log_every(data_loader, 10, header)):
-        batch = {k: samples[k].to(device, non_blocking=True) for k in keys if k in samples}
-        batch["input_ids"] = samples["ori_input_ids" if USE_ORI_INPUT_IDS else "input_ids"].to(device, non_blocking=True)
-        if "mlm_positions" in samples:
-            batch["mlm_positions"] = samples["mlm_positions"].to(device, non_blocking=True)
+        batch = to_device_batch(samples, device)
         total, parts = train_step(model, batch, idx, t2i_on)
-        vals = torch.stack([total.detach().float()] + [parts[k].detach().float() for k in
-                                                      ("loss_mlm", "loss_itm", "loss_sup_cls", "loss_sub_cls", "loss_t2i")]).tolist()
-        if not math.isfinite(vals[0]):
-            print(f" [ Warning!!! ] Total Loss is {vals[0]} (loss_mlm={vals[1]} | loss_itm={vals[2]} | loss_sup_cls={vals[3]} | "
-                  f"loss_sub_cls={vals[4]} | loss_t2i={vals[5]}), non-finite value")
+        readback.post(total, parts)
         optimizer.zero_grad()
         is_second_order = hasattr(optimizer, "is_second_order") and optimizer.is_second_order
         loss_scaler(total, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=is_second_order)
         if model_ema is not None:
             model_ema.update(model)
-        logger.update(total_loss=vals[0], loss_mlm=vals[1], loss_itm=vals[2], loss_sup_cls=vals[3], loss_sub_cls=vals[4], loss_t2i=vals[5])
+        vals = readback.get()                  # waits for this iteration's forward only; backward + step are already queued
+        if not math.isfinite(vals[0]):
+            print(f" [ Warning!!! ] Total Loss is {vals[0]} (loss_mlm={vals[1]} | loss_itm={vals[2]} | loss_sup_cls={vals[3]} | "
+                  f"loss_sub_cls={vals[4]} | loss_t2i={vals[5]}), non-finite value")
+        logger.update(**dict(zip(LOSS_KEYS, vals)))
         logger.update(lr=optimizer.param_groups[0]["lr"])
     logger.synchronize_between_processes(device)
     print("Averaged stats:", logger)
@@ -142,8 +179,14 @@ class BF16Scaler:
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False):
         loss.backward(create_graph=create_graph)
+        # main_vl.py passes --clip-grad (default None = no clipping).  timm's NativeScaler tests `is not None`, so the engine's
+        # own default max_norm=0 would scale every gradient to zero there; here 0 means "no clipping" as well.
         if clip_grad:
             assert parameters is not None
+            parameters = list(parameters)
+            store = getattr(getattr(optimizer, "model", None), "store", None)
+            if store is not None:
+                store.apply_pending_scale()                                    # clipping reads the gradients: they must be final
             torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
         optimizer.step()
 

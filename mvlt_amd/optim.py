@@ -30,6 +30,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step = 0
         self._m = self._v = self._wd_mask = None
         self._hp = None
+        self._pending = None                  # (m, v) of a checkpoint loaded before the flat store exists
+        model.store.scale_in_optimizer = True   # a data-parallel wrapper may leave its 1/world factor to this optimizer's kernel
 
     def _ensure(self):
         S = self.model.store
@@ -38,6 +40,13 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._m is None or self._m.numel() != S.total or self._m.device != S.P.device:
             self._m = torch.zeros_like(S.P)
             self._v = torch.zeros_like(S.P)
+            if self._pending is not None:        # moments of a checkpoint that was loaded before the first forward
+                pm, pv = self._pending
+                if pm.numel() != S.total:
+                    raise RuntimeError(f"FusedAdamW: checkpoint moments have {pm.numel()} elements, the model's flat store {S.total}")
+                self._m.copy_(pm)
+                self._v.copy_(pv)
+                self._pending = None
             self._hp = torch.zeros(8, device=S.P.device)
             # one byte per parameter: 1 = weight decay applies (timm's split: not for 1-D tensors / biases)
             ids_nd = {id(p) for p in self.param_groups[0]["params"]}
@@ -58,13 +67,14 @@ class FusedAdamW(torch.optim.Optimizer):
         g0, g1 = self.param_groups
         b1, b2 = g0["betas"]
         assert g0["lr"] == g1["lr"], "FusedAdamW steps both param groups with one learning rate (as timm's scheduler sets them)"
-        row = [g0["lr"], b1, b2, g0["eps"], g1["weight_decay"], 1 - b1 ** self._step, 1 - b2 ** self._step, 1.0]
+        gscale, S.pending_grad_scale = S.pending_grad_scale, 1.0      # 1/world of the data-parallel mean, applied in the kernel
+        row = [g0["lr"], b1, b2, g0["eps"], g1["weight_decay"], 1 - b1 ** self._step, 1 - b2 ** self._step, gscale]
         self._hp.copy_(torch.tensor(row, dtype=torch.float32), non_blocking=True)
         ops.adamw_step(S.P, S.G, self._m, self._v, S.C, S.total, self._hp, self._wd_mask)
-        # W^T / permuted conv operand copies are refreshed by the next forward; the plain bf16 copy S.C is already current
-        # (valid as long as nothing else writes P before that forward: any torch in-place op bumps P._version)
+        # W^T / permuted conv operand copies are refreshed by the next forward; the plain bf16 copy S.C is already current,
+        # which holds as long as nothing else writes the parameters before that forward (FlatStore.versions() notices)
         S.force_dirty = True
-        S._c_fresh_version = S.P._version if S.C is not None else None
+        S._c_fresh_version = S.versions() if S.C is not None else None
         return loss
 
     def zero_grad(self, set_to_none=True):
@@ -72,15 +82,24 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def state_dict(self):
         sd = super().state_dict()
-        sd["fused"] = dict(step=self._step, m=None if self._m is None else self._m.cpu(), v=None if self._v is None else self._v.cpu())
+        m, v = (self._m, self._v) if self._m is not None else (self._pending or (None, None))
+        sd["fused"] = dict(step=self._step, m=None if m is None else m.cpu(), v=None if v is None else v.cpu())
         return sd
 
     def load_state_dict(self, sd):
+        """Works before the first forward too (the reference resumes in that order: main_vl.py:308 builds the optimizer,
+        :340 loads its state, the first forward comes later): the moments then wait in `_pending` until `_ensure`."""
+        sd = dict(sd)                                  # the caller's checkpoint dict stays as it was
         fused = sd.pop("fused", None)
         super().load_state_dict(sd)
         if fused is not None:
             self._step = fused["step"]
-            if fused["m"] is not None and self.model.store.P is not None:
-                self._ensure()
-                self._m.copy_(fused["m"])
-                self._v.copy_(fused["v"])
+            if fused["m"] is not None:
+                if self.model.store.P is not None:
+                    self._pending = None
+                    self._ensure()
+                    self._m.copy_(fused["m"])
+                    self._v.copy_(fused["v"])
+                else:
+                    self._m = self._v = None
+                    self._pending = (fused["m"].detach().clone(), fused["v"].detach().clone())

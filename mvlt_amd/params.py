@@ -61,6 +61,7 @@ class ZeroPool:
 
     def __init__(self, device):
         self.device, self.buf, self.used, self.need = device, None, 0, 0
+        self.pending = 0          # forwards with a graph whose backward has not finished: their scratch is still owned
 
     @classmethod
     def of(cls, device):
@@ -69,14 +70,25 @@ class ZeroPool:
             cls._pools[key] = cls(device)
         return cls._pools[key]
 
-    def reset(self):
+    def reset(self, grad_on=False):
+        """Start a new step.  While an earlier forward still waits for its backward (gradient accumulation over micro-batches, an
+        eval / EMA forward between forward and backward) its pooled tensors must survive: the buffer is then left to them (they
+        hold the storage) and this step draws from a fresh one."""
         want = max(self.need, self.used)
+        if self.pending > 0 and self.buf is not None:
+            want = max(want, self.buf.numel())
+            self.buf = None
+        if grad_on:
+            self.pending += 1
         if self.buf is None or want > self.buf.numel():
-            self.buf = torch.empty(int(want * 1.25) + (1 << 20), dtype=torch.uint8, device=self.device)
+            self.buf = torch.empty(max(int(want * 1.25) + (1 << 20), want), dtype=torch.uint8, device=self.device)
             want = self.buf.numel()                              # a fresh buffer is zeroed in full
         if want:
             self.buf[:want].zero_()
         self.used, self.need = 0, 0
+
+    def backward_done(self):
+        self.pending = max(0, self.pending - 1)
 
     def take(self, shape, dtype):
         n = 1
@@ -107,6 +119,7 @@ class FlatStore:
         self.params = OrderedDict()       # name -> Parameter (unique)
         self.total = 0
         self._cast_version = -1
+        self._c_fresh_version = None
         self.extra = {}                   # derived operand copies: name -> tensor
         self._finalize_queued = False
         self.force_dirty = True
@@ -114,6 +127,8 @@ class FlatStore:
         self.on_backward_done = None      # optional callable(store): data-parallel gradient exchange hook
         self.on_range_ready = None        # optional callable(store, lo, hi): G[lo:hi] is final (overlapped all-reduce)
         self._ranges_done = []
+        self.scale_in_optimizer = False   # set by FusedAdamW: its kernel multiplies the gradient by `pending_grad_scale`
+        self.pending_grad_scale = 1.0     # factor still owed to G (1/world after a data-parallel SUM all-reduce)
 
     # ------------------------------------------------------------------ layout
     def _index(self):
@@ -161,6 +176,8 @@ class FlatStore:
         self.device = device
         self.extra = {}
         self._cast_version = -1
+        self._c_fresh_version = None
+        self._plist = list(self.params.values())
         self.force_dirty = True
 
     def ensure(self, device):
@@ -183,13 +200,21 @@ class FlatStore:
         return src[off:off + n].view(shape)
 
     # ------------------------------------------------------------------ operand copies
+    def versions(self):
+        """Write counter of the master parameters.  After materialize() every Parameter is its own view of P with its own
+        version counter: load_state_dict, torch.optim steps, EMA copies and p.mul_() bump the Parameter's, collectives and
+        flat-buffer ops on P bump P's -- so both are read (a few hundred integer attribute reads per forward).  Writers that
+        go through the C ABI (FusedAdamW) bump neither and set force_dirty."""
+        return self.P._version + sum(p._version for p in self._plist)
+
     def refresh(self, transposed, conv_perm, conv3=()):
         """Bring compute-dtype copies up to date with the fp32 masters.
         transposed: names of 2-D weights needing W^T; conv_perm: names of kernel==stride conv weights used as patch
         GEMMs; conv3: names of the MIM decoder's 3x3 conv weights (forward taps + flipped/transposed dgrad taps)."""
-        if not self.force_dirty and self._cast_version == self.P._version:
+        ver = self.versions()
+        if not self.force_dirty and self._cast_version == ver:
             return
-        if self.C is not None and getattr(self, "_c_fresh_version", None) != self.P._version:
+        if self.C is not None and self._c_fresh_version != ver:
             ops.cast_bf16(self.P, self.C, self.total)        # (the fused AdamW step writes the bf16 copy itself: skipped then)
         self._c_fresh_version = None
         key = (tuple(transposed), tuple(conv_perm), tuple(conv3), self.compute_dtype, self.P.data_ptr())
@@ -198,7 +223,7 @@ class FlatStore:
             self._prep_key = key
         if self._prep_n:
             ops.weight_prep(self._prep_desc, self._prep_blk, self._prep_n, self._prep_blocks, self.compute_dtype)
-        self._cast_version = self.P._version
+        self._cast_version = ver
         self.force_dirty = False
 
     def _build_prep(self, transposed, conv_perm, conv3):
@@ -261,22 +286,33 @@ class FlatStore:
         self._prep_blocks = starts[-1]
 
     # ------------------------------------------------------------------ gradients
-    def begin_step(self):
-        """Zero G unless the caller is deliberately accumulating into .grad tensors that alias it
-        (optimizer.zero_grad(set_to_none=True) leaves .grad None: the usual case)."""
-        name, first = next(iter(self.params.items()))
+    def begin_backward(self):
+        """First HIP-scheduled node of a backward pass: every kernel of the pass ACCUMULATES into G, so G must hold what the
+        caller's `.grad` tensors stand for at this moment -- zeros when they are None (optimizer.zero_grad(), the reference
+        order forward -> zero_grad -> backward, engine_grid_masking.py:40-127) or foreign tensors (autograd adds the slices we
+        return to those), the running sum when they alias G (accumulation over several backward passes without zero_grad;
+        zero_grad(set_to_none=False) zeroes G through the alias).  Deciding here and not in the forward is what makes the
+        second and later optimizer steps correct: during the forward `.grad` still aliases G from the previous step."""
+        name, first = next(iter(self.fn_params))
         if first.grad is None or first.grad.data_ptr() != self.grad(name).data_ptr():
             self.G.zero_()
+            self.pending_grad_scale = 1.0
+        else:
+            self.apply_pending_scale()
+        self._ranges_done = []
 
     def queue_finalize(self):
-        """Called from inside a backward node: run `on_backward_done` once, when this backward pass ends."""
+        """Called at the top of every HIP-scheduled backward node: the first call of a backward pass prepares G
+        (`begin_backward`) and queues `_finalize` to run once when this pass ends."""
         if self._finalize_queued:
             return
         self._finalize_queued = True
+        self.begin_backward()
         torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
 
     def _finalize(self):
         self._finalize_queued = False
+        ZeroPool.of(self.G.device).backward_done()
         self.fold_copies()
         if self.on_backward_done is not None:
             self.on_backward_done(self)
@@ -340,6 +376,19 @@ class FlatStore:
             lo, hi = self.stage_range(i)
             self._ranges_done.append((lo, hi))
             self.on_range_ready(self, lo, hi)
+
+    def scale_grads(self, factor):
+        """G *= factor, now or (when the fused optimizer owns the next step) inside its kernel."""
+        if self.scale_in_optimizer:
+            self.pending_grad_scale *= factor
+        else:
+            self.G.mul_(factor)
+
+    def apply_pending_scale(self):
+        """make G itself carry the owed factor (anything that READS gradients before the optimizer step: clipping, logging)"""
+        if self.pending_grad_scale != 1.0:
+            self.G.mul_(self.pending_grad_scale)
+            self.pending_grad_scale = 1.0
 
     def sync_grads(self):
         """Make G the truth for every parameter (flat-buffer optimizers call this before stepping): gradients that

@@ -62,6 +62,16 @@ class TrunkStep:
         self.saved = []          # per stage dict
         self.training = model.training
 
+    def _mark(self):
+        """bench.py: HIP events around the Block kernels of a stage (SRAttention + MLP incl. their LayerNorms), in pairs, on the
+        launch stream -- the blocks-only GPU time behind north_star's MFMA-utilisation figure.  Off unless model._block_events
+        is a list."""
+        ev = getattr(self.m, "_block_events", None)
+        if ev is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev.append(e)
+
     # ---- parameter access
     def w(self, name):
         return self.S.comp(name)
@@ -190,10 +200,12 @@ class TrunkStep:
                           y_map=rowmap(T, N, HW))
         sv["x_in_prev"] = xp
         sv["blocks"] = []
+        self._mark()
         for j in range(m.depths[i]):
             x, bsv = self._block_forward(i, j, x, blk_index)
             sv["blocks"].append(bsv)
             blk_index += 1
+        self._mark()
         if self.dt != self.rt:               # MFMA-operand copy of the stage output (next stage's convs, the heads)
             xb = _empty((B, N, C), dt, dev)
             ops.cast_bf16(x, xb, x.numel())
@@ -313,8 +325,10 @@ class TrunkStep:
     def _stage_backward(self, i, sv, dx):
         m, B, T, dt, dev = self.m, self.B, self.T, self.dt, self.dev
         C, HW, N, side = sv["C"], sv["HW"], sv["N"], sv["side"]
+        self._mark()
         for j in reversed(range(m.depths[i])):
             dx = self._block_backward(i, j, sv["blocks"][j], dx)
+        self._mark()
         pe, ten = f"patch_embed{i+1}.", f"text_embed{i+1}."
         f32 = torch.float32
         # pos-embed / text-pos-embed gradients: sum over the batch of d(x0)
@@ -685,17 +699,49 @@ class _MLMFusedFn(torch.autograd.Function):
 
 
 # =============================================================================================== top level
-def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None):
+class _HostCount:
+    """A device int32 counter on its way to the host without draining the launch queue: an asynchronous copy into pinned
+    memory plus an event recorded right behind it.  `get()` waits for that event only -- the kernels queued after it (the
+    whole trunk forward, when the selection is the first launch of the step) keep the GPU busy meanwhile."""
+    _pins = {}
+
+    def __init__(self, cnt):
+        key = (cnt.device.index, cnt.numel())
+        pin = self._pins.get(key)
+        if pin is None:
+            pin = self._pins[key] = torch.empty(cnt.numel(), dtype=cnt.dtype).pin_memory()
+        self.pin = pin
+        pin.copy_(cnt, non_blocking=True)
+        self.ev = torch.cuda.Event()
+        self.ev.record()
+
+    def get(self):
+        self.ev.synchronize()
+        return int(self.pin[0])
+
+
+def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_count=None):
+    """mlm_labels: (B, T) int64 with -1 = not selected -> fused masked-row MLM head + loss (`mlm_loss`).
+    mlm_positions: optional precomputed selection (ascending flat indices, int32, on the device).
+    mlm_count: optional number of selected positions as a host int (the engine counts on the host when the loader hands it
+    CPU labels; the device prefetcher brings it along) -- without it the count comes back through `_HostCount`."""
     S = model.store
     dev = images.device
     S.ensure(dev)
-    ZeroPool.of(dev).reset()                                      # one fill for all of this step's zero-initialised scratch
-    S.refresh(model._transposed, model._conv_perm, model._conv3 if model.mim_impl == "hip" else ())
     grad_on = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
-    if grad_on:
-        S.begin_step()
-    x1, x2, x3, x4 = _TrunkFn.apply(model, images, ids, grad_on, *[p for _, p in S.fn_params])
+    ZeroPool.of(dev).reset(grad_on)                               # one fill for all of this step's zero-initialised scratch
     lt = model.loss_type
+    sel = None
+    if lt['mlm'] and mlm_labels is not None and mlm_positions is None:
+        # masked-index selection (bit-exact vs torch.nonzero): first launch of the step, so that its count is on the host long
+        # before the MLM head needs it to size its launches
+        flat = mlm_labels.reshape(-1).contiguous()
+        idx = torch.empty(flat.numel(), device=dev, dtype=torch.int32)
+        cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+        ops.masked_select(flat, idx, cnt)
+        sel = (idx, mlm_count if mlm_count is not None else _HostCount(cnt))
+    S.refresh(model._transposed, model._conv_perm, model._conv3 if model.mim_impl == "hip" else ())
+    x1, x2, x3, x4 = _TrunkFn.apply(model, images, ids, grad_on, *[p for _, p in S.fn_params])
     B = images.shape[0]
     side4 = images.shape[2] // model.patch_size // 8
     HW4 = side4 * side4
@@ -703,12 +749,9 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None):
     if lt['mlm']:
         if mlm_labels is not None:
             flat = mlm_labels.reshape(-1).contiguous()
-            if mlm_positions is None:
-                cap = flat.numel()
-                idx = torch.empty(cap, device=dev, dtype=torch.int32)
-                cnt = torch.zeros(1, device=dev, dtype=torch.int32)
-                ops.masked_select(flat, idx, cnt)
-                mlm_positions = idx[: int(cnt.item())]
+            if sel is not None:
+                idx, n = sel
+                mlm_positions = idx[: (n if isinstance(n, int) else n.get())]
             labels_sel = flat[mlm_positions.long()].contiguous()
             out["mlm_loss"] = _MLMFusedFn.apply(x4, model, HW4, mlm_positions.contiguous(), labels_sel)
             out["mlm_positions"] = mlm_positions

@@ -388,3 +388,44 @@ def step_loss(sd, cfg, batch, step_idx=0, train=True, masks=None, bn_out=None):
 
 def to_torch_batch(np_batch):
     return {k: torch.from_numpy(v) for k, v in np_batch.items()}
+
+
+# --------------------------------------------------------------------------- optimizer + engine loop
+def adamw_param_groups(named_params, weight_decay):
+    """timm==0.3.2 optim_factory.add_weight_decay as create_optimizer applies it (call site main_vl.py:308; timm is not
+    vendored): 1-D tensors and names ending in '.bias' get weight_decay 0, everything else `weight_decay`; group order
+    [no_decay, decay].  named_params: iterable of (name, tensor); a tied tensor must appear once."""
+    no_decay, decay = [], []
+    for name, p in named_params:
+        (no_decay if (p.dim() == 1 or name.endswith(".bias")) else decay).append(p)
+    return [dict(params=no_decay, weight_decay=0.0), dict(params=decay, weight_decay=weight_decay)]
+
+
+def train_loop(sd, cfg, batches, masks_per_iter, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8):
+    """The reference's epoch loop on the functional model (engine_grid_masking.py:38-143): per iteration idx -- clean image
+    on even idx, grid-masked on odd idx when t2i is on (:72-78), the loss composition (:81-102), optimizer.zero_grad(),
+    backward, AdamW step (:122-127; torch.optim.AdamW with timm's param split, main_vl.py:308) -- carrying the BatchNorm
+    running statistics from one iteration to the next.  Returns (list of per-iteration loss dicts, final state dict)."""
+    leaf = OrderedDict()
+    for k, v in sd.items():
+        if k == TIED[0]:
+            continue
+        leaf[k] = v.clone().requires_grad_(True) if (v.is_floating_point() and "running_" not in k) else v.clone()
+    if cfg.loss_type["mlm"]:
+        leaf[TIED[0]] = leaf[TIED[1]]
+    named = [(k, v) for k, v in leaf.items() if k != TIED[0] and v.requires_grad]
+    opt = torch.optim.AdamW(adamw_param_groups(named, weight_decay), lr=lr, betas=betas, eps=eps)
+    hist = []
+    for idx, batch in enumerate(batches):
+        bn_out = {}
+        ls, _ = step_loss(leaf, cfg, batch, idx, train=True, masks=masks_per_iter[idx] if masks_per_iter else None, bn_out=bn_out)
+        opt.zero_grad()
+        ls["total_loss"].backward()
+        opt.step()
+        for k, v in bn_out.items():
+            leaf[k] = v.detach()
+        for k in list(leaf):
+            if k.endswith("num_batches_tracked") and cfg.loss_type["t2i"]:
+                leaf[k] = leaf[k] + 1
+        hist.append({k: float(v) for k, v in ls.items()})
+    return hist, OrderedDict((k, v.detach()) for k, v in leaf.items())

@@ -40,8 +40,22 @@ CASES = {
     "tiny256_all": dict(variant="pvlt_tiny", img=256, T=128, B=2, lt=dict(mlm=1, itm=1, t2i=1, cls=1), dp=0.0, train=False),
     "tiny224_pretrain": dict(variant="pvlt_tiny", img=224, T=128, B=1, lt=dict(mlm=1, itm=1, t2i=1, cls=0), dp=0.0, train=False),
     "tiny384_pretrain": dict(variant="pvlt_tiny", img=384, T=128, B=1, lt=dict(mlm=1, itm=1, t2i=1, cls=0), dp=0.0, train=False),
-    "medium384_pretrain": dict(variant="pvlt_medium", img=384, T=128, B=1, lt=dict(mlm=1, itm=1, t2i=1, cls=0), dp=0.0, train=False),
+    "medium384_pretrain": dict(variant="pvlt_medium", img=384, T=128, B=1, lt=dict(mlm=1, itm=1, t2i=1, cls=0), dp=0.0, train=True),
     "small96_T20_ragged": dict(variant="pvlt_small", img=96, T=20, B=3, lt=dict(mlm=1, itm=1, t2i=1, cls=1), dp=0.1, train=True),
+}
+
+
+# engine loop (train_one_epoch_vl semantics incl. AdamW): per-iteration losses, parameter deltas and BN statistics after `iters`
+# iterations over `iters` different batches (engine_grid_masking.py:38-143, main_vl.py:308)
+LOOP_CASES = {
+    "tiny256_loop": dict(variant="pvlt_tiny", img=256, T=128, B=4, lt=dict(mlm=1, itm=1, t2i=1, cls=0), dp=0.1, iters=4, lr=1e-3, wd=0.05),
+    "tiny256_ft_loop": dict(variant="pvlt_tiny", img=256, T=128, B=4, lt=dict(mlm=0, itm=0, t2i=0, cls=1), dp=0.1, iters=3, lr=1e-3, wd=0.05),
+}
+
+# eval callers (engine_grid_masking.py:153-474 with libs/vl_scores.py): per-batch metrics of evaluate_vl, the 101-candidate
+# ITM ranking of evaluate_retrieval, the predictions and sklearn metrics of evaluate_recognition
+EVAL_CASES = {
+    "tiny128_eval": dict(variant="pvlt_tiny", img=128, T=32, B=6, nb=2, lt=dict(mlm=1, itm=1, t2i=1, cls=1), n_query=2, n_cand=101),
 }
 
 
@@ -256,13 +270,199 @@ def run_case(name, c):
     print(f"[{name}] wrote {path} ({os.path.getsize(path)/1024:.1f} KiB, {len(G)} arrays)")
 
 
+def loop_view(name, delta):
+    """The part of a parameter delta that is comparable between implementations after AdamW steps.  The K half of every
+    `attn.kv.bias` has a mathematically ZERO gradient (softmax is invariant to a per-query shift of the scores, and a key
+    bias shifts all scores of a query by q.b), so what reaches AdamW there is pure rounding noise, which m / sqrt(v)
+    normalises to full-size +-lr steps: the reference and the oracle -- both fp32 PyTorch -- already disagree by 8-16 % on
+    that half.  Only the V half is compared."""
+    if name.endswith("attn.kv.bias"):
+        return delta[delta.numel() // 2:]
+    return delta
+
+
+def build_ref(c, T, dp):
+    from libs import pvlt as ref_pvlt
+    cfg = O.Cfg(c["variant"], c["lt"], 224, 768, T, dp)
+    sd = O.filled_state_dict(cfg, SEED)
+    ref = getattr(ref_pvlt, c["variant"])(pretrained=True, token_hidden_size=768, num_text_tokens=T, loss_type=c["lt"],
+                                         pretrained_pth=None, drop_path_rate=dp, drop_rate=0.0, num_classes=1000, in_chans=3)
+    ref.load_state_dict(sd, strict=True)
+    return cfg, sd, ref
+
+
+def run_loop_case(name, c):
+    """The reference model driven the way train_one_epoch_vl drives it (engine_grid_masking.py:38-143; the engine module itself
+    needs timm.data / torchvision / mmcv and a GPU, so its loop body is restated here around the REAL model and
+    torch.optim.AdamW with timm's parameter split), checked against oracle.train_loop."""
+    from timm.models.layers import DropPath
+    cfg, sd, ref = build_ref(c, c["T"], c["dp"])
+    ref.train()
+    named = [(k, p) for k, p in ref.named_parameters()]           # named_parameters() de-duplicates the tied decoder weight
+    opt = torch.optim.AdamW(O.adamw_param_groups(named, c["wd"]), lr=c["lr"], betas=(0.9, 0.999), eps=1e-8)
+    batches = [O.to_torch_batch(filler.make_batch(SEED + 100 * it, c["B"], c["img"], c["T"])) for it in range(c["iters"])]
+    masks = [make_masks(cfg, c["B"], c["T"], SEED + it) for it in range(c["iters"])]
+    G = {"meta": np.array([SEED, c["B"], c["img"], c["T"], c["dp"], c["iters"], c["lr"], c["wd"]], dtype=np.float64)}
+    hist_ref = []
+    for idx, batch in enumerate(batches):
+        ref.text_embeddings.dropout = FixedDropout(masks[idx]["bert"], 0.1)
+        q = []
+        for k in range(sum(cfg.depths)):
+            if cfg.dpr[k] > 0:
+                q += [masks[idx]["droppath"][k], masks[idx]["droppath2"][k]]
+        DropPath.QUEUE = q
+        img = batch["masked_images"] if (idx % 2 == 1 and c["lt"]["t2i"]) else batch["image"]
+        out = ref(img, batch["input_ids"])
+        ls = O.losses(out, batch)
+        opt.zero_grad()
+        ls["total_loss"].backward()
+        opt.step()
+        assert len(q) == 0
+        DropPath.QUEUE = None
+        hist_ref.append({k: float(v) for k, v in ls.items()})
+    hist_o, sd_o = O.train_loop(sd, cfg, batches, masks, c["lr"], c["wd"])
+    worst = 0.0
+    for it, (hr, ho) in enumerate(zip(hist_ref, hist_o)):
+        for k, v in hr.items():
+            worst = max(worst, abs(v - ho[k]) / max(1e-12, abs(v)))
+            G[f"loop/loss/{it}/{k}"] = np.array(v)
+    sd_ref = ref.state_dict()
+    worst_d = 0.0
+    for k, v in sd_ref.items():
+        if k == O.TIED[0]:
+            continue
+        if not v.is_floating_point():
+            assert int(v) == int(sd_o[k]) == c["iters"], (k, int(v), int(sd_o[k]))
+            G[f"loop/int/{k}"] = np.array(int(v))
+            continue
+        d_ref = loop_view(k, (v - sd[k]).double())
+        d_o = loop_view(k, (sd_o[k] - sd[k]).double())
+        if d_ref.norm().item() > 0:
+            e = ((d_o - d_ref).norm() / d_ref.norm()).item()
+            if e > 1e-3:
+                print("   note: delta", k, "rel err", round(e, 5))
+            worst_d = max(worst_d, e)
+        G[f"loop/delta/{k}/norm"] = np.array(d_ref.norm().item())
+        G[f"loop/delta/{k}/sample"] = sample(d_ref, 64)
+    assert worst < 2e-4 and worst_d < 5e-3, (name, "oracle != reference (loop)", worst, worst_d)
+    print(f"[{name}] {c['iters']} engine iterations: oracle-vs-reference worst loss rel err {worst:.2e}, worst parameter-delta rel err {worst_d:.2e}")
+    print(f"[{name}] losses per iteration:", [round(h['total_loss'], 5) for h in hist_ref])
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **G)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path)/1024:.1f} KiB, {len(G)} arrays)")
+
+
+def eval_batch(seed, it, B, img, T, ref):
+    """a filler batch whose labels are made half right on purpose: for every second masked position / sample the label is the
+    reference model's own top-1, so the accuracies land near 0.5 and react to any argmax that moves"""
+    nb = filler.make_batch(seed + 100 * it, B, img, T)
+    batch = O.to_torch_batch(nb)
+    with torch.no_grad():
+        o_mlm = ref(batch["image"], batch["input_ids"])
+        o_1 = ref(batch["image"], batch["ori_input_ids"])
+    pos = O.masked_positions(batch["mlm_labels"])
+    lab = batch["mlm_labels"].reshape(-1).clone()
+    top = o_mlm["mlm_logits"].reshape(-1, O.VOCAB)[pos].argmax(-1)
+    lab[pos[::2]] = top[::2]
+    batch["mlm_labels"] = lab.reshape(B, T)
+    for key, lk in (("itm_logits", "itm_labels"), ("sup_cls_logits", "sup_cls_labels"), ("sub_cls_logits", "sub_cls_labels")):
+        top = o_1[key].reshape(B, -1).argmax(-1)
+        n = o_1[key].shape[-1]
+        l = batch[lk].reshape(-1).clone()
+        l[::2] = top[::2]
+        l[1::2] = (top[1::2] + 1) % n
+        batch[lk] = l.reshape(B, 1)
+    return batch
+
+
+def run_eval_case(name, c):
+    from libs import vl_scores as VS                      # the reference's own metric functions (torch + math only)
+    from sklearn.metrics import accuracy_score, f1_score
+    cfg, sd, ref = build_ref(c, c["T"], 0.0)
+    ref.eval()
+    B, img, T = c["B"], c["img"], c["T"]
+    G = {"meta": np.array([SEED, B, img, T, c["nb"], c["n_query"], c["n_cand"]], dtype=np.float64)}
+    # ---- evaluate_vl (engine_grid_masking.py:153-333), per batch
+    keys = ("mlm_acc", "itm_acc", "sup_cls_acc", "sub_cls_acc", "t2i_psnr", "total_loss")
+    sums = {k: 0.0 for k in keys}
+    for it in range(c["nb"]):
+        batch = eval_batch(SEED, it, B, img, T, ref)
+        for k in ("mlm_labels", "itm_labels", "sup_cls_labels", "sub_cls_labels"):
+            G[f"vl/{it}/{k}"] = batch[k].numpy().copy()
+        with torch.no_grad():
+            o_mlm = ref(batch["image"], batch["input_ids"])
+            o_1 = ref(batch["image"], batch["ori_input_ids"])
+            o_3 = ref(batch["masked_images"], batch["ori_input_ids"])
+        total = 0.0
+        m = {}
+        total += 1 * torch.nn.CrossEntropyLoss(ignore_index=-1)(o_mlm["mlm_logits"].view(-1, 30522), batch["mlm_labels"].view(-1)).item()
+        m["mlm_acc"] = VS.compute_mlm_score(o_mlm["mlm_logits"], batch["mlm_labels"])
+        total += 1 * torch.nn.CrossEntropyLoss()(o_1["itm_logits"].view(-1, 2), batch["itm_labels"].view(-1)).item()
+        m["itm_acc"] = VS.compute_score_with_logits(o_1["itm_logits"].view(-1, 2), batch["itm_labels"].view(-1)).sum().item() / B
+        total += torch.nn.CrossEntropyLoss()(o_1["sup_cls_logits"].view(-1, 48), batch["sup_cls_labels"].view(-1)).item()
+        total += torch.nn.CrossEntropyLoss()(o_1["sub_cls_logits"].view(-1, 122), batch["sub_cls_labels"].view(-1)).item()
+        m["sup_cls_acc"] = VS.compute_score_with_logits(o_1["sup_cls_logits"].view(-1, 48), batch["sup_cls_labels"].view(-1)).sum().item() / B
+        m["sub_cls_acc"] = VS.compute_score_with_logits(o_1["sub_cls_logits"].view(-1, 122), batch["sub_cls_labels"].view(-1)).sum().item() / B
+        total += 10 * torch.nn.SmoothL1Loss()(o_3["t2i_logits"], batch["image"]).item()
+        m["t2i_psnr"] = VS.compute_psnr(o_3["t2i_logits"], batch["image"])
+        m["total_loss"] = total
+        for k in keys:
+            G[f"vl/{it}/{k}"] = np.array(float(m[k]))
+            sums[k] += float(m[k]) * B
+        # recognition predictions of the same forward (evaluate_recognition, :396-474)
+        G[f"recog/{it}/sup_pred"] = torch.max(torch.softmax(o_1["sup_cls_logits"].view(-1, 48), -1), -1)[1].numpy().copy()
+        G[f"recog/{it}/sub_pred"] = torch.max(torch.softmax(o_1["sub_cls_logits"].view(-1, 122), -1), -1)[1].numpy().copy()
+        G[f"recog/{it}/sup_top2"] = o_1["sup_cls_logits"].view(-1, 48).topk(2, -1)[0].numpy().copy()
+        G[f"recog/{it}/sub_top2"] = o_1["sub_cls_logits"].view(-1, 122).topk(2, -1)[0].numpy().copy()
+    for k in keys:
+        G[f"vl/avg/{k}"] = np.array(sums[k] / (B * c["nb"]))
+    print(f"[{name}] evaluate_vl averages:", {k: round(float(G[f'vl/avg/{k}']), 5) for k in keys})
+    sl = np.concatenate([G[f"vl/{it}/sup_cls_labels"].reshape(-1) for it in range(c["nb"])])
+    sp = np.concatenate([G[f"recog/{it}/sup_pred"] for it in range(c["nb"])])
+    bl = np.concatenate([G[f"vl/{it}/sub_cls_labels"].reshape(-1) for it in range(c["nb"])])
+    bp = np.concatenate([G[f"recog/{it}/sub_pred"] for it in range(c["nb"])])
+    for tag, l, p_ in (("sup", sl, sp), ("sub", bl, bp)):       # calculate_cls_metrics (:477-486)
+        G[f"recog/{tag}_metrics"] = np.array([accuracy_score(l, p_), f1_score(l, p_, average="macro"), f1_score(l, p_, average="micro"),
+                                              f1_score(l, p_, average="weighted")])
+    print(f"[{name}] recognition metrics (acc, macro, micro, weighted): sup {G['recog/sup_metrics'].round(4)}, sub {G['recog/sub_metrics'].round(4)}")
+    # ---- evaluate_retrieval (:336-393): n_cand candidates per query, candidate 0 is the match
+    for qi in range(c["n_query"]):
+        cand = retrieval_query(SEED, qi, c["n_cand"], img, T)
+        with torch.no_grad():
+            logits = ref(cand["images_101"].squeeze(), cand["ori_input_ids_101"].squeeze())["itm_logits"].view(-1, 2)
+        sm = torch.softmax(logits, dim=-1)
+        srt, ind = torch.sort(sm[:, 1], dim=-1, descending=True)
+        rank0 = int(np.argwhere(ind.numpy() == 0))
+        G[f"retr/{qi}/score"] = sm[:, 1].numpy().copy()
+        G[f"retr/{qi}/order"] = ind.numpy().astype(np.int64)
+        G[f"retr/{qi}/rank0"] = np.array(rank0)
+        print(f"[{name}] retrieval query {qi}: rank of candidate 0 = {rank0}, score spread {float(srt[0]):.4f}..{float(srt[-1]):.4f}")
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **G)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path)/1024:.1f} KiB, {len(G)} arrays)")
+
+
+def retrieval_query(seed, qi, n_cand, img, T):
+    """one item of the reference's retrieval loader (mcloader/fashion_gen.py:499-505): `images_101` (1, n, 3, S, S) and
+    `ori_input_ids_101` (1, n, T) -- text retrieval style: the image repeated, n captions"""
+    nb = filler.make_batch(seed + 1000 + qi, n_cand, img, T)
+    images = np.repeat(nb["image"][:1], n_cand, axis=0)
+    return dict(images_101=torch.from_numpy(images)[None], ori_input_ids_101=torch.from_numpy(nb["ori_input_ids"])[None],
+                info_list=[dict(img_name=f"q{qi}_{j}") for j in range(n_cand)])
+
+
 def main():
     install_shims()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or (list(CASES) + list(LOOP_CASES) + list(EVAL_CASES))
     for n in names:
-        run_case(n, CASES[n])
+        if n in LOOP_CASES:
+            run_loop_case(n, LOOP_CASES[n])
+        elif n in EVAL_CASES:
+            run_eval_case(n, EVAL_CASES[n])
+        else:
+            run_case(n, CASES[n])
 
 
 if __name__ == "__main__":

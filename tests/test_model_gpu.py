@@ -115,7 +115,7 @@ def head_prob_err(a, b):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("name", list(CASES))
-def test_eval_forward_parity(golden_dir, name, dtype):
+def test_eval_forward_parity(golden_dir, parity, name, dtype):
     """eval forward vs the REFERENCE's own numbers (golden fixture: strided samples of every stage output and head
     output, full small-head logits, MLM top-8 at the masked positions, a 16x16 grid of the MIM output); the small
     ragged case is additionally compared tensor-for-tensor with the oracle run live on this box's CPU."""
@@ -133,14 +133,14 @@ def test_eval_forward_parity(golden_dir, name, dtype):
             tap = k.split("/")[2]
             if tap in model._taps:
                 e = err_metric(sample(model._taps[tap], 1024), g[k], dtype)
-                if not e < tol:
+                if not parity(f"tap/{tap}", e, tol):
                     bad[k] = e
         if k.startswith("eval/out/") and k.endswith("/sample"):
             key = k.split("/")[2]
             if dtype == torch.bfloat16 and key == "itm_logits":
                 continue                      # checked through its class probabilities below (eval/full/itm_logits)
             e = err_metric(sample(out[key].float(), 4096), g[k], dtype)
-            if not e < tol_for(g, key, dtype):
+            if not parity(f"out/{key}", e, tol_for(g, key, dtype)):
                 bad[k] = e
         if k.startswith("eval/full/"):
             key = k.split("/")[2]
@@ -149,11 +149,12 @@ def test_eval_forward_parity(golden_dir, name, dtype):
                 # B x 2 numbers: a relative error of the logits measures cancellation luck (the reference's own bf16
                 # autocast is 1.7e-2..4.6e-2 off on them); bound the class probabilities they turn into instead
                 e = head_prob_err(out[key].float().cpu().numpy(), g[k])
-                if not e < TOL[dtype]:
+                if not parity(f"full/{key}(prob)", e, TOL[dtype]):
                     bad[k + "(prob)"] = e
+                parity(f"full-logits-info/{key}", err_metric(out[key].float().cpu().numpy(), g[k], dtype), 1.0)
                 continue
             e = err_metric(out[key].float().cpu().numpy(), g[k], dtype)
-            if not e < tol_for(g, key, dtype):
+            if not parity(f"full/{key}", e, tol_for(g, key, dtype)):
                 bad[k] = e
     for key in ("mlm_logits", "itm_logits", "sup_cls_logits", "sub_cls_logits", "t2i_logits"):
         assert (out[key] is None) == (f"eval/out/{key}/sample" not in g.files), key
@@ -164,27 +165,28 @@ def test_eval_forward_parity(golden_dir, name, dtype):
         rows = out["mlm_logits"].reshape(-1, 30522)[pos.to(dev)].float().cpu()
         tv, ti = rows.topk(8, dim=-1)
         e = err_metric(tv.numpy(), g["eval/mlm/top8_val"], dtype)
-        if not e < tol:
+        if not parity("mlm_top8", e, tol):
             bad["mlm_top8"] = e
         agree = float((ti.numpy()[:, 0] == g["eval/mlm/top8_idx"][:, 0]).mean())
+        parity("mlm_argmax_disagreement", 1.0 - agree, 0.01 if dtype == torch.float32 else 0.15)
         assert agree >= (0.99 if dtype == torch.float32 else 0.85), ("MLM argmax agreement", agree)
     if out["t2i_logits"] is not None:
         s_ = max(1, batch["image"].shape[-1] // 16)
         grid = out["t2i_logits"][:, :, ::s_, ::s_].float().cpu().numpy()
         e = err_metric(grid, g["eval/t2i/grid"], dtype)
-        if not e < tol_for(g, "t2i_logits", dtype):
+        if not parity("t2i_grid", e, tol_for(g, "t2i_logits", dtype)):
             bad["t2i_grid"] = e
     if name in LIVE_ORACLE:
         ref, taps_o = oracle_eval(name, sd, cfg, batch)
         for i in range(4):
             for k in (f"img_feat{i+1}", f"text_feat{i+1}"):
                 e = err_metric(model._taps[k].cpu().numpy(), taps_o[k].numpy(), dtype)
-                if not e < tol:
+                if not parity("oracle-tap/" + k, e, tol):
                     bad["oracle/" + k] = e
         for k, v in ref.items():
             if v is not None and not (dtype == torch.bfloat16 and k == "itm_logits"):
                 e = err_metric(out[k].float().cpu().numpy(), v.numpy(), dtype)
-                if not e < tol_for(g, k, dtype):
+                if not parity("oracle-out/" + k, e, tol_for(g, k, dtype)):
                     bad["oracle/" + k] = e
     assert not bad, (name, str(dtype), bad)
     # masked-index selection, bit-exact
@@ -208,8 +210,8 @@ def _losses_like_engine(out, batch, dev):
 
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("name", ["tiny256_pretrain", "small96_T20_ragged", "tiny256_ft"])
-def test_train_step_parity(golden_dir, name, dtype, fused):
+@pytest.mark.parametrize("name", ["tiny256_pretrain", "small96_T20_ragged", "tiny256_ft", "medium384_pretrain"])
+def test_train_step_parity(golden_dir, parity, name, dtype, fused):
     """one train-mode step with injected dropout / DropPath masks: losses, every parameter-gradient norm and a strided
     sample of every gradient vs the REFERENCE's values in the golden fixture; the small ragged case also compares every
     full gradient tensor with the oracle run live."""
@@ -217,6 +219,8 @@ def test_train_step_parity(golden_dir, name, dtype, fused):
     model, cfg, sd, batch, g, seed = build(name, golden_dir, dtype)
     if fused and not cfg.loss_type["mlm"]:
         pytest.skip("no MLM head")
+    if name == "medium384_pretrain" and not fused:
+        pytest.skip("config #4 (PVT-medium, 384 px, M = 272 keys) is checked through the engine's fused MLM path")
     dev = torch.device("cuda:0")
     step_idx = 1 if cfg.loss_type["t2i"] else 0
     B, T = batch["image"].shape[0], batch["input_ids"].shape[1]
@@ -233,7 +237,7 @@ def test_train_step_parity(golden_dir, name, dtype, fused):
         gk = f"train{step_idx}/loss/{k}"
         if gk in g.files:
             ref = float(g[gk])
-            assert abs(float(ls[k]) - ref) <= 2 * tol * max(1.0, abs(ref)), (k, float(ls[k]), ref)
+            assert parity(f"loss/{k}", abs(float(ls[k]) - ref) / max(1.0, abs(ref)), 2 * tol), (k, float(ls[k]), ref)
     gtol = 5e-3 if dtype == torch.float32 else 8e-2
     bad, n_checked = {}, 0
     for k, p in model.named_parameters():
@@ -249,7 +253,9 @@ def test_train_step_parity(golden_dir, name, dtype, fused):
         smp = sample(p.grad, 32)
         ref_s = g[f"train{step_idx}/grad/{k}/sample"]
         es = float(np.abs(smp - ref_s).max() / max(np.abs(ref_s).max(), 1e-3 * refn / max(1.0, p.numel() ** 0.5)))
-        if abs(gn - refn) > gtol * refn or es > 4 * gtol:
+        ok_n = parity("grad-norm/" + k, abs(gn - refn) / refn, gtol)
+        ok_s = parity("grad-sample/" + k, es, 4 * gtol)
+        if not (ok_n and ok_s):
             bad[k] = (gn, refn, es)
     assert n_checked > 50
     assert not bad, (name, str(dtype), len(bad), sorted(bad.items(), key=lambda kv: -abs(kv[1][0] - kv[1][1]) / kv[1][1])[:10])
@@ -261,7 +267,7 @@ def test_train_step_parity(golden_dir, name, dtype, fused):
             if ref_g is None or ref_g.double().norm().item() < 1e-7:
                 continue
             e = ((p.grad.detach().double().cpu() - ref_g.double()).norm() / ref_g.double().norm()).item()
-            if not e < gtol:
+            if not parity("grad-full-vs-oracle/" + k, e, gtol):
                 worst[k] = e
         assert not worst, (name, str(dtype), sorted(worst.items(), key=lambda kv: -kv[1])[:12])
 

@@ -104,3 +104,40 @@ def test_train_step_matches_reference_golden(golden_dir, name):
     assert n > 100
     for k, v in bn.items():
         assert close(v.numpy(), g[f"train{step_idx}/bn/{k}"]), k
+
+
+@pytest.mark.parametrize("name,variant,lt", [("tiny256_loop", "pvlt_tiny", dict(mlm=1, itm=1, t2i=1, cls=0)),
+                                             ("tiny256_ft_loop", "pvlt_tiny", dict(mlm=0, itm=0, t2i=0, cls=1))])
+def test_engine_loop_matches_reference_golden(golden_dir, name, variant, lt):
+    """oracle.train_loop (engine iteration order + AdamW with timm's split) against the REAL reference model driven the same
+    way: per-iteration losses, every parameter's delta after the AdamW steps, BatchNorm counters."""
+    from tests.golden.make_golden import loop_view, make_masks
+    torch.set_num_threads(min(8, usable_cores()))
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    seed, B, img, T, dp, iters, lr, wd = g["meta"]
+    seed, B, img, T, iters = int(seed), int(B), int(img), int(T), int(iters)
+    cfg = O.Cfg(variant, lt, 224, 768, T, float(dp))
+    sd = O.filled_state_dict(cfg, seed)
+    batches = [O.to_torch_batch(filler.make_batch(seed + 100 * it, B, img, T)) for it in range(iters)]
+    masks = [make_masks(cfg, B, T, seed + it) for it in range(iters)]
+    hist, sd_o = O.train_loop(sd, cfg, batches, masks, float(lr), float(wd))
+    for it, h in enumerate(hist):
+        for k, v in h.items():
+            ref = float(g[f"loop/loss/{it}/{k}"])
+            assert abs(v - ref) <= TOL * max(1.0, abs(ref)), (it, k)
+    n = 0
+    for k, v in sd_o.items():
+        if k == O.TIED[0]:
+            continue
+        if not v.is_floating_point():
+            assert int(v) == int(g[f"loop/int/{k}"]) == iters
+            continue
+        refn = float(g[f"loop/delta/{k}/norm"])
+        if refn == 0.0:
+            continue
+        d = loop_view(k, (v - sd[k]).double())
+        assert abs(d.norm().item() - refn) <= 1e-2 * refn, k
+        rs = g[f"loop/delta/{k}/sample"]
+        assert np.linalg.norm(sample(d, 64) - rs) <= 2e-2 * np.linalg.norm(rs) + 1e-12, k
+        n += 1
+    assert n > 50
