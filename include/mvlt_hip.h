@@ -187,6 +187,22 @@ int mvlt_patchify(const float* img, void* out, int B, int Cin, int H, int W, int
  * set CrossEntropyLoss(ignore_index=-1) averages over (reference engine_grid_masking.py:84). */
 int mvlt_masked_select(const long* labels, int n, long ignore_index, int* idx, int* count, void* stream);
 
+/* ---- device-side batch preparation (what the reference's dataset does per sample on the host, mcloader/fashion_gen.py) ----
+ * All three draw from Philox4x32-10 with key = seed and counter = (element, sample id, stream): sample b of a call has id
+ * sample0 + b, so results do not depend on batch composition; oracle/batchprep_oracle.py restates them bit for bit.
+ *
+ * mvlt_grid_mask_flags: flags[b, gh*gw] (1 = masked patch).  mode 0: exactly num_mask patches, uniformly.  mode 1: the
+ *   reference generator `generate_grid_mask` (fashion_gen.py:225-254): one shuffle of [0]*(P-num_mask)+[1]*num_mask, then patch
+ *   row i re-shuffles the window shuffled[i : i+gw].  At most 4096 patches per sample.
+ * mvlt_grid_mask_apply: masked[b,c,y,x] = flags[b, y/patch, x/patch] ? fill : image[b,c,y,x] on NCHW fp32 -- the
+ *   `image.clone().masked_fill_(mask, 1e-6)` of fashion_gen.py:176 (fill = 1e-6, patch = 16).
+ * mvlt_token_mask: `random_masking_features` (fashion_gen.py:383-409) on token ids: positions t >= 1 whose id is not
+ *   PAD(0)/CLS(101)/SEP(102) are selected with probability 0.15; selected -> [MASK]=103 (80 %), uniform id in [0, vocab) (10 %),
+ *   unchanged (10 %); labels = original id where selected, -1 elsewhere.  ori_ids / input_ids / labels: int64 [B, T]. */
+int mvlt_grid_mask_flags(uint8_t* flags, int B, int gh, int gw, int num_mask, int mode, uint64_t seed, uint64_t sample0, void* stream);
+int mvlt_grid_mask_apply(const float* image, const uint8_t* flags, float* masked, int B, int C, int H, int W, int patch, float fill, void* stream);
+int mvlt_token_mask(const long* ori_ids, long* input_ids, long* labels, int B, int T, uint64_t seed, uint64_t sample0, int vocab, void* stream);
+
 /* dst[r,:] = src[map(idx[r]),:]  and  dst[map(idx[r]),:] (+)= src[r,:]   (idx rows unique; map = mode-0 rowmap or NULL) */
 int mvlt_gather_rows(const void* src, const int* idx, void* dst, int rows, int C, int ld_src, const mvlt_rowmap* src_map, int dtype, void* stream);
 int mvlt_scatter_rows(const void* src, const int* idx, void* dst, int rows, int C, int ld_dst, const mvlt_rowmap* dst_map, int accumulate, int dtype, void* stream);

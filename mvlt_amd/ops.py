@@ -312,3 +312,32 @@ def mlp_bwd_dw(x, dy, w1, w2t, b1, dw1, db1, dw2, db2, M, Cdim, hid, *, row_scal
     a = L.MlpArgs(ptr(x), ptr(dy), ptr(w1), None, ptr(w2t), ptr(b1), None, None, ptr(row_scale), rows_per_scale,
                   None, None, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), M, Cdim, hid)
     check(L.lib.mvlt_mlp_bwd_dw(C.byref(a), stream_ptr()), "mvlt_mlp_bwd_dw")
+
+
+# ------------------------------------------------------------------ device-side batch preparation (csrc/batchprep.hip)
+_u64 = C.c_uint64
+L.lib.mvlt_grid_mask_flags.argtypes = [_vp, _i, _i, _i, _i, _i, _u64, _u64, _vp]
+L.lib.mvlt_grid_mask_apply.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]
+L.lib.mvlt_token_mask.argtypes = [_vp, _vp, _vp, _i, _i, _u64, _u64, _i, _vp]
+
+
+def grid_mask_flags(flags, B, gh, gw, num_mask, mode, seed, sample0):
+    _need_cuda(flags)
+    assert flags.dtype == torch.uint8 and flags.is_contiguous() and flags.numel() == B * gh * gw
+    check(L.lib.mvlt_grid_mask_flags(_p(flags), B, gh, gw, num_mask, mode, seed, sample0, stream_ptr()), "mvlt_grid_mask_flags")
+    return flags
+
+
+def grid_mask_apply(image, flags, masked, patch=16, fill=1e-6):
+    _need_cuda(image, flags, masked)
+    assert image.dtype == torch.float32 and masked.dtype == torch.float32 and image.is_contiguous() and masked.is_contiguous()
+    B, Cc, H, W = image.shape
+    check(L.lib.mvlt_grid_mask_apply(_p(image), _p(flags), _p(masked), B, Cc, H, W, patch, fill, stream_ptr()), "mvlt_grid_mask_apply")
+    return masked
+
+
+def token_mask(ori_ids, input_ids, labels, seed, sample0, vocab=30522):
+    _need_cuda(ori_ids, input_ids, labels)
+    assert ori_ids.dtype == input_ids.dtype == labels.dtype == torch.int64 and ori_ids.is_contiguous()
+    B, T = ori_ids.shape
+    check(L.lib.mvlt_token_mask(_p(ori_ids), _p(input_ids), _p(labels), B, T, seed, sample0, vocab, stream_ptr()), "mvlt_token_mask")

@@ -451,13 +451,124 @@ def retrieval_query(seed, qi, n_cand, img, T):
                 info_list=[dict(img_name=f"q{qi}_{j}") for j in range(n_cand)])
 
 
+def run_batchprep_case(name="batchprep_ref"):
+    """Pin the decision logic of oracle/batchprep_oracle.py against the reference's OWN dataset functions
+    (mcloader/fashion_gen.py:225-254 generate_grid_mask, :383-409 random_masking_features), run here with their random draws
+    replaced by the oracle's Philox-derived ones: np.random.shuffle applies the oracle's permutations, random.random /
+    random.choice return the oracle's draws.  The module imports cv2 and torchvision at the top (absent in this image, unused
+    by the two functions): empty stand-in modules are registered for the import only."""
+    import random
+    import types
+    from oracle import batchprep_oracle as BP
+    for mod in ("cv2", "torchvision", "torchvision.transforms"):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    from mcloader import fashion_gen as FG
+    G = {}
+    seed = SEED
+    # ---- grid mask: (S, ratio) cases x samples; the reference is driven with the oracle's permutations
+    cases = [(256, 0.5), (384, 0.5), (256, 0.75), (224, 0.25)]
+    G["grid/cases"] = np.array(cases, dtype=np.float64)
+    real_shuffle = np.random.shuffle
+    for ci, (S, ratio) in enumerate(cases):
+        g = S // 16
+        P = g * g
+        for sample in range(4):
+            k1 = BP.draws(seed, sample, np.arange(P), BP.STREAM_GRID)[0]
+            k2 = BP.draws(seed, sample, np.arange(P), BP.STREAM_ROW)[0].reshape(g, g)
+            pg, prow = BP.perm_from_keys(k1), [BP.perm_from_keys(k2[i]) for i in range(g)]
+            queue = [pg] + prow
+
+            def fake_shuffle(x, queue=queue):
+                perm = queue.pop(0)
+                assert len(perm) == len(x)
+                x[:] = [x[j] for j in perm]
+
+            np.random.shuffle = fake_shuffle
+            try:
+                m = FG.FashionGenDatasetPreTrain.generate_grid_mask(None, input_size=(S, S), mask_ratio=ratio, patch_size=16)
+            finally:
+                np.random.shuffle = real_shuffle
+            assert not queue and m.shape == (1, S, S)
+            ref_flags = m[0, ::16, ::16].astype(np.uint8)
+            assert np.array_equal(np.repeat(np.repeat(ref_flags, 16, 0), 16, 1), m[0].astype(np.uint8))      # patches are constant
+            mine = BP.grid_flags(seed, sample, g, g, int(ratio * P), 1)
+            assert np.array_equal(mine, ref_flags), ("grid mask restatement != reference", S, ratio, sample)
+            G[f"grid/{ci}/{sample}"] = ref_flags
+        print(f"[{name}] generate_grid_mask S={S} ratio={ratio}: oracle == reference on 4 samples; realised ratios",
+              [round(float(G[f'grid/{ci}/{s_}'].mean()), 3) for s_ in range(4)])
+    # masked_fill (fashion_gen.py:176) on one sample
+    img = filler.unit(seed, "bp_image", 3 * 256 * 256).reshape(3, 256, 256).astype(np.float32)
+    flags = G["grid/0/0"]
+    mask_full = np.repeat(np.repeat(flags, 16, 0), 16, 1)[None].astype(np.float64)          # (1, S, S) like the reference's img_mask
+    ref_masked = torch.from_numpy(img).clone().masked_fill_(torch.Tensor(mask_full).byte().bool(), value=torch.tensor(1e-6)).numpy()
+    assert np.array_equal(BP.apply_grid_mask(img, flags), ref_masked)
+    G["fill/sample"] = ref_masked[:, ::7, ::5].copy()
+    # ---- token masking: the reference method on token strings "<id>", vocab maps them back
+    vocab = {str(i): i for i in range(BP.VOCAB)}
+    vocab["[MASK]"] = BP.TOK_MASK
+    vocab.pop(str(BP.TOK_MASK))
+    items = list(vocab.items())
+    fake_self = types.SimpleNamespace(word_mask_rate=0.15, tokenizer=types.SimpleNamespace(vocab=vocab))
+    T = 128
+    real_random, real_choice = random.random, random.choice
+    n_sel = 0
+    for sample in range(6):
+        nb = filler.make_batch(seed + sample, 1, 32, T)
+        ori = nb["ori_input_ids"][0]
+        L = int(np.nonzero(ori == BP.TOK_SEP)[0][0]) - 1
+        x0, x1, x2, _ = BP.draws(seed, sample, np.arange(T), BP.STREAM_TOKEN)
+        r1, r2, r3 = x0 >> np.uint32(8), x1 >> np.uint32(8), x2
+        state = dict(t=1)
+
+        def fake_random():
+            t = state["t"]
+            state["t"] += 1
+            state["cur"] = t
+            # a draw that makes the reference take the oracle's branch: prob < 0.15 iff selected, prob / 0.15 = r2 / 2^24
+            return 0.15 * (float(r2[t]) / 2 ** 24) if r1[t] < BP.T15 else 0.5
+
+        def fake_choice(seq):
+            return seq[int((int(r3[state["cur"]]) * BP.VOCAB) >> 32)]
+
+        tokens = [str(int(v)) if int(v) != BP.TOK_MASK else "[MASK]" for v in ori[1:1 + L]]
+        random.random, random.choice = fake_random, fake_choice
+        try:
+            out_tokens, lm_label = FG.FashionGenDatasetPreTrain.random_masking_features(fake_self, list(tokens))
+        finally:
+            random.random, random.choice = real_random, real_choice
+        # label / id assembly of text_process (fashion_gen.py:340-364)
+        ref_ids = np.zeros(T, dtype=np.int64)
+        ref_ids[0], ref_ids[1 + L] = BP.TOK_CLS, BP.TOK_SEP
+        ref_ids[1:1 + L] = [vocab[t_] for t_ in out_tokens]
+        ref_lab = np.array([-1] + lm_label + [-1] * (T - L - 1) , dtype=np.int64)[:T]
+        ids, lab = BP.mask_tokens(seed, sample, ori)
+        # items order: the uniform pick indexes list(vocab.items()); with "103" renamed to "[MASK]" and moved to the end the index of
+        # id i is i for i < 103 and i - 1 above -- map the oracle's uniform id through the same table for the comparison
+        pick = {i: items[i][1] for i in range(BP.VOCAB)}
+        ids_cmp = ids.copy()
+        rnd_pos = (lab != -1) & (ids != BP.TOK_MASK) & (ids != ori)
+        ids_cmp[rnd_pos] = [pick[int(v)] for v in ids[rnd_pos]]
+        assert np.array_equal(lab, ref_lab), ("token labels restatement != reference", sample)
+        assert np.array_equal(ids_cmp, ref_ids), ("token ids restatement != reference", sample)
+        n_sel += int((lab != -1).sum())
+        G[f"tok/{sample}/ori"], G[f"tok/{sample}/ids"], G[f"tok/{sample}/labels"] = ori, ids, lab
+    print(f"[{name}] random_masking_features: oracle == reference on 6 captions ({n_sel} selected positions)")
+    G["meta"] = np.array([seed], dtype=np.float64)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **G)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path)/1024:.1f} KiB, {len(G)} arrays)")
+
+
 def main():
     install_shims()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    names = sys.argv[1:] or (list(CASES) + list(LOOP_CASES) + list(EVAL_CASES))
+    names = sys.argv[1:] or (list(CASES) + list(LOOP_CASES) + list(EVAL_CASES) + ["batchprep_ref"])
     for n in names:
-        if n in LOOP_CASES:
+        if n == "batchprep_ref":
+            run_batchprep_case(n)
+        elif n in LOOP_CASES:
             run_loop_case(n, LOOP_CASES[n])
         elif n in EVAL_CASES:
             run_eval_case(n, EVAL_CASES[n])

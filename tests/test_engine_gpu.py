@@ -116,7 +116,7 @@ def test_train_one_epoch_vl_matches_reference_loop(golden_dir, parity, name, dty
     for it, mean in enumerate(seen):
         want = batches[it]["masked_images" if (it % 2 == 1 and cfg.loss_type["t2i"]) else "image"].mean().item()
         assert abs(mean - want) < 1e-5, (it, mean, want)
-    ltol = 2e-3 if dtype == torch.float32 else 4e-2
+    ltol = 1e-3 if dtype == torch.float32 else 2e-2
     for k in RESULT_KEYS - {"lr"}:
         vals = [float(g[f"loop/loss/{it}/{k}"]) if f"loop/loss/{it}/{k}" in g.files else 0.0 for it in range(iters)]
         ref = sum(vals) / iters
@@ -230,4 +230,5 @@ def test_masked_selection_count_paths_agree():
         b = m(x, ids, mlm_labels=lab, mlm_count=n)
         c = m(x, ids, mlm_labels=lab, mlm_positions=pos)
     assert torch.equal(a["mlm_positions"], pos) and torch.equal(b["mlm_positions"], pos)          # bit-exact selection
-    assert float(a["mlm_loss"]) == float(b["mlm_loss"]) == float(c["mlm_loss"])
+    la, lb, lc = float(a["mlm_loss"]), float(b["mlm_loss"]), float(c["mlm_loss"])       # (the loss sum uses fp32 atomics: equal up to order)
+    assert abs(la - lb) <= 1e-5 * abs(la) and abs(la - lc) <= 1e-5 * abs(la), (la, lb, lc)

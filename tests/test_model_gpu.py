@@ -95,15 +95,11 @@ def err_metric(a, b, dtype):
 
 
 def tol_for(g, key, dtype):
-    """2e-2 for bf16 (north_star), except where bf16 ITSELF is noisier than that on this output: the fixture stores the
-    error of the REFERENCE run under torch.autocast(bf16) against its own fp32 forward (eval/bf16_floor/<key>; e.g.
-    1.2e-2..1.8e-2 on the MIM output, whose three-way feature products triple the trunk's rounding noise).  The floor is
-    a one-draw estimate of white rounding noise, so the bound is 2x it."""
-    if dtype == torch.float32:
-        return TOL[dtype]
-    fk = f"eval/bf16_floor/{key}"
-    floor = float(g[fk]) if fk in g.files else 0.0
-    return max(TOL[dtype], 2.0 * floor)
+    """north_star's bounds, flat: 1e-3 (fp32 path), 2e-2 (bf16 path).  Round 1 allowed 2x the reference's own bf16-autocast
+    noise floor (stored in the fixtures as eval/bf16_floor/<key>) on the MIM output; the achieved errors printed at the end of
+    the run (conftest.parity) show every output under 2e-2 -- worst 1.6e-2, t2i_logits of pvlt_medium at 384 px, where the
+    reference's own autocast run is 1.4e-2 off its fp32 self -- so the exception is gone."""
+    return TOL[dtype]
 
 
 def head_prob_err(a, b):
@@ -237,7 +233,7 @@ def test_train_step_parity(golden_dir, parity, name, dtype, fused):
         gk = f"train{step_idx}/loss/{k}"
         if gk in g.files:
             ref = float(g[gk])
-            assert parity(f"loss/{k}", abs(float(ls[k]) - ref) / max(1.0, abs(ref)), 2 * tol), (k, float(ls[k]), ref)
+            assert parity(f"loss/{k}", abs(float(ls[k]) - ref) / max(1.0, abs(ref)), tol), (k, float(ls[k]), ref)
     gtol = 5e-3 if dtype == torch.float32 else 8e-2
     bad, n_checked = {}, 0
     for k, p in model.named_parameters():
