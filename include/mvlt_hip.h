@@ -85,6 +85,9 @@ typedef struct mvlt_gemm_tn_args {
   int splits;                /* 0 = choose */
   float* colsum_b;           /* optional [N2] += sum_m B[m,:] (at most one of colsum_a / colsum_b) */
   int trans_c;               /* store C transposed: C[n2*ldc + n1] (lets the narrow operand take the 64-wide tile side) */
+  int c_taps, c_seg;         /* c_taps > 1: logical column n2 = tap*c_seg + c is stored at column c*c_taps + tap -- a conv weight
+                              * gradient computed in the gather's [out][tap][cin] order lands in nn.Conv2d's [out][cin][kh][kw]
+                              * layout directly (N2 == c_taps*c_seg, trans_c == 0) */
 } mvlt_gemm_tn_args;
 int mvlt_gemm_tn(const mvlt_gemm_tn_args* args, void* stream);
 
@@ -186,6 +189,16 @@ int mvlt_patchify(const float* img, void* out, int B, int Cin, int H, int W, int
 /* Masked-index selection (bit-exact): idx[0..*count) = ascending p with labels[p] != ignore_index.  This is the row
  * set CrossEntropyLoss(ignore_index=-1) averages over (reference engine_grid_masking.py:84). */
 int mvlt_masked_select(const long* labels, int n, long ignore_index, int* idx, int* count, void* stream);
+
+/* Bilinear resize (align_corners=False, PyTorch index rule) of a token-major fp32 map in[Hin*Win, C] -> out[Hout*Wout, C]:
+ * F.interpolate on the learned position embeddings, reference libs/pvlt.py:291-297 (`_get_pos_embed`).  adjoint != 0: `in` is
+ * the gradient w.r.t. the resized [Hout*Wout, C] map and is ACCUMULATED (atomics) into out[Hin*Win, C], the gradient of the
+ * source map. */
+int mvlt_resize_bilinear_tokens(const float* in, int ld_in, float* out, int ld_out, int Hin, int Win, int Hout, int Wout, int C, int adjoint,
+                                void* stream);
+
+/* out = dy * gelu'(h), exact-erf GELU, elementwise over n values (autograd of reference libs/vl_heads.py:13-14,31-32) */
+int mvlt_gelu_bwd(const void* dy, const void* h, void* out, long n, int dtype, void* stream);
 
 /* ---- device-side batch preparation (what the reference's dataset does per sample on the host, mcloader/fashion_gen.py) ----
  * All three draw from Philox4x32-10 with key = seed and counter = (element, sample id, stream): sample b of a call has id

@@ -461,6 +461,44 @@ inline int grid_for(long work, int cap = 4096) {
   return (int)g;
 }
 
+
+// ------------------------------------------------------------------ bilinear resize of a token-major [Hin*Win, C] fp32 map
+// PyTorch's upsample_bilinear2d index rule for align_corners=False (what F.interpolate(mode="bilinear") runs at reference
+// libs/pvlt.py:295-297 on the learned position embeddings): src = (dst + 0.5) * in/out - 0.5 clamped at 0, neighbours
+// floor(src) and min(floor(src)+1, in-1).  ADJ = false: out[(y,x), c] = sum of 4 weighted inputs.  ADJ = true: the adjoint --
+// `in` is the gradient w.r.t. the resized map, every element is scattered (atomics) into the gradient of the source map `out`.
+template <bool ADJ>
+__global__ __launch_bounds__(NT) void resize_tokens_kernel(const float* in, int ld_in, float* out, int ld_out, int Hin, int Win, int Hout, int Wout,
+                                                           int C, float sh, float sw) {
+  const long n = (long)Hout * Wout * C;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const int c = (int)(i % C);
+    const int px = (int)(i / C);
+    const int y = px / Wout, x = px - y * Wout;
+    const float fy = fmaxf(sh * ((float)y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sw * ((float)x + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    if constexpr (!ADJ) {
+      out[(long)px * ld_out + c] = w00 * in[(long)(y0 * Win + x0) * ld_in + c] + w01 * in[(long)(y0 * Win + x1) * ld_in + c] +
+                                   w10 * in[(long)(y1 * Win + x0) * ld_in + c] + w11 * in[(long)(y1 * Win + x1) * ld_in + c];
+    } else {
+      const float g = in[(long)px * ld_in + c];
+      atomicAdd(&out[(long)(y0 * Win + x0) * ld_out + c], w00 * g);
+      atomicAdd(&out[(long)(y0 * Win + x1) * ld_out + c], w01 * g);
+      atomicAdd(&out[(long)(y1 * Win + x0) * ld_out + c], w10 * g);
+      atomicAdd(&out[(long)(y1 * Win + x1) * ld_out + c], w11 * g);
+    }
+  }
+}
+
+// out = dy * gelu'(h) (exact-erf GELU; BertHeadTransform backward, reference libs/vl_heads.py:13-14,31-32)
+template <typename T>
+__global__ __launch_bounds__(NT) void gelu_bwd_kernel(const T* dy, const T* h, T* out, long n) {
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT)
+    out[i] = (T)((float)dy[i] * gelu_erf_grad((float)h[i]));
+}
 }  // namespace
 
 extern "C" int mvlt_bert_embed_fwd(const long* ids, const float* word, const float* pos, const float* type0, const float* gamma,
@@ -502,6 +540,24 @@ extern "C" int mvlt_patchify(const float* img, void* out, int B, int Cin, int H,
   if (dtype == 0) hipLaunchKernelGGL((patchify_kernel<bf16>), grid, block, 0, (hipStream_t)stream, img, (bf16*)out, B, Cin, H, W, k);
   else hipLaunchKernelGGL((patchify_kernel<float>), grid, block, 0, (hipStream_t)stream, img, (float*)out, B, Cin, H, W, k);
   return mvlt_check_launch("mvlt_patchify");
+}
+
+extern "C" int mvlt_resize_bilinear_tokens(const float* in, int ld_in, float* out, int ld_out, int Hin, int Win, int Hout, int Wout, int C, int adjoint,
+                                           void* stream) {
+  MVLT_REQUIRE(in && out && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && C > 0 && ld_in >= C && ld_out >= C, "mvlt_resize_bilinear_tokens: bad arguments");
+  const long n = (long)Hout * Wout * C;
+  const float sh = (float)Hin / (float)Hout, sw = (float)Win / (float)Wout;
+  if (adjoint) hipLaunchKernelGGL((resize_tokens_kernel<true>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, in, ld_in, out, ld_out, Hin, Win, Hout, Wout, C, sh, sw);
+  else hipLaunchKernelGGL((resize_tokens_kernel<false>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, in, ld_in, out, ld_out, Hin, Win, Hout, Wout, C, sh, sw);
+  return mvlt_check_launch("mvlt_resize_bilinear_tokens");
+}
+
+extern "C" int mvlt_gelu_bwd(const void* dy, const void* h, void* out, long n, int dtype, void* stream) {
+  MVLT_REQUIRE(dy && h && out && n >= 0 && (dtype == 0 || dtype == 1), "mvlt_gelu_bwd: bad arguments");
+  if (n == 0) return MVLT_OK;
+  if (dtype == 0) hipLaunchKernelGGL((gelu_bwd_kernel<bf16>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)h, (bf16*)out, n);
+  else hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, (const float*)dy, (const float*)h, (float*)out, n);
+  return mvlt_check_launch("mvlt_gelu_bwd");
 }
 
 extern "C" int mvlt_masked_select(const long* labels, int n, long ignore_index, int* idx, int* count, void* stream) {

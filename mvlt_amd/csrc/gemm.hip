@@ -702,6 +702,13 @@ template <> struct TElem<float> { static constexpr int ROWB = (TBK + 4) * 4; }; 
 // fragment read, which therefore stays contiguous) spreads them over 8 banks (2-way on ds_write_b32 is free).
 __device__ __forceinline__ int tsw(int n, int pair) { return pair ^ (((n >> 3) & 7) << 2); }
 
+// destination column of logical output column n2 (mvlt_gemm_tn_args.c_taps / c_seg: [tap][cin] -> [cin][tap])
+__device__ __forceinline__ int tn_dst_col(const mvlt_gemm_tn_args& p, int n2) {
+  if (p.c_taps <= 1) return n2;
+  const int tap = n2 / p.c_seg;
+  return (n2 - tap * p.c_seg) * p.c_taps + tap;
+}
+
 template <typename T, int BN>
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, int m_per_split) {
   constexpr int PC = Elem<T>::PER_CHUNK;             // elements per 16-B global chunk
@@ -887,7 +894,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mvlt_gemm_tn_args p, 
       for (int r = 0; r < 4; ++r) {
         int n1 = n1_0 + wm * 64 + i * 16 + 4 * fg + r;
         int n2 = n2_0 + wn * WN + j * 16 + fr;
-        if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.trans_c ? &p.C[(long)n2 * p.ldc + n1] : &p.C[(long)n1 * p.ldc + n2], acc[i][j][r]);
+        if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.trans_c ? &p.C[(long)n2 * p.ldc + n1] : &p.C[(long)n1 * p.ldc + tn_dst_col(p, n2)], acc[i][j][r]);
       }
 }
 
@@ -1182,7 +1189,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_a
       for (int r = 0; r < 4; ++r) {
         int n1 = n1_0 + wm * WM + i * 16 + 4 * fg + r;
         int n2 = n2_0 + wn * WN + j * 16 + fr;
-        if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.trans_c ? &p.C[(long)n2 * p.ldc + n1] : &p.C[(long)n1 * p.ldc + n2], acc[i][j][r]);
+        if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.trans_c ? &p.C[(long)n2 * p.ldc + n1] : &p.C[(long)n1 * p.ldc + tn_dst_col(p, n2)], acc[i][j][r]);
       }
 }
 
@@ -1482,6 +1489,7 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
   MVLT_REQUIRE(a->a_map.mode == 0, "mvlt_gemm_tn: A cannot be a patch gather");
   MVLT_REQUIRE(!(a->colsum_a && a->colsum_b), "mvlt_gemm_tn: at most one of colsum_a / colsum_b");
   MVLT_REQUIRE(a->b_map.mode == 0 || a->N2 == a->b_map.r * a->b_map.r * a->b_map.c_seg, "mvlt_gemm_tn: gather N2 != r*r*c_seg");
+  MVLT_REQUIRE(a->c_taps <= 1 || (a->trans_c == 0 && a->c_seg > 0 && a->N2 == a->c_taps * a->c_seg), "mvlt_gemm_tn: c_taps needs trans_c == 0 and N2 == c_taps*c_seg");
   if (a->M == 0) return MVLT_OK;
   hipStream_t s = (hipStream_t)stream;
   const int mtiles = (a->M + TBK - 1) / TBK;

@@ -52,6 +52,38 @@ class _SmoothL1Fn(torch.autograd.Function):
         return grad, None
 
 
+class _CrossEntropyFn(torch.autograd.Function):
+    """CrossEntropyLoss(mean) over the rows of a small fp32 logits matrix (ITM: B x 2, CLS: B x 48 / B x 122; reference
+    engine_grid_masking.py:90,94,95) on the HIP row kernels the MLM head uses: one launch forward, one backward, instead of ATen's
+    log_softmax / nll_loss pairs."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        from . import ops
+        rows, V = logits.shape
+        lse = torch.empty(rows, device=logits.device, dtype=torch.float32)
+        acc = torch.zeros(2, device=logits.device, dtype=torch.float32)            # [loss sum, row count]
+        ops.cross_entropy_fwd(logits, labels, lse, acc[0:1], acc[1:2], rows, V, V, ignore_index=-100)
+        ctx.save_for_backward(logits, labels, lse, acc)
+        return acc[0] / acc[1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import ops
+        logits, labels, lse, acc = ctx.saved_tensors
+        rows, V = logits.shape
+        dl = torch.empty_like(logits)
+        ops.cross_entropy_bwd(logits, labels, lse, gout.reshape(1).float().contiguous(), acc[1:2], dl, rows, V, V, V, ignore_index=-100)
+        return dl, None
+
+
+def cross_entropy(logits, labels):
+    """F.cross_entropy(logits, labels) for 2-D logits; HIP on the GPU (fp32 logits), ATen elsewhere (CPU oracle runs)"""
+    if logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and labels.dtype == torch.int64:
+        return _CrossEntropyFn.apply(logits.contiguous(), labels.contiguous())
+    return F.cross_entropy(logits, labels)
+
+
 def smooth_l1(pred, target):
     """the T2I loss of reference engine_grid_masking.py:99; HIP on the GPU, ATen elsewhere (CPU oracle runs, odd shapes)"""
     if pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.shape == target.shape and pred.numel() % 4 == 0:
@@ -72,11 +104,11 @@ def compute_losses(outputs, images, mlm_labels, itm_labels, sup_cls_labels, sub_
         parts["loss_mlm"] = MLM_LOSS_WEIGHT * F.cross_entropy(outputs["mlm_logits"].reshape(-1, 30522).float(), mlm_labels.view(-1), ignore_index=-1)
         total = total + parts["loss_mlm"]
     if outputs["itm_logits"] is not None:
-        parts["loss_itm"] = ITM_LOSS_WEIGHT * F.cross_entropy(outputs["itm_logits"].view(-1, 2).float(), itm_labels.view(-1))
+        parts["loss_itm"] = ITM_LOSS_WEIGHT * cross_entropy(outputs["itm_logits"].view(-1, 2).float(), itm_labels.view(-1))
         total = total + parts["loss_itm"]
     if outputs["sup_cls_logits"] is not None:
-        parts["loss_sup_cls"] = F.cross_entropy(outputs["sup_cls_logits"].view(-1, 48).float(), sup_cls_labels.view(-1))
-        parts["loss_sub_cls"] = F.cross_entropy(outputs["sub_cls_logits"].view(-1, 122).float(), sub_cls_labels.view(-1))
+        parts["loss_sup_cls"] = cross_entropy(outputs["sup_cls_logits"].view(-1, 48).float(), sup_cls_labels.view(-1))
+        parts["loss_sub_cls"] = cross_entropy(outputs["sub_cls_logits"].view(-1, 122).float(), sub_cls_labels.view(-1))
         total = total + parts["loss_sup_cls"] + parts["loss_sub_cls"]
     if outputs["t2i_logits"] is not None:
         parts["loss_t2i"] = T2I_LOSS_WEIGHT * smooth_l1(outputs["t2i_logits"].float(), images)

@@ -139,10 +139,9 @@ class MimStep:
         dz = _e((M, cout), dev, dt)
         ops.bn_bwd_apply(dy, lddy, r["z"], cout, r["mean"], r["rstd"], S.master(p + ".1.weight"), red[0], red[1], M, cout, dz, cout,
                          g_beta=S.grad(p + ".1.bias"), g_gamma=S.grad(p + ".1.weight"))
-        # wgrad in [out][dy][dx][cin] order, folded back to nn.Conv2d's [out][cin][3][3]
-        dWk = _z((cout, 9 * cin), dev)
-        ops.gemm_tn(dz, r["xin"], dWk, M, cout, 9 * cin, cout, r["ld_in"], 9 * cin, b_map=r["amap"])
-        S.grad(p + ".0.weight").add_(dWk.view(cout, 3, 3, cin).permute(0, 3, 1, 2))
+        # wgrad computed in the gather's [out][dy][dx][cin] order, accumulated at nn.Conv2d's [out][cin][3][3] place
+        ops.gemm_tn(dz, r["xin"], S.grad(p + ".0.weight").view(cout, 9 * cin), M, cout, 9 * cin, cout, r["ld_in"], 9 * cin, b_map=r["amap"],
+                    taps=9, seg=cin)
         # dgrad: gather dz over the same grid with flipped taps
         gmap = conv3map(r["side"], r["side"], r["side"] * r["side"], cout)
         if dx is None:
@@ -217,6 +216,7 @@ class _MimFn(torch.autograd.Function):
         step.S.queue_finalize()
         g2, g3, g4 = step.backward(dout)
         ctx.step = None
+        step.S.announce_prefix("t2i_head.")          # the decoder's gradients are final: reduce them under the trunk backward
         return g2, g3, g4, None, None, None
 
 

@@ -38,18 +38,19 @@ def weight_prep(desc_dev, blk_dev, ndesc, total_blocks, dtype):
           "mvlt_weight_prep")
 
 
-def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, colsum=None, splits=0):
-    """C[N1,N2] += A[M,N1]^T @ B[M,N2] (fp32 atomics); colsum[N1] += A.sum(0)."""
+def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, colsum=None, splits=0, taps=0, seg=0):
+    """C[N1,N2] += A[M,N1]^T @ B[M,N2] (fp32 atomics); colsum[N1] += A.sum(0).  taps > 1: logical column tap*seg + c is
+    accumulated at column c*taps + tap (conv weight gradients straight into the [out][cin][kh][kw] layout)."""
     assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype == torch.float32
     if colsum is not None:
         assert colsum.dtype == torch.float32
     a_map, b_map = a_map or _ID, b_map or _ID
-    if N1 <= 64 < N2 and b_map.mode == 0:
+    if N1 <= 64 < N2 and b_map.mode == 0 and taps <= 1:
         # the kernel's tile is 128 (N1 side) x 64/128 (N2 side): give the narrow operand the 64-wide side by computing
         # C^T = B^T A and storing it transposed; the bias gradient becomes the column sum of the (now) B operand
-        a = L.GemmTNArgs(ptr(B), ptr(A), ptr(C_out), M, N2, N1, ldb, lda, ldc, DT[A.dtype], b_map, a_map, None, splits, ptr(colsum), 1)
+        a = L.GemmTNArgs(ptr(B), ptr(A), ptr(C_out), M, N2, N1, ldb, lda, ldc, DT[A.dtype], b_map, a_map, None, splits, ptr(colsum), 1, 0, 0)
     else:
-        a = L.GemmTNArgs(ptr(A), ptr(B), ptr(C_out), M, N1, N2, lda, ldb, ldc, DT[A.dtype], a_map, b_map, ptr(colsum), splits, None, 0)
+        a = L.GemmTNArgs(ptr(A), ptr(B), ptr(C_out), M, N1, N2, lda, ldb, ldc, DT[A.dtype], a_map, b_map, ptr(colsum), splits, None, 0, taps, seg)
     check(L.lib.mvlt_gemm_tn(C.byref(a), stream_ptr()), "mvlt_gemm_tn")
     return C_out
 
@@ -341,3 +342,24 @@ def token_mask(ori_ids, input_ids, labels, seed, sample0, vocab=30522):
     assert ori_ids.dtype == input_ids.dtype == labels.dtype == torch.int64 and ori_ids.is_contiguous()
     B, T = ori_ids.shape
     check(L.lib.mvlt_token_mask(_p(ori_ids), _p(input_ids), _p(labels), B, T, seed, sample0, vocab, stream_ptr()), "mvlt_token_mask")
+
+
+# ------------------------------------------------------------------ position-embedding resize, GELU backward (csrc/elementwise.hip)
+L.lib.mvlt_resize_bilinear_tokens.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
+L.lib.mvlt_gelu_bwd.argtypes = [_vp, _vp, _vp, _l, _i, _vp]
+
+
+def resize_bilinear_tokens(src, dst, hin, win, hout, wout, Cdim, adjoint=False):
+    """src [hin*win, C] -> dst [hout*wout, C] (fp32, rows Cdim floats apart); adjoint: src is d(dst-shaped), accumulated into dst = d(source map)"""
+    _need_cuda(src, dst)
+    assert src.dtype == torch.float32 and dst.dtype == torch.float32 and src.stride(-1) == 1 and dst.stride(-1) == 1
+    check(L.lib.mvlt_resize_bilinear_tokens(_p(src), src.stride(0), _p(dst), dst.stride(0), hin, win, hout, wout, Cdim, 1 if adjoint else 0, stream_ptr()),
+          "mvlt_resize_bilinear_tokens")
+    return dst
+
+
+def gelu_bwd(dy, h, out):
+    _need_cuda(dy, h, out)
+    assert dy.dtype == h.dtype == out.dtype and dy.is_contiguous() and h.is_contiguous() and out.is_contiguous()
+    check(L.lib.mvlt_gelu_bwd(_p(dy), _p(h), _p(out), dy.numel(), DT[dy.dtype], stream_ptr()), "mvlt_gelu_bwd")
+    return out

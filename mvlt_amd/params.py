@@ -377,6 +377,27 @@ class FlatStore:
             self._ranges_done.append((lo, hi))
             self.on_range_ready(self, lo, hi)
 
+    def prefix_range(self, prefixes):
+        """[lo, hi) of the parameters whose names start with one of `prefixes` (they are contiguous in registration order)"""
+        names = [n for n in self.offsets if n.startswith(prefixes)]
+        if not names:
+            return None
+        lo = self.offsets[names[0]][0]
+        o, n, _ = self.offsets[names[-1]]
+        hi = o + (n + ALIGN - 1) // ALIGN * ALIGN
+        assert sum((self.offsets[k][1] + ALIGN - 1) // ALIGN * ALIGN for k in names) == hi - lo, ("not contiguous", prefixes)
+        return lo, hi
+
+    def announce_prefix(self, *prefixes):
+        """a head's backward finished: the gradients of its own parameters are final (heads run before the trunk in a backward
+        pass, so these ranges travel while the whole trunk backward is still ahead)"""
+        if self.on_range_ready is None:
+            return
+        r = self.prefix_range(tuple(prefixes))
+        if r is not None:
+            self._ranges_done.append(r)
+            self.on_range_ready(self, *r)
+
     def scale_grads(self, factor):
         """G *= factor, now or (when the fused optimizer owns the next step) inside its kernel."""
         if self.scale_in_optimizer:

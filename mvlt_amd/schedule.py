@@ -98,17 +98,17 @@ class TrunkStep:
     def lnk(self):
         return self.S.ln_kwargs() if _LN_COPIES else {}
 
-    # ---- pos embed (tiny, parameter-only: torch bilinear; its backward is taken with torch.autograd on demand)
+    # ---- pos embed: learned for the constructor grid, bilinearly resized (align_corners=False) to this input's grid
     def _pos(self, i, param):
         m = self.m
-        HW = self.side[i] ** 2
-        pe = param[:, 1:] if i == 3 else param
+        side, C = self.side[i], m.dims[i]
+        HW = side * side
+        pe = (param[:, 1:] if i == 3 else param)[0]                 # (grid*grid, C) rows of the flat buffer; stage 4 skips the cls slot
         if HW == m.grids[0] ** 2:          # reference libs/pvlt.py:292 compares with stage-1's constructor grid
-            return pe[0].contiguous()
-        gsz = m.grids[i]
-        t = pe.reshape(1, gsz, gsz, -1).permute(0, 3, 1, 2)
-        t = F.interpolate(t, size=(self.side[i], self.side[i]), mode="bilinear")
-        return t.reshape(1, -1, HW).permute(0, 2, 1)[0].contiguous()
+            return pe
+        out = _empty((HW, C), torch.float32, self.dev)
+        ops.resize_bilinear_tokens(pe, out, m.grids[i], m.grids[i], side, side, C)
+        return out
 
     def _droppath_scales(self, blk_index):
         m = self.m
@@ -354,10 +354,9 @@ class TrunkStep:
         Cp, Np, HWp, sp = m.dims[i - 1], self.saved[i - 1]["N"], self.saved[i - 1]["HW"], self.side[i - 1]
         xp = sv["x_in_prev"]
         pm = sv["pm_in"]
-        # conv weight gradient in [out][kh][kw][cin] order, folded back to [out][cin][kh][kw]
-        dWk = pool_zeros((C, 4 * Cp), f32, dev)
-        ops.gemm_tn(d_pe, xp, dWk, B * HW, C, 4 * Cp, C, Cp, 4 * Cp, b_map=pm, colsum=self.g(pe + "proj.bias"))
-        self.g(pe + "proj.weight").add_(dWk.view(C, 2, 2, Cp).permute(0, 3, 1, 2))
+        # conv weight gradient: computed in the gather's [out][kh][kw][cin] order, accumulated at its [out][cin][kh][kw] place
+        ops.gemm_tn(d_pe, xp, self.g(pe + "proj.weight").view(C, 4 * Cp), B * HW, C, 4 * Cp, C, Cp, 4 * Cp, b_map=pm,
+                    colsum=self.g(pe + "proj.bias"), taps=4, seg=Cp)
         ops.gemm_tn(d_te, xp, self.g(ten + "0.weight"), B * T, C, Cp, C, Cp, Cp, b_map=rowmap(T, Np, HWp), colsum=self.g(ten + "0.bias"))
         dxp = _empty((B, Np, Cp), dt, dev)
         ops.gemm_nt(d_pe, self.wKT(pe + "proj.weight"), dxp, B * HW, 4 * Cp, C, C, C, Cp, c_map=pm)          # image rows (each once)
@@ -366,18 +365,14 @@ class TrunkStep:
 
     def _pos_backward(self, i, dpos):
         m = self.m
-        HW = self.side[i] ** 2
-        gname = f"pos_embed{i+1}"
-        gv = self.g(gname)
+        side = self.side[i]
+        HW = side * side
+        gv = self.g(f"pos_embed{i+1}")
+        gv = (gv[:, 1:] if i == 3 else gv)[0]
         if HW == m.grids[0] ** 2:
-            (gv[:, 1:] if i == 3 else gv)[0].add_(dpos)
+            gv.add_(dpos)
             return
-        # adjoint of the bilinear resize, called directly (no nested autograd inside a backward node)
-        gsz, side, C = m.grids[i], self.side[i], dpos.shape[1]
-        g_out = dpos.t().reshape(1, C, side, side).contiguous()
-        g_in = torch.ops.aten.upsample_bilinear2d_backward(g_out, [side, side], [1, C, gsz, gsz], False, None, None)
-        g_in = g_in.reshape(C, gsz * gsz).t()
-        (gv[:, 1:] if i == 3 else gv)[0].add_(g_in)
+        ops.resize_bilinear_tokens(dpos, gv, m.grids[i], m.grids[i], side, side, dpos.shape[1], adjoint=True)   # accumulates into G
 
     def _bert_backward(self, d_emb):
         m, B, T = self.m, self.B, self.T
@@ -458,9 +453,8 @@ class TrunkStep:
             ops.layernorm_bwd(dkvin, bs["sr_pre"], dsr, self.f32(p + "attn.norm.weight"), bs["msr"], bs["rsr"], B * HWr, C, C, C, C,
                               dgamma=self.gl(p + "attn.norm.weight"), dbeta=self.gl(p + "attn.norm.bias"), **self.lnk())
             K = r * r * C
-            dWk = pool_zeros((C, K), f32, dev)
-            ops.gemm_tn(dsr, bs["xn1"], dWk, B * HWr, C, K, C, C, K, b_map=pm, colsum=self.g(p + "attn.sr.bias"))
-            self.g(p + "attn.sr.weight").add_(dWk.view(C, r, r, C).permute(0, 3, 1, 2))
+            ops.gemm_tn(dsr, bs["xn1"], self.g(p + "attn.sr.weight").view(C, K), B * HWr, C, K, C, C, K, b_map=pm,
+                        colsum=self.g(p + "attn.sr.bias"), taps=r * r, seg=C)
             ops.gemm_nt(dsr, self.wKT(p + "attn.sr.weight"), dxn1, B * HWr, K, C, C, C, C, c_map=pm, R=dxn1)
         else:
             ops.gemm_tn(dkv, bs["xn1"], gkvw, M, 2 * C, C, 2 * C, C, C, colsum=gkvb)
@@ -567,6 +561,7 @@ class _ClsHeadFn(torch.autograd.Function):
         dx4 = torch.zeros_like(x4)
         _embed_ln_bwd(model, name + "_head_embed", de, saved, x4, a_map, B, C, dx4, a_map, False)
         ctx.pack = None
+        S.announce_prefix(name + "_head_embed.", name + "_head.")
         return dx4, None, None, None
 
 
@@ -591,16 +586,11 @@ def _mlm_transform_bwd(model, dt_, saved, rows_in, R):
     dga = _empty((R, Hd), dt, dev)
     ops.layernorm_bwd(dt_, ga, dga, S.master("mlm_head.transform.LayerNorm.weight"), mean, rstd, R, Hd, Hd, Hd, Hd,
                       dgamma=S.grad("mlm_head.transform.LayerNorm.weight"), dbeta=S.grad("mlm_head.transform.LayerNorm.bias"))
-    # d(pre-activation) = dga * gelu'(hp): run the (identity-weighted) product through the GEMM-free elementwise path
-    dhp = (dga.float() * _gelu_grad(hp.float())).to(dt)
+    dhp = ops.gelu_bwd(dga, hp, torch.empty_like(dga))             # d(pre-activation) = dga * gelu'(hp)
     ops.gemm_tn(dhp, rows_in, S.grad("mlm_head.transform.dense.weight"), R, Hd, Hd, Hd, Hd, Hd, colsum=S.grad("mlm_head.transform.dense.bias"))
     din = _empty((R, Hd), dt, dev)
     ops.gemm_nt(dhp, S.extra["mlm_head.transform.dense.weight::T"], din, R, Hd, Hd, Hd, Hd, Hd)
     return din
-
-
-def _gelu_grad(x):
-    return 0.5 * (1.0 + torch.erf(x * 0.7071067811865476)) + x * 0.3989422804014327 * torch.exp(-0.5 * x * x)
 
 
 class _MLMFullFn(torch.autograd.Function):
@@ -654,6 +644,9 @@ def _mlm_decoder_bwd(model, dl, t, sv_t, e, sv_e, A, a_map, R, lda, dA, c_map=No
         ops.gemm_nt(dl, wT, dtr, R, Hd, VOCAB_LD, VOCAB_LD, VOCAB_LD, Hd)
     de = _mlm_transform_bwd(model, dtr, sv_t, e, R)
     _embed_ln_bwd(model, "mlm_head_embed", de, sv_e, A, a_map, R, lda, dA, c_map if c_map is not None else a_map, False)
+    # final now: the head's own parameters.  The tied decoder weight is the word-embedding table, which bert_embed_bwd still adds
+    # to at the very end of the pass: it travels with the leftovers.
+    S.announce_prefix("mlm_head_embed.", "mlm_head.")
 
 
 class _MLMFusedFn(torch.autograd.Function):

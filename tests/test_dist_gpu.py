@@ -1,0 +1,120 @@
+"""GPU, two processes sharing the one MI355X of the test box (gloo backend on device tensors -- RCCL refuses two ranks on one
+device): the data-parallel path with the REAL model and kernels.  Each rank steps its own batch through
+mvlt_amd.dist.DataParallel (ranges all-reduced as the backward announces them) or through stock
+torch.nn.parallel.DistributedDataParallel (what reference main_vl.py:298-302 constructs); the gradients both ranks end up
+with must be the mean of the two single-rank gradients -- DDP's mean-of-means, including unequal masked-token counts per
+rank -- and the parameters after a FusedAdamW step must match a single-process step on that mean gradient."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+LT = dict(mlm=1, itm=1, t2i=1, cls=0)
+T, IMG, B = 32, 64, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(seed=9):
+    from mvlt_amd import pvlt
+    from oracle import pvlt_oracle as O
+    cfg = O.Cfg("pvlt_tiny", LT, 224, 768, T, 0.0)
+    m = pvlt.pvlt_tiny(pretrained=False, token_hidden_size=768, num_text_tokens=T, loss_type=LT, pretrained_pth=None, drop_path_rate=0.0,
+                       compute_dtype=torch.float32)
+    m.load_state_dict(O.filled_state_dict(cfg, seed), strict=True)
+    m.cuda()
+    m.train()
+    m.injected_masks = dict(bert=torch.ones(B, T, 768), droppath=[torch.ones(B)] * 8, droppath2=[torch.ones(B)] * 8)
+    return m
+
+
+def _batch(rank):
+    from oracle import filler
+    from oracle import pvlt_oracle as O
+    b = O.to_torch_batch(filler.make_batch(70 + rank, B, IMG, T))
+    if rank == 1:                       # make the masked-token counts differ between the ranks (mean of means != global mean)
+        b["mlm_labels"][0, 3] = b["ori_input_ids"][0, 3]
+        b["mlm_labels"][1, 4] = b["ori_input_ids"][1, 4]
+    return {k: v.cuda() for k, v in b.items()}
+
+
+def _grads(model, batch, idx=1):
+    from mvlt_amd.engine import train_step
+    total, _ = train_step(model, batch, idx, True)
+    for p in model.parameters():
+        p.grad = None
+    total.backward()
+    torch.cuda.synchronize()
+    return total
+
+
+def _worker(rank, world, port, kind, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mvlt_amd.dist import DataParallel
+        from mvlt_amd.optim import FusedAdamW
+        core = _model(seed=9 + rank)                 # different start weights: the wrapper must broadcast rank 0's
+        if kind == "ours":
+            model = DataParallel(core)
+        else:
+            model = torch.nn.parallel.DistributedDataParallel(core, device_ids=[0])
+        opt = FusedAdamW(core, lr=1e-3, weight_decay=0.05)
+        batch = _batch(rank)
+        _grads(model, batch)
+        S = core.store
+        S.sync_grads()
+        scale = S.pending_grad_scale                 # 1/world still owed to the fused optimizer's kernel (DataParallel only)
+        g_mine = (S.G * scale).cpu()
+        opt.step()
+        torch.cuda.synchronize()
+        # single-process reference, computed by every rank for itself: both batches through a plain model with rank 0's weights,
+        # gradients averaged, one FusedAdamW step on the mean
+        ref = _model(seed=9)
+        gs = []
+        for r in range(world):
+            _grads(ref, _batch(r))
+            gs.append(ref.store.G.clone())
+        gmean = sum(gs) / world
+        ropt = FusedAdamW(ref, lr=1e-3, weight_decay=0.05)
+        ref.store.G.copy_(gmean)
+        for n_, p_ in ref.store.params.items():
+            p_.grad = ref.store.grad(n_)
+        ropt.step()
+        torch.cuda.synchronize()
+        e_g = ((g_mine.double() - gmean.cpu().double()).norm() / gmean.cpu().double().norm()).item()
+        e_p = ((S.P.double() - ref.store.P.double()).norm() / ref.store.P.double().norm()).item()
+        q.put(dict(rank=rank, e_g=e_g, e_p=e_p, p_sum=float(S.P.double().sum()), p_abs=float(S.P.double().abs().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["ours", "torch_ddp"])
+def test_two_ranks_average_gradients_like_ddp(kind, parity):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0, r1 = res
+    for r in res:
+        assert parity(f"dp-{kind}/grad-rank{r['rank']}", r["e_g"], 1e-5), r
+        assert parity(f"dp-{kind}/params-after-step-rank{r['rank']}", r["e_p"], 1e-6), r
+    assert abs(r0["p_sum"] - r1["p_sum"]) <= 1e-9 * r0["p_abs"]           # both ranks hold the same parameters after the step

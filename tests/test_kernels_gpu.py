@@ -647,3 +647,86 @@ def test_ew_mul3_bwd(ops):
     ops.ew_mul3_bwd(dyw, 3 * Cd, a, b, c, Cd, da, db, dc, M, Cd)
     dy = dyw[:, :Cd]
     assert maxrel(da, dy * b * c) < 1e-6 and maxrel(db, dy * a * c) < 1e-6 and maxrel(dc, dy * a * b) < 1e-6
+
+
+# ------------------------------------------------------------------ round 2 additions
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("r,Hin,Cin,Cout", [(2, 8, 64, 128), (8, 16, 64, 64), (4, 8, 128, 128)])
+def test_gemm_tn_conv_weight_layout(ops, dtype, r, Hin, Cin, Cout):
+    """c_taps / c_seg: the weight gradient of a kernel==stride conv lands in nn.Conv2d's [out][cin][kh][kw] layout directly"""
+    from mvlt_amd._lib import patchmap
+    Bsz, T = 2, 5
+    HWi, Ho = Hin * Hin, Hin // r
+    X = rnd(Bsz, HWi + T, Cin, dtype=dtype)
+    M, K = Bsz * Ho * Ho, r * r * Cin
+    dY = rnd(M, Cout, dtype=dtype, seed=3)
+    dW = torch.zeros(Cout, Cin, r, r, device=dev(), dtype=torch.float32)
+    cs = torch.zeros(Cout, device=dev(), dtype=torch.float32)
+    ops.gemm_tn(dY, X, dW.view(Cout, K), M, Cout, K, Cout, Cin, K, b_map=patchmap(r, Hin, HWi + T, Ho * Ho, Ho, Cin), colsum=cs, taps=r * r, seg=Cin)
+    img = X[:, :HWi].float().transpose(1, 2).reshape(Bsz, Cin, Hin, Hin)
+    Wc = torch.zeros(Cout, Cin, r, r, device=dev(), requires_grad=True)
+    bc = torch.zeros(Cout, device=dev(), requires_grad=True)
+    y = F.conv2d(img, Wc, bc, stride=r).flatten(2).transpose(1, 2).reshape(M, Cout)
+    (y * dY.float()).sum().backward()
+    assert maxrel(dW, Wc.grad) < TOL[dtype]
+    assert maxrel(cs, bc.grad) < TOL[dtype]
+
+
+def test_gemm_tn_conv3x3_weight_layout(ops):
+    from mvlt_amd._lib import conv3map
+    Bsz, side, Cin, Cout = 2, 8, 64, 128
+    M = Bsz * side * side
+    X = rnd(M, Cin, dtype=torch.bfloat16)
+    dY = rnd(M, Cout, dtype=torch.bfloat16, seed=2)
+    dW = torch.zeros(Cout, Cin, 3, 3, device=dev(), dtype=torch.float32)
+    ops.gemm_tn(dY, X, dW.view(Cout, 9 * Cin), M, Cout, 9 * Cin, Cout, Cin, 9 * Cin, b_map=conv3map(side, side, side * side, Cin), taps=9, seg=Cin)
+    img = X.float().reshape(Bsz, side, side, Cin).permute(0, 3, 1, 2)
+    Wc = torch.zeros(Cout, Cin, 3, 3, device=dev(), requires_grad=True)
+    y = F.conv2d(img, Wc, None, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    (y * dY.float()).sum().backward()
+    assert maxrel(dW, Wc.grad) < TOL[torch.bfloat16]
+
+
+@pytest.mark.parametrize("gin,gout,C,skip", [(56, 64, 64, 0), (28, 48, 128, 0), (7, 12, 512, 1), (14, 16, 320, 0), (3, 2, 64, 0)])
+def test_pos_embed_resize_matches_interpolate(ops, gin, gout, C, skip):
+    """mvlt_resize_bilinear_tokens vs F.interpolate(mode='bilinear') (align_corners=False) on a (1, n, C) position embedding
+    (reference libs/pvlt.py:291-297), forward and adjoint; skip=1: stage 4 skips the leading cls slot"""
+    param = rnd(1, gin * gin + skip, C, dtype=torch.float32)
+    pe = param[:, skip:][0]
+    out = torch.empty(gout * gout, C, device=dev())
+    ops.resize_bilinear_tokens(pe, out, gin, gin, gout, gout, C)
+    pr = param.clone().requires_grad_(True)
+    t = pr[:, skip:].reshape(1, gin, gin, C).permute(0, 3, 1, 2)
+    ref = F.interpolate(t, size=(gout, gout), mode="bilinear").reshape(1, C, gout * gout).permute(0, 2, 1)[0]
+    assert (out - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    dy = rnd(gout * gout, C, dtype=torch.float32, seed=7)
+    ref.backward(dy)
+    g = torch.zeros_like(param)
+    g[:, :skip] = 3.0                                             # untouched slot
+    ops.resize_bilinear_tokens(dy, g[:, skip:][0], gin, gin, gout, gout, C, adjoint=True)
+    assert maxrel(g[:, skip:], pr.grad[:, skip:]) < 1e-5
+    assert skip == 0 or float(g[0, 0, 0]) == 3.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gelu_bwd(ops, dtype):
+    dy, h = rnd(777, 768, dtype=dtype), rnd(777, 768, dtype=dtype, seed=1, scale=2.0)
+    out = ops.gelu_bwd(dy, h, torch.empty_like(dy))
+    hr = h.float().requires_grad_(True)
+    F.gelu(hr).backward(dy.float())
+    assert maxrel(out.float(), hr.grad) < TOL[dtype]
+
+
+def test_small_head_cross_entropy_fn():
+    """engine.cross_entropy (HIP row kernels behind autograd) vs F.cross_entropy for the ITM / CLS heads"""
+    from mvlt_amd.engine import cross_entropy
+    for V in (2, 48, 122):
+        lg = rnd(37, V, dtype=torch.float32, scale=3.0).requires_grad_(True)
+        lab = torch.randint(0, V, (37,), device=dev())
+        loss = cross_entropy(lg, lab)
+        (loss * 1.7).backward()
+        lr = lg.detach().clone().requires_grad_(True)
+        ref = F.cross_entropy(lr, lab)
+        (ref * 1.7).backward()
+        assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+        assert maxrel(lg.grad, lr.grad) < 1e-5
