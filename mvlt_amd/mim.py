@@ -140,8 +140,8 @@ class MimStep:
         ops.bn_bwd_apply(dy, lddy, r["z"], cout, r["mean"], r["rstd"], S.master(p + ".1.weight"), red[0], red[1], M, cout, dz, cout,
                          g_beta=S.grad(p + ".1.bias"), g_gamma=S.grad(p + ".1.weight"))
         # wgrad computed in the gather's [out][dy][dx][cin] order, accumulated at nn.Conv2d's [out][cin][3][3] place
-        ops.gemm_tn(dz, r["xin"], S.grad(p + ".0.weight").view(cout, 9 * cin), M, cout, 9 * cin, cout, r["ld_in"], 9 * cin, b_map=r["amap"],
-                    taps=9, seg=cin)
+        from .schedule import conv_wgrad
+        conv_wgrad(dz, r["xin"], S.grad(p + ".0.weight"), M, cout, 9 * cin, cout, r["ld_in"], r["amap"], 9, cin)
         # dgrad: gather dz over the same grid with flipped taps
         gmap = conv3map(r["side"], r["side"], r["side"] * r["side"], cout)
         if dx is None:

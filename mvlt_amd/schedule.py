@@ -25,6 +25,20 @@ def _empty(shape, dtype, dev):
 
 _LN_COPIES = not os.environ.get("MVLT_LN_NO_COPIES")      # A/B switch: LayerNorm parameter gradients by plain atomics
 _NO_DX2 = bool(os.environ.get("MVLT_NO_DX2"))      # A/B switch: DropPath-scaled gradient copy by a separate pass
+# A/B switch: conv weight gradients accumulated straight into the [out][cin][kh][kw] layout by the wgrad epilogue (strided atomics)
+# instead of a pooled [out][kh][kw][cin] buffer + one permuted add
+WGRAD_TAPS = bool(os.environ.get("MVLT_WGRAD_TAPS"))
+
+
+def conv_wgrad(dz, xin, gW, M, cout, K, ld_dz, ld_in, bmap, taps, cin, colsum=None):
+    """weight gradient of a gathered-row convolution into gW = G slice of nn.Conv2d's (out, cin, kh, kw) weight"""
+    if WGRAD_TAPS:
+        ops.gemm_tn(dz, xin, gW.view(cout, K), M, cout, K, ld_dz, ld_in, K, b_map=bmap, colsum=colsum, taps=taps, seg=cin)
+        return
+    dWk = pool_zeros((cout, K), torch.float32, dz.device)
+    ops.gemm_tn(dz, xin, dWk, M, cout, K, ld_dz, ld_in, K, b_map=bmap, colsum=colsum)
+    kk = int(round(taps ** 0.5))
+    gW.add_(dWk.view(cout, kk, kk, cin).permute(0, 3, 1, 2))
 
 
 
@@ -355,8 +369,7 @@ class TrunkStep:
         xp = sv["x_in_prev"]
         pm = sv["pm_in"]
         # conv weight gradient: computed in the gather's [out][kh][kw][cin] order, accumulated at its [out][cin][kh][kw] place
-        ops.gemm_tn(d_pe, xp, self.g(pe + "proj.weight").view(C, 4 * Cp), B * HW, C, 4 * Cp, C, Cp, 4 * Cp, b_map=pm,
-                    colsum=self.g(pe + "proj.bias"), taps=4, seg=Cp)
+        conv_wgrad(d_pe, xp, self.g(pe + "proj.weight"), B * HW, C, 4 * Cp, C, Cp, pm, 4, Cp, colsum=self.g(pe + "proj.bias"))
         ops.gemm_tn(d_te, xp, self.g(ten + "0.weight"), B * T, C, Cp, C, Cp, Cp, b_map=rowmap(T, Np, HWp), colsum=self.g(ten + "0.bias"))
         dxp = _empty((B, Np, Cp), dt, dev)
         ops.gemm_nt(d_pe, self.wKT(pe + "proj.weight"), dxp, B * HW, 4 * Cp, C, C, C, Cp, c_map=pm)          # image rows (each once)
@@ -453,8 +466,7 @@ class TrunkStep:
             ops.layernorm_bwd(dkvin, bs["sr_pre"], dsr, self.f32(p + "attn.norm.weight"), bs["msr"], bs["rsr"], B * HWr, C, C, C, C,
                               dgamma=self.gl(p + "attn.norm.weight"), dbeta=self.gl(p + "attn.norm.bias"), **self.lnk())
             K = r * r * C
-            ops.gemm_tn(dsr, bs["xn1"], self.g(p + "attn.sr.weight").view(C, K), B * HWr, C, K, C, C, K, b_map=pm,
-                        colsum=self.g(p + "attn.sr.bias"), taps=r * r, seg=C)
+            conv_wgrad(dsr, bs["xn1"], self.g(p + "attn.sr.weight"), B * HWr, C, K, C, C, pm, r * r, C, colsum=self.g(p + "attn.sr.bias"))
             ops.gemm_nt(dsr, self.wKT(p + "attn.sr.weight"), dxn1, B * HWr, K, C, C, C, C, c_map=pm, R=dxn1)
         else:
             ops.gemm_tn(dkv, bs["xn1"], gkvw, M, 2 * C, C, 2 * C, C, C, colsum=gkvb)
