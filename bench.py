@@ -191,7 +191,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # MVLT_DP_FORCE_COLLECTIVES=1 (test switch): build the process group and the data-parallel wrapper at world size 1 too, so that
+    # a one-GPU box runs the RCCL calls of the N > 1 path (launched through torch.distributed.run --nproc-per-node 1)
+    use_pg = world > 1 or bool(os.environ.get("MVLT_DP_FORCE_COLLECTIVES"))
+    if use_pg:
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -207,7 +210,7 @@ def main():
                                       pretrained_pth=None, drop_path_rate=0.1, drop_rate=0.0, num_classes=1000, in_chans=3)
     model.cuda(device)
     core = model
-    if world > 1:
+    if use_pg:
         model = DataParallel(model)
     B = args.batch
     batch = synth_batch(B, args.img, 128, device, 1234 + rank)       # resident in HBM before the timed region starts
@@ -280,7 +283,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

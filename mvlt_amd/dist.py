@@ -12,9 +12,14 @@ kept large (>= 16 MB where the layout allows) instead of DDP's 25 MB + 1 MB firs
 Stock torch DistributedDataParallel also works on the model (its reducer hooks fire from the trunk's autograd node);
 this wrapper is the overlapped, copy-free path.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+
+# test switch: issue every collective even at world size 1 (a one-GPU box then exercises the RCCL calls of the N > 1 path)
+_FORCE = bool(os.environ.get("MVLT_DP_FORCE_COLLECTIVES"))
 
 
 class DataParallel(nn.Module):
@@ -26,6 +31,7 @@ class DataParallel(nn.Module):
         self.pg = process_group
         self.broadcast_buffers = broadcast_buffers
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (_FORCE and dist.is_initialized())
         self._works = []
         self._synced_init = False
         module.store.on_backward_done = self._finish
@@ -33,14 +39,14 @@ class DataParallel(nn.Module):
 
     # parameters start identical on every rank (DDP broadcasts rank 0's at construction)
     def _sync_init(self):
-        if self.world > 1:
+        if self.active:
             S = self.module.store
             dist.broadcast(S.P, 0, group=self.pg)
             S.force_dirty = True
         self._synced_init = True
 
     def forward(self, *a, **k):
-        if self.world > 1:
+        if self.active:
             S = self.module.store
             dev = a[0].device
             S.ensure(dev)
@@ -54,7 +60,7 @@ class DataParallel(nn.Module):
         """BatchNorm running stats of the MIM decoder follow rank 0 (DDP's broadcast_buffers=True): one coalesced broadcast,
         not one small collective per buffer."""
         bufs = [b for b in self.module.buffers() if b.is_floating_point()]
-        if not bufs or self.world <= 1:
+        if not bufs or not self.active:
             return
         try:
             dist._broadcast_coalesced(self.pg if self.pg is not None else dist.group.WORLD, bufs, 64 << 20, 0)
@@ -64,11 +70,11 @@ class DataParallel(nn.Module):
 
     def _range_ready(self, store, lo, hi):
         """called by the backward schedule when G[lo:hi] is final on the compute stream"""
-        if self.world > 1 and hi > lo:
+        if self.active and hi > lo:
             self._works.append(dist.all_reduce(store.G[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _finish(self, store):
-        if self.world <= 1:
+        if not self.active:
             return
         store.sync_grads()                                 # MIM-decoder grads that autograd produced itself
         done = getattr(store, "_ranges_done", [])

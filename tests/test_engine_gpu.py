@@ -232,3 +232,27 @@ def test_masked_selection_count_paths_agree():
     assert torch.equal(a["mlm_positions"], pos) and torch.equal(b["mlm_positions"], pos)          # bit-exact selection
     la, lb, lc = float(a["mlm_loss"]), float(b["mlm_loss"]), float(c["mlm_loss"])       # (the loss sum uses fp32 atomics: equal up to order)
     assert abs(la - lb) <= 1e-5 * abs(la) and abs(la - lc) <= 1e-5 * abs(la), (la, lb, lc)
+
+
+def test_no_masked_position_in_the_batch_behaves_like_torch():
+    """edge case: a batch without a single selected MLM position.  CrossEntropyLoss(ignore_index=-1) over zero rows is NaN in the
+    reference (mean of nothing); the fused masked-row path must give the same NaN without launching on an empty grid, and the
+    full-logits path must agree."""
+    from mvlt_amd import pvlt
+    from mvlt_amd.engine import compute_losses
+    lt = dict(mlm=1, itm=1, t2i=0, cls=0)
+    T, B, img = 16, 2, 64
+    dev = torch.device("cuda:0")
+    cfg = O.Cfg("pvlt_tiny", lt, 224, 768, T, 0.0)
+    m = pvlt.pvlt_tiny(pretrained=False, token_hidden_size=768, num_text_tokens=T, loss_type=lt, pretrained_pth=None, compute_dtype=torch.float32)
+    m.load_state_dict(O.filled_state_dict(cfg, 8), strict=True)
+    m.cuda().train()
+    b = {k: v.to(dev) for k, v in O.to_torch_batch(filler.make_batch(8, B, img, T)).items()}
+    b["mlm_labels"].fill_(-1)
+    for kw in (dict(mlm_labels=b["mlm_labels"]), dict(mlm_labels=b["mlm_labels"], mlm_count=0), {}):
+        out = m(b["image"], b["input_ids"], **kw)
+        total, parts = compute_losses(out, b["image"], b["mlm_labels"], b["itm_labels"], b["sup_cls_labels"], b["sub_cls_labels"])
+        assert torch.isnan(parts["loss_mlm"]).item() and torch.isfinite(parts["loss_itm"]).item()
+        parts["loss_itm"].backward()                      # the other heads still train
+        torch.cuda.synchronize()
+        assert torch.isfinite(m.itm_head.linear.weight.grad).all()
