@@ -757,8 +757,13 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_cou
             if sel is not None:
                 idx, n = sel
                 mlm_positions = idx[: (n if isinstance(n, int) else n.get())]
-            labels_sel = flat[mlm_positions.long()].contiguous()
-            out["mlm_loss"] = _MLMFusedFn.apply(x4, model, HW4, mlm_positions.contiguous(), labels_sel)
+            if mlm_positions.numel() == 0:
+                # nothing selected in this batch: CrossEntropyLoss(ignore_index=-1) averages over zero rows -> NaN, and no row
+                # sends a gradient back (reference engine_grid_masking.py:84 behaves the same way)
+                out["mlm_loss"] = torch.full((), float("nan"), device=dev)
+            else:
+                labels_sel = flat[mlm_positions.long()].contiguous()
+                out["mlm_loss"] = _MLMFusedFn.apply(x4, model, HW4, mlm_positions.contiguous(), labels_sel)
             out["mlm_positions"] = mlm_positions
         else:
             out["mlm_logits"] = _MLMFullFn.apply(x4, model, HW4)
