@@ -1,0 +1,22 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): the measurement set of a round -- bench line, kernel-trace stats of the bench command, per-shape
+# GEMM inventory, SQ counters of the hot kernels, HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the roofline launches.
+#   gpurun --timeout 2400 -- 'bash tools/collect_round.sh r02'        then copy gpurun_out/<tag>_* into profiles/
+set -u
+tag=${1:-r02}
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_n1.json 2> gpurun_out/${tag}_bench_n1.err
+cut -c1-300 gpurun_out/${tag}_bench_n1.json
+bash tools/profile_bench.sh $tag --steps 6 --warmup 3 > /dev/null 2>&1
+cp gpurun_out/kernel_stats_$tag.csv gpurun_out/${tag}_kernel_stats.csv 2>/dev/null
+python3 tools/gemm_shapes.py > gpurun_out/${tag}_gemm_shapes.txt 2>&1
+bash tools/pmc_collect.sh $tag > /dev/null 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  out=gpurun_out/pmc_${tag}_$c; rm -rf "$out"; mkdir -p "$out"
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out" -o p -- python3 tools/roofline_launch.py > "$out/stdout.txt" 2> "$out/stderr.txt"
+  find "$out" -name "*kernel_trace.csv" -delete
+done
+python3 tools/roofline_traffic.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE gpurun_out/${tag}_roofline_traffic.json
+cat gpurun_out/${tag}_roofline_traffic.json | head -c 600
+ls gpurun_out | grep "^${tag}_"
