@@ -11,6 +11,7 @@ Memory layout (sized for 288 GB HBM: everything stays resident)
       copy W^T (dgrad operand) and conv weights a [out][kh][kw][cin] re-ordering (patch-GEMM operand)
 """
 import math
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -59,9 +60,13 @@ class ZeroPool:
     pool are valid until the next `reset()` (= next training/eval step): only use it for schedule-internal scratch."""
     _pools = {}
 
+    class Token:
+        """held by the autograd node of a forward that took pooled scratch: alive = that forward's backward is still pending"""
+        __slots__ = ("__weakref__",)
+
     def __init__(self, device):
         self.device, self.buf, self.used, self.need = device, None, 0, 0
-        self.pending = 0          # forwards with a graph whose backward has not finished: their scratch is still owned
+        self._live = weakref.WeakSet()   # tokens of forwards whose backward has not run (and whose graph has not been freed) yet
 
     @classmethod
     def of(cls, device):
@@ -70,25 +75,30 @@ class ZeroPool:
             cls._pools[key] = cls(device)
         return cls._pools[key]
 
+    @property
+    def pending(self):
+        return len(self._live)
+
     def reset(self, grad_on=False):
-        """Start a new step.  While an earlier forward still waits for its backward (gradient accumulation over micro-batches, an
-        eval / EMA forward between forward and backward) its pooled tensors must survive: the buffer is then left to them (they
-        hold the storage) and this step draws from a fresh one."""
+        """Start a new step; returns a token when `grad_on` (the caller parks it on its autograd node: the pool counts a forward as
+        pending for exactly as long as that node lives -- until its backward has run or its graph was dropped).  While an earlier
+        forward is pending (gradient accumulation over micro-batches, an eval / EMA forward between forward and backward) its pooled
+        tensors must survive: the buffer is then left to them (they hold the storage) and this step draws from a fresh one of the
+        size a step needs (never sized from the abandoned buffer: that grew geometrically when a forward never got its backward)."""
         want = max(self.need, self.used)
-        if self.pending > 0 and self.buf is not None:
-            want = max(want, self.buf.numel())
+        if self.pending > 0:
             self.buf = None
+        tok = None
         if grad_on:
-            self.pending += 1
+            tok = ZeroPool.Token()
+            self._live.add(tok)
         if self.buf is None or want > self.buf.numel():
-            self.buf = torch.empty(max(int(want * 1.25) + (1 << 20), want), dtype=torch.uint8, device=self.device)
+            self.buf = torch.empty(int(want * 1.25) + (1 << 20), dtype=torch.uint8, device=self.device)
             want = self.buf.numel()                              # a fresh buffer is zeroed in full
         if want:
             self.buf[:want].zero_()
         self.used, self.need = 0, 0
-
-    def backward_done(self):
-        self.pending = max(0, self.pending - 1)
+        return tok
 
     def take(self, shape, dtype):
         n = 1
@@ -312,7 +322,6 @@ class FlatStore:
 
     def _finalize(self):
         self._finalize_queued = False
-        ZeroPool.of(self.G.device).backward_done()
         self.fold_copies()
         if self.on_backward_done is not None:
             self.on_backward_done(self)

@@ -489,6 +489,7 @@ class _TrunkFn(torch.autograd.Function):
         step = TrunkStep(model, images, ids, need_grad)
         outs = step.forward()
         ctx.step = step
+        ctx.pool_token, model._pool_token = model._pool_token, None      # this node's life = the time the step's pooled scratch is owned
         ctx.mark_non_differentiable(outs[0])
         return tuple(outs)
 
@@ -499,6 +500,7 @@ class _TrunkFn(torch.autograd.Function):
         S.queue_finalize()
         step.backward([None, d2, d3, d4])
         ctx.step = None
+        ctx.pool_token = None
         grads = []
         for k, (name, p) in enumerate(S.fn_params):
             gv = S.grad(name)
@@ -734,7 +736,7 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_cou
     dev = images.device
     S.ensure(dev)
     grad_on = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
-    ZeroPool.of(dev).reset(grad_on)                               # one fill for all of this step's zero-initialised scratch
+    model._pool_token = ZeroPool.of(dev).reset(grad_on)           # one fill for all of this step's zero-initialised scratch
     lt = model.loss_type
     sel = None
     if lt['mlm'] and mlm_labels is not None and mlm_positions is None:

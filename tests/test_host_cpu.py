@@ -316,21 +316,32 @@ def test_fused_adamw_state_loads_before_the_first_forward():
 
 
 def test_zero_pool_leaves_scratch_to_a_pending_backward():
-    """a second forward before the backward of the first must not re-zero / re-issue the first one's scratch."""
+    """a second forward before the backward of the first must not re-zero / re-issue the first one's scratch; a
+    forward whose graph is dropped without a backward must not pin the pool (nor make it grow) forever."""
     from mvlt_amd.params import ZeroPool
     pool = ZeroPool(torch.device("cpu"))
-    pool.reset(True)
+    t0 = pool.reset(True)
     pool.take((16,), torch.float32)
-    pool.reset(True)                              # step 2 (buffer exists now); its backward is still pending below
-    pool.backward_done()
+    del t0                                        # step 1: backward ran (its node released the token)
+    t1 = pool.reset(True)                         # step 2 (the pool has a buffer now); its backward is still pending below
     a = pool.take((16,), torch.float32)
     a += 5.0
     assert pool.pending == 1
     pool.reset(False)                             # an eval forward in between: must not touch `a`
     b = pool.take((16,), torch.float32)
     assert float(a.sum()) == 80.0 and float(b.sum()) == 0.0 and a.data_ptr() != b.data_ptr()
-    pool.backward_done()
+    del t1
     assert pool.pending == 0
+    # forwards with grad whose graphs are dropped without a backward: pending falls back to 0 and the buffer does not grow
+    sizes = []
+    for _ in range(50):
+        tok = pool.reset(True)
+        pool.take((1000,), torch.float32)
+        sizes.append(pool.buf.numel())
+        del tok
+    assert pool.pending == 0 and max(sizes[1:]) == min(sizes[1:])
+    keep = [pool.reset(True) for _ in range(20)]  # even with every token kept alive the buffer size stays what a step needs
+    assert pool.pending == 20 and pool.buf.numel() <= sizes[-1]
 
 
 # ------------------------------------------------------------------ eval callers: metric helpers and result keys
