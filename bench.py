@@ -284,6 +284,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if use_pg:
+        dist.barrier()                                    # rank 0 is still timing its roofline launches: leave together
         dist.destroy_process_group()
 
 
