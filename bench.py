@@ -180,6 +180,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
     ap.add_argument("--img", type=int, default=256)
     ap.add_argument("--model", default="pvlt_tiny")
+    ap.add_argument("--task", default="pretrain", choices=["pretrain", "finetune"],
+                    help="pretrain = {mlm,itm,t2i} (BASELINE configs 2-4); finetune = {cls} only (config 5, dws_mvlt_ft_exp48)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -205,7 +207,7 @@ def main():
     import engine_grid_masking as E                        # the drop-in module path reference main_vl.py:198 imports
 
     torch.manual_seed(1234 + rank)
-    loss_type = dict(mlm=1, itm=1, t2i=1, cls=0)
+    loss_type = dict(mlm=1, itm=1, t2i=1, cls=0) if args.task == "pretrain" else dict(mlm=0, itm=0, t2i=0, cls=1)
     model = getattr(pvlt, args.model)(pretrained=False, token_hidden_size=768, num_text_tokens=128, loss_type=loss_type,
                                       pretrained_pth=None, drop_path_rate=0.1, drop_rate=0.0, num_classes=1000, in_chans=3)
     model.cuda(device)
@@ -252,15 +254,22 @@ def main():
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
         line = {
-            "metric": "image-text pairs/sec/node, PVT-tiny MVLT pre-train step", "value": round(pairs_s, 2), "unit": "pairs/s",
+            "metric": "image-text pairs/sec/node, PVT-tiny MVLT pre-train step" if (args.model, args.task) == ("pvlt_tiny", "pretrain")
+            else f"image-text pairs/sec/node, {args.model} MVLT {args.task} step", "value": round(pairs_s, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.model} MVLT pre-train (MLM+MIM+ITM), {args.img}x{args.img} RGB + 128 tokens, "
+            "config": {"workload": f"{args.model} MVLT " + ("pre-train (MLM+MIM+ITM)" if args.task == "pretrain" else "fine-tune (CLS heads)") + f", {args.img}x{args.img} RGB + 128 tokens, "
                                    f"batch {B}/GPU (global {B * world}), train_one_epoch_vl: fwd+loss+bwd+allreduce+AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "fused AdamW (fp32 master)",
                        "entry": "engine_grid_masking.train_one_epoch_vl", "epoch_avg_loss": round(stats["total_loss"], 4)},
         }
-        if args.model == "pvlt_tiny" and args.img == 256:
+        # SURVEY.md 8d train-step FLOPs per pair of the other BASELINE configurations (reference-equivalent = 3 x forward)
+        other = {("pvlt_medium", 384, "pretrain"): 197.25e9, ("pvlt_tiny", 256, "finetune"): 25.00e9}.get((args.model, args.img, args.task))
+        if other:
+            line["flops"] = {"reference_equivalent_gflop_per_pair": other / 1e9,
+                             "step_tflops_reference_equivalent": round(pairs_s / world * other / 1e12, 1),
+                             "mfma_frac_reference_equivalent": round(pairs_s / world * other / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        if args.model == "pvlt_tiny" and args.img == 256 and args.task == "pretrain":
             executed = 3 * (FWD_ALL - FWD_MLM) + 3 * FWD_MLM * n_sel / (B * 128) + 2 * FWD_FC1_RECOMPUTED
             per_gpu = pairs_s / world
             line["flops"] = {
