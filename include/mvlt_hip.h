@@ -282,6 +282,12 @@ typedef struct mvlt_mlp_args {
   void* h_out;                        /* fwd: optional bf16 [M,hid] pre-activation */
   float* dw1; float* db1; float* dw2; float* db2;      /* bwd_dw */
   int M, C, hid;
+  /* fwd only, optional: LayerNorm folded into the kernel's operand load (Block.norm2 + Mlp, reference libs/pvlt.py:142).  When
+   * ln_x != NULL the kernel reads the fp32 rows ln_x[M,C] (= `residual`, the block's mid stream) instead of `x`, normalises them
+   * (two-pass statistics per row, eps = ln_eps, affine ln_gamma / ln_beta), uses the result as the fc1 operand and stores it to
+   * ln_y[M,C] (bf16, what `x` would have held: the backward passes read it) together with the row statistics ln_mean / ln_rstd. */
+  const float* ln_x; const float* ln_gamma; const float* ln_beta; float ln_eps;
+  void* ln_y; float* ln_mean; float* ln_rstd;
 } mvlt_mlp_args;
 int mvlt_mlp_fwd(const mvlt_mlp_args* args, void* stream);
 int mvlt_mlp_bwd_dx(const mvlt_mlp_args* args, void* stream);

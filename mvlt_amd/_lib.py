@@ -90,7 +90,9 @@ class MlpArgs(C.Structure):
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("w1", c_void_p), ("wb", c_void_p), ("wc", c_void_p),
                 ("b1", c_void_p), ("b2", c_void_p), ("residual", c_void_p), ("row_scale", c_void_p), ("rows_per_scale", c_int),
                 ("out", c_void_p), ("h_out", c_void_p), ("dw1", c_void_p), ("db1", c_void_p), ("dw2", c_void_p), ("db2", c_void_p),
-                ("M", c_int), ("C", c_int), ("hid", c_int)]
+                ("M", c_int), ("C", c_int), ("hid", c_int),
+                ("ln_x", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
+                ("ln_y", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p)]
 
 
 lib.mvlt_last_error.restype = C.c_char_p

@@ -61,6 +61,54 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
   // ---- B-operand fragments of this wave's tokens (x, and dy for the backward): 8 consecutive channels of token fr per
   // lane, straight from global memory (used by every hidden chunk, never re-read: no LDS copy)
   bf16x8 xfr[MT][KS_C], yfr[MODE == 1 ? MT : 1][KS_C];
+  if (MODE == 0 && p.ln_x) {
+    // LayerNorm folded into the operand load (Block.norm2): the four fg-lanes of a token hold its whole fp32 row (KS_C x 8 channels
+    // each), so the row statistics are two xor-shuffles away; the normalised row is this wave's fc1 operand AND is stored for the
+    // backward passes, which replaces a separate LayerNorm launch (fp32 row read + bf16 row written once more)
+    const float inv_c = 1.0f / (float)C;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + wave * WR + mt * 16 + fr;
+      const bool ok = m < p.M;
+      float v[KS_C][8];
+      float sum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS_C; ++ks) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const float* src = p.ln_x + (long)m * C + ks * 32 + fg * 8;
+          a = *(const f32x4*)src; b = *(const f32x4*)(src + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[ks][e] = a[e]; v[ks][4 + e] = b[e]; sum += a[e] + b[e]; }
+      }
+      sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+      const float mean = sum * inv_c;
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS_C; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[ks][e] - mean; q += d * d; }
+      q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+      const float rstd = rsqrtf(q * inv_c + p.ln_eps);
+      if (ok && fg == 0) { p.ln_mean[m] = mean; p.ln_rstd[m] = rstd; }
+#pragma unroll
+      for (int ks = 0; ks < KS_C; ++ks) {
+        const float* gp = p.ln_gamma + ks * 32 + fg * 8;
+        const float* bp = p.ln_beta + ks * 32 + fg * 8;
+        const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4), be0 = *(const f32x4*)bp, be1 = *(const f32x4*)(bp + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (bf16)((v[ks][e] - mean) * rstd * g0[e] + be0[e]);
+          o[4 + e] = (bf16)((v[ks][4 + e] - mean) * rstd * g1[e] + be1[e]);
+        }
+        if (!ok) o = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        xfr[mt][ks] = o;
+        if (ok) *(bf16x8*)((bf16*)p.ln_y + (long)m * C + ks * 32 + fg * 8) = o;
+      }
+    }
+  } else {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -74,6 +122,7 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
       xfr[mt][ks] = __builtin_bit_cast(bf16x8, v);
       if (MODE == 1) yfr[mt][ks] = __builtin_bit_cast(bf16x8, w);
     }
+  }
   // ---- weight-chunk staging (global -> registers -> LDS), double buffered
   constexpr int WA_IT = JC * (C / 8) / NT;   // 2 (C=64) / 4 (C=128)
   constexpr int WB_IT = C * (JC / 8) / NT;   // 2 / 4
@@ -480,7 +529,7 @@ template <int C, int MODE> int launch(const mvlt_mlp_args& a, hipStream_t s) {
 }
 
 int check(const mvlt_mlp_args* a, const char* who) {
-  MVLT_REQUIRE(a && a->x && a->w1 && a->wb && a->b1 && a->out, "%s: null pointer", who);
+  MVLT_REQUIRE(a && (a->x || a->ln_x) && a->w1 && a->wb && a->b1 && a->out, "%s: null pointer", who);
   MVLT_REQUIRE(a->C == 64 || a->C == 128, "%s: C must be 64 or 128 (stage 1 / 2), got %d", who, a->C);
   MVLT_REQUIRE(a->hid > 0 && a->hid % 64 == 0, "%s: hidden size must be a multiple of 64", who);
   MVLT_REQUIRE(!a->row_scale || a->rows_per_scale > 0, "%s: row_scale needs rows_per_scale", who);
@@ -492,6 +541,8 @@ int check(const mvlt_mlp_args* a, const char* who) {
 extern "C" int mvlt_mlp_fwd(const mvlt_mlp_args* a, void* stream) {
   if (int e = check(a, "mvlt_mlp_fwd")) return e;
   MVLT_REQUIRE(a->b2 && a->residual, "mvlt_mlp_fwd: b2 and residual are required");
+  MVLT_REQUIRE(!a->ln_x || (a->ln_gamma && a->ln_beta && a->ln_y && a->ln_mean && a->ln_rstd && ((uintptr_t)a->ln_x & 15) == 0 && ((uintptr_t)a->ln_y & 15) == 0),
+               "mvlt_mlp_fwd: the folded LayerNorm needs gamma, beta, y, mean, rstd and 16-byte aligned rows");
   if (a->M <= 0) return MVLT_OK;
   return a->C == 64 ? launch<64, 0>(*a, (hipStream_t)stream) : launch<128, 0>(*a, (hipStream_t)stream);
 }

@@ -291,11 +291,20 @@ def upsample_bwd(dy, lddy, nchw, B, H, W, Cdim, scale, dx, lddx, accumulate=Fals
 
 
 # ------------------------------------------------------------------ fused MLP (csrc/mlp.hip), bf16, C in {64, 128}
-def mlp_fwd(x, w1, b1, w2, b2, residual, out, M, Cdim, hid, *, row_scale=None, rows_per_scale=0, h_out=None):
-    assert x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
-    assert residual.dtype == torch.float32 and out.dtype == torch.float32
+def mlp_fwd(x, w1, b1, w2, b2, residual, out, M, Cdim, hid, *, row_scale=None, rows_per_scale=0, h_out=None, ln=None):
+    """ln = (gamma, beta, eps, y, mean, rstd): LayerNorm(residual) folded into the operand load -- `x` is then not read (may be None);
+    y (bf16 [M, C]) receives the normalised rows, mean / rstd (fp32 [M]) the row statistics."""
+    assert w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
+    assert residual.dtype == torch.float32 and out.dtype == torch.float32 and residual.is_contiguous()
+    if ln is None:
+        assert x.dtype == torch.bfloat16
+        tail = (None, None, None, 0.0, None, None, None)
+    else:
+        g, b, eps, y, mean, rstd = ln
+        assert g.dtype == b.dtype == mean.dtype == rstd.dtype == torch.float32 and y.dtype == torch.bfloat16 and y.is_contiguous()
+        tail = (ptr(residual), ptr(g), ptr(b), eps, ptr(y), ptr(mean), ptr(rstd))
     a = L.MlpArgs(ptr(x), None, ptr(w1), ptr(w2), None, ptr(b1), ptr(b2), ptr(residual), ptr(row_scale), rows_per_scale,
-                  ptr(out), ptr(h_out), None, None, None, None, M, Cdim, hid)
+                  ptr(out), ptr(h_out), None, None, None, None, M, Cdim, hid, *tail)
     check(L.lib.mvlt_mlp_fwd(C.byref(a), stream_ptr()), "mvlt_mlp_fwd")
     return out
 
@@ -303,7 +312,7 @@ def mlp_fwd(x, w1, b1, w2, b2, residual, out, M, Cdim, hid, *, row_scale=None, r
 def mlp_bwd_dx(x, dy, w1, w1t, w2t, b1, out, M, Cdim, hid, *, row_scale=None, rows_per_scale=0):
     assert x.dtype == dy.dtype == out.dtype == torch.bfloat16
     a = L.MlpArgs(ptr(x), ptr(dy), ptr(w1), ptr(w1t), ptr(w2t), ptr(b1), None, None, ptr(row_scale), rows_per_scale,
-                  ptr(out), None, None, None, None, None, M, Cdim, hid)
+                  ptr(out), None, None, None, None, None, M, Cdim, hid, None, None, None, 0.0, None, None, None)
     check(L.lib.mvlt_mlp_bwd_dx(C.byref(a), stream_ptr()), "mvlt_mlp_bwd_dx")
     return out
 
@@ -311,7 +320,7 @@ def mlp_bwd_dx(x, dy, w1, w1t, w2t, b1, out, M, Cdim, hid, *, row_scale=None, ro
 def mlp_bwd_dw(x, dy, w1, w2t, b1, dw1, db1, dw2, db2, M, Cdim, hid, *, row_scale=None, rows_per_scale=0):
     assert x.dtype == dy.dtype == torch.bfloat16 and dw1.dtype == torch.float32
     a = L.MlpArgs(ptr(x), ptr(dy), ptr(w1), None, ptr(w2t), ptr(b1), None, None, ptr(row_scale), rows_per_scale,
-                  None, None, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), M, Cdim, hid)
+                  None, None, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), M, Cdim, hid, None, None, None, 0.0, None, None, None)
     check(L.lib.mvlt_mlp_bwd_dw(C.byref(a), stream_ptr()), "mvlt_mlp_bwd_dw")
 
 

@@ -25,6 +25,7 @@ def _empty(shape, dtype, dev):
 
 _LN_COPIES = not os.environ.get("MVLT_LN_NO_COPIES")      # A/B switch: LayerNorm parameter gradients by plain atomics
 _NO_DX2 = bool(os.environ.get("MVLT_NO_DX2"))      # A/B switch: DropPath-scaled gradient copy by a separate pass
+_NO_LN_FOLD = bool(os.environ.get("MVLT_NO_LN_FOLD"))      # A/B switch: LN2 as its own launch in front of the fused MLP
 # A/B switch: conv weight gradients accumulated straight into the [out][cin][kh][kw] layout by the wgrad epilogue (strided atomics)
 # instead of a pooled [out][kh][kw][cin] buffer + one permuted add
 WGRAD_TAPS = bool(os.environ.get("MVLT_WGRAD_TAPS"))
@@ -289,16 +290,20 @@ class TrunkStep:
         # LN2 + MLP (fc1 + exact GELU, fc2) + DropPath + residual
         xn2 = _empty((B, N, C), dt, dev)
         bs["m2"], bs["r2"] = _empty((M,), f32, dev), _empty((M,), f32, dev)
-        ops.layernorm_fwd(xm, xn2, self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m2"], rstd=bs["r2"])
         bs["xn2"] = xn2
         xo = _empty((B, N, C), self.rt, dev)
         bs["fused_mlp"] = fused = (dt == torch.bfloat16 and C in (64, 128))
         if fused:
-            # stages 1-2: fc1 -> GELU -> fc2 -> DropPath -> +residual in ONE kernel; the (tokens x hidden) activation stays
-            # on chip and is recomputed by the fused backward kernels (nothing saved but LN2's output)
-            ops.mlp_fwd(xn2, self.w(p + "mlp.fc1.weight"), self.f32(p + "mlp.fc1.bias"), self.w(p + "mlp.fc2.weight"),
-                        self.f32(p + "mlp.fc2.bias"), xm, xo, M, C, hid, row_scale=s2, rows_per_scale=N)
+            # stages 1-2: LN2 -> fc1 -> GELU -> fc2 -> DropPath -> +residual in ONE kernel.  The (tokens x hidden) activation stays on
+            # chip and is recomputed by the fused backward kernels; LN2 is folded into the operand load (the kernel reads the fp32
+            # mid stream once for both the normalisation and the residual, and stores LN2's output + statistics for the backward)
+            ln = None if _NO_LN_FOLD else (self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), EPS_BLOCK, xn2, bs["m2"], bs["r2"])
+            if ln is None:
+                ops.layernorm_fwd(xm, xn2, self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m2"], rstd=bs["r2"])
+            ops.mlp_fwd(None if ln else xn2, self.w(p + "mlp.fc1.weight"), self.f32(p + "mlp.fc1.bias"), self.w(p + "mlp.fc2.weight"),
+                        self.f32(p + "mlp.fc2.bias"), xm, xo, M, C, hid, row_scale=s2, rows_per_scale=N, ln=ln)
         else:
+            ops.layernorm_fwd(xm, xn2, self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m2"], rstd=bs["r2"])
             hpre = _empty((M, hid), dt, dev) if self.need_grad else None
             gact = _empty((M, hid), dt, dev)
             ops.gemm_nt(xn2, self.w(p + "mlp.fc1.weight"), gact, M, hid, C, C, C, hid, bias=self.f32(p + "mlp.fc1.bias"), act=1, H=hpre)

@@ -730,3 +730,29 @@ def test_small_head_cross_entropy_fn():
         (ref * 1.7).backward()
         assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
         assert maxrel(lg.grad, lr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("Cdim,hid,M,Bsz", [(64, 512, 3 * 400, 3), (128, 1024, 2 * 333, 2), (64, 512, 130, 1)])
+def test_fused_mlp_with_folded_layernorm(ops, Cdim, hid, M, Bsz):
+    """mvlt_mlp_fwd with ln_x: LayerNorm(norm2, eps 1e-6) folded into the operand load must equal mvlt_layernorm_fwd followed by the
+    plain fused MLP -- same output, same stored LN output and row statistics"""
+    bf = torch.bfloat16
+    xm = rnd(M, Cdim, dtype=torch.float32, scale=1.5) + 0.3
+    g, b = 1 + 0.2 * rnd(Cdim, dtype=torch.float32, seed=1), 0.1 * rnd(Cdim, dtype=torch.float32, seed=2)
+    w1 = (rnd(hid, Cdim, dtype=torch.float32, seed=3) * Cdim ** -0.5).to(bf)
+    w2 = (rnd(Cdim, hid, dtype=torch.float32, seed=4) * hid ** -0.5).to(bf)
+    b1, b2 = 0.1 * rnd(hid, dtype=torch.float32, seed=5), 0.1 * rnd(Cdim, dtype=torch.float32, seed=6)
+    rs = (torch.arange(Bsz, device=dev()) % 2).float() * 1.25
+    xn = torch.empty(M, Cdim, device=dev(), dtype=bf)
+    mean, rstd = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    ops.layernorm_fwd(xm, xn, g, b, M, Cdim, Cdim, Cdim, 1e-6, mean=mean, rstd=rstd)
+    ref = ops.mlp_fwd(xn, w1, b1, w2, b2, xm, torch.empty_like(xm), M, Cdim, hid, row_scale=rs, rows_per_scale=M // Bsz)
+    xn2 = torch.empty_like(xn)
+    mean2, rstd2 = torch.empty_like(mean), torch.empty_like(rstd)
+    out = ops.mlp_fwd(None, w1, b1, w2, b2, xm, torch.empty_like(xm), M, Cdim, hid, row_scale=rs, rows_per_scale=M // Bsz,
+                      ln=(g, b, 1e-6, xn2, mean2, rstd2))
+    assert maxrel(mean2, mean) < 1e-5 and maxrel(rstd2, rstd) < 1e-5
+    assert (xn2.float() - xn.float()).abs().max().item() <= 2 ** -7 * xn.float().abs().max().item()      # at most one bf16 ulp apart
+    assert maxrel(out, ref) < 5e-3
+    tref = F.layer_norm(xm, (Cdim,), g, b, 1e-6)
+    assert maxrel(xn2.float(), tref) < TOL[bf]
