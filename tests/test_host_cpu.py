@@ -431,3 +431,26 @@ def test_integration_md_binding_snippet_matches_the_header():
     exec(block, ns)
     assert C.sizeof(ns["RowMap"]) == L.lib.mvlt_sizeof(b"mvlt_rowmap")
     assert C.sizeof(ns["GemmNTArgs"]) == L.lib.mvlt_sizeof(b"mvlt_gemm_nt_args")
+
+
+def test_cosine_schedule_per_epoch_values():
+    """mvlt_amd.sched: the reference's per-epoch cosine schedule (main_vl.py:69-87,310,439; timm CosineLRScheduler restated)"""
+    import math
+    import types
+    from mvlt_amd.sched import create_scheduler
+    w = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.AdamW([dict(params=[w], weight_decay=0.0), dict(params=[torch.nn.Parameter(torch.zeros(2, 2))], weight_decay=0.05)], lr=5e-4)
+    args = types.SimpleNamespace(sched="cosine", epochs=100, min_lr=1e-5, warmup_lr=1e-6, warmup_epochs=5, cooldown_epochs=10)
+    s, n = create_scheduler(args, opt)
+    assert n == 110 and opt.param_groups[0]["lr"] == 1e-6                 # warm-up start value set at construction
+    want = {0: 1e-6, 1: 1e-6 + (5e-4 - 1e-6) / 5, 4: 1e-6 + 4 * (5e-4 - 1e-6) / 5,
+            5: 1e-5 + 0.5 * (5e-4 - 1e-5) * (1 + math.cos(math.pi * 5 / 100)), 50: 1e-5 + 0.5 * (5e-4 - 1e-5),
+            99: 1e-5 + 0.5 * (5e-4 - 1e-5) * (1 + math.cos(math.pi * 0.99)), 100: 1e-5, 109: 1e-5}
+    for ep, lr in want.items():
+        s.step(ep)
+        assert opt.param_groups[0]["lr"] == pytest.approx(lr, rel=1e-12) and opt.param_groups[1]["lr"] == opt.param_groups[0]["lr"]
+    sd = s.state_dict()
+    s2, _ = create_scheduler(args, opt)
+    s2.load_state_dict(sd)
+    s2.step(50)
+    assert opt.param_groups[1]["lr"] == pytest.approx(want[50])
