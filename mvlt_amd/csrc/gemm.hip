@@ -1193,6 +1193,172 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_a
       }
 }
 
+// ------------------------------------------------------------------------------------------------ conv3x3 weight gradient, LDS halo
+// dW[o][tap][c] += sum over pixels dz[pixel][o] * x[pixel + tap][c]: the weight gradient of the MIM decoder's conv3x3 (reference
+// libs/vl_heads.py:116-129) on pixel-major data.  As the generic TN GEMM with the 3x3 gather on B (BMODE 2 above) every tap re-fetches
+// its shifted copy of the input rows through the LDS-DMA path -- 9 x 64 rows of B per 64-pixel k-tile -- and that path, not the MFMAs,
+// bounds the GEMM loops of this chip (round-2 ablations): 96 B/clk/CU asked of a path that sustains ~16-20.
+// Here a workgroup owns a 64 (out) x 9 (taps) x 64 (in) block of dW in registers (36 accumulator tiles per wave) and, per k-tile of
+// 64 pixels (= 64 / W whole image rows), loads the pixels' HALO once -- (64/W + 2) x (W + 2) input rows of 64 channels, 17 KB at
+// W = 32 instead of 72 KB -- and forms all nine taps' B fragments from it by transposed LDS reads at shifted row addresses (pixels of
+// a fragment are consecutive in one image row, so a tap is a constant row offset; out-of-image halo rows come from the zero page).
+// 25 KB through the DMA path per 4.7 MFLOP: ~22 B/clk/CU at full MFMA rate.
+template <int W>
+__global__ __launch_bounds__(NTHREADS, 2) void conv3_wgrad_kernel(mvlt_gemm_tn_args p, int tiles_per_split, int n_o, int n_c, int splits) {
+  using TA = DmaTile<64>;
+  constexpr int R = 64 / W;                         // image rows per 64-pixel k-tile
+  constexpr int HW2 = W + 2, HR = (R + 2) * HW2;    // halo rows (one pixel each, 64 channels = 128 B)
+  constexpr int H_IT = (HR * 8 + NTHREADS - 1) / NTHREADS;          // DMA instructions per thread for the halo (last one partly idle)
+  constexpr int HALO_BYTES = H_IT * NTHREADS * 16;
+  constexpr int STAGE = TA::BYTES + HALO_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][dz tile | halo tile]
+  const int txy = n_o * n_c;
+  int bz, xy;
+  if (splits >= 8) {
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    const int zq = kq / txy;
+    xy = kq - zq * txy;
+    bz = zq * 8 + xcd;
+    if (bz >= splits) return;
+  } else {
+    bz = blockIdx.x / txy;
+    xy = blockIdx.x - bz * txy;
+  }
+  const int bo = xy % n_o, bc = xy / n_o;
+  const int o0 = bo * 64, c0 = bc * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned smem_lds = (unsigned)(uintptr_t)smem;
+  const int ntiles = p.M / 64;
+  const int t_begin = bz * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
+  const int Himg = p.b_map.h_in, cin = p.b_map.c_seg, tokens_in = p.b_map.tokens_in;
+  const int tiles_per_img = Himg * W / 64;
+  const char* zsrc = (const char*)g_zero_page + ((tid * 16 + (blockIdx.x & 15) * 4096) & 65535);
+
+  // ---- loader geometry.  dz tile: as the TN kernel's A tile (64 pixels x 64 outputs, chunks swizzled by TA::h on the source side)
+  const int a_row0 = tid / TA::CH;
+  const int a_col = o0 + (((tid % TA::CH) ^ (TA::h(a_row0) << 1)) << 3);
+  const char* a_src = (const char*)p.A + 2 * a_col;
+  const unsigned a_rowb = 2u * (unsigned)p.lda, b_rowb = 2u * (unsigned)p.ldb;
+  // halo tile: LDS row hr = (hy, hx) of the padded (R+2) x (W+2) window; slot s of row hr holds source chunk s ^ (hh(hr) << 1).
+  // The bank hash of this tile uses bit 1 of the row only: a fragment's second read sits 4 rows below its first at ANY row
+  // alignment here (taps shift the rows by +-1 and +-(W+2)), so the hash must not change under +4 (TA::h does when bit 2 is set).
+  // Rows r..r+3 land on four distinct (bank half, window) pairs, the +8 group repeats them: 2-way conflicts, LDS stays off the
+  // critical path (72 transposed reads per 36 MFMAs).
+  auto hh = [](int row) { return (row >> 1) & 1; };
+  int h_dy[H_IT], h_off[H_IT];
+  bool h_xok[H_IT];
+#pragma unroll
+  for (int j = 0; j < H_IT; ++j) {
+    const int q = tid + j * NTHREADS, hr = q >> 3, sl = q & 7;
+    const int hy = hr / HW2, hx = hr - hy * HW2;
+    h_dy[j] = hy - 1;
+    h_xok[j] = hr < HR && (unsigned)(hx - 1) < (unsigned)W;
+    h_off[j] = (hx - 1) * (int)b_rowb + 2 * (c0 + ((sl ^ (hh(hr) << 1)) << 3));
+  }
+  auto issue = [&](int tile, int slot) {
+    const int img = tile / tiles_per_img, y0 = (tile - img * tiles_per_img) * R;
+#pragma unroll
+    for (int j = 0; j < TA::IT; ++j) {
+      const unsigned m = (unsigned)(tile * 64 + j * TA::RPP + a_row0);
+      glds16(a_src + (unsigned long long)m * a_rowb, __builtin_amdgcn_readfirstlane(smem_lds + slot * STAGE + (j * NTHREADS + wave * 64) * 16));
+    }
+    const char* img_base = (const char*)p.B + (unsigned long long)(unsigned)(img * tokens_in) * b_rowb;
+#pragma unroll
+    for (int j = 0; j < H_IT; ++j) {
+      const int y = y0 + h_dy[j];
+      const bool ok = h_xok[j] && (unsigned)y < (unsigned)Himg;
+      glds16(ok ? img_base + (long)(y * W) * (long)b_rowb + h_off[j] : zsrc,
+             __builtin_amdgcn_readfirstlane(smem_lds + slot * STAGE + TA::BYTES + (j * NTHREADS + wave * 64) * 16));
+    }
+  };
+
+  // ---- fragment geometry (transposed reads: lane (g, L) supplies k-row 8g + (L >> 2) and the row 4 below, 8-B piece L & 3)
+  const int g = lane >> 4, L = lane & 15;
+  const int frow = 8 * g + (L >> 2);
+  int aoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) aoff[i] = TA::frag_off(frow, wm * 2 + i, L);
+  // B fragment of (k32 step ks, tap t, channel tile j): halo row of pixel ks*32 + frow shifted by the tap
+  int boff[2][9];                                   // channel tile j = 0; j = 1 is the neighbouring 32-B window: offset ^ 32
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int pix = ks * 32 + frow, py = pix / W, px = pix - py * W;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int hr = (py + t / 3) * HW2 + px + t % 3;             // (py + 1 + dy, px + 1 + dx) with dy = t/3 - 1, dx = t%3 - 1
+      boff[ks][t] = TA::BYTES + hr * 128 + (((wn * 2) ^ hh(hr)) << 5) + ((L & 3) << 3);
+    }
+  }
+  f32x4 acc[2][9][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16* const nb = nullptr;
+
+  if (t_begin < t_end) issue(t_begin, 0);
+  int slot = 0;
+  for (int tile = t_begin; tile < t_end; ++tile, slot ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // tile has landed for every wave; everyone is done reading the slot refilled next
+    asm volatile("" ::: "memory");
+    if (tile + 1 < t_end) issue(tile + 1, slot ^ 1);
+    const char* sS = smem + slot * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 fa[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = tr_frag(sS + aoff[i] + ks * 32 * TA::ROWB, TA::ROWB);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        u32x4 fb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = tr_frag(sS + (boff[ks][t] ^ (j << 5)), 128);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma16(acc[i][t][j], fa[i], fa[i], fb[j], fb[j], nb);
+      }
+    }
+  }
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n1 = o0 + wm * 32 + i * 16 + 4 * fg + r;
+          const int n2 = t * cin + c0 + wn * 32 + j * 16 + fr;
+          atomicAdd(&p.C[(long)n1 * p.ldc + n2], acc[i][t][j][r]);
+        }
+}
+
+template <int W> int launch_conv3_wgrad(const mvlt_gemm_tn_args& a, hipStream_t s) {
+  constexpr int R = 64 / W, HR = (R + 2) * (W + 2), H_IT = (HR * 8 + NTHREADS - 1) / NTHREADS;
+  const size_t lds = (size_t)2 * (DmaTile<64>::BYTES + H_IT * NTHREADS * 16);
+  const int n_o = a.N1 / 64, n_c = a.b_map.c_seg / 64, ntiles = a.M / 64;
+  // every split flushes its whole 64 x 576 block with fp32 atomics: at least 16 k-tiles of work per flush, about two workgroups per
+  // CU when the shape allows (262144 x 64 x 576: 640 splits of 7 tiles 108 us, 256 splits of 16 tiles measured below)
+  static const int min_tiles = getenv("MVLT_CONV_WGRAD_MINT") ? atoi(getenv("MVLT_CONV_WGRAD_MINT")) : 16;
+  int splits = (512 + n_o * n_c - 1) / (n_o * n_c);
+  if (splits > ntiles / min_tiles) splits = ntiles / min_tiles;
+  if (splits < 1) splits = 1;
+  if (splits >= 8) splits = (splits + 4) / 8 * 8;
+  if (splits > ntiles) splits = ntiles;
+  const int tps = (ntiles + splits - 1) / splits;
+  splits = (ntiles + tps - 1) / tps;
+  dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * n_o * n_c)), block(NTHREADS);
+  hipFuncSetAttribute((const void*)conv3_wgrad_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv3_wgrad_kernel<W>), grid, block, lds, s, a, tps, n_o, n_c, splits);
+  return mvlt_check_launch("mvlt_gemm_tn");
+}
+
 // ------------------------------------------------------------------------------------------------ NT, bf16, LDS-DMA
 // gemm_nt_kernel<bf16,BN> with the operand tiles filled by global_load_lds_dwordx4 instead of load -> VGPR ->
 // ds_write_b128 (LDS stores run at ~80 B/clk/CU, a third of the read rate, and were as expensive as the MFMAs).  The
@@ -1493,6 +1659,18 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
   if (a->M == 0) return MVLT_OK;
   hipStream_t s = (hipStream_t)stream;
   const int mtiles = (a->M + TBK - 1) / TBK;
+  // conv3x3 weight gradient with an LDS-resident halo (conv3_wgrad_kernel): 3x3 gather on B over a W x H grid with W in {8, 16, 32},
+  // whole 64-pixel k-tiles inside one image, 64-multiples of channels, plain [out][tap*cin + c] output
+  static const bool conv_wgrad_ok = !getenv("MVLT_NO_CONV_WGRAD");
+  if (conv_wgrad_ok && a->dtype == 0 && a->b_map.mode == 2 && a->a_map.mode == 0 && a->a_map.rows_per_batch == 0 && !a->trans_c && a->c_taps <= 1 &&
+      !a->colsum_a && !a->colsum_b && a->N1 % 64 == 0 && a->b_map.c_seg % 64 == 0 && a->N2 == 9 * a->b_map.c_seg && a->M % 64 == 0 &&
+      (a->b_map.w_in == 8 || a->b_map.w_in == 16 || a->b_map.w_in == 32) && (a->b_map.h_in * a->b_map.w_in) % 64 == 0 &&
+      a->M % (a->b_map.h_in * a->b_map.w_in) == 0 && a->ldb >= a->b_map.c_seg) {
+    hipStream_t s2 = (hipStream_t)stream;
+    if (a->b_map.w_in == 32) return launch_conv3_wgrad<32>(*a, s2);
+    if (a->b_map.w_in == 16) return launch_conv3_wgrad<16>(*a, s2);
+    return launch_conv3_wgrad<8>(*a, s2);
+  }
   if (a->dtype == 0 && a->M < (1 << 24) && !getenv("MVLT_TN_LEGACY")) {
     // LDS-DMA kernel: A tile 128 or 64 wide, B tile 128 or 64 wide; ~1024 workgroups, splits a multiple of the 8 XCDs
     // outputs of at most 128 x 128 take 64 x 64 tiles: every output cache line receives one atomic request per m-split, those

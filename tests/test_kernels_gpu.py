@@ -756,3 +756,28 @@ def test_fused_mlp_with_folded_layernorm(ops, Cdim, hid, M, Bsz):
     assert maxrel(out, ref) < 5e-3
     tref = F.layer_norm(xm, (Cdim,), g, b, 1e-6)
     assert maxrel(xn2.float(), tref) < TOL[bf]
+
+
+@pytest.mark.parametrize("side,Cin,Cout,Bsz,tokens_extra", [(32, 64, 64, 3, 0), (32, 192, 192, 2, 0), (16, 128, 64, 5, 128), (8, 64, 128, 9, 128),
+                                                           (32, 128, 64, 1, 128), (16, 64, 64, 4, 0)])
+def test_conv3x3_wgrad_lds_halo(ops, side, Cin, Cout, Bsz, tokens_extra):
+    """conv3_wgrad_kernel (mvlt_gemm_tn with the 3x3 gather on B, W in {8, 16, 32}): the nine taps' fragments come from ONE LDS-resident
+    halo per 64-pixel k-tile; checked against autograd of F.conv2d, accumulate semantics, and the generic gathered TN GEMM."""
+    import os
+    from mvlt_amd._lib import conv3map
+    tokens_in = side * side + tokens_extra                     # stage buffers carry the text tokens behind the image tokens
+    X = rnd(Bsz, tokens_in, Cin, dtype=torch.bfloat16)
+    M = Bsz * side * side
+    dY = rnd(M, Cout, dtype=torch.bfloat16, seed=2)
+    dW = torch.zeros(Cout, 9 * Cin, device=dev(), dtype=torch.float32)
+    amap = conv3map(side, side, tokens_in, Cin)
+    ops.gemm_tn(dY, X, dW, M, Cout, 9 * Cin, Cout, Cin, 9 * Cin, b_map=amap)
+    img = X[:, : side * side].float().reshape(Bsz, side, side, Cin).permute(0, 3, 1, 2)
+    Wc = torch.zeros(Cout, Cin, 3, 3, device=dev(), requires_grad=True)
+    y = F.conv2d(img, Wc, None, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    (y * dY.float()).sum().backward()
+    ref = Wc.grad.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)      # [out][tap][cin]
+    assert maxrel(dW, ref) < TOL[torch.bfloat16]
+    assert rel(dW, ref) < 5e-3
+    ops.gemm_tn(dY, X, dW, M, Cout, 9 * Cin, Cout, Cin, 9 * Cin, b_map=amap)
+    assert rel(dW, 2 * ref) < 5e-3
