@@ -1659,14 +1659,15 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
   if (a->M == 0) return MVLT_OK;
   hipStream_t s = (hipStream_t)stream;
   const int mtiles = (a->M + TBK - 1) / TBK;
-  // conv3x3 weight gradient with an LDS-resident halo (conv3_wgrad_kernel): 3x3 gather on B over a W x H grid with W in {8, 16, 32},
+  // conv3x3 weight gradient with an LDS-resident halo (conv3_wgrad_kernel): 3x3 gather on B over a W x H grid with W in {8, 16, 32, 64},
   // whole 64-pixel k-tiles inside one image, 64-multiples of channels, plain [out][tap*cin + c] output
   static const bool conv_wgrad_ok = !getenv("MVLT_NO_CONV_WGRAD");
   if (conv_wgrad_ok && a->dtype == 0 && a->b_map.mode == 2 && a->a_map.mode == 0 && a->a_map.rows_per_batch == 0 && !a->trans_c && a->c_taps <= 1 &&
       !a->colsum_a && !a->colsum_b && a->N1 % 64 == 0 && a->b_map.c_seg % 64 == 0 && a->N2 == 9 * a->b_map.c_seg && a->M % 64 == 0 &&
-      (a->b_map.w_in == 8 || a->b_map.w_in == 16 || a->b_map.w_in == 32) && (a->b_map.h_in * a->b_map.w_in) % 64 == 0 &&
+      (a->b_map.w_in == 8 || a->b_map.w_in == 16 || a->b_map.w_in == 32 || a->b_map.w_in == 64) && (a->b_map.h_in * a->b_map.w_in) % 64 == 0 &&
       a->M % (a->b_map.h_in * a->b_map.w_in) == 0 && a->ldb >= a->b_map.c_seg) {
     hipStream_t s2 = (hipStream_t)stream;
+    if (a->b_map.w_in == 64) return launch_conv3_wgrad<64>(*a, s2);
     if (a->b_map.w_in == 32) return launch_conv3_wgrad<32>(*a, s2);
     if (a->b_map.w_in == 16) return launch_conv3_wgrad<16>(*a, s2);
     return launch_conv3_wgrad<8>(*a, s2);

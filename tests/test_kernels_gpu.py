@@ -759,7 +759,8 @@ def test_fused_mlp_with_folded_layernorm(ops, Cdim, hid, M, Bsz):
 
 
 @pytest.mark.parametrize("side,Cin,Cout,Bsz,tokens_extra", [(32, 64, 64, 3, 0), (32, 192, 192, 2, 0), (16, 128, 64, 5, 128), (8, 64, 128, 9, 128),
-                                                           (32, 128, 64, 1, 128), (16, 64, 64, 4, 0)])
+                                                           (32, 128, 64, 1, 128), (16, 64, 64, 4, 0), (64, 64, 64, 2, 0), (8, 64, 64, 1, 0),
+                                                           (24, 64, 64, 2, 0)])      # 24: not a halo width -> generic gathered GEMM
 def test_conv3x3_wgrad_lds_halo(ops, side, Cin, Cout, Bsz, tokens_extra):
     """conv3_wgrad_kernel (mvlt_gemm_tn with the 3x3 gather on B, W in {8, 16, 32}): the nine taps' fragments come from ONE LDS-resident
     halo per 64-pixel k-tile; checked against autograd of F.conv2d, accumulate semantics, and the generic gathered TN GEMM."""
