@@ -42,6 +42,13 @@ def main():
     todo.append(lambda: ops.gemm_nt(a, w, o, M, N, K, K, K, N, bias=bias, act=1, H=h))
     dwg = torch.zeros(N, K, device=dev)
     todo.append(lambda: ops.gemm_tn(o, a, dwg, M, N, K, N, K, K))
+    # MIM decoder: weight gradient of the 192 -> 192 conv3x3 at 32 x 32 (conv3_wgrad_kernel: LDS-resident halo)
+    from mvlt_amd._lib import conv3map
+    Mc, Cc2 = B * 1024, 192
+    xz, dz = torch.randn(B, 1024, Cc2, device=dev).to(bf), torch.randn(Mc, Cc2, device=dev).to(bf)
+    dwc = torch.zeros(Cc2, 9 * Cc2, device=dev)
+    cmap = conv3map(32, 32, 1024, Cc2)
+    todo.append(lambda: ops.gemm_tn(dz, xz, dwc, Mc, Cc2, 9 * Cc2, Cc2, Cc2, 9 * Cc2, b_map=cmap))
     # stage-1 attention: B x 1 head, 4224 queries, 192 keys
     Nq, Mk, Cc = 4224, 192, 64
     q, kv = torch.randn(B, Nq, Cc, device=dev).to(bf), torch.randn(B, Mk, 2 * Cc, device=dev).to(bf)
