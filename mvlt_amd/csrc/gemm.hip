@@ -1515,6 +1515,167 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
   else nt_epilogue_lean<BN, EPI, TM_>(p, acc, smem, m0, n0, wave, lane);
 }
 
+// ------------------------------------------------------------------------------------------------ conv3x3 forward / dgrad, LDS halo
+// C[pixel][n] = sum over taps t and channels c of x[pixel + tap t][c] * B[n][t*cin + c]: the MIM decoder's conv3x3 (and its input
+// gradient, the same gather with flipped taps) as the NT GEMM with a_map mode 2.  In gemm_nt_dma_kernel every k-step fetches its own
+// shifted copy of the 128 input rows through the LDS-DMA path, nine times per 64 channels.  Here the K loop runs channel slice
+// outermost: per 64-channel slice the tile's HALO -- (128/W + 2) x (W + 2) input rows, 26 KB at W = 32 -- is loaded once and all
+// nine taps read their A fragments from it at shifted row addresses (ds_read_b128, the row's 16-B chunks XOR-swizzled by the halo
+// row); only the weight tiles still stream per k-step.  A traffic per 128 x 192-channel tile: 78 KB instead of 432 KB.  Same tile
+// and wave geometry as gemm_nt_dma_kernel (128 x BN, 4 waves, two workgroups per CU), so its epilogues are used unchanged.
+template <int W, int BN, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void conv3_nt_kernel(mvlt_gemm_nt_args p) {
+  constexpr int BK = 64, ROWB = 128, CH = 8;
+  constexpr int RPL = NTHREADS / CH;
+  constexpr int WN = BN / 2, TN_ = WN / 16, TM_ = 4;
+  constexpr int B_ITERS = BN * CH / NTHREADS;
+  constexpr int R = BM / W, HW2 = W + 2, HR = (R + 2) * HW2;          // image rows per tile; halo rows (one pixel, 64 channels = 128 B)
+  constexpr int H_IT = (HR * 8 + NTHREADS - 1) / NTHREADS;
+  constexpr int HALO_BYTES = H_IT * NTHREADS * 16;
+  constexpr int BSTAGE = BN * ROWB;
+  auto swzk = [](int row, int chunk) { return chunk ^ ((row >> 1) & 7); };
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // [halo slice | B stage 0 | B stage 1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_m = p.M / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, bgroup = bid >> 3;
+  const int tile_m = (bgroup / tiles_n) * 8 + xcd, tile_n = bgroup % tiles_n;
+  if (tile_m >= tiles_m) return;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const unsigned smem_lds = (unsigned)(uintptr_t)smem;
+  const int Himg = p.a_map.h_in, cin = p.a_map.c_seg, tokens_in = p.a_map.tokens_in;
+  const int tiles_per_img = Himg * W / BM;
+  const int img = tile_m / tiles_per_img, y0 = (tile_m - img * tiles_per_img) * R;
+  const char* zsrc = (const char*)g_zero_page + ((tid * 16 + (bid & 15) * 4096) & 65535);
+  const unsigned a_rowb = 2u * (unsigned)p.lda;
+  const char* img_base = (const char*)p.A + (unsigned long long)(unsigned)(img * tokens_in) * a_rowb;
+
+  // ---- halo loader: LDS row hr = (hy, hx) of the padded window; slot s of row hr holds source chunk swzk(hr, s)
+  const char* h_src[H_IT];
+#pragma unroll
+  for (int j = 0; j < H_IT; ++j) {
+    const int q = tid + j * NTHREADS, hr = q >> 3, sl = q & 7;
+    const int hy = hr / HW2, hx = hr - hy * HW2;
+    const int y = y0 + hy - 1, x = hx - 1;
+    const bool ok = hr < HR && (unsigned)y < (unsigned)Himg && (unsigned)x < (unsigned)W;
+    h_src[j] = ok ? img_base + (long)(y * W + x) * (long)a_rowb + 2 * (swzk(hr, sl) << 3) : nullptr;
+  }
+  auto issue_halo = [&](int kc) {
+#pragma unroll
+    for (int j = 0; j < H_IT; ++j)
+      glds16(h_src[j] ? h_src[j] + kc * 128 : zsrc, __builtin_amdgcn_readfirstlane(smem_lds + (j * NTHREADS + wave * 64) * 16));
+  };
+  // ---- weight loader (as gemm_nt_dma_kernel): row n of the tile, chunk swizzled by row
+  const int row_in = tid / CH;
+  const int chunk = swzk(row_in, tid % CH);
+  const char* b_ptr[B_ITERS];
+  bool b_ok[B_ITERS];
+#pragma unroll
+  for (int i = 0; i < B_ITERS; ++i) {
+    int n = n0 + row_in + RPL * i;
+    b_ok[i] = n < p.N;
+    b_ptr[i] = (const char*)p.B + (unsigned long long)(unsigned)(b_ok[i] ? n : 0) * (2u * (unsigned)p.ldb) + chunk * 16;
+  }
+  auto issue_b = [&](int kc, int t, int slot) {
+    const int koff = (t * cin + kc * 64) * 2;
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i)
+      glds16(b_ok[i] ? b_ptr[i] + koff : zsrc, __builtin_amdgcn_readfirstlane(smem_lds + HALO_BYTES + slot * BSTAGE + (i * NTHREADS + wave * 64) * 16));
+  };
+
+  f32x4 acc[TM_][TN_];
+#pragma unroll
+  for (int i = 0; i < TM_; ++i)
+#pragma unroll
+    for (int j = 0; j < TN_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  // halo row of this lane's pixel in each of the wave's four 16-pixel tiles, tap (0, 0)
+  int hbase[TM_];
+#pragma unroll
+  for (int i = 0; i < TM_; ++i) {
+    const int pix = wm * 64 + i * 16 + fr, py = pix / W, px = pix - py * W;
+    hbase[i] = (py + 1) * HW2 + px + 1;
+  }
+  const int nkc = cin / 64;
+  int bslot = 0;
+  for (int kc = 0; kc < nkc; ++kc) {
+    // the previous slice's A reads (and the B stage refilled below) are done for every wave
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_halo(kc);
+    if (kc == 0) issue_b(0, 0, bslot);                     // later slices: their first weight tile was issued during the previous tap 8
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // weight tile (kc, t) (and a fresh halo) landed; reads of the other stage done
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t + 1 < 9) issue_b(kc, t + 1, bslot ^ 1);
+      else if (kc + 1 < nkc) issue_b(kc + 1, 0, bslot ^ 1);
+      const int tapoff = (t / 3 - 1) * HW2 + (t % 3 - 1);
+      const char* b_s = smem + HALO_BYTES + bslot * BSTAGE + (wn * WN) * ROWB;
+      bslot ^= 1;
+      u32x4 fa[2][TM_], fb[2][TN_];
+#pragma unroll
+      for (int i = 0; i < TM_; ++i) {
+        const int hr = hbase[i] + tapoff;
+        const char* rowp = smem + hr * 128;
+        const int sw = (hr >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fa[ks][i] = *(const u32x4*)(rowp + (((ks * 4 + fg) ^ sw) << 4));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) {
+          int r = j * 16 + fr;
+          fb[ks][j] = *(const u32x4*)(b_s + r * ROWB + swzk(wn * WN + r, ks * 4 + fg) * 16);
+        }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM_; ++i)
+#pragma unroll
+          for (int j = 0; j < TN_; ++j) mma16(acc[i][j], fa[ks][i], fa[ks][i], fb[ks][j], fb[ks][j], (bf16*)nullptr);
+      }
+    }
+  }
+  __syncthreads();                   // last reads are done before the epilogue reuses the LDS
+  if constexpr (BN == 192) nt_epilogue_192<EPI>(p, acc, smem, m0, n0, wave, lane);
+  else nt_epilogue_lean<BN, EPI, TM_>(p, acc, smem, m0, n0, wave, lane);
+}
+
+template <int W, int BN, int EPI> void launch_conv3_nt(const mvlt_gemm_nt_args& a, hipStream_t s) {
+  constexpr int R = BM / W, HR = (R + 2) * (W + 2), H_IT = (HR * 8 + NTHREADS - 1) / NTHREADS;
+  size_t lds = (size_t)H_IT * NTHREADS * 16 + (size_t)2 * BN * ROW_BYTES;
+  const size_t stage = (size_t)4 * 32 * (BN / 2 + 4) * sizeof(float);
+  if (lds < stage) lds = stage;
+  const int tiles_m = a.M / BM, tiles_n = (a.N + BN - 1) / BN;
+  dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n)), block(NTHREADS);
+  hipFuncSetAttribute((const void*)conv3_nt_kernel<W, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv3_nt_kernel<W, BN, EPI>), grid, block, lds, s, a);
+}
+template <int W> bool dispatch_conv3_nt(const mvlt_gemm_nt_args& a, int epi, hipStream_t s) {
+  const bool wide = a.N % 192 == 0 && a.N % 128 != 0 && (epi == 1 || epi == 5) && a.c_map.mode == 0;
+  if (wide) { if (epi == 1) launch_conv3_nt<W, 192, 1>(a, s); else launch_conv3_nt<W, 192, 5>(a, s); return true; }
+  if (a.N <= 64) {
+    switch (epi) {
+      case 1: launch_conv3_nt<W, 64, 1>(a, s); return true;
+      case 2: launch_conv3_nt<W, 64, 2>(a, s); return true;
+      case 5: launch_conv3_nt<W, 64, 5>(a, s); return true;
+      default: return false;
+    }
+  }
+  switch (epi) {
+    case 1: launch_conv3_nt<W, 128, 1>(a, s); return true;
+    case 2: launch_conv3_nt<W, 128, 2>(a, s); return true;
+    case 5: launch_conv3_nt<W, 128, 5>(a, s); return true;
+    default: return false;
+  }
+}
+
 int check_rowmap(const mvlt_rowmap& m, const char* who) {
   if (m.mode == 0) {
     MVLT_REQUIRE(m.rows_per_batch >= 0, "%s: rows_per_batch < 0", who);
@@ -1612,6 +1773,16 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     else if (a->a_map.mode == 1) MVLT_NT_LAUNCH_E(BN_, 1, BK_);                                                      \
     else MVLT_NT_LAUNCH_E(BN_, 2, BK_);                                                                              \
   } while (0)
+    // conv3x3 (a_map mode 2) on an LDS-resident, channel-sliced halo: grids of width 16 / 32 / 64, whole 128-pixel tiles inside one
+    // image, 64-multiples of gathered channels, lean epilogue, identity or batch-strided output rows
+    static const bool conv_nt_ok = !getenv("MVLT_NO_CONV_NT");
+    if (conv_nt_ok && a->a_map.mode == 2 && (epi == 1 || epi == 2 || epi == 5) && a->split_k <= 1 && a->a_map.c_seg % 64 == 0 && a->c_map.mode == 0 &&
+        (a->a_map.w_in == 16 || a->a_map.w_in == 32 || a->a_map.w_in == 64) && (a->a_map.h_in * a->a_map.w_in) % BM == 0 && a->M % BM == 0 &&
+        a->M % (a->a_map.h_in * a->a_map.w_in) == 0 && a->a_map.hw_out == a->a_map.h_in * a->a_map.w_in && a->a_map.w_out == a->a_map.w_in &&
+        a->K == 9 * a->a_map.c_seg && a->lda >= a->a_map.c_seg && a->ldb >= a->K) {
+      bool done = a->a_map.w_in == 32 ? dispatch_conv3_nt<32>(*a, epi, s) : a->a_map.w_in == 16 ? dispatch_conv3_nt<16>(*a, epi, s) : dispatch_conv3_nt<64>(*a, epi, s);
+      if (done) return mvlt_check_launch("mvlt_gemm_nt");
+    }
     // N % 192 == 0 (the 192-channel convolutions): one 192-wide tile instead of 128 + a half-empty 128
     const bool wide = !narrow && a->N % 192 == 0 && a->N % 128 != 0 && (epi == 1 || epi == 5) && a->c_map.mode == 0 && a->a_map.mode != 1 &&
                       a->K >= 128 && !getenv("MVLT_NT_NO192");

@@ -782,3 +782,50 @@ def test_conv3x3_wgrad_lds_halo(ops, side, Cin, Cout, Bsz, tokens_extra):
     assert rel(dW, ref) < 5e-3
     ops.gemm_tn(dY, X, dW, M, Cout, 9 * Cin, Cout, Cin, 9 * Cin, b_map=amap)
     assert rel(dW, 2 * ref) < 5e-3
+
+
+@pytest.mark.parametrize("side,Cin,Cout,Bsz,tokens_extra,variant",
+                         [(32, 192, 192, 2, 0, "stats"), (32, 192, 192, 1, 0, "plain"), (32, 128, 128, 2, 128, "plain"), (32, 64, 64, 3, 0, "stats"),
+                          (16, 128, 64, 5, 128, "plain"), (16, 64, 320, 4, 0, "strided"), (64, 64, 64, 1, 0, "acc"), (32, 64, 128, 2, 0, "acc"),
+                          (16, 320, 64, 2, 0, "plain"),          # 320 channels: 5 slices
+                          (8, 64, 64, 3, 0, "plain"), (24, 64, 64, 2, 0, "plain"), (32, 72, 64, 1, 0, "plain")])      # not halo shapes -> generic gather
+def test_conv3x3_nt_lds_halo(ops, side, Cin, Cout, Bsz, tokens_extra, variant):
+    """conv3_nt_kernel (mvlt_gemm_nt with the 3x3 gather on A, W in {16, 32, 64}, 64-multiples of channels): the nine taps read their A
+    fragments from one LDS-resident halo per 64-channel slice.  Checked against F.conv2d for the epilogues the MIM decoder uses: plain
+    store, BatchNorm column statistics, accumulate into R, and batch-strided output rows."""
+    from mvlt_amd._lib import conv3map, rowmap
+    bf = torch.bfloat16
+    tokens_in = side * side + tokens_extra
+    X = rnd(Bsz, tokens_in, Cin, dtype=bf)
+    Wk = rnd(Cout, 9 * Cin, dtype=bf, scale=0.05, seed=3)                     # [out][tap][cin]
+    M = Bsz * side * side
+    amap = conv3map(side, side, tokens_in, Cin)
+    img = X[:, : side * side].float().reshape(Bsz, side, side, Cin).permute(0, 3, 1, 2)
+    Wc = Wk.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(img, Wc, None, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    if variant == "plain":
+        out = torch.empty(M, Cout, device=dev(), dtype=torch.float32)
+        ops.gemm_nt(X, Wk, out, M, Cout, 9 * Cin, Cin, 9 * Cin, Cout, a_map=amap)
+        assert maxrel(out, ref) < TOL[bf]
+        out16 = torch.empty(M, Cout, device=dev(), dtype=bf)
+        ops.gemm_nt(X, Wk, out16, M, Cout, 9 * Cin, Cin, 9 * Cin, Cout, a_map=amap)
+        assert maxrel(out16.float(), ref) < 2 * TOL[bf]
+    elif variant == "stats":
+        out = torch.empty(M, Cout, device=dev(), dtype=torch.float32)
+        st = torch.zeros(2, 4, Cout, device=dev())
+        ops.gemm_nt(X, Wk, out, M, Cout, 9 * Cin, Cin, 9 * Cin, Cout, a_map=amap, col_sum=st[0], col_sumsq=st[1], col_copies=4)
+        assert maxrel(out, ref) < TOL[bf]
+        assert maxrel(st[0].sum(0), out.sum(0)) < 1e-4
+        assert maxrel(st[1].sum(0), (out * out).sum(0)) < 1e-4
+    elif variant == "acc":
+        base = rnd(M, Cout, dtype=torch.float32, seed=5)
+        out = base.clone()
+        ops.gemm_nt(X, Wk, out, M, Cout, 9 * Cin, Cin, 9 * Cin, Cout, a_map=amap, R=out)
+        assert maxrel(out, ref + base) < TOL[bf]
+    else:                                                                 # rows of image b land at b * stride + offset of a wider buffer
+        stride, off = side * side + 7, 3
+        buf = torch.full((Bsz * stride, Cout), 7.0, device=dev(), dtype=bf)
+        ops.gemm_nt(X, Wk, buf, M, Cout, 9 * Cin, Cin, 9 * Cin, Cout, a_map=amap, c_map=rowmap(side * side, stride, off))
+        got = buf.view(Bsz, stride, Cout)[:, off: off + side * side].reshape(M, Cout).float()
+        assert maxrel(got, ref) < 2 * TOL[bf]
+        assert (buf.view(Bsz, stride, Cout)[:, :off] == 7.0).all() and (buf.view(Bsz, stride, Cout)[:, off + side * side:] == 7.0).all()
