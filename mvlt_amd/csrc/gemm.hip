@@ -1521,7 +1521,7 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
 // shifted copy of the 128 input rows through the LDS-DMA path, nine times per 64 channels.  Here the K loop runs channel slice
 // outermost: per 64-channel slice the tile's HALO -- (128/W + 2) x (W + 2) input rows, 26 KB at W = 32 -- is loaded once and all
 // nine taps read their A fragments from it at shifted row addresses (ds_read_b128, the row's 16-B chunks XOR-swizzled by the halo
-// row); only the weight tiles still stream per k-step.  A traffic per 128 x 192-channel tile: 78 KB instead of 432 KB.  Same tile
+// row, conflict-free from any first row); only the weight tiles still stream per k-step.  A traffic per 128 x 192-channel tile: 78 KB instead of 432 KB.  Same tile
 // and wave geometry as gemm_nt_dma_kernel (128 x BN, 4 waves, two workgroups per CU), so its epilogues are used unchanged.
 template <int W, int BN, int EPI>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3_nt_kernel(mvlt_gemm_nt_args p) {
@@ -1534,6 +1534,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_nt_kernel(mvlt_gemm_nt_args
   constexpr int HALO_BYTES = H_IT * NTHREADS * 16;
   constexpr int BSTAGE = BN * ROWB;
   auto swzk = [](int row, int chunk) { return chunk ^ ((row >> 1) & 7); };
+  // halo rows are read at arbitrary (tap-shifted) offsets: chunk ^ (((row >> 1) & 3) << 1) keeps every 16-lane group of a
+  // ds_read_b128 -- 16 consecutive rows, lanes 4..11 of them one chunk further -- on 16 distinct 16-B bank slots from ANY first row
+  // (the (row >> 1) & 7 form used for the 16-aligned tiles is 2-way conflicted from three first rows in four)
+  auto swzh = [](int row) { return ((row >> 1) & 3) << 1; };
   extern __shared__ __attribute__((aligned(16))) char smem[];          // [halo slice | B stage 0 | B stage 1]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -1560,7 +1564,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_nt_kernel(mvlt_gemm_nt_args
     const int hy = hr / HW2, hx = hr - hy * HW2;
     const int y = y0 + hy - 1, x = hx - 1;
     const bool ok = hr < HR && (unsigned)y < (unsigned)Himg && (unsigned)x < (unsigned)W;
-    h_src[j] = ok ? img_base + (long)(y * W + x) * (long)a_rowb + 2 * (swzk(hr, sl) << 3) : nullptr;
+    h_src[j] = ok ? img_base + (long)(y * W + x) * (long)a_rowb + 2 * ((sl ^ swzh(hr)) << 3) : nullptr;
   }
   auto issue_halo = [&](int kc) {
 #pragma unroll
@@ -1611,6 +1615,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_nt_kernel(mvlt_gemm_nt_args
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // weight tile (kc, t) (and a fresh halo) landed; reads of the other stage done
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      // all pieces of the next weight tile right behind the barrier: one piece between each pair of MFMA groups instead was 5 % slower
       if (t + 1 < 9) issue_b(kc, t + 1, bslot ^ 1);
       else if (kc + 1 < nkc) issue_b(kc + 1, 0, bslot ^ 1);
       const int tapoff = (t / 3 - 1) * HW2 + (t % 3 - 1);
@@ -1621,7 +1626,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_nt_kernel(mvlt_gemm_nt_args
       for (int i = 0; i < TM_; ++i) {
         const int hr = hbase[i] + tapoff;
         const char* rowp = smem + hr * 128;
-        const int sw = (hr >> 1) & 7;
+        const int sw = swzh(hr);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fa[ks][i] = *(const u32x4*)(rowp + (((ks * 4 + fg) ^ sw) << 4));
       }
