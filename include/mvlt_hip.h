@@ -215,6 +215,14 @@ int mvlt_gelu_bwd(const void* dy, const void* h, void* out, long n, int dtype, v
 int mvlt_grid_mask_flags(uint8_t* flags, int B, int gh, int gw, int num_mask, int mode, uint64_t seed, uint64_t sample0, void* stream);
 int mvlt_grid_mask_apply(const float* image, const uint8_t* flags, float* masked, int B, int C, int H, int W, int patch, float fill, void* stream);
 int mvlt_token_mask(const long* ori_ids, long* input_ids, long* labels, int B, int T, uint64_t seed, uint64_t sample0, int vocab, void* stream);
+/* Train-mode masks of the step, from the same generator (key = seed, counter = (element, call, stream 2 / 3)), `call` = the
+ * caller's running count of draws:
+ * mvlt_keep_mask: keep[i] = 1 with probability 1 - drop_p (16-bit draws) -- nn.Dropout(0.1) inside BertEmbeddings (reference
+ *   libs/pvlt.py:232-233,326 via transformers); the forward / backward kernels take it as their `keep` operand.
+ * mvlt_droppath_scales: out[r][j] = keep / (1 - rates[r]), keep ~ Bernoulli(1 - rates[r]) per (block r, sample j) on 24-bit
+ *   draws -- timm DropPath (libs/pvlt.py:135,141-142): x / keep_prob * mask, one mask value per sample. */
+int mvlt_keep_mask(uint8_t* keep, long n, float drop_p, uint64_t seed, uint64_t call, void* stream);
+int mvlt_droppath_scales(float* out, const float* rates, int nrate, int per, uint64_t seed, uint64_t call, void* stream);
 
 /* dst[r,:] = src[map(idx[r]),:]  and  dst[map(idx[r]),:] (+)= src[r,:]   (idx rows unique; map = mode-0 rowmap or NULL) */
 int mvlt_gather_rows(const void* src, const int* idx, void* dst, int rows, int C, int ld_src, const mvlt_rowmap* src_map, int dtype, void* stream);
@@ -315,9 +323,11 @@ int mvlt_ew_mul(float* out, int ldo, const float* a, int lda, const float* b, in
 int mvlt_ew_mul3_bwd(const float* dy, int lddy, const float* a, const float* b, const float* c, int ld, float* da, float* db, float* dc,
                      long M, int C, void* stream);
 /* bilinear resize by an integer factor, align_corners=True.  x fp32 [B,H,W,C] (row stride ldx) -> [B,sH,sW,C] (bf16/fp32,
- * row stride ldo) or NCHW fp32 [B,C,sH,sW]; bwd is the exact adjoint in gather form (no atomics). */
+ * row stride ldo) or NCHW fp32 [B,C,sH,sW]; bwd is the exact adjoint in gather form (no atomics); its dx is fp32 (dx_dtype 1) or,
+ * behind the NCHW upsample only, bf16 (dx_dtype 0: the [pixels][8]-padded operand of the score conv's gradient GEMMs). */
 int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, int C, int scale, void* out, int ldo, int out_dtype, int nchw, void* stream);
-int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int H, int W, int C, int scale, float* dx, int lddx, int accumulate, void* stream);
+int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int H, int W, int C, int scale, void* dx, int lddx, int accumulate, int dx_dtype,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -90,6 +90,37 @@ __global__ __launch_bounds__(NT) void token_mask_kernel(const long* ori, long* i
   ids[i] = out;
   labels[i] = sel ? id : -1;
 }
+// ---- train-mode masks of the step itself (nn.Dropout inside BertEmbeddings, timm DropPath per block; reference libs/pvlt.py:135,233),
+// from the same counter-based generator: one launch each instead of ATen's rand / compare / cast / divide chains.
+// keep[i] = draw_i >= drop_p on 16-bit draws (eight per Philox call, one 8-byte store per thread); counter = (i / 8, call, 2, call >> 32).
+__global__ __launch_bounds__(NT) void keep_mask_kernel(uint8_t* keep, long n, uint32_t thr16, uint64_t seed, uint64_t call) {
+  const long g = (long)blockIdx.x * NT + threadIdx.x;
+  if (g * 8 >= n) return;
+  const u4 d = draws(seed, call, (uint32_t)g, 2);
+  const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+  uint8_t k[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) k[e] = ((w[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) >= thr16;
+  if (g * 8 + 8 <= n) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v |= (uint64_t)k[e] << (8 * e);
+    *(uint64_t*)(keep + g * 8) = v;
+  } else {
+    for (int e = 0; g * 8 + e < n; ++e) keep[g * 8 + e] = k[e];
+  }
+}
+// out[r][j] = (draw >= rate[r]) / (1 - rate[r]) on 24-bit draws: DropPath's per-sample keep factor (timm drop_path: x / keep_prob * mask);
+// counter = (r * per + j, call, 3, call >> 32)
+__global__ __launch_bounds__(NT) void droppath_scales_kernel(float* out, const float* rates, int nrate, int per, uint64_t seed, uint64_t call) {
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= nrate * per) return;
+  const float rate = rates[i / per];
+  const uint32_t thr = (uint32_t)(rate * 16777216.0f);
+  const uint32_t d = draws(seed, call, (uint32_t)i, 3).x >> 8;
+  out[i] = d >= thr ? 1.0f / (1.0f - rate) : 0.0f;
+}
+
 }  // namespace
 
 extern "C" int mvlt_grid_mask_flags(uint8_t* flags, int B, int gh, int gw, int num_mask, int mode, uint64_t seed, uint64_t sample0, void* stream) {
@@ -121,4 +152,20 @@ extern "C" int mvlt_token_mask(const long* ori_ids, long* input_ids, long* label
   hipLaunchKernelGGL(token_mask_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, ori_ids, input_ids, labels, n, T, seed,
                      sample0, vocab, 2516583, 13421773, 15099495);
   return mvlt_check_launch("mvlt_token_mask");
+}
+
+extern "C" int mvlt_keep_mask(uint8_t* keep, long n, float drop_p, uint64_t seed, uint64_t call, void* stream) {
+  MVLT_REQUIRE(keep && n >= 0 && drop_p >= 0.f && drop_p < 1.f && ((uintptr_t)keep & 7) == 0, "mvlt_keep_mask: bad arguments");
+  if (n == 0) return MVLT_OK;
+  const long groups = (n + 7) / 8;
+  hipLaunchKernelGGL(keep_mask_kernel, dim3((unsigned)((groups + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, keep, n, (uint32_t)(drop_p * 65536.0f), seed,
+                     call);
+  return mvlt_check_launch("mvlt_keep_mask");
+}
+
+extern "C" int mvlt_droppath_scales(float* out, const float* rates, int nrate, int per, uint64_t seed, uint64_t call, void* stream) {
+  MVLT_REQUIRE(out && rates && nrate >= 0 && per >= 0, "mvlt_droppath_scales: bad arguments");
+  if (nrate * per == 0) return MVLT_OK;
+  hipLaunchKernelGGL(droppath_scales_kernel, dim3((unsigned)((nrate * per + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, out, rates, nrate, per, seed, call);
+  return mvlt_check_launch("mvlt_droppath_scales");
 }

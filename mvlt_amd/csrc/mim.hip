@@ -381,7 +381,8 @@ __global__ __launch_bounds__(NT) void upsample_bwd_row_kernel(const float* dy, i
 }
 // backward, NCHW dy (final x8 upsample, C = 3): workgroup = (b, c, iy).  Pass 1: thread ox folds its output column over
 // the rows that touch iy (coalesced plane-row reads) into LDS; pass 2: thread ix folds the <= 2s+1 columns that touch it.
-__global__ __launch_bounds__(NT) void upsample_bwd_nchw_kernel(const float* dy, int H, int W, int C, int s, float* dx, int lddx, int accumulate) {
+template <typename TO>
+__global__ __launch_bounds__(NT) void upsample_bwd_nchw_kernel(const float* dy, int H, int W, int C, int s, TO* dx, int lddx, int accumulate) {
   extern __shared__ float colsum[];                // [Wo]
   const int Ho = H * s, Wo = W * s;
   const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
@@ -412,13 +413,14 @@ __global__ __launch_bounds__(NT) void upsample_bwd_nchw_kernel(const float* dy, 
       const float wxi = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
       t += wxi * colsum[ox];
     }
-    float* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
-    *d = accumulate ? *d + t : t;
+    TO* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
+    *d = from_f32<TO>(accumulate ? to_f32<TO>(*d) + t : t);
   }
 }
 
 // the same for Wo % 4 == 0, Wo <= 256: 16-byte loads, the ~2s contributing output rows split over the four waves
-__global__ __launch_bounds__(NT) void upsample_bwd_nchw4_kernel(const float* dy, int H, int W, int C, int s, float* dx, int lddx, int accumulate) {
+template <typename TO>
+__global__ __launch_bounds__(NT) void upsample_bwd_nchw4_kernel(const float* dy, int H, int W, int C, int s, TO* dx, int lddx, int accumulate) {
   __shared__ __attribute__((aligned(16))) float part[4][256];
   const int Ho = H * s, Wo = W * s;
   const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
@@ -450,8 +452,8 @@ __global__ __launch_bounds__(NT) void upsample_bwd_nchw4_kernel(const float* dy,
       const float wxi = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
       acc += wxi * (part[0][ox] + part[1][ox] + part[2][ox] + part[3][ox]);
     }
-    float* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
-    *d = accumulate ? *d + acc : acc;
+    TO* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
+    *d = from_f32<TO>(accumulate ? to_f32<TO>(*d) + acc : acc);
   }
 }
 
@@ -581,17 +583,26 @@ extern "C" int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, i
   return mvlt_check_launch("mvlt_upsample_fwd");
 }
 
-extern "C" int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int H, int W, int C, int scale, float* dx, int lddx, int accumulate, void* stream) {
-  MVLT_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1, "mvlt_upsample_bwd: bad arguments");
+extern "C" int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int H, int W, int C, int scale, void* dx_, int lddx, int accumulate, int dx_dtype,
+                                 void* stream) {
+  MVLT_REQUIRE(dy && dx_ && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1, "mvlt_upsample_bwd: bad arguments");
+  MVLT_REQUIRE(dx_dtype == 1 || (dx_dtype == 0 && nchw), "mvlt_upsample_bwd: bf16 dx only behind the NCHW (final x8) upsample");
+  float* dx = (float*)dx_;
   long total = (long)B * H * W * C;
   if (nchw && (size_t)W * scale * sizeof(float) <= 64 * 1024) {
-    if ((W * scale) % 4 == 0 && W * scale <= 256 && ((uintptr_t)dy & 15) == 0)
-      hipLaunchKernelGGL(upsample_bwd_nchw4_kernel, dim3((unsigned)(B * C * H)), dim3(NT), 0, (hipStream_t)stream, dy, H, W, C, scale, dx, lddx, accumulate);
-    else
-      hipLaunchKernelGGL(upsample_bwd_nchw_kernel, dim3((unsigned)(B * C * H)), dim3(NT), (size_t)W * scale * sizeof(float), (hipStream_t)stream, dy, H, W, C,
-                         scale, dx, lddx, accumulate);
+    const dim3 grid((unsigned)(B * C * H));
+    const size_t lds = (size_t)W * scale * sizeof(float);
+    const bool v4 = (W * scale) % 4 == 0 && W * scale <= 256 && ((uintptr_t)dy & 15) == 0;
+    if (dx_dtype == 0) {
+      if (v4) hipLaunchKernelGGL(upsample_bwd_nchw4_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)stream, dy, H, W, C, scale, (bf16*)dx_, lddx, accumulate);
+      else hipLaunchKernelGGL(upsample_bwd_nchw_kernel<bf16>, grid, dim3(NT), lds, (hipStream_t)stream, dy, H, W, C, scale, (bf16*)dx_, lddx, accumulate);
+    } else {
+      if (v4) hipLaunchKernelGGL(upsample_bwd_nchw4_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, dy, H, W, C, scale, dx, lddx, accumulate);
+      else hipLaunchKernelGGL(upsample_bwd_nchw_kernel<float>, grid, dim3(NT), lds, (hipStream_t)stream, dy, H, W, C, scale, dx, lddx, accumulate);
+    }
     return mvlt_check_launch("mvlt_upsample_bwd");
   }
+  MVLT_REQUIRE(dx_dtype == 1, "mvlt_upsample_bwd: bf16 dx needs the row-buffered NCHW path (W * scale * 4 <= 64 KB)");
   if (!nchw && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0) {
     const int chunks = (W * (C / 4) + NT - 1) / NT;
     hipLaunchKernelGGL(upsample_bwd_row_kernel, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, H, W, C, scale, dx, lddx,

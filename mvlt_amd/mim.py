@@ -141,7 +141,7 @@ class MimStep:
                          g_beta=S.grad(p + ".1.bias"), g_gamma=S.grad(p + ".1.weight"))
         # wgrad computed in the gather's [out][dy][dx][cin] order, accumulated at nn.Conv2d's [out][cin][3][3] place
         from .schedule import conv_wgrad
-        conv_wgrad(dz, r["xin"], S.grad(p + ".0.weight"), M, cout, 9 * cin, cout, r["ld_in"], r["amap"], 9, cin)
+        conv_wgrad(S, p + ".0.weight", dz, r["xin"], M, cout, 9 * cin, cout, r["ld_in"], r["amap"], 9, cin)
         # dgrad: gather dz over the same grid with flipped taps
         gmap = conv3map(r["side"], r["side"], r["side"] * r["side"], cout)
         if dx is None:
@@ -157,10 +157,8 @@ class MimStep:
         k = self.keep
         dout = dout.contiguous().float()
         # score head
-        dsc = _e((M1, 3), dev)
-        ops.upsample_bwd(dout, 0, True, B, s1, s1, 3, 8, dsc, 3)
-        dsc_p = _z((M1, 8), dev, dt)
-        dsc_p[:, :3] = dsc.to(dt)
+        dsc_p = _z((M1, 8), dev, dt)                     # [pixels][3 -> 8] in the compute dtype: the operand of the two GEMMs below
+        ops.upsample_bwd(dout, 0, True, B, s1, s1, 3, 8, dsc_p, 8)
         # weight gradient and, as the GEMM's column sum, the bias gradient (a torch sum over a [262144, 3] matrix took 92 us)
         ops.gemm_tn(dsc_p, k["e16"], S.grad("t2i_head.score.0.weight").view(3, 3 * ch), M1, 3, 3 * ch, 8, 3 * ch, 3 * ch,
                     colsum=S.grad("t2i_head.score.0.bias"))
@@ -216,6 +214,7 @@ class _MimFn(torch.autograd.Function):
         step.S.queue_finalize()
         g2, g3, g4 = step.backward(dout)
         ctx.step = None
+        step.S.fold_copies()                          # the conv weight gradients leave the tap arena for G
         step.S.announce_prefix("t2i_head.")          # the decoder's gradients are final: reduce them under the trunk backward
         return g2, g3, g4, None, None, None
 

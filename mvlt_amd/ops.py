@@ -242,7 +242,7 @@ L.lib.mvlt_bn_bwd_reduce.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _l, _i, _vp, _v
 L.lib.mvlt_bn_bwd_apply.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _vp, _i, _vp]
 L.lib.mvlt_ew_mul.argtypes = [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _l, _i, _i, _vp, _i, _i, _vp]
 L.lib.mvlt_upsample_fwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]
-L.lib.mvlt_upsample_bwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]
+L.lib.mvlt_upsample_bwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]
 
 
 def col_stats(z, ldz, M, Cdim, s, ss):
@@ -286,8 +286,9 @@ def upsample_fwd(x, ldx, B, H, W, Cdim, scale, out, ldo, nchw=False):
 
 
 def upsample_bwd(dy, lddy, nchw, B, H, W, Cdim, scale, dx, lddx, accumulate=False):
-    check(L.lib.mvlt_upsample_bwd(_p(dy), lddy, 1 if nchw else 0, B, H, W, Cdim, scale, _p(dx), lddx, 1 if accumulate else 0, stream_ptr()),
-          "mvlt_upsample_bwd")
+    assert dy.dtype == torch.float32 and dx.dtype in DT
+    check(L.lib.mvlt_upsample_bwd(_p(dy), lddy, 1 if nchw else 0, B, H, W, Cdim, scale, _p(dx), lddx, 1 if accumulate else 0, DT[dx.dtype],
+                                  stream_ptr()), "mvlt_upsample_bwd")
 
 
 # ------------------------------------------------------------------ fused MLP (csrc/mlp.hip), bf16, C in {64, 128}
@@ -351,6 +352,27 @@ def token_mask(ori_ids, input_ids, labels, seed, sample0, vocab=30522):
     assert ori_ids.dtype == input_ids.dtype == labels.dtype == torch.int64 and ori_ids.is_contiguous()
     B, T = ori_ids.shape
     check(L.lib.mvlt_token_mask(_p(ori_ids), _p(input_ids), _p(labels), B, T, seed, sample0, vocab, stream_ptr()), "mvlt_token_mask")
+
+
+L.lib.mvlt_keep_mask.argtypes = [_vp, _l, _f, _u64, _u64, _vp]
+L.lib.mvlt_droppath_scales.argtypes = [_vp, _vp, _i, _i, _u64, _u64, _vp]
+
+
+def keep_mask(keep, drop_p, seed, call):
+    """keep (uint8, any shape, contiguous) <- Bernoulli(1 - drop_p) from Philox(seed; call)"""
+    _need_cuda(keep)
+    assert keep.dtype == torch.uint8 and keep.is_contiguous()
+    check(L.lib.mvlt_keep_mask(_p(keep), keep.numel(), drop_p, seed & (2 ** 64 - 1), call, stream_ptr()), "mvlt_keep_mask")
+    return keep
+
+
+def droppath_scales(out, rates, seed, call):
+    """out (fp32 [nrate, ...]) <- Bernoulli(1 - rates[r]) / (1 - rates[r]) per element of row r"""
+    _need_cuda(out, rates)
+    assert out.dtype == rates.dtype == torch.float32 and out.is_contiguous() and rates.is_contiguous() and out.shape[0] == rates.numel()
+    check(L.lib.mvlt_droppath_scales(_p(out), _p(rates), rates.numel(), out.numel() // max(1, rates.numel()), seed & (2 ** 64 - 1), call, stream_ptr()),
+          "mvlt_droppath_scales")
+    return out
 
 
 # ------------------------------------------------------------------ position-embedding resize, GELU backward (csrc/elementwise.hip)

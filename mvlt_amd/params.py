@@ -310,6 +310,9 @@ class FlatStore:
         else:
             self.apply_pending_scale()
         self._ranges_done = []
+        if getattr(self, "_tap_lo", None) is not None:       # a backward that died between a conv weight-gradient GEMM and its fold
+            self._tap_arena.zero_()
+            self._tap_lo = self._tap_hi = None
 
     def queue_finalize(self):
         """Called at the top of every HIP-scheduled backward node: the first call of a backward pass prepares G
@@ -370,12 +373,42 @@ class FlatStore:
         return self._ln_arena[0, slot:slot + n]
 
     def fold_copies(self):
-        """sum the accumulator copies touched since the last fold into G"""
+        """sum the accumulator copies (LayerNorm parameters) and the tap-ordered conv weight gradients touched since the last fold into G"""
+        from . import ops
+        if getattr(self, "_tap_lo", None) is not None:
+            ops.fold_copies(self._tap_arena, 1, self._tap_arena.numel(), self._tap_index, self._tap_lo, self._tap_hi, self.G)
+            self._tap_lo = self._tap_hi = None
         if getattr(self, "_ln_lo", None) is None:
             return
-        from . import ops
         ops.fold_copies(self._ln_arena, self.LN_COPIES, self.ln_stride, self._ln_index, self._ln_lo, self._ln_hi, self.G)
         self._ln_lo = self._ln_hi = None
+
+    # ---- conv weight gradients in the gather's order ----------------------------------------------------------------------
+    # The gathered TN GEMM produces a conv weight gradient as [out][kh][kw][cin]; nn.Conv2d keeps [out][cin][kh][kw].  Each conv
+    # weight owns a slot of a persistent fp32 arena that the GEMM accumulates into, and the fold launch above adds the touched range
+    # to G through an index table (arena element (o, t, c) -> G element (o, c, t)) and zeroes it again: one launch per backward
+    # stage instead of one permuted ATen add per convolution (24 per step).
+    def grad_taps(self, name, cout, taps, cin):
+        """arena view [cout][taps * cin] standing in for self.grad(name) as the output of the gathered weight-gradient GEMM"""
+        if getattr(self, "_tap_arena", None) is None or self._tap_arena.device != self.G.device:
+            total = sum(n for _, n, shape in self.offsets.values() if len(shape) == 4)
+            self._tap_arena = torch.zeros((total + 63) // 64 * 64, device=self.G.device, dtype=torch.float32)
+            self._tap_index = torch.zeros(self._tap_arena.numel(), device=self.G.device, dtype=torch.int32)
+            self._tap_slots, self._tap_next, self._tap_lo, self._tap_hi = {}, 0, None, None
+        goff, n, _ = self.offsets[name]
+        assert n == cout * taps * cin, (name, n, cout, taps, cin)
+        slot = self._tap_slots.get(name)
+        if slot is None:
+            slot = self._tap_slots[name] = self._tap_next
+            dev = self.G.device
+            o = torch.arange(cout, device=dev, dtype=torch.int64)[:, None, None]
+            t = torch.arange(taps, device=dev, dtype=torch.int64)[None, :, None]
+            c = torch.arange(cin, device=dev, dtype=torch.int64)[None, None, :]
+            self._tap_index[slot:slot + n] = (goff + (o * cin + c) * taps + t).reshape(-1).to(torch.int32)
+            self._tap_next += n
+        self._tap_lo = slot if self._tap_lo is None else min(self._tap_lo, slot)
+        self._tap_hi = slot + n if self._tap_hi is None else max(self._tap_hi, slot + n)
+        return self._tap_arena[slot:slot + n].view(cout, taps * cin)
 
     def announce_stage(self, i):
         """backward of stage i finished: its parameter gradients are final -> let the data-parallel wrapper start

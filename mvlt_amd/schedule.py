@@ -26,21 +26,32 @@ def _empty(shape, dtype, dev):
 _LN_COPIES = not os.environ.get("MVLT_LN_NO_COPIES")      # A/B switch: LayerNorm parameter gradients by plain atomics
 _NO_DX2 = bool(os.environ.get("MVLT_NO_DX2"))      # A/B switch: DropPath-scaled gradient copy by a separate pass
 _NO_LN_FOLD = bool(os.environ.get("MVLT_NO_LN_FOLD"))      # A/B switch: LN2 as its own launch in front of the fused MLP
-# A/B switch: conv weight gradients accumulated straight into the [out][cin][kh][kw] layout by the wgrad epilogue (strided atomics)
-# instead of a pooled [out][kh][kw][cin] buffer + one permuted add
+# A/B switches: conv weight gradients accumulated straight into the [out][cin][kh][kw] layout by the wgrad epilogue (strided atomics),
+# or through a pooled [out][kh][kw][cin] buffer + one permuted ATen add per convolution, instead of the store's tap arena
 WGRAD_TAPS = bool(os.environ.get("MVLT_WGRAD_TAPS"))
+WGRAD_ADD = bool(os.environ.get("MVLT_WGRAD_ADD"))
 
 
-def conv_wgrad(dz, xin, gW, M, cout, K, ld_dz, ld_in, bmap, taps, cin, colsum=None):
-    """weight gradient of a gathered-row convolution into gW = G slice of nn.Conv2d's (out, cin, kh, kw) weight"""
+def conv_wgrad(S, name, dz, xin, M, cout, K, ld_dz, ld_in, bmap, taps, cin, colsum=None):
+    """weight gradient of a gathered-row convolution into the G slice of nn.Conv2d's (out, cin, kh, kw) weight `name`: accumulated in
+    the gather's (out, kh, kw, cin) order in the store's tap arena, which S.fold_copies() adds to G at the (out, cin, kh, kw) places"""
     if WGRAD_TAPS:
-        ops.gemm_tn(dz, xin, gW.view(cout, K), M, cout, K, ld_dz, ld_in, K, b_map=bmap, colsum=colsum, taps=taps, seg=cin)
+        ops.gemm_tn(dz, xin, S.grad(name).view(cout, K), M, cout, K, ld_dz, ld_in, K, b_map=bmap, colsum=colsum, taps=taps, seg=cin)
         return
-    dWk = pool_zeros((cout, K), torch.float32, dz.device)
-    ops.gemm_tn(dz, xin, dWk, M, cout, K, ld_dz, ld_in, K, b_map=bmap, colsum=colsum)
-    kk = int(round(taps ** 0.5))
-    gW.add_(dWk.view(cout, kk, kk, cin).permute(0, 3, 1, 2))
+    if WGRAD_ADD:
+        dWk = pool_zeros((cout, K), torch.float32, dz.device)
+        ops.gemm_tn(dz, xin, dWk, M, cout, K, ld_dz, ld_in, K, b_map=bmap, colsum=colsum)
+        kk = int(round(taps ** 0.5))
+        S.grad(name).add_(dWk.view(cout, kk, kk, cin).permute(0, 3, 1, 2))
+        return
+    ops.gemm_tn(dz, xin, S.grad_taps(name, cout, taps, cin), M, cout, K, ld_dz, ld_in, K, b_map=bmap, colsum=colsum)
 
+
+def _step_rng(model):
+    """(seed, call) of the next draw of the step's own train-mode masks (BERT dropout, DropPath): the seed is torch's
+    (torch.manual_seed(args.seed + rank), reference main_vl.py:207-209, so ranks draw different masks), the counter runs per model"""
+    model._rng_calls = getattr(model, "_rng_calls", 0) + 1
+    return torch.initial_seed(), model._rng_calls
 
 
 class Names:
@@ -139,9 +150,8 @@ class TrunkStep:
                 # every block's two keep masks in one draw (4 small launches per step instead of 8 per block)
                 rates = getattr(m, "_dpr_dev", None)
                 if rates is None or rates.device != self.dev:
-                    rates = m._dpr_dev = torch.tensor(list(m.dpr), device=self.dev, dtype=torch.float32).view(-1, 1, 1)
-                keep = (torch.rand(len(m.dpr), 2, self.B, device=self.dev) >= rates).float()
-                self._dp_all = keep / (1.0 - rates)
+                    rates = m._dpr_dev = torch.tensor(list(m.dpr), device=self.dev, dtype=torch.float32)
+                self._dp_all = ops.droppath_scales(_empty((len(m.dpr), 2, self.B), torch.float32, self.dev), rates, *_step_rng(m))
             return self._dp_all[blk_index, 0], self._dp_all[blk_index, 1]
         return (k1 / (1.0 - rate)).contiguous(), (k2 / (1.0 - rate)).contiguous()
 
@@ -160,7 +170,7 @@ class TrunkStep:
             if inj is not None:
                 self.keep = inj["bert"].to(dev).reshape(rows, m.hidden).to(torch.uint8).contiguous()
             else:
-                self.keep = (torch.rand(rows, m.hidden, device=dev) >= BERT_DROP).to(torch.uint8)
+                self.keep = ops.keep_mask(_empty((rows, m.hidden), torch.uint8, dev), BERT_DROP, *_step_rng(m))
         ops.bert_embed_fwd(self.ids, self.f32(te + "word_embeddings.weight"), self.f32(te + "position_embeddings.weight"),
                            self.f32(te + "token_type_embeddings.weight"), self.f32(te + "LayerNorm.weight"),
                            self.f32(te + "LayerNorm.bias"), self.keep, BERT_DROP, self.emb, self.emb_mean, self.emb_rstd,
@@ -374,7 +384,7 @@ class TrunkStep:
         xp = sv["x_in_prev"]
         pm = sv["pm_in"]
         # conv weight gradient: computed in the gather's [out][kh][kw][cin] order, accumulated at its [out][cin][kh][kw] place
-        conv_wgrad(d_pe, xp, self.g(pe + "proj.weight"), B * HW, C, 4 * Cp, C, Cp, pm, 4, Cp, colsum=self.g(pe + "proj.bias"))
+        conv_wgrad(self.S, pe + "proj.weight", d_pe, xp, B * HW, C, 4 * Cp, C, Cp, pm, 4, Cp, colsum=self.g(pe + "proj.bias"))
         ops.gemm_tn(d_te, xp, self.g(ten + "0.weight"), B * T, C, Cp, C, Cp, Cp, b_map=rowmap(T, Np, HWp), colsum=self.g(ten + "0.bias"))
         dxp = _empty((B, Np, Cp), dt, dev)
         ops.gemm_nt(d_pe, self.wKT(pe + "proj.weight"), dxp, B * HW, 4 * Cp, C, C, C, Cp, c_map=pm)          # image rows (each once)
@@ -471,7 +481,7 @@ class TrunkStep:
             ops.layernorm_bwd(dkvin, bs["sr_pre"], dsr, self.f32(p + "attn.norm.weight"), bs["msr"], bs["rsr"], B * HWr, C, C, C, C,
                               dgamma=self.gl(p + "attn.norm.weight"), dbeta=self.gl(p + "attn.norm.bias"), **self.lnk())
             K = r * r * C
-            conv_wgrad(dsr, bs["xn1"], self.g(p + "attn.sr.weight"), B * HWr, C, K, C, C, pm, r * r, C, colsum=self.g(p + "attn.sr.bias"))
+            conv_wgrad(self.S, p + "attn.sr.weight", dsr, bs["xn1"], B * HWr, C, K, C, C, pm, r * r, C, colsum=self.g(p + "attn.sr.bias"))
             ops.gemm_nt(dsr, self.wKT(p + "attn.sr.weight"), dxn1, B * HWr, K, C, C, C, C, c_map=pm, R=dxn1)
         else:
             ops.gemm_tn(dkv, bs["xn1"], gkvw, M, 2 * C, C, 2 * C, C, C, colsum=gkvb)

@@ -53,6 +53,32 @@ def test_device_masks_equal_the_reference_made_fixture(golden_dir):
         assert np.array_equal(ids[s].cpu().numpy(), g[f"tok/{s}/ids"]) and np.array_equal(lab[s].cpu().numpy(), g[f"tok/{s}/labels"])
 
 
+@pytest.mark.parametrize("n,p,seed,call", [(8 * 1000, 0.1, 5, 0), (32768 * 768, 0.1, (1 << 40) + 9, (1 << 33) + 2), (1003, 0.5, 1, 7), (8, 0.0, 2, 3)])
+def test_step_dropout_mask_is_bit_exact(n, p, seed, call):
+    """mvlt_keep_mask (the nn.Dropout of BertEmbeddings, reference libs/pvlt.py:232-233) against the numpy restatement"""
+    from mvlt_amd import ops
+    keep = torch.full((n + 8,), 7, dtype=torch.uint8, device=DEV)
+    ops.keep_mask(keep[:n], p, seed, call)
+    want = BP.keep_mask(seed, call, n, p)
+    assert np.array_equal(keep[:n].cpu().numpy(), want)
+    assert (keep[n:] == 7).all()                                  # nothing written past n
+    if n > 100000:
+        assert abs(float(want.mean()) - (1.0 - p)) < 1e-3
+
+
+def test_step_droppath_scales_are_bit_exact():
+    """mvlt_droppath_scales (timm DropPath's per-sample keep / keep_prob, reference libs/pvlt.py:135,141-142)"""
+    from mvlt_amd import ops
+    rates = np.linspace(0.0, 0.3, 8).astype(np.float32)
+    out = torch.empty(8, 2, 256, device=DEV)
+    ops.droppath_scales(out, torch.from_numpy(rates).to(DEV), 123, 45)
+    want = BP.droppath_scales(123, 45, rates, 512).reshape(8, 2, 256)
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert (want[0] == 1.0).all()                                 # rate 0 keeps everything
+    kept = (want[-1] > 0).mean()
+    assert abs(kept - 0.7) < 0.08 and np.allclose(want[-1][want[-1] > 0], 1.0 / 0.7, rtol=1e-6)
+
+
 def _cpu_batches(n, B, S, T):
     return [O.to_torch_batch(filler.make_batch(40 + i, B, S, T)) for i in range(n)]
 

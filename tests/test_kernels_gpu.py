@@ -577,6 +577,11 @@ def test_upsample_fwd_bwd(ops, B, H, C, s, nchw, out_dtype):
     ops.upsample_bwd(dy, 0 if nchw else C, nchw, B, H, H, C, s, dx, C, accumulate=True)
     want = base + xt.grad.permute(0, 2, 3, 1).reshape(B * H * H, C)
     assert maxrel(dx, want) < 1e-5
+    if nchw:                     # bf16 dx, rows padded to 8 (the score conv's gradient operand, mim.py): pad columns stay untouched
+        dx16 = torch.zeros(B * H * H, 8, device=dev(), dtype=torch.bfloat16)
+        ops.upsample_bwd(dy, 0, True, B, H, H, C, s, dx16, 8)
+        assert maxrel(dx16[:, :C].float(), want - base) < TOL[torch.bfloat16]
+        assert (dx16[:, C:] == 0).all()
 
 
 # ------------------------------------------------------------------ train-mode BatchNorm over pixel-major matrices
