@@ -199,6 +199,11 @@ int mvlt_resize_bilinear_tokens(const float* in, int ld_in, float* out, int ld_o
 
 /* out = dy * gelu'(h), exact-erf GELU, elementwise over n values (autograd of reference libs/vl_heads.py:13-14,31-32) */
 int mvlt_gelu_bwd(const void* dy, const void* h, void* out, long n, int dtype, void* stream);
+/* The engine's loss composition (reference engine_grid_masking.py:81-102: total = mlm + itm + sup_cls + sub_cls + 10 * t2i) in one
+ * launch: losses = HOST array of 5 device pointers to fp32 scalars (NULL = head off), weights = HOST array of 5 floats;
+ * out (device, 6 floats) = [total, w0 * l0, ..., w4 * l4]; total (device, 1 float) = the total once more, as the tensor the
+ * backward pass starts from. */
+int mvlt_loss_compose(const float* const* losses, const float* weights, float* out, float* total, void* stream);
 
 /* ---- device-side batch preparation (what the reference's dataset does per sample on the host, mcloader/fashion_gen.py) ----
  * All three draw from Philox4x32-10 with key = seed and counter = (element, sample id, stream): sample b of a call has id

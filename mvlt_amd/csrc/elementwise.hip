@@ -499,6 +499,21 @@ __global__ __launch_bounds__(NT) void gelu_bwd_kernel(const T* dy, const T* h, T
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT)
     out[i] = (T)((float)dy[i] * gelu_erf_grad((float)h[i]));
 }
+// out[0] = sum_i w[i] * (*p[i]), out[1 + i] = w[i] * (*p[i]) (0 where p[i] is null): the loss composition of reference
+// engine_grid_masking.py:81-102 (mlm + itm + sup_cls + sub_cls + 10 * t2i) in one launch instead of a chain of 0-dim ATen ops
+struct LossPtrs { const float* p[5]; float w[5]; };
+__global__ void loss_compose_kernel(LossPtrs a, float* out, float* total_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float total = 0.f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const float v = a.p[i] ? a.w[i] * *a.p[i] : 0.f;
+    out[1 + i] = v;
+    total += v;
+  }
+  out[0] = total;
+  *total_out = total;
+}
 }  // namespace
 
 extern "C" int mvlt_bert_embed_fwd(const long* ids, const float* word, const float* pos, const float* type0, const float* gamma,
@@ -665,4 +680,12 @@ extern "C" int mvlt_transpose_cast(const float* in, void* out, int R, int Ccols,
   if (dtype == 0) hipLaunchKernelGGL((transpose_cast_kernel<bf16>), grid, block, 0, (hipStream_t)stream, in, (bf16*)out, R, Ccols, ld_out);
   else hipLaunchKernelGGL((transpose_cast_kernel<float>), grid, block, 0, (hipStream_t)stream, in, (float*)out, R, Ccols, ld_out);
   return mvlt_check_launch("mvlt_transpose_cast");
+}
+
+extern "C" int mvlt_loss_compose(const float* const* losses, const float* weights, float* out, float* total, void* stream) {
+  MVLT_REQUIRE(losses && weights && out && total, "mvlt_loss_compose: null argument");
+  LossPtrs a;
+  for (int i = 0; i < 5; ++i) { a.p[i] = losses[i]; a.w[i] = weights[i]; }
+  hipLaunchKernelGGL(loss_compose_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out, total);
+  return mvlt_check_launch("mvlt_loss_compose");
 }

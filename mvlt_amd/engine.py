@@ -91,9 +91,61 @@ def smooth_l1(pred, target):
     return F.smooth_l1_loss(pred, target)
 
 
+class _ComposeFn(torch.autograd.Function):
+    """total and [total, w_i * loss_i ...] of up to five fp32 device scalars in one HIP launch (None = head off); backward is one multiply"""
+    _w = {}
+
+    @staticmethod
+    def forward(ctx, weights, *losses):
+        from . import ops
+        live = next(l for l in losses if l is not None)
+        out = torch.empty(len(LOSS_KEYS), device=live.device, dtype=torch.float32)
+        total = torch.empty((), device=live.device, dtype=torch.float32)
+        ops.loss_compose([None if l is None else l.detach() for l in losses], weights, out, total)
+        ctx.weights, ctx.live = weights, [l is not None for l in losses]
+        ctx.set_materialize_grads(False)                 # the parts are only logged in the engine: their gradient arrives as None
+        return total, out
+
+    @staticmethod
+    def backward(ctx, gtotal, gout):
+        ref = gtotal if gtotal is not None else gout
+        key = (ref.device, ctx.weights)
+        w = _ComposeFn._w.get(key)
+        if w is None:
+            w = _ComposeFn._w[key] = torch.tensor(ctx.weights, device=ref.device, dtype=torch.float32)
+        if gout is None:
+            g = gtotal * w                               # d total / d loss_i = w_i
+        else:                                            # someone differentiated a part (or the packed total) as well
+            g = (gout[1:] + gout[0] + (gtotal if gtotal is not None else 0.0)) * w
+        return (None, *[g[i] if live else None for i, live in enumerate(ctx.live)])
+
+
+def _compose_hip(losses):
+    """losses: dict LOSS_KEYS[1:] -> fp32 device scalar or None; -> (total, parts) with `total._packed` = the six values in
+    LOSS_KEYS order (what the engine's read-back copies to the host)"""
+    weights = (float(MLM_LOSS_WEIGHT), float(ITM_LOSS_WEIGHT), 1.0, 1.0, float(T2I_LOSS_WEIGHT))
+    total, packed = _ComposeFn.apply(weights, *[losses[k] for k in LOSS_KEYS[1:]])
+    total._packed = packed
+    return total, {k: packed[1 + i] for i, k in enumerate(LOSS_KEYS[1:])}
+
+
 def compute_losses(outputs, images, mlm_labels, itm_labels, sup_cls_labels, sub_cls_labels):
     """Loss composition of reference engine_grid_masking.py:81-102.  Returns (total, dict of the five parts)."""
     dev = images.device
+    if images.is_cuda and outputs["mlm_logits"] is None:
+        # device path: every loss is one HIP reduction, the composition one more launch
+        ls = dict.fromkeys(LOSS_KEYS[1:])
+        if outputs.get("mlm_loss") is not None:
+            ls["loss_mlm"] = outputs["mlm_loss"].float()
+        if outputs["itm_logits"] is not None:
+            ls["loss_itm"] = cross_entropy(outputs["itm_logits"].view(-1, 2).float(), itm_labels.view(-1))
+        if outputs["sup_cls_logits"] is not None:
+            ls["loss_sup_cls"] = cross_entropy(outputs["sup_cls_logits"].view(-1, 48).float(), sup_cls_labels.view(-1))
+            ls["loss_sub_cls"] = cross_entropy(outputs["sub_cls_logits"].view(-1, 122).float(), sub_cls_labels.view(-1))
+        if outputs["t2i_logits"] is not None:
+            ls["loss_t2i"] = smooth_l1(outputs["t2i_logits"].float(), images)
+        if any(v is not None for v in ls.values()):
+            return _compose_hip(ls)
     zero = torch.zeros((), device=dev)
     parts = dict(loss_mlm=zero, loss_itm=zero, loss_sup_cls=zero, loss_sub_cls=zero, loss_t2i=zero)
     total = 0
@@ -141,7 +193,10 @@ class _LossReadback:
         self.ev = torch.cuda.Event()
 
     def post(self, total, parts):
-        vals = torch.stack([total.detach().float()] + [parts[k].detach().float() for k in LOSS_KEYS[1:]])
+        vals = getattr(total, "_packed", None)             # compute_losses' device path: the six values already sit in one tensor
+        if vals is None:
+            vals = torch.stack([total.detach().float()] + [parts[k].detach().float() for k in LOSS_KEYS[1:]])
+        vals = vals.detach()
         self.pin.copy_(vals, non_blocking=True)
         self.ev.record()
 

@@ -150,7 +150,7 @@ class MimStep:
                     R=dx if accumulate else None)
         return dx
 
-    def backward(self, dout):
+    def backward(self, dout, sink=None):
         S, dev, dt, B = self.S, self.dev, self.dt, self.B
         s1, s2, s3, M1, M2, M3 = self.s1, self.s2, self.s3, self.M1, self.M2, self.M3
         ch = 64
@@ -192,32 +192,35 @@ class MimStep:
         # reductions: gradients w.r.t. the image tokens of the stage outputs (text rows stay zero)
         grads = []
         for name, dy, x, side in (("reduction1", dlow, self.x[0], s1), ("reduction2", dmid, self.x[1], s2), ("reduction3", dhigh, self.x[2], s3)):
-            dxs = torch.empty_like(x)                      # image rows are all written by the conv dgrad below;
-            dxs[:, side * side:].zero_()                   # only the text rows need the explicit zeros
+            if name == "reduction3" and sink is not None:
+                dxs, ret = sink.take(x.shape, x.dtype, x.device)      # the heads' common buffer: image rows are this decoder's
+            else:
+                dxs = ret = S.own(torch.empty_like(x))     # image rows are all written by the conv dgrad below;
+                dxs[:, side * side:].zero_()               # only the text rows need the explicit zeros
             self.bn_conv_bwd(name, dy, ch, dx=dxs, lddx=x.shape[2], dx_map=rowmap(side * side, x.shape[1], 0))
-            grads.append(dxs)
+            grads.append(ret)
         self.rec, self.keep = {}, {}
         return grads
 
 
 class _MimFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2, x3, x4, model, sides, need_grad):
+    def forward(ctx, x2, x3, x4, model, sides, need_grad, sink=None):
         step = MimStep(model, x2, x3, x4, sides, model.training, need_grad)
         out = step.forward()
-        ctx.step = step
+        ctx.step, ctx.sink = step, sink
         return out
 
     @staticmethod
     def backward(ctx, dout):
         step = ctx.step
         step.S.queue_finalize()
-        g2, g3, g4 = step.backward(dout)
-        ctx.step = None
+        g2, g3, g4 = step.backward(dout, ctx.sink)
+        ctx.step = ctx.sink = None
         step.S.fold_copies()                          # the conv weight gradients leave the tap arena for G
         step.S.announce_prefix("t2i_head.")          # the decoder's gradients are final: reduce them under the trunk backward
-        return g2, g3, g4, None, None, None
+        return g2, g3, g4, None, None, None, None
 
 
-def mim_head(model, x2, x3, x4, sides, need_grad):
-    return _MimFn.apply(x2, x3, x4, model, sides, need_grad)
+def mim_head(model, x2, x3, x4, sides, need_grad, sink=None):
+    return _MimFn.apply(x2, x3, x4, model, sides, need_grad, sink)

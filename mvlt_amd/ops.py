@@ -378,6 +378,18 @@ def droppath_scales(out, rates, seed, call):
 # ------------------------------------------------------------------ position-embedding resize, GELU backward (csrc/elementwise.hip)
 L.lib.mvlt_resize_bilinear_tokens.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
 L.lib.mvlt_gelu_bwd.argtypes = [_vp, _vp, _vp, _l, _i, _vp]
+L.lib.mvlt_loss_compose.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_float), _vp, _vp, _vp]
+
+
+def loss_compose(losses, weights, out, total):
+    """out[0] = total[0] = sum_i weights[i] * losses[i], out[1 + i] = weights[i] * losses[i]; losses: five fp32 device scalars or None"""
+    assert len(losses) == len(weights) == 5 and out.dtype == total.dtype == torch.float32 and out.numel() >= 6 and out.is_contiguous()
+    for t in losses:
+        assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1)
+    ptrs = (C.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in losses])
+    ws = (C.c_float * 5)(*[float(w) for w in weights])
+    check(L.lib.mvlt_loss_compose(ptrs, ws, _p(out), _p(total), stream_ptr()), "mvlt_loss_compose")
+    return out
 
 
 def resize_bilinear_tokens(src, dst, hin, win, hout, wout, Cdim, adjoint=False):

@@ -310,9 +310,19 @@ class FlatStore:
         else:
             self.apply_pending_scale()
         self._ranges_done = []
+        self._own = set()
         if getattr(self, "_tap_lo", None) is not None:       # a backward that died between a conv weight-gradient GEMM and its fold
             self._tap_arena.zero_()
             self._tap_lo = self._tap_hi = None
+
+    def own(self, t):
+        """register a gradient tensor a backward node of this pass created itself: later nodes of the same pass may then accumulate
+        into it in place instead of cloning (autograd hands gradients over by reference; tensors of unknown origin are never written)"""
+        self._own.add(t.data_ptr())
+        return t
+
+    def owns(self, t):
+        return t is not None and t.data_ptr() in getattr(self, "_own", ())
 
     def queue_finalize(self):
         """Called at the top of every HIP-scheduled backward node: the first call of a backward pass prepares G

@@ -335,23 +335,31 @@ class TrunkStep:
 
     def backward(self, dxs):
         """dxs: gradients w.r.t. the four stage outputs (None allowed).  Fills the flat gradient buffer."""
-        m, B, T, dt, dev = self.m, self.B, self.T, self.dt, self.dev
-        dx = None
+        m, B, T, dt, dev, S = self.m, self.B, self.T, self.dt, self.dev, self.S
+        # gradient tensors the head nodes of this pass created themselves (the heads' shared buffer, the MIM decoder's outputs) may be
+        # written in place; anything else autograd hands us is copied first
+        own = [d is not None and d.dtype == dt and d.is_contiguous() and S.owns(d) for d in dxs]
+        dx, merged = None, False
         for i in (3, 2, 1, 0):
             sv = self.saved[i]
             d_out = dxs[i]
-            if d_out is not None:
+            if d_out is not None and not merged:
                 d_out = d_out.to(dt)
-                # never write into a gradient tensor autograd handed us: start from a private copy
-                dx = d_out.contiguous().clone() if dx is None else dx.add_(d_out)
+                if dx is None:
+                    dx = d_out if own[i] else d_out.contiguous().clone()
+                else:
+                    dx.add_(d_out)
             if dx is None:
                 continue
-            dx = self._stage_backward(i, sv, dx.view(B, sv["N"], sv["C"]))
+            # the stage's input gradient is accumulated straight into the previous stage's own head gradient where there is one
+            into = dxs[i - 1] if i > 0 and own[i - 1] else None
+            dx = self._stage_backward(i, sv, dx.view(B, sv["N"], sv["C"]), into)
+            merged = into is not None
             self.S.announce_stage(i)
         self.S.fold_copies()
         self.saved = []
 
-    def _stage_backward(self, i, sv, dx):
+    def _stage_backward(self, i, sv, dx, into=None):
         m, B, T, dt, dev = self.m, self.B, self.T, self.dt, self.dev
         C, HW, N, side = sv["C"], sv["HW"], sv["N"], sv["side"]
         self._mark()
@@ -386,9 +394,9 @@ class TrunkStep:
         # conv weight gradient: computed in the gather's [out][kh][kw][cin] order, accumulated at its [out][cin][kh][kw] place
         conv_wgrad(self.S, pe + "proj.weight", d_pe, xp, B * HW, C, 4 * Cp, C, Cp, pm, 4, Cp, colsum=self.g(pe + "proj.bias"))
         ops.gemm_tn(d_te, xp, self.g(ten + "0.weight"), B * T, C, Cp, C, Cp, Cp, b_map=rowmap(T, Np, HWp), colsum=self.g(ten + "0.bias"))
-        dxp = _empty((B, Np, Cp), dt, dev)
-        ops.gemm_nt(d_pe, self.wKT(pe + "proj.weight"), dxp, B * HW, 4 * Cp, C, C, C, Cp, c_map=pm)          # image rows (each once)
-        ops.gemm_nt(d_te, self.wT(ten + "0.weight"), dxp, B * T, Cp, C, C, C, Cp, c_map=rowmap(T, Np, HWp))   # text rows
+        dxp = into.view(B, Np, Cp) if into is not None else _empty((B, Np, Cp), dt, dev)
+        ops.gemm_nt(d_pe, self.wKT(pe + "proj.weight"), dxp, B * HW, 4 * Cp, C, C, C, Cp, c_map=pm, R=into)          # image rows (each once)
+        ops.gemm_nt(d_te, self.wT(ten + "0.weight"), dxp, B * T, Cp, C, C, C, Cp, c_map=rowmap(T, Np, HWp), R=into)   # text rows
         return dxp
 
     def _pos_backward(self, i, dpos):
@@ -529,6 +537,23 @@ class _TrunkFn(torch.autograd.Function):
 
 
 # =============================================================================================== heads
+class _GradSink:
+    """One dense gradient buffer for the last stage's output, shared by its consumers -- MLM / ITM / CLS heads (a few text rows each) and
+    the MIM decoder (the image rows).  Every head's backward adds its rows into the same zero-initialised buffer; the first one hands
+    it to autograd and the others return None, instead of one zero-filled dense tensor per head plus autograd's dense adds (3 fills and
+    2 adds of 50 MB at batch 256).  The trunk node runs after all of them (autograd's dependency count), when the buffer is complete."""
+
+    def __init__(self, store):
+        self.S, self.buf = store, None
+
+    def take(self, shape, dtype, dev):
+        """-> (buffer, what this caller returns to autograd for the shared input)"""
+        if self.buf is None:
+            self.buf = self.S.own(torch.zeros(shape, dtype=dtype, device=dev))
+            return self.buf, self.buf
+        return self.buf, None
+
+
 def _embed_ln_fwd(model, prefix, A, a_map, rows, lda):
     """head_embed: Linear(512 -> 768) + LN(1e-5) on `rows` rows of A (through a_map)."""
     S, dt, dev = model.store, model.compute_dtype, A.device
@@ -557,7 +582,7 @@ class _ClsHeadFn(torch.autograd.Function):
     (reference libs/pvlt.py:375-388, libs/vl_heads.py:73-104)."""
 
     @staticmethod
-    def forward(ctx, x4, model, name, HW):
+    def forward(ctx, x4, model, name, HW, sink):
         S, dt, dev = model.store, model.compute_dtype, x4.device
         B, N, C = x4.shape
         n_out = S.master(name + "_head.linear.weight").shape[0]
@@ -566,12 +591,12 @@ class _ClsHeadFn(torch.autograd.Function):
         bias = (S.master(name + "_head.linear.bias") + S.master(name + "_head.linear_bias")).contiguous()
         logits = _empty((B, n_out), torch.float32, dev)
         ops.gemm_nt(e, S.comp(name + "_head.linear.weight"), logits, B, n_out, model.hidden, model.hidden, model.hidden, n_out, bias=bias)
-        ctx.pack = (model, name, HW, x4, e, saved, a_map)
+        ctx.pack = (model, name, HW, x4, e, saved, a_map, sink)
         return logits.view(B, 1, n_out)
 
     @staticmethod
     def backward(ctx, dlogits):
-        model, name, HW, x4, e, saved, a_map = ctx.pack
+        model, name, HW, x4, e, saved, a_map, sink = ctx.pack
         S, dt, dev = model.store, model.compute_dtype, x4.device
         S.queue_finalize()
         B, N, C = x4.shape
@@ -587,11 +612,11 @@ class _ClsHeadFn(torch.autograd.Function):
         de = _empty((B, Hd), dt, dev)
         wT = S.extra[name + "_head.linear.weight::T"]          # [768, n_pad]
         ops.gemm_nt(dl, wT, de, B, Hd, n_pad, n_pad, wT.shape[1], Hd)
-        dx4 = torch.zeros_like(x4)
-        _embed_ln_bwd(model, name + "_head_embed", de, saved, x4, a_map, B, C, dx4, a_map, False)
+        dx4, ret = (sink or _GradSink(S)).take(x4.shape, dt, dev)
+        _embed_ln_bwd(model, name + "_head_embed", de, saved, x4, a_map, B, C, dx4, a_map, True)
         ctx.pack = None
         S.announce_prefix(name + "_head_embed.", name + "_head.")
-        return dx4, None, None, None
+        return ret, None, None, None, None
 
 
 def _mlm_transform_fwd(model, rows_in, R):
@@ -626,7 +651,7 @@ class _MLMFullFn(torch.autograd.Function):
     """Reference-shaped MLM head: logits for every token, (B, T, 30522) (reference libs/pvlt.py:368-370)."""
 
     @staticmethod
-    def forward(ctx, x4, model, HW):
+    def forward(ctx, x4, model, HW, sink):
         S, dt, dev = model.store, model.compute_dtype, x4.device
         B, N, C = x4.shape
         T = N - HW
@@ -637,12 +662,12 @@ class _MLMFullFn(torch.autograd.Function):
         buf = _empty((R, VOCAB_LD), torch.float32, dev)
         ops.gemm_nt(t, S.comp("text_embeddings.word_embeddings.weight"), buf, R, VOCAB, model.hidden, model.hidden, model.hidden, VOCAB_LD,
                     bias=S.master("mlm_head.bias"))
-        ctx.pack = (model, HW, x4, e, sv_e, t, sv_t, a_map)
+        ctx.pack = (model, HW, x4, e, sv_e, t, sv_t, a_map, sink)
         return buf.view(B, T, VOCAB_LD)[:, :, :VOCAB]
 
     @staticmethod
     def backward(ctx, dlogits):
-        model, HW, x4, e, sv_e, t, sv_t, a_map = ctx.pack
+        model, HW, x4, e, sv_e, t, sv_t, a_map, sink = ctx.pack
         S, dt, dev = model.store, model.compute_dtype, x4.device
         S.queue_finalize()
         B, N, C = x4.shape
@@ -650,13 +675,13 @@ class _MLMFullFn(torch.autograd.Function):
         R = B * T
         dl = torch.zeros(R, VOCAB_LD, device=dev, dtype=dt)
         dl[:, :VOCAB] = dlogits.reshape(R, VOCAB).to(dt)
-        dx4 = torch.zeros_like(x4)
-        _mlm_decoder_bwd(model, dl, t, sv_t, e, sv_e, x4, a_map, R, C, dx4)
+        dx4, ret = (sink or _GradSink(S)).take(x4.shape, dt, dev)
+        _mlm_decoder_bwd(model, dl, t, sv_t, e, sv_e, x4, a_map, R, C, dx4, accumulate=True)
         ctx.pack = None
-        return dx4, None, None
+        return ret, None, None, None
 
 
-def _mlm_decoder_bwd(model, dl, t, sv_t, e, sv_e, A, a_map, R, lda, dA, c_map=None):
+def _mlm_decoder_bwd(model, dl, t, sv_t, e, sv_e, A, a_map, R, lda, dA, c_map=None, accumulate=False):
     """shared tail of both MLM paths: dl (R, VOCAB_LD) in the compute dtype -> every MLM-head gradient + dA rows."""
     S, dt, dev = model.store, model.compute_dtype, dl.device
     Hd = model.hidden
@@ -672,7 +697,7 @@ def _mlm_decoder_bwd(model, dl, t, sv_t, e, sv_e, A, a_map, R, lda, dA, c_map=No
         dtr = _empty((R, Hd), dt, dev)
         ops.gemm_nt(dl, wT, dtr, R, Hd, VOCAB_LD, VOCAB_LD, VOCAB_LD, Hd)
     de = _mlm_transform_bwd(model, dtr, sv_t, e, R)
-    _embed_ln_bwd(model, "mlm_head_embed", de, sv_e, A, a_map, R, lda, dA, c_map if c_map is not None else a_map, False)
+    _embed_ln_bwd(model, "mlm_head_embed", de, sv_e, A, a_map, R, lda, dA, c_map if c_map is not None else a_map, accumulate)
     # final now: the head's own parameters.  The tied decoder weight is the word-embedding table, which bert_embed_bwd still adds
     # to at the very end of the pass: it travels with the leftovers.
     S.announce_prefix("mlm_head_embed.", "mlm_head.")
@@ -683,7 +708,7 @@ class _MLMFusedFn(torch.autograd.Function):
     b*T+t indices with label != -1) is the masked-index selection; rows CE would ignore are never computed."""
 
     @staticmethod
-    def forward(ctx, x4, model, HW, positions, labels_sel):
+    def forward(ctx, x4, model, HW, positions, labels_sel, sink):
         S, dt, dev = model.store, model.compute_dtype, x4.device
         B, N, C = x4.shape
         T = N - HW
@@ -699,12 +724,12 @@ class _MLMFusedFn(torch.autograd.Function):
         lse = _empty((R,), torch.float32, dev)
         acc = torch.zeros(2, device=dev, dtype=torch.float32)          # [loss_sum, count] (saved for backward: not pooled)
         ops.cross_entropy_fwd(logits, labels_sel, lse, acc[0:1], acc[1:2], R, VOCAB, VOCAB_LD)
-        ctx.pack = (model, HW, x4.shape, rows, e, sv_e, t, sv_t, logits, lse, acc, positions, labels_sel, tmap)
+        ctx.pack = (model, HW, x4.shape, rows, e, sv_e, t, sv_t, logits, lse, acc, positions, labels_sel, tmap, sink)
         return acc[0] / acc[1]          # mean over selected rows (NaN when none, like torch)
 
     @staticmethod
     def backward(ctx, gloss):
-        model, HW, xshape, rows, e, sv_e, t, sv_t, logits, lse, acc, positions, labels_sel, tmap = ctx.pack
+        model, HW, xshape, rows, e, sv_e, t, sv_t, logits, lse, acc, positions, labels_sel, tmap, sink = ctx.pack
         S, dt, dev = model.store, model.compute_dtype, rows.device
         S.queue_finalize()
         B, N, C = xshape
@@ -714,10 +739,10 @@ class _MLMFusedFn(torch.autograd.Function):
         ops.cross_entropy_bwd(logits, labels_sel, lse, gs, acc[1:2], dl, R, VOCAB, VOCAB_LD, VOCAB_LD)
         drows = _empty((R, C), dt, dev)
         _mlm_decoder_bwd(model, dl, t, sv_t, e, sv_e, rows, None, R, C, drows, c_map=None)
-        dx4 = torch.zeros(xshape, device=dev, dtype=dt)
-        ops.scatter_rows(drows, positions, dx4, R, C, C, dst_map=tmap)
+        dx4, ret = (sink or _GradSink(S)).take(xshape, dt, dev)
+        ops.scatter_rows(drows, positions, dx4, R, C, C, dst_map=tmap, accumulate=True)
         ctx.pack = None
-        return dx4, None, None, None, None
+        return ret, None, None, None, None, None
 
 
 # =============================================================================================== top level
@@ -764,6 +789,7 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_cou
         sel = (idx, mlm_count if mlm_count is not None else _HostCount(cnt))
     S.refresh(model._transposed, model._conv_perm, model._conv3 if model.mim_impl == "hip" else ())
     x1, x2, x3, x4 = _TrunkFn.apply(model, images, ids, grad_on, *[p for _, p in S.fn_params])
+    sink = _GradSink(S) if grad_on else None            # the heads' common gradient buffer for x4
     B = images.shape[0]
     side4 = images.shape[2] // model.patch_size // 8
     HW4 = side4 * side4
@@ -780,15 +806,15 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_cou
                 out["mlm_loss"] = torch.full((), float("nan"), device=dev)
             else:
                 labels_sel = flat[mlm_positions.long()].contiguous()
-                out["mlm_loss"] = _MLMFusedFn.apply(x4, model, HW4, mlm_positions.contiguous(), labels_sel)
+                out["mlm_loss"] = _MLMFusedFn.apply(x4, model, HW4, mlm_positions.contiguous(), labels_sel, sink)
             out["mlm_positions"] = mlm_positions
         else:
-            out["mlm_logits"] = _MLMFullFn.apply(x4, model, HW4)
+            out["mlm_logits"] = _MLMFullFn.apply(x4, model, HW4, sink)
     if lt['itm']:
-        out["itm_logits"] = _ClsHeadFn.apply(x4, model, "itm", HW4)
+        out["itm_logits"] = _ClsHeadFn.apply(x4, model, "itm", HW4, sink)
     if lt['cls']:
-        out["sup_cls_logits"] = _ClsHeadFn.apply(x4, model, "sup_cls", HW4)
-        out["sub_cls_logits"] = _ClsHeadFn.apply(x4, model, "sub_cls", HW4)
+        out["sup_cls_logits"] = _ClsHeadFn.apply(x4, model, "sup_cls", HW4, sink)
+        out["sub_cls_logits"] = _ClsHeadFn.apply(x4, model, "sub_cls", HW4, sink)
     if lt['t2i']:
         feats = []
         for x, i in ((x2, 1), (x3, 2), (x4, 3)):
@@ -800,7 +826,7 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_cou
             if grad_on and not model.training:
                 raise NotImplementedError("MIM decoder backward with eval-mode BatchNorm is not scheduled (no reference config needs it)")
             sides = tuple(images.shape[2] // model.patch_size // (2 ** i) for i in (1, 2, 3))
-            out["t2i_logits"] = mim_head(model, x2, x3, x4, sides, grad_on)
+            out["t2i_logits"] = mim_head(model, x2, x3, x4, sides, grad_on, sink)
         else:
             out["t2i_logits"] = model.t2i_head.run(*feats, conv_dtype=model.compute_dtype)
     return out
