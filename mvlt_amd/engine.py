@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from .metrics import MetricLogger, SmoothedValue
+from .params import pool_zeros
 
 MLM_LOSS_WEIGHT, ITM_LOSS_WEIGHT, T2I_LOSS_WEIGHT = 1, 1, 10      # reference engine_grid_masking.py:23
 USE_ORI_INPUT_IDS = False
@@ -38,7 +39,7 @@ class _SmoothL1Fn(torch.autograd.Function):
     def forward(ctx, pred, target):
         from . import ops
         pred, target = pred.contiguous(), target.contiguous()
-        acc = torch.zeros(1, device=pred.device, dtype=torch.float32)
+        acc = pool_zeros((1,), torch.float32, pred.device)            # the step's zeroed scratch (valid until the next forward)
         ops.smooth_l1_fwd(pred, target, acc)
         ctx.save_for_backward(pred, target)
         return (acc / pred.numel()).reshape(())
@@ -62,7 +63,7 @@ class _CrossEntropyFn(torch.autograd.Function):
         from . import ops
         rows, V = logits.shape
         lse = torch.empty(rows, device=logits.device, dtype=torch.float32)
-        acc = torch.zeros(2, device=logits.device, dtype=torch.float32)            # [loss sum, row count]
+        acc = pool_zeros((2,), torch.float32, logits.device)          # [loss sum, row count]
         ops.cross_entropy_fwd(logits, labels, lse, acc[0:1], acc[1:2], rows, V, V, ignore_index=-100)
         ctx.save_for_backward(logits, labels, lse, acc)
         return acc[0] / acc[1]

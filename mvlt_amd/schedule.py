@@ -513,6 +513,7 @@ class _TrunkFn(torch.autograd.Function):
         outs = step.forward()
         ctx.step = step
         ctx.pool_token, model._pool_token = model._pool_token, None      # this node's life = the time the step's pooled scratch is owned
+        ctx.set_materialize_grads(False)          # unused stage outputs send None, not a zero tensor of their size (138 MB at stage 1)
         ctx.mark_non_differentiable(outs[0])
         return tuple(outs)
 
@@ -722,7 +723,7 @@ class _MLMFusedFn(torch.autograd.Function):
         ops.gemm_nt(t, S.comp("text_embeddings.word_embeddings.weight"), logits, R, VOCAB, model.hidden, model.hidden, model.hidden, VOCAB_LD,
                     bias=S.master("mlm_head.bias"))
         lse = _empty((R,), torch.float32, dev)
-        acc = torch.zeros(2, device=dev, dtype=torch.float32)          # [loss_sum, count] (saved for backward: not pooled)
+        acc = pool_zeros((2,), torch.float32, dev)                     # [loss_sum, count]; pooled scratch lives until the next forward
         ops.cross_entropy_fwd(logits, labels_sel, lse, acc[0:1], acc[1:2], R, VOCAB, VOCAB_LD)
         ctx.pack = (model, HW, x4.shape, rows, e, sv_e, t, sv_t, logits, lse, acc, positions, labels_sel, tmap, sink)
         return acc[0] / acc[1]          # mean over selected rows (NaN when none, like torch)
@@ -784,7 +785,7 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_cou
         # before the MLM head needs it to size its launches
         flat = mlm_labels.reshape(-1).contiguous()
         idx = torch.empty(flat.numel(), device=dev, dtype=torch.int32)
-        cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+        cnt = pool_zeros((1,), torch.int32, dev)
         ops.masked_select(flat, idx, cnt)
         sel = (idx, mlm_count if mlm_count is not None else _HostCount(cnt))
     S.refresh(model._transposed, model._conv_perm, model._conv3 if model.mim_impl == "hip" else ())
