@@ -145,30 +145,43 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(mvlt_attn_args p, int n
     for (int blk = 0; blk < NBLK; ++blk) {
       const int t0 = blk * BT;
       f32x16 acc[BT];
+      // K fragments one tile ahead of their MFMAs (two tiles' worth live): a tile's four LDS reads issued right in front of the MFMAs
+      // that use them put one LDS latency in front of every tile, and both waves of a SIMD stall the same way
+      Frag<T> kf[2][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[0][s] = load_frag8<T>(sK + Lds<T>::off(t0 * 32 + l31, 16 * s + 8 * g));
 #pragma unroll
       for (int ti = 0; ti < BT; ++ti) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+        if (ti + 1 < BT && t0 + ti + 1 < NKT) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) kf[(ti + 1) & 1][s] = load_frag8<T>(sK + Lds<T>::off((t0 + ti + 1) * 32 + l31, 16 * s + 8 * g));
+        }
         if (t0 + ti < NKT) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            Frag<T> kf = load_frag8<T>(sK + Lds<T>::off((t0 + ti) * 32 + l31, 16 * s + 8 * g));
-            mma32(acc[ti], kf, qf[s]);          // rows = keys, cols = queries
-          }
+          for (int s = 0; s < 4; ++s) mma32(acc[ti], kf[ti & 1][s], qf[s]);          // rows = keys, cols = queries
         }
-        __builtin_amdgcn_sched_barrier(0);      // keep only one tile's K fragments live (register budget: 2 waves/SIMD)
+        __builtin_amdgcn_sched_barrier(0);      // keep only two tiles' K fragments live (register budget: 2 waves/SIMD)
       }
       // acc[ti][r] = S[q = l31][key = 32 (t0+ti) + (r&3) + 8 (r>>2) + 4 g]
       float mb = -INFINITY;
+      if (p.M == MP && NKT % NBLK == 0) {         // no padded key anywhere (M = 192 at 256 px): no masking pass
 #pragma unroll
-      for (int ti = 0; ti < BT; ++ti)
+        for (int ti = 0; ti < BT; ++ti)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int key = 32 * (t0 + ti) + (r & 3) + 8 * (r >> 2) + 4 * g;
-          float sv = (t0 + ti < NKT && key < p.M) ? acc[ti][r] : -INFINITY;
-          acc[ti][r] = sv;
-          mb = fmaxf(mb, sv);
-        }
+          for (int r = 0; r < 16; ++r) mb = fmaxf(mb, acc[ti][r]);
+      } else {
+#pragma unroll
+        for (int ti = 0; ti < BT; ++ti)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int key = 32 * (t0 + ti) + (r & 3) + 8 * (r >> 2) + 4 * g;
+            float sv = (t0 + ti < NKT && key < p.M) ? acc[ti][r] : -INFINITY;
+            acc[ti][r] = sv;
+            mb = fmaxf(mb, sv);
+          }
+      }
       mb = fmaxf(mb, __shfl_xor(mb, 32));
       const float m_new = fmaxf(m_run, mb);     // finite: every block holds >= 1 valid key
       if (blk > 0) {
@@ -180,31 +193,41 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(mvlt_attn_args p, int n
           for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
       }
       m_run = m_new;
+      // bf16: the bare v_exp_f32 (libm's exp2f wraps it in a denormal-range rescale, five more VALU per score; results below 2^-126
+      // feed a bf16 P and a sum >= 1 either way); the fp32 parity path keeps libm's
+      const float mneg = -m_new * sl2;
 #pragma unroll
       for (int ti = 0; ti < BT; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float e = exp2f((acc[ti][r] - m_new) * sl2);
+          float e;
+          if constexpr (sizeof(T) == 2) e = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[ti][r], sl2, mneg));
+          else e = exp2f((acc[ti][r] - m_new) * sl2);
           acc[ti][r] = e;
           sum_loc += e;
         }
+      // PV: step u = (key tile, 16-key half); the V^T fragments of step u + 1 are read while step u's MFMAs run
+      Frag<T> vf[2][2];
+      {
+        const int kb = 32 * t0 + 4 * g;
 #pragma unroll
-      for (int ti = 0; ti < BT; ++ti) {
+        for (int dt = 0; dt < 2; ++dt) { const T* vr = sVt + (32 * dt + l31) * VS + kb; vf[0][dt] = load_frag44<T>(vr, vr + 8); }
+      }
+#pragma unroll
+      for (int u = 0; u < 2 * BT; ++u) {
+        const int ti = u >> 1, s2 = u & 1;
         if (t0 + ti >= NKT) continue;
+        if (u + 1 < 2 * BT && t0 + ((u + 1) >> 1) < NKT) {
+          const int kb = 32 * (t0 + ((u + 1) >> 1)) + 16 * ((u + 1) & 1) + 4 * g;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          Frag<T> pf;                           // B operand: P^T, k-slot (g, jj) <-> key 32kt + 16 s2 + 4g + 8 (jj>>2) + (jj&3)
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) pf.v[jj] = (T)acc[ti][8 * s2 + jj];
-          const int kb = 32 * (t0 + ti) + 16 * s2 + 4 * g;
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const T* vr = sVt + (32 * dt + l31) * VS + kb;
-            Frag<T> vf = load_frag44<T>(vr, vr + 8);
-            mma32(oacc[dt], vf, pf);            // rows = d, cols = queries
-          }
-          __builtin_amdgcn_sched_barrier(0);    // do not hoist every V^T fragment above the first PV MFMA
+          for (int dt = 0; dt < 2; ++dt) { const T* vr = sVt + (32 * dt + l31) * VS + kb; vf[(u + 1) & 1][dt] = load_frag44<T>(vr, vr + 8); }
         }
+        Frag<T> pf;                             // B operand: P^T, k-slot (g, jj) <-> key 32kt + 16 s2 + 4g + 8 (jj>>2) + (jj&3)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) pf.v[jj] = (T)acc[ti][8 * s2 + jj];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) mma32(oacc[dt], vf[u & 1][dt], pf);            // rows = d, cols = queries
+        __builtin_amdgcn_sched_barrier(0);      // do not hoist every V^T fragment above the first PV MFMA
       }
     }
     const float sum = sum_loc + __shfl_xor(sum_loc, 32);
