@@ -148,9 +148,10 @@ def roofline_cases(B, device):
 
 
 def time_dominant_kernel(model, B, device):
-    """Roofline of the dominant kernel family of the step, `gemm_nt_dma_kernel` (~30 % of GPU time in profiles/): its
+    """Roofline of the dominant kernel family of the step, the NT GEMMs on LDS-DMA rings (~30 % of GPU time in profiles/): the
     largest in-step launch is the MIM decoder's 192->192 conv3x3 at 32x32 (conv4 / conv_concat3 forward and their
-    input gradients) = a gathered-row GEMM with M = B*1024, N = 192, K = 9*192, MFMA-bound (AI ~ 575 F/B).  Timed
+    input gradients) = a gathered-row GEMM with M = B*1024, N = 192, K = 9*192, MFMA-bound (AI ~ 575 F/B), run by
+    `conv3_nt_kernel` (the family's loop with the 3x3-gathered operand on a channel-sliced LDS halo).  Timed
     with HIP events on torch's current stream, which is the stream mvlt_gemm_nt launches on.  `traffic` = HBM bytes
     per launch from the committed PMC passes (profiles/*_roofline_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, collected
     offline because counters cannot be read inside this process).  Also reported: the HBM-bound K=64 shape
@@ -163,7 +164,7 @@ def time_dominant_kernel(model, B, device):
     if tj:
         t = json.load(open(os.path.join(ROOT, "profiles", tj[-1])))
         traffic, traffic2 = t.get("conv192", {}).get("hbm_bytes"), t.get("proj64", {}).get("hbm_bytes")
-    return dict(kernel="gemm_nt_dma_kernel<192, 2, 1, 64, 128> (bf16, 128x192 tile, 3x3-gather A, plain epilogue): MIM conv3x3 192->192 @32x32 as GEMM (M=B*1024, N=192, K=1728)",
+    return dict(kernel="conv3_nt_kernel<32, 192, 1> (bf16, 128x192 tile, 3x3-gather A from an LDS halo, plain epilogue): MIM conv3x3 192->192 @32x32 as GEMM (M=B*1024, N=192, K=1728)",
                 bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_BF16_TFLOPS, 4),
                 traffic=traffic, ms_per_launch=round(ms, 4), algorithmic_flops=flops,
                 hbm_bound_sibling=dict(kernel="gemm_nt_dma_kernel<64, 0, 1, 64, 128> (bf16, 128x64 tile): K=64 N=64 projection, M=B*4224", bound="hbm",

@@ -301,6 +301,10 @@ typedef struct mvlt_mlp_args {
    * ln_y[M,C] (bf16, what `x` would have held: the backward passes read it) together with the row statistics ln_mean / ln_rstd. */
   const float* ln_x; const float* ln_gamma; const float* ln_beta; float ln_eps;
   void* ln_y; float* ln_mean; float* ln_rstd;
+  /* fwd only, optional: bf16 [M,C] copy of the output (the MFMA-operand form the next stage's convolutions and the heads read).  `out`
+   * may then be NULL: the last block of a stage has no fp32 consumer (reference libs/pvlt.py:331-345: the stage output goes to
+   * the next patch embedding / the heads only). */
+  void* out_op;
 } mvlt_mlp_args;
 int mvlt_mlp_fwd(const mvlt_mlp_args* args, void* stream);
 int mvlt_mlp_bwd_dx(const mvlt_mlp_args* args, void* stream);

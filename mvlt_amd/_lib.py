@@ -92,7 +92,7 @@ class MlpArgs(C.Structure):
                 ("out", c_void_p), ("h_out", c_void_p), ("dw1", c_void_p), ("db1", c_void_p), ("dw2", c_void_p), ("db2", c_void_p),
                 ("M", c_int), ("C", c_int), ("hid", c_int),
                 ("ln_x", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
-                ("ln_y", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p)]
+                ("ln_y", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("out_op", c_void_p)]
 
 
 lib.mvlt_last_error.restype = C.c_char_p

@@ -262,9 +262,17 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
         float rr[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (v[e] + b2v[e]) * rs + rr[e];
-        float* O = (float*)p.out + idx;
-        *(f32x4*)O = f32x4{v[0], v[1], v[2], v[3]};
-        *(f32x4*)(O + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        if (p.out) {
+          float* O = (float*)p.out + idx;
+          *(f32x4*)O = f32x4{v[0], v[1], v[2], v[3]};
+          *(f32x4*)(O + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+        if (p.out_op) {                  // MFMA-operand copy of the block output (the last block of a stage writes only this one)
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+          *(bf16x8*)((bf16*)p.out_op + idx) = o;
+        }
       } else {
         bf16x8 o;
 #pragma unroll
@@ -529,7 +537,7 @@ template <int C, int MODE> int launch(const mvlt_mlp_args& a, hipStream_t s) {
 }
 
 int check(const mvlt_mlp_args* a, const char* who) {
-  MVLT_REQUIRE(a && (a->x || a->ln_x) && a->w1 && a->wb && a->b1 && a->out, "%s: null pointer", who);
+  MVLT_REQUIRE(a && (a->x || a->ln_x) && a->w1 && a->wb && a->b1 && (a->out || a->out_op), "%s: null pointer", who);
   MVLT_REQUIRE(a->C == 64 || a->C == 128, "%s: C must be 64 or 128 (stage 1 / 2), got %d", who, a->C);
   MVLT_REQUIRE(a->hid > 0 && a->hid % 64 == 0, "%s: hidden size must be a multiple of 64", who);
   MVLT_REQUIRE(!a->row_scale || a->rows_per_scale > 0, "%s: row_scale needs rows_per_scale", who);
@@ -541,6 +549,7 @@ int check(const mvlt_mlp_args* a, const char* who) {
 extern "C" int mvlt_mlp_fwd(const mvlt_mlp_args* a, void* stream) {
   if (int e = check(a, "mvlt_mlp_fwd")) return e;
   MVLT_REQUIRE(a->b2 && a->residual, "mvlt_mlp_fwd: b2 and residual are required");
+  MVLT_REQUIRE(!a->out_op || ((uintptr_t)a->out_op & 15) == 0, "mvlt_mlp_fwd: out_op must be 16-byte aligned");
   MVLT_REQUIRE(!a->ln_x || (a->ln_gamma && a->ln_beta && a->ln_y && a->ln_mean && a->ln_rstd && ((uintptr_t)a->ln_x & 15) == 0 && ((uintptr_t)a->ln_y & 15) == 0),
                "mvlt_mlp_fwd: the folded LayerNorm needs gamma, beta, y, mean, rstd and 16-byte aligned rows");
   if (a->M <= 0) return MVLT_OK;

@@ -25,6 +25,7 @@ def _empty(shape, dtype, dev):
 
 _LN_COPIES = not os.environ.get("MVLT_LN_NO_COPIES")      # A/B switch: LayerNorm parameter gradients by plain atomics
 _NO_DX2 = bool(os.environ.get("MVLT_NO_DX2"))      # A/B switch: DropPath-scaled gradient copy by a separate pass
+_NO_OUT_OP = bool(os.environ.get("MVLT_NO_OUT_OP"))        # A/B switch: fp32 stage output + separate cast pass
 _NO_LN_FOLD = bool(os.environ.get("MVLT_NO_LN_FOLD"))      # A/B switch: LN2 as its own launch in front of the fused MLP
 # A/B switches: conv weight gradients accumulated straight into the [out][cin][kh][kw] layout by the wgrad epilogue (strided atomics),
 # or through a pooled [out][kh][kw][cin] buffer + one permuted ATen add per convolution, instead of the store's tap arena
@@ -231,7 +232,7 @@ class TrunkStep:
             sv["blocks"].append(bsv)
             blk_index += 1
         self._mark()
-        if self.dt != self.rt:               # MFMA-operand copy of the stage output (next stage's convs, the heads)
+        if x.dtype != dt:                    # MFMA-operand copy of the stage output (next stage's convs, the heads)
             xb = _empty((B, N, C), dt, dev)
             ops.cast_bf16(x, xb, x.numel())
             x = xb
@@ -301,8 +302,11 @@ class TrunkStep:
         xn2 = _empty((B, N, C), dt, dev)
         bs["m2"], bs["r2"] = _empty((M,), f32, dev), _empty((M,), f32, dev)
         bs["xn2"] = xn2
-        xo = _empty((B, N, C), self.rt, dev)
         bs["fused_mlp"] = fused = (dt == torch.bfloat16 and C in (64, 128))
+        # the last block of a stage has no fp32 consumer (its output feeds the next stage's patch embedding and the heads, which read
+        # the MFMA-operand copy): the fused MLP then writes that copy itself and no fp32 stream -- no separate cast pass
+        last_op = fused and j == m.depths[i] - 1 and self.dt != self.rt and not _NO_OUT_OP
+        xo = _empty((B, N, C), dt if last_op else self.rt, dev)
         if fused:
             # stages 1-2: LN2 -> fc1 -> GELU -> fc2 -> DropPath -> +residual in ONE kernel.  The (tokens x hidden) activation stays on
             # chip and is recomputed by the fused backward kernels; LN2 is folded into the operand load (the kernel reads the fp32
@@ -311,7 +315,8 @@ class TrunkStep:
             if ln is None:
                 ops.layernorm_fwd(xm, xn2, self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m2"], rstd=bs["r2"])
             ops.mlp_fwd(None if ln else xn2, self.w(p + "mlp.fc1.weight"), self.f32(p + "mlp.fc1.bias"), self.w(p + "mlp.fc2.weight"),
-                        self.f32(p + "mlp.fc2.bias"), xm, xo, M, C, hid, row_scale=s2, rows_per_scale=N, ln=ln)
+                        self.f32(p + "mlp.fc2.bias"), xm, None if last_op else xo, M, C, hid, row_scale=s2, rows_per_scale=N, ln=ln,
+                        out_op=xo if last_op else None)
         else:
             ops.layernorm_fwd(xm, xn2, self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m2"], rstd=bs["r2"])
             hpre = _empty((M, hid), dt, dev) if self.need_grad else None

@@ -761,6 +761,14 @@ def test_fused_mlp_with_folded_layernorm(ops, Cdim, hid, M, Bsz):
     assert maxrel(out, ref) < 5e-3
     tref = F.layer_norm(xm, (Cdim,), g, b, 1e-6)
     assert maxrel(xn2.float(), tref) < TOL[bf]
+    # out_op: the bf16 copy of the output next to (or instead of) the fp32 stream -- exactly the rounded fp32 values
+    o16a, o16b = torch.empty_like(xn), torch.empty_like(xn)
+    out_b = ops.mlp_fwd(None, w1, b1, w2, b2, xm, torch.empty_like(xm), M, Cdim, hid, row_scale=rs, rows_per_scale=M // Bsz,
+                        ln=(g, b, 1e-6, xn2, mean2, rstd2), out_op=o16a)
+    got = ops.mlp_fwd(None, w1, b1, w2, b2, xm, None, M, Cdim, hid, row_scale=rs, rows_per_scale=M // Bsz,
+                      ln=(g, b, 1e-6, xn2, mean2, rstd2), out_op=o16b)
+    assert got is o16b and torch.equal(out_b, out)
+    assert torch.equal(o16a, out.to(bf)) and torch.equal(o16b, o16a)
 
 
 @pytest.mark.parametrize("side,Cin,Cout,Bsz,tokens_extra", [(32, 64, 64, 3, 0), (32, 192, 192, 2, 0), (16, 128, 64, 5, 128), (8, 64, 128, 9, 128),
