@@ -305,6 +305,11 @@ typedef struct mvlt_mlp_args {
    * may then be NULL: the last block of a stage has no fp32 consumer (reference libs/pvlt.py:331-345: the stage output goes to
    * the next patch embedding / the heads only). */
   void* out_op;
+  /* fwd only, optional: LayerNorm of the OUTPUT rows (the NEXT block's norm1, reference libs/pvlt.py:141) computed in the epilogue
+   * while a row is in registers: post_y[M,C] (bf16) = LN(out; post_gamma, post_beta, post_eps), row statistics to post_mean /
+   * post_rstd -- that block then needs no LayerNorm launch of its own. */
+  const float* post_gamma; const float* post_beta; float post_eps;
+  void* post_y; float* post_mean; float* post_rstd;
 } mvlt_mlp_args;
 int mvlt_mlp_fwd(const mvlt_mlp_args* args, void* stream);
 int mvlt_mlp_bwd_dx(const mvlt_mlp_args* args, void* stream);

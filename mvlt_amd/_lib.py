@@ -92,7 +92,9 @@ class MlpArgs(C.Structure):
                 ("out", c_void_p), ("h_out", c_void_p), ("dw1", c_void_p), ("db1", c_void_p), ("dw2", c_void_p), ("db2", c_void_p),
                 ("M", c_int), ("C", c_int), ("hid", c_int),
                 ("ln_x", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
-                ("ln_y", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("out_op", c_void_p)]
+                ("ln_y", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("out_op", c_void_p),
+                ("post_gamma", c_void_p), ("post_beta", c_void_p), ("post_eps", c_float),
+                ("post_y", c_void_p), ("post_mean", c_void_p), ("post_rstd", c_void_p)]
 
 
 lib.mvlt_last_error.restype = C.c_char_p

@@ -273,6 +273,32 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
           for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
           *(bf16x8*)((bf16*)p.out_op + idx) = o;
         }
+        if (p.post_y) {
+          // LayerNorm of the OUTPUT row (the next block's norm1, reference libs/pvlt.py:141) while the row is here: its CPR lanes hold
+          // 8 channels each, so the two-pass statistics are log2(CPR) xor-shuffles; saves that block's LayerNorm launch (fp32 row read)
+          float sum = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sum += v[e];
+#pragma unroll
+          for (int o = 1; o < CPR; o <<= 1) sum += __shfl_xor(sum, o);
+          const float mean = sum * (1.0f / (float)C);
+          float q = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; q += d * d; }
+#pragma unroll
+          for (int o = 1; o < CPR; o <<= 1) q += __shfl_xor(q, o);
+          const float rstd = rsqrtf(q * (1.0f / (float)C) + p.post_eps);
+          if (ch == 0) { p.post_mean[m] = mean; p.post_rstd[m] = rstd; }
+          const f32x4 g0 = *(const f32x4*)(p.post_gamma + nc), g1 = *(const f32x4*)(p.post_gamma + nc + 4);
+          const f32x4 be0 = *(const f32x4*)(p.post_beta + nc), be1 = *(const f32x4*)(p.post_beta + nc + 4);
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = (bf16)((v[e] - mean) * rstd * g0[e] + be0[e]);
+            o[4 + e] = (bf16)((v[4 + e] - mean) * rstd * g1[e] + be1[e]);
+          }
+          *(bf16x8*)((bf16*)p.post_y + idx) = o;
+        }
       } else {
         bf16x8 o;
 #pragma unroll
@@ -550,6 +576,8 @@ extern "C" int mvlt_mlp_fwd(const mvlt_mlp_args* a, void* stream) {
   if (int e = check(a, "mvlt_mlp_fwd")) return e;
   MVLT_REQUIRE(a->b2 && a->residual, "mvlt_mlp_fwd: b2 and residual are required");
   MVLT_REQUIRE(!a->out_op || ((uintptr_t)a->out_op & 15) == 0, "mvlt_mlp_fwd: out_op must be 16-byte aligned");
+  MVLT_REQUIRE(!a->post_y || (a->post_gamma && a->post_beta && a->post_mean && a->post_rstd && ((uintptr_t)a->post_y & 15) == 0),
+               "mvlt_mlp_fwd: post_y needs post_gamma / post_beta / post_mean / post_rstd and 16-byte alignment");
   MVLT_REQUIRE(!a->ln_x || (a->ln_gamma && a->ln_beta && a->ln_y && a->ln_mean && a->ln_rstd && ((uintptr_t)a->ln_x & 15) == 0 && ((uintptr_t)a->ln_y & 15) == 0),
                "mvlt_mlp_fwd: the folded LayerNorm needs gamma, beta, y, mean, rstd and 16-byte aligned rows");
   if (a->M <= 0) return MVLT_OK;

@@ -292,10 +292,11 @@ def upsample_bwd(dy, lddy, nchw, B, H, W, Cdim, scale, dx, lddx, accumulate=Fals
 
 
 # ------------------------------------------------------------------ fused MLP (csrc/mlp.hip), bf16, C in {64, 128}
-def mlp_fwd(x, w1, b1, w2, b2, residual, out, M, Cdim, hid, *, row_scale=None, rows_per_scale=0, h_out=None, ln=None, out_op=None):
+def mlp_fwd(x, w1, b1, w2, b2, residual, out, M, Cdim, hid, *, row_scale=None, rows_per_scale=0, h_out=None, ln=None, out_op=None, post_ln=None):
     """ln = (gamma, beta, eps, y, mean, rstd): LayerNorm(residual) folded into the operand load -- `x` is then not read (may be None);
     y (bf16 [M, C]) receives the normalised rows, mean / rstd (fp32 [M]) the row statistics.
-    out_op: optional bf16 [M, C] copy of the output; `out` (fp32) may be None when only the copy is wanted."""
+    out_op: optional bf16 [M, C] copy of the output; `out` (fp32) may be None when only the copy is wanted.
+    post_ln = (gamma, beta, eps, y, mean, rstd): LayerNorm of the OUTPUT rows (the next block's norm1) from the epilogue."""
     assert w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
     assert residual.dtype == torch.float32 and residual.is_contiguous() and (out is not None or out_op is not None)
     assert out is None or out.dtype == torch.float32
@@ -307,8 +308,13 @@ def mlp_fwd(x, w1, b1, w2, b2, residual, out, M, Cdim, hid, *, row_scale=None, r
         g, b, eps, y, mean, rstd = ln
         assert g.dtype == b.dtype == mean.dtype == rstd.dtype == torch.float32 and y.dtype == torch.bfloat16 and y.is_contiguous()
         tail = (ptr(residual), ptr(g), ptr(b), eps, ptr(y), ptr(mean), ptr(rstd))
+    post = (None, None, 0.0, None, None, None)
+    if post_ln is not None:
+        pg, pb, peps, py, pm, pr = post_ln
+        assert pg.dtype == pb.dtype == pm.dtype == pr.dtype == torch.float32 and py.dtype == torch.bfloat16 and py.is_contiguous()
+        post = (ptr(pg), ptr(pb), peps, ptr(py), ptr(pm), ptr(pr))
     a = L.MlpArgs(ptr(x), None, ptr(w1), ptr(w2), None, ptr(b1), ptr(b2), ptr(residual), ptr(row_scale), rows_per_scale,
-                  ptr(out), ptr(h_out), None, None, None, None, M, Cdim, hid, *tail, ptr(out_op))
+                  ptr(out), ptr(h_out), None, None, None, None, M, Cdim, hid, *tail, ptr(out_op), *post)
     check(L.lib.mvlt_mlp_fwd(C.byref(a), stream_ptr()), "mvlt_mlp_fwd")
     return out if out is not None else out_op
 

@@ -25,6 +25,7 @@ def _empty(shape, dtype, dev):
 
 _LN_COPIES = not os.environ.get("MVLT_LN_NO_COPIES")      # A/B switch: LayerNorm parameter gradients by plain atomics
 _NO_DX2 = bool(os.environ.get("MVLT_NO_DX2"))      # A/B switch: DropPath-scaled gradient copy by a separate pass
+_NO_POST_LN = bool(os.environ.get("MVLT_NO_POST_LN"))      # A/B switch: every block launches its own norm1
 _NO_OUT_OP = bool(os.environ.get("MVLT_NO_OUT_OP"))        # A/B switch: fp32 stage output + separate cast pass
 _NO_LN_FOLD = bool(os.environ.get("MVLT_NO_LN_FOLD"))      # A/B switch: LN2 as its own launch in front of the fused MLP
 # A/B switches: conv weight gradients accumulated straight into the [out][cin][kh][kw] layout by the wgrad epilogue (strided atomics),
@@ -256,10 +257,15 @@ class TrunkStep:
         bs = dict(x=x)
         s1, s2 = self._droppath_scales(blk_index)
         bs["s1"], bs["s2"] = s1, s2
-        # LN1
-        xn1 = _empty((B, N, C), dt, dev)
-        bs["m1"], bs["r1"] = _empty((M,), f32, dev), _empty((M,), f32, dev)
-        ops.layernorm_fwd(x, xn1, self.f32(p + "norm1.weight"), self.f32(p + "norm1.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m1"], rstd=bs["r1"])
+        # LN1 (already done by the previous block's fused MLP epilogue where there is one)
+        pre = getattr(self, "_pre_ln1", None)
+        self._pre_ln1 = None
+        if pre is not None:
+            xn1, bs["m1"], bs["r1"] = pre
+        else:
+            xn1 = _empty((B, N, C), dt, dev)
+            bs["m1"], bs["r1"] = _empty((M,), f32, dev), _empty((M,), f32, dev)
+            ops.layernorm_fwd(x, xn1, self.f32(p + "norm1.weight"), self.f32(p + "norm1.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m1"], rstd=bs["r1"])
         bs["xn1"] = xn1
         # q
         q = _empty((B, N, C), dt, dev)
@@ -314,9 +320,15 @@ class TrunkStep:
             ln = None if _NO_LN_FOLD else (self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), EPS_BLOCK, xn2, bs["m2"], bs["r2"])
             if ln is None:
                 ops.layernorm_fwd(xm, xn2, self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m2"], rstd=bs["r2"])
+            post = None
+            if j + 1 < m.depths[i] and not _NO_POST_LN:
+                # the next block's norm1 rides on this kernel's epilogue (the output row is in registers there)
+                pn = Names.blk(i, j + 1)
+                self._pre_ln1 = (_empty((B, N, C), dt, dev), _empty((M,), f32, dev), _empty((M,), f32, dev))
+                post = (self.f32(pn + "norm1.weight"), self.f32(pn + "norm1.bias"), EPS_BLOCK, *self._pre_ln1)
             ops.mlp_fwd(None if ln else xn2, self.w(p + "mlp.fc1.weight"), self.f32(p + "mlp.fc1.bias"), self.w(p + "mlp.fc2.weight"),
                         self.f32(p + "mlp.fc2.bias"), xm, None if last_op else xo, M, C, hid, row_scale=s2, rows_per_scale=N, ln=ln,
-                        out_op=xo if last_op else None)
+                        out_op=xo if last_op else None, post_ln=post)
         else:
             ops.layernorm_fwd(xm, xn2, self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m2"], rstd=bs["r2"])
             hpre = _empty((M, hid), dt, dev) if self.need_grad else None

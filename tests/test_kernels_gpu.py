@@ -769,6 +769,16 @@ def test_fused_mlp_with_folded_layernorm(ops, Cdim, hid, M, Bsz):
                       ln=(g, b, 1e-6, xn2, mean2, rstd2), out_op=o16b)
     assert got is o16b and torch.equal(out_b, out)
     assert torch.equal(o16a, out.to(bf)) and torch.equal(o16b, o16a)
+    # post_ln: the NEXT block's norm1 of the output rows from the epilogue == mvlt_layernorm_fwd of the stored output
+    g3, b3 = 1 + 0.2 * rnd(Cdim, dtype=torch.float32, seed=7), 0.1 * rnd(Cdim, dtype=torch.float32, seed=8)
+    yn, mn, rn = torch.empty_like(xn), torch.empty_like(mean), torch.empty_like(rstd)
+    out_c = ops.mlp_fwd(None, w1, b1, w2, b2, xm, torch.empty_like(xm), M, Cdim, hid, row_scale=rs, rows_per_scale=M // Bsz,
+                        ln=(g, b, 1e-6, xn2, mean2, rstd2), post_ln=(g3, b3, 1e-6, yn, mn, rn))
+    assert torch.equal(out_c, out)
+    yr, mr, rr = torch.empty_like(xn), torch.empty_like(mean), torch.empty_like(rstd)
+    ops.layernorm_fwd(out, yr, g3, b3, M, Cdim, Cdim, Cdim, 1e-6, mean=mr, rstd=rr)
+    assert maxrel(mn, mr) < 1e-5 and maxrel(rn, rr) < 1e-5
+    assert (yn.float() - yr.float()).abs().max().item() <= 2 ** -7 * yr.float().abs().max().item()
 
 
 @pytest.mark.parametrize("side,Cin,Cout,Bsz,tokens_extra", [(32, 64, 64, 3, 0), (32, 192, 192, 2, 0), (16, 128, 64, 5, 128), (8, 64, 128, 9, 128),
