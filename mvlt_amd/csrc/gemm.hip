@@ -1862,6 +1862,10 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
       splits = ((t1 * t2 == 1 ? 384 : 512) + t1 * t2 - 1) / (t1 * t2);     // a single output tile: 384 (1081344 x 64 x 64: 54.7 -> 48.9 us)
       if (splits >= 8) splits = (splits + 4) / 8 * 8;
       if (splits > 4096) splits = 4096;
+      // ... and a split must bring at least 8 k-tiles of work to its N1*N2 atomics: the kv / text-row weight gradients (32768 or 16384
+      // rows, 256 x 128 outputs) ran 256 splits of 1-2 k-tiles, 49 us where 32-64 splits take 20-26 us
+      static const int min_tiles = getenv("MVLT_TN_MINT") ? atoi(getenv("MVLT_TN_MINT")) : 8;
+      if (min_tiles > 1 && splits > mtiles / min_tiles) splits = mtiles / min_tiles;
     }
     if (splits > mtiles) splits = mtiles;
     if (splits < 1) splits = 1;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM bytes per kernel over whole training steps: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE, each with --kernel-trace only) over
 `bench.py --steps S --warmup 0 --no-cpu-baseline`, joined per kernel name.
-    python3 tools/step_traffic.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> <steps>   -> table on stdout
+    python3 tools/step_traffic.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> [steps]   -> table on stdout (steps = AdamW launches seen)
 read bytes = 2 x FETCH_SIZE KiB (gfx950 half-count correction, MI355X_MICROARCH.md), written = WRITE_SIZE KiB."""
 import csv, glob, re, sys
 from collections import defaultdict
@@ -22,9 +22,11 @@ def load(d, counter):
 
 
 if __name__ == "__main__":
-    rd, wr, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    rd, wr = sys.argv[1], sys.argv[2]
     R, durR, calls = load(rd, "FETCH_SIZE")
     W, durW, _ = load(wr, "WRITE_SIZE")
+    # steps actually executed (bench.py adds its blocks-only timing iterations to --steps): one AdamW launch per step
+    steps = max([c for n, c in calls.items() if n.startswith("adamw_kernel")] or [int(sys.argv[3])])
     rows = []
     for n in R:
         rb, wb = 2 * R[n] * 1024 / steps, W.get(n, 0.0) * 1024 / steps
@@ -32,7 +34,7 @@ if __name__ == "__main__":
         rows.append((rb + wb, rb, wb, us, calls[n] / steps, n))
     rows.sort(reverse=True)
     tot = sum(r[0] for r in rows)
-    print(f"total HBM bytes per step (all launches incl. setup amortised over {steps} steps): {tot / 1e9:.2f} GB")
+    print(f"total HBM bytes per step (all launches of the bench process, setup included, over the {steps} steps it ran): {tot / 1e9:.2f} GB")
     print(f"{'MB/step':>9} {'read':>8} {'written':>8} {'us/step':>9} {'TB/s':>6} {'calls':>6}  kernel")
     for t, rb, wb, us, c, n in rows[:45]:
         print(f"{t / 1e6:9.1f} {rb / 1e6:8.1f} {wb / 1e6:8.1f} {us:9.1f} {t / us / 1e6 if us else 0:6.2f} {c:6.1f}  {n}")
