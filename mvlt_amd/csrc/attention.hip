@@ -680,6 +680,31 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
     __syncthreads();                                   // (C) every wave's dS columns are parked
 
     // ---- dQ[32 x 64] = dS[32 x MP] K[MP x 64]: 8 output tiles (16 x 16) dealt round-robin to the waves -> sdQ
+    if constexpr (NW == 4) {
+      // four waves: wave w owns output tiles (qs = 0, dt = w) and (qs = 1, dt = w) -- the same K^T fragments serve both, the two
+      // accumulator chains are independent, and a k-step's three fragment reads are issued one step ahead of its two MFMAs
+      const int dt = wave;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const T* pa0 = sdS + fr * KS + 8 * fg;
+      const T* pa1 = sdS + (16 + fr) * KS + 8 * fg;
+      const T* pb = sKt + (dt * 16 + fr) * KS + 8 * fg;
+      Frag<T> a0 = load_frag8<T>(pa0), a1 = load_frag8<T>(pa1), bb = load_frag8<T>(pb);
+#pragma unroll
+      for (int ks = 0; ks < MP / 32; ++ks) {
+        Frag<T> n0 = a0, n1 = a1, nb = bb;
+        if (ks + 1 < MP / 32) {
+          n0 = load_frag8<T>(pa0 + 32 * (ks + 1)); n1 = load_frag8<T>(pa1 + 32 * (ks + 1)); nb = load_frag8<T>(pb + 32 * (ks + 1));
+        }
+        mma16(acc0, a0, bb);
+        mma16(acc1, a1, bb);
+        a0 = n0; a1 = n1; bb = nb;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sdQ[(4 * fg + r) * HD + dt * 16 + fr] = (T)acc0[r];
+        sdQ[(16 + 4 * fg + r) * HD + dt * 16 + fr] = (T)acc1[r];
+      }
+    } else {
     for (int tile = wave; tile < 8; tile += NW) {
       const int qs = tile >> 2, dt = tile & 3;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -691,6 +716,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) sdQ[(qs * 16 + 4 * fg + r) * HD + dt * 16 + fr] = (T)acc[r];
+    }
     }
     q_prev = q0;
   }
