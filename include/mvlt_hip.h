@@ -310,10 +310,22 @@ typedef struct mvlt_mlp_args {
    * post_rstd -- that block then needs no LayerNorm launch of its own. */
   const float* post_gamma; const float* post_beta; float post_eps;
   void* post_y; float* post_mean; float* post_rstd;
+  /* bwd_dx only, optional: the backward of the LayerNorm in FRONT of the MLP (Block.norm2) from the epilogue, where the row of
+   * d(LN output) is in registers.  lnb_x [M,C] fp32 = the LayerNorm's input (the block's mid stream), lnb_mean / lnb_rstd [M] its row
+   * statistics, lnb_gamma [C]; lnb_dx [M,C] bf16 is the gradient stream, updated in place (dx += LN backward; it may be the tensor
+   * passed as `dy`: a workgroup reads its rows of dy before it writes them); lnb_dx2 (optional, bf16 [M,C]) = the updated rows times
+   * lnb_dx2_scale[row / lnb_dx2_rows_per_scale] (the attention branch's DropPath factor); lnb_partials [ceil(M / 128)][2 C] fp32
+   * receives every workgroup's column sums (d gamma | d beta) for mvlt_add_column_sums.  `out` is not written then. */
+  const float* lnb_x; const float* lnb_mean; const float* lnb_rstd; const float* lnb_gamma;
+  void* lnb_dx; void* lnb_dx2; const float* lnb_dx2_scale; int lnb_dx2_rows_per_scale;
+  float* lnb_partials;
 } mvlt_mlp_args;
 int mvlt_mlp_fwd(const mvlt_mlp_args* args, void* stream);
 int mvlt_mlp_bwd_dx(const mvlt_mlp_args* args, void* stream);
 int mvlt_mlp_bwd_dw(const mvlt_mlp_args* args, void* stream);
+/* dst0[c] += sum over rows of in[r][c] (c < n0), dst1[c - n0] += the same for c >= n0; in: fp32 [rows][cols], row stride ld.  Folds the
+ * per-workgroup LayerNorm parameter-gradient partials of mvlt_mlp_bwd_dx (lnb_partials) into the two gradient slices. */
+int mvlt_add_column_sums(const float* in, long rows, int cols, int ld, float* dst0, int n0, float* dst1, void* stream);
 
 /* ---- MIM decoder helpers (mvlt_amd/csrc/mim.hip): train-mode BatchNorm over pixel-major [M, C] fp32 matrices, the
  * align_corners=True bilinear resizes and the feature products of reference libs/vl_heads.py:136-165.  The conv3x3

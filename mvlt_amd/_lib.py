@@ -94,7 +94,10 @@ class MlpArgs(C.Structure):
                 ("ln_x", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
                 ("ln_y", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("out_op", c_void_p),
                 ("post_gamma", c_void_p), ("post_beta", c_void_p), ("post_eps", c_float),
-                ("post_y", c_void_p), ("post_mean", c_void_p), ("post_rstd", c_void_p)]
+                ("post_y", c_void_p), ("post_mean", c_void_p), ("post_rstd", c_void_p),
+                ("lnb_x", c_void_p), ("lnb_mean", c_void_p), ("lnb_rstd", c_void_p), ("lnb_gamma", c_void_p),
+                ("lnb_dx", c_void_p), ("lnb_dx2", c_void_p), ("lnb_dx2_scale", c_void_p), ("lnb_dx2_rows_per_scale", c_int),
+                ("lnb_partials", c_void_p)]
 
 
 lib.mvlt_last_error.restype = C.c_char_p
@@ -113,7 +116,7 @@ EXPORTS = ["mvlt_last_error", "mvlt_abi_version", "mvlt_sizeof", "mvlt_gemm_nt",
            "mvlt_transpose_cast", "mvlt_row_scale", "mvlt_weight_prep", "mvlt_col_stats", "mvlt_bn_finalize", "mvlt_bn_norm", "mvlt_bn_bwd_reduce", "mvlt_bn_bwd_apply", "mvlt_ew_mul3_bwd",
            "mvlt_ew_mul", "mvlt_upsample_fwd", "mvlt_upsample_bwd", "mvlt_mlp_fwd", "mvlt_mlp_bwd_dx", "mvlt_mlp_bwd_dw",
            "mvlt_grid_mask_flags", "mvlt_grid_mask_apply", "mvlt_token_mask", "mvlt_resize_bilinear_tokens", "mvlt_gelu_bwd",
-           "mvlt_keep_mask", "mvlt_droppath_scales", "mvlt_loss_compose"]
+           "mvlt_keep_mask", "mvlt_droppath_scales", "mvlt_loss_compose", "mvlt_add_column_sums"]
 
 DT = {torch.bfloat16: 0, torch.float32: 1}
 

@@ -514,6 +514,16 @@ __global__ void loss_compose_kernel(LossPtrs a, float* out, float* total_out) {
   out[0] = total;
   *total_out = total;
 }
+// dst[c] += sum over rows of in[r][c]: a workgroup sums a slab of rows for every column (threads = columns, coalesced row reads),
+// one atomic per column and slab
+__global__ __launch_bounds__(256) void add_column_sums_kernel(const float* in, long rows, int cols, int ld, float* dst0, int n0, float* dst1, int rows_per_wg) {
+  const long r0 = (long)blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    float t = 0.f;
+    for (long r = r0; r < r1; ++r) t += in[r * ld + c];
+    atomicAdd(c < n0 ? dst0 + c : dst1 + (c - n0), t);
+  }
+}
 }  // namespace
 
 extern "C" int mvlt_bert_embed_fwd(const long* ids, const float* word, const float* pos, const float* type0, const float* gamma,
@@ -688,4 +698,13 @@ extern "C" int mvlt_loss_compose(const float* const* losses, const float* weight
   for (int i = 0; i < 5; ++i) { a.p[i] = losses[i]; a.w[i] = weights[i]; }
   hipLaunchKernelGGL(loss_compose_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out, total);
   return mvlt_check_launch("mvlt_loss_compose");
+}
+
+extern "C" int mvlt_add_column_sums(const float* in, long rows, int cols, int ld, float* dst0, int n0, float* dst1, void* stream) {
+  MVLT_REQUIRE(in && dst0 && rows >= 0 && cols > 0 && ld >= cols && n0 >= 0 && n0 <= cols && (n0 == cols || dst1), "mvlt_add_column_sums: bad arguments");
+  if (rows == 0) return MVLT_OK;
+  const int rows_per_wg = 64;
+  hipLaunchKernelGGL(add_column_sums_kernel, dim3((unsigned)((rows + rows_per_wg - 1) / rows_per_wg)), dim3(256), 0, (hipStream_t)stream, in, rows, cols, ld, dst0, n0,
+                     dst1, rows_per_wg);
+  return mvlt_check_launch("mvlt_add_column_sums");
 }

@@ -236,6 +236,12 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
   float b2v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) b2v[e] = (MODE == 0) ? p.b2[nc + e] : 0.f;
+  // MODE 1 with lnb_x: the backward of the LayerNorm in front of this MLP (Block.norm2) rides on the epilogue -- the row of
+  // d(LN output) is in registers here (CPR lanes x 8 channels), so its two row reductions are log2(CPR) xor-shuffles
+  const bool lnb = MODE == 1 && p.lnb_x != nullptr;
+  float lgam[8], accg[8], accb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { lgam[e] = lnb ? p.lnb_gamma[nc + e] : 0.f; accg[e] = 0.f; accb[e] = 0.f; }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -299,13 +305,62 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
           }
           *(bf16x8*)((bf16*)p.post_y + idx) = o;
         }
-      } else {
+      } else if (!lnb) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)(v[e] * rs);
         *(bf16x8*)((bf16*)p.out + idx) = o;
+      } else {
+        // dx (+)= LayerNorm backward of d(LN output) = v * rs; optional second output dx2 = dx * DropPath factor of the other branch
+        const float* xr = p.lnb_x + idx;
+        const f32x4 x0 = *(const f32x4*)xr, x1 = *(const f32x4*)(xr + 4);
+        const bf16x8 old = *(const bf16x8*)((const bf16*)p.lnb_dx + idx);
+        const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        const float mean = p.lnb_mean[m], rstd = p.lnb_rstd[m];
+        float g[8], xh[8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dyn = v[e] * rs;
+          xh[e] = (xs[e] - mean) * rstd;
+          g[e] = dyn * lgam[e];
+          s1 += g[e]; s2 += g[e] * xh[e];
+          accg[e] += dyn * xh[e]; accb[e] += dyn;
+        }
+#pragma unroll
+        for (int o = 1; o < CPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        s1 *= 1.0f / (float)C; s2 *= 1.0f / (float)C;
+        float dxv[8];
+        bf16x8 o1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dxv[e] = rstd * (g[e] - s1 - xh[e] * s2) + (float)old[e]; o1[e] = (bf16)dxv[e]; }
+        *(bf16x8*)((bf16*)p.lnb_dx + idx) = o1;
+        if (p.lnb_dx2) {
+          const float sc = p.lnb_dx2_scale[m / p.lnb_dx2_rows_per_scale];
+          bf16x8 o2;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o2[e] = (bf16)(dxv[e] * sc);
+          *(bf16x8*)((bf16*)p.lnb_dx2 + idx) = o2;
+        }
       }
     }
+  }
+  if (MODE == 1 && lnb) {
+    // column sums of this workgroup's rows (d gamma | d beta): lanes with the same channel chunk, then the four waves through LDS,
+    // stored plainly per workgroup; mvlt_add_column_sums adds them to the gradient (no same-address atomics from 8000 workgroups)
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { accg[e] += __shfl_xor(accg[e], o); accb[e] += __shfl_xor(accb[e], o); }
+    __syncthreads();                                  // every wave is done with its staging rows
+    float* part = (float*)smem;                      // [4 waves][2 C]
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { part[wave * 2 * C + nc + e] = accg[e]; part[wave * 2 * C + C + nc + e] = accb[e]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * C; c += NT)
+      p.lnb_partials[(long)blockIdx.x * 2 * C + c] = part[c] + part[2 * C + c] + part[4 * C + c] + part[6 * C + c];
   }
 }
 
@@ -563,7 +618,7 @@ template <int C, int MODE> int launch(const mvlt_mlp_args& a, hipStream_t s) {
 }
 
 int check(const mvlt_mlp_args* a, const char* who) {
-  MVLT_REQUIRE(a && (a->x || a->ln_x) && a->w1 && a->wb && a->b1 && (a->out || a->out_op), "%s: null pointer", who);
+  MVLT_REQUIRE(a && (a->x || a->ln_x) && a->w1 && a->wb && a->b1 && (a->out || a->out_op || a->lnb_x), "%s: null pointer", who);
   MVLT_REQUIRE(a->C == 64 || a->C == 128, "%s: C must be 64 or 128 (stage 1 / 2), got %d", who, a->C);
   MVLT_REQUIRE(a->hid > 0 && a->hid % 64 == 0, "%s: hidden size must be a multiple of 64", who);
   MVLT_REQUIRE(!a->row_scale || a->rows_per_scale > 0, "%s: row_scale needs rows_per_scale", who);
@@ -587,6 +642,9 @@ extern "C" int mvlt_mlp_fwd(const mvlt_mlp_args* a, void* stream) {
 extern "C" int mvlt_mlp_bwd_dx(const mvlt_mlp_args* a, void* stream) {
   if (int e = check(a, "mvlt_mlp_bwd_dx")) return e;
   MVLT_REQUIRE(a->dy && a->wc, "mvlt_mlp_bwd_dx: dy and wc (W2^T) are required");
+  MVLT_REQUIRE(!a->lnb_x || (a->lnb_mean && a->lnb_rstd && a->lnb_gamma && a->lnb_dx && a->lnb_partials && (!a->lnb_dx2 || (a->lnb_dx2_scale && a->lnb_dx2_rows_per_scale > 0)) &&
+                             ((uintptr_t)a->lnb_x & 15) == 0 && ((uintptr_t)a->lnb_dx & 15) == 0 && ((uintptr_t)a->lnb_dx2 & 15) == 0),
+               "mvlt_mlp_bwd_dx: lnb_x needs lnb_mean / lnb_rstd / lnb_gamma / lnb_dx / lnb_partials (and a scale for lnb_dx2), 16-byte aligned");
   if (a->M <= 0) return MVLT_OK;
   return a->C == 64 ? launch<64, 1>(*a, (hipStream_t)stream) : launch<128, 1>(*a, (hipStream_t)stream);
 }

@@ -319,12 +319,41 @@ def mlp_fwd(x, w1, b1, w2, b2, residual, out, M, Cdim, hid, *, row_scale=None, r
     return out if out is not None else out_op
 
 
-def mlp_bwd_dx(x, dy, w1, w1t, w2t, b1, out, M, Cdim, hid, *, row_scale=None, rows_per_scale=0):
-    assert x.dtype == dy.dtype == out.dtype == torch.bfloat16
+def mlp_bwd_dx(x, dy, w1, w1t, w2t, b1, out, M, Cdim, hid, *, row_scale=None, rows_per_scale=0, ln_bwd=None):
+    """ln_bwd = dict(x, mean, rstd, gamma, dx, dgamma, dbeta[, dx2, dx2_scale, dx2_rows_per_scale]): the backward of the LayerNorm in
+    front of the MLP from this kernel's epilogue -- dx (bf16 [M, C], may be `dy`) += LN backward in place, dx2 = its scaled copy,
+    dgamma / dbeta += the column sums (through per-workgroup partials and one mvlt_add_column_sums launch); `out` is not written."""
+    assert x.dtype == dy.dtype == torch.bfloat16 and (out is None or out.dtype == torch.bfloat16)
+    tail = (None, None, None, 0.0, None, None, None, None, None, None, 0.0, None, None, None)      # ln_* , out_op, post_*
+    if ln_bwd is None:
+        a = L.MlpArgs(ptr(x), ptr(dy), ptr(w1), ptr(w1t), ptr(w2t), ptr(b1), None, None, ptr(row_scale), rows_per_scale,
+                      ptr(out), None, None, None, None, None, M, Cdim, hid, *tail)
+        check(L.lib.mvlt_mlp_bwd_dx(C.byref(a), stream_ptr()), "mvlt_mlp_bwd_dx")
+        return out
+    k = ln_bwd
+    assert k["x"].dtype == torch.float32 and k["dx"].dtype == torch.bfloat16 and k["dx"].is_contiguous() and k["x"].is_contiguous()
+    assert k["mean"].dtype == k["rstd"].dtype == k["gamma"].dtype == k["dgamma"].dtype == k["dbeta"].dtype == torch.float32
+    dx2 = k.get("dx2")
+    assert dx2 is None or (dx2.dtype == torch.bfloat16 and dx2.is_contiguous() and k["dx2_scale"].dtype == torch.float32)
+    nwg = (M + 127) // 128
+    partials = torch.empty(nwg, 2 * Cdim, device=x.device, dtype=torch.float32)
     a = L.MlpArgs(ptr(x), ptr(dy), ptr(w1), ptr(w1t), ptr(w2t), ptr(b1), None, None, ptr(row_scale), rows_per_scale,
-                  ptr(out), None, None, None, None, None, M, Cdim, hid, None, None, None, 0.0, None, None, None)
+                  None, None, None, None, None, None, M, Cdim, hid, *tail,
+                  ptr(k["x"]), ptr(k["mean"]), ptr(k["rstd"]), ptr(k["gamma"]), ptr(k["dx"]), ptr(dx2), ptr(k.get("dx2_scale")),
+                  int(k.get("dx2_rows_per_scale", 0)), ptr(partials))
     check(L.lib.mvlt_mlp_bwd_dx(C.byref(a), stream_ptr()), "mvlt_mlp_bwd_dx")
-    return out
+    add_column_sums(partials, k["dgamma"], k["dbeta"])
+    return k["dx"]
+
+
+L.lib.mvlt_add_column_sums.argtypes = [_vp, _l, _i, _i, _vp, _i, _vp, _vp]
+
+
+def add_column_sums(partials, dst0, dst1):
+    """dst0 += column sums of partials[:, :n0], dst1 += those of partials[:, n0:] (fp32)"""
+    rows, cols = partials.shape
+    assert partials.dtype == dst0.dtype == dst1.dtype == torch.float32 and partials.is_contiguous() and dst0.numel() + dst1.numel() == cols
+    check(L.lib.mvlt_add_column_sums(_p(partials), rows, cols, cols, _p(dst0), dst0.numel(), _p(dst1), stream_ptr()), "mvlt_add_column_sums")
 
 
 def mlp_bwd_dw(x, dy, w1, w2t, b1, dw1, db1, dw2, db2, M, Cdim, hid, *, row_scale=None, rows_per_scale=0):

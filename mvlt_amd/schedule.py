@@ -25,6 +25,7 @@ def _empty(shape, dtype, dev):
 
 _LN_COPIES = not os.environ.get("MVLT_LN_NO_COPIES")      # A/B switch: LayerNorm parameter gradients by plain atomics
 _NO_DX2 = bool(os.environ.get("MVLT_NO_DX2"))      # A/B switch: DropPath-scaled gradient copy by a separate pass
+_NO_LNB_FUSE = bool(os.environ.get("MVLT_NO_LNB_FUSE"))    # A/B switch: norm2's backward as its own launch behind the fused-MLP dx kernel
 _NO_POST_LN = bool(os.environ.get("MVLT_NO_POST_LN"))      # A/B switch: every block launches its own norm1
 _NO_OUT_OP = bool(os.environ.get("MVLT_NO_OUT_OP"))        # A/B switch: fp32 stage output + separate cast pass
 _NO_LN_FOLD = bool(os.environ.get("MVLT_NO_LN_FOLD"))      # A/B switch: LN2 as its own launch in front of the fused MLP
@@ -448,12 +449,25 @@ class TrunkStep:
         f32 = torch.float32
         # ---- MLP branch: x_out = x_mid + s2 * (fc2(gelu(fc1(LN2(x_mid)))))
         dxn2 = _empty((M, C), dt, dev)
+        ln2_done = False
         if bs["fused_mlp"]:
             w1, w2t = self.w(p + "mlp.fc1.weight"), self.wT(p + "mlp.fc2.weight")
             ops.mlp_bwd_dw(bs["xn2"], dx, w1, w2t, self.f32(p + "mlp.fc1.bias"), self.g(p + "mlp.fc1.weight"), self.g(p + "mlp.fc1.bias"),
                            self.g(p + "mlp.fc2.weight"), self.g(p + "mlp.fc2.bias"), M, C, hid, row_scale=bs["s2"], rows_per_scale=N)
-            ops.mlp_bwd_dx(bs["xn2"], dx, w1, self.wT(p + "mlp.fc1.weight"), w2t, self.f32(p + "mlp.fc1.bias"), dxn2, M, C, hid,
-                           row_scale=bs["s2"], rows_per_scale=N)
+            if not _NO_LNB_FUSE:
+                # ... and norm2's backward rides on the dx kernel's epilogue (the row of d(LN output) is in registers there): dx is
+                # updated in place, the DropPath-scaled copy for the attention branch comes out of the same pass, no dxn2 round trip
+                fuse = bs["s1"] is not None and not _NO_DX2
+                dy1 = _empty((M, C), dx.dtype, dev) if fuse else dx
+                ops.mlp_bwd_dx(bs["xn2"], dx, w1, self.wT(p + "mlp.fc1.weight"), w2t, self.f32(p + "mlp.fc1.bias"), None, M, C, hid,
+                               row_scale=bs["s2"], rows_per_scale=N,
+                               ln_bwd=dict(x=bs["xm"], mean=bs["m2"], rstd=bs["r2"], gamma=self.f32(p + "norm2.weight"), dx=dx,
+                                           dgamma=self.gl(p + "norm2.weight"), dbeta=self.gl(p + "norm2.bias"),
+                                           dx2=dy1 if fuse else None, dx2_scale=bs["s1"], dx2_rows_per_scale=N))
+                ln2_done = True
+            else:
+                ops.mlp_bwd_dx(bs["xn2"], dx, w1, self.wT(p + "mlp.fc1.weight"), w2t, self.f32(p + "mlp.fc1.bias"), dxn2, M, C, hid,
+                               row_scale=bs["s2"], rows_per_scale=N)
         else:
             dy2 = self._scaled(dx, bs["s2"], N)
             ops.gemm_tn(dy2, bs["gact"], self.g(p + "mlp.fc2.weight"), M, C, hid, C, hid, hid, colsum=self.g(p + "mlp.fc2.bias"))
@@ -465,11 +479,12 @@ class TrunkStep:
             del dh
         # dx += LN2 backward = d(x_mid); the same kernel writes its DropPath-scaled copy, the gradient of the attention branch
         # x_mid = x + s1 * proj(attn(LN1(x)))
-        fuse = bs["s1"] is not None and not _NO_DX2
-        dy1 = _empty((M, C), dx.dtype, dev) if fuse else dx
-        ops.layernorm_bwd(dxn2, bs["xm"], dx, self.f32(p + "norm2.weight"), bs["m2"], bs["r2"], M, C, C, C, C,
-                          dgamma=self.gl(p + "norm2.weight"), dbeta=self.gl(p + "norm2.bias"), **self.lnk(), accumulate=True,
-                          dx2=dy1 if fuse else None, dx2_scale=bs["s1"], dx2_rows_per_scale=N, lddx2=C)
+        if not ln2_done:
+            fuse = bs["s1"] is not None and not _NO_DX2
+            dy1 = _empty((M, C), dx.dtype, dev) if fuse else dx
+            ops.layernorm_bwd(dxn2, bs["xm"], dx, self.f32(p + "norm2.weight"), bs["m2"], bs["r2"], M, C, C, C, C,
+                              dgamma=self.gl(p + "norm2.weight"), dbeta=self.gl(p + "norm2.bias"), **self.lnk(), accumulate=True,
+                              dx2=dy1 if fuse else None, dx2_scale=bs["s1"], dx2_rows_per_scale=N, lddx2=C)
         if not fuse:
             dy1 = self._scaled(dx, bs["s1"], N)
         ops.gemm_tn(dy1, bs["ao"], self.g(p + "attn.proj.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.proj.bias"))

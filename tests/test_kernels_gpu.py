@@ -550,6 +550,48 @@ def test_fused_mlp(ops, Cdim, hid, M, Bsz):
         assert maxrel(a, r) < 3e-2, nm
 
 
+@pytest.mark.parametrize("Cdim,hid,M,Bsz", [(64, 512, 3 * 400, 3), (128, 1024, 2 * 333, 2), (64, 512, 130, 1)])
+def test_fused_mlp_dx_with_layernorm_backward(ops, Cdim, hid, M, Bsz):
+    """mvlt_mlp_bwd_dx with lnb_x: norm2's backward from the dx kernel's epilogue (dx += LN backward in place, DropPath-scaled copy,
+    parameter gradients through per-workgroup partials) against the two separate launches it replaces"""
+    bf = torch.bfloat16
+    xm = rnd(M, Cdim, dtype=torch.float32, scale=1.5) + 0.3
+    g, b = 1 + 0.2 * rnd(Cdim, dtype=torch.float32, seed=1), 0.1 * rnd(Cdim, dtype=torch.float32, seed=2)
+    xn = torch.empty(M, Cdim, device=dev(), dtype=bf)
+    mean, rstd = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    ops.layernorm_fwd(xm, xn, g, b, M, Cdim, Cdim, Cdim, 1e-6, mean=mean, rstd=rstd)
+    w1, w2 = rnd(hid, Cdim, dtype=bf, seed=3, scale=Cdim ** -0.5), rnd(Cdim, hid, dtype=bf, seed=4, scale=hid ** -0.5)
+    b1 = 0.1 * rnd(hid, dtype=torch.float32, seed=5)
+    s2 = torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.9][:Bsz], device=dev())
+    s1 = torch.tensor([0.0, 1.0 / 0.8, 1.0 / 0.8][:Bsz], device=dev())
+    rps = M // Bsz
+    dy = rnd(M, Cdim, dtype=bf, seed=7)                      # gradient w.r.t. the block output = the residual gradient stream
+    w1t, w2t = w1.t().contiguous(), w2.t().contiguous()
+    # reference: the two launches
+    dxn = torch.empty(M, Cdim, device=dev(), dtype=bf)
+    ops.mlp_bwd_dx(xn, dy, w1, w1t, w2t, b1, dxn, M, Cdim, hid, row_scale=s2, rows_per_scale=rps)
+    dx_ref, dx2_ref = dy.clone(), torch.empty_like(dy)
+    dg_ref, db_ref = torch.zeros(Cdim, device=dev()), torch.zeros(Cdim, device=dev())
+    ops.layernorm_bwd(dxn, xm, dx_ref, g, mean, rstd, M, Cdim, Cdim, Cdim, Cdim, dgamma=dg_ref, dbeta=db_ref, accumulate=True,
+                      dx2=dx2_ref, dx2_scale=s1, dx2_rows_per_scale=rps, lddx2=Cdim)
+    # fused
+    dx, dx2 = dy.clone(), torch.empty_like(dy)
+    dg, db = torch.full((Cdim,), 2.0, device=dev()), torch.full((Cdim,), -1.0, device=dev())       # accumulate semantics
+    ops.mlp_bwd_dx(xn, dx, w1, w1t, w2t, b1, None, M, Cdim, hid, row_scale=s2, rows_per_scale=rps,
+                   ln_bwd=dict(x=xm, mean=mean, rstd=rstd, gamma=g, dx=dx, dgamma=dg, dbeta=db, dx2=dx2, dx2_scale=s1, dx2_rows_per_scale=rps))
+    scale = (dx_ref.float() - dy.float()).abs().max().item()
+    assert (dx.float() - dx_ref.float()).abs().max().item() <= 2e-2 * scale + 2 ** -7 * dy.float().abs().max().item()
+    assert rel(dx.float() - dy.float(), dx_ref.float() - dy.float()) < 2e-2          # bf16 rounding of dxn in the two-launch path only
+    assert rel(dx2.float(), dx2_ref.float()) < 2e-2
+    assert maxrel(dg - 2.0, dg_ref) < 2e-2 and maxrel(db + 1.0, db_ref) < 2e-2
+    # without the second output
+    dx_b = dy.clone()
+    dg_b, db_b = torch.zeros(Cdim, device=dev()), torch.zeros(Cdim, device=dev())
+    ops.mlp_bwd_dx(xn, dx_b, w1, w1t, w2t, b1, None, M, Cdim, hid, row_scale=s2, rows_per_scale=rps,
+                   ln_bwd=dict(x=xm, mean=mean, rstd=rstd, gamma=g, dx=dx_b, dgamma=dg_b, dbeta=db_b))
+    assert torch.equal(dx_b, dx)
+
+
 # ------------------------------------------------------------------ bilinear upsample (align_corners=True) and its adjoint
 @pytest.mark.parametrize("B,H,C,s,nchw,out_dtype", [(2, 8, 64, 2, False, torch.float32), (3, 6, 192, 2, False, torch.bfloat16),
                                                     (2, 8, 3, 8, True, torch.float32), (1, 5, 6, 3, False, torch.float32),
