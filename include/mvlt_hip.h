@@ -106,6 +106,10 @@ typedef struct mvlt_layernorm_args {
   float eps;
   int dtype;                          /* of x */
   int y_dtype;                        /* of y (bf16 GEMM operand out of an fp32 residual stream, or the reverse) */
+  /* optional chained second LayerNorm of the row just produced (the first block's norm1 behind the patch / text embedding's
+   * LayerNorm + pos-embed, reference libs/pvlt.py:141,169,208): y2 (bf16, rows laid out like y: same y_map / ldy) =
+   * LN(y; gamma2, beta2, eps2); mean2 / rstd2 are indexed by the PHYSICAL row of y.  C in {64, 128, 320, 512, 768} only. */
+  void* y2; const float* gamma2; const float* beta2; float eps2; float* mean2; float* rstd2;
 } mvlt_layernorm_args;
 int mvlt_layernorm_fwd(const mvlt_layernorm_args* args, void* stream);
 

@@ -57,7 +57,8 @@ class LayerNormArgs(C.Structure):
     _fields_ = [("x", c_void_p), ("y", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
                 ("mean", c_void_p), ("rstd", c_void_p), ("add", c_void_p), ("add_rows", c_int),
                 ("rows", c_int), ("C", c_int), ("ldx", c_int), ("ldy", c_int),
-                ("x_map", RowMap), ("y_map", RowMap), ("eps", c_float), ("dtype", c_int), ("y_dtype", c_int)]
+                ("x_map", RowMap), ("y_map", RowMap), ("eps", c_float), ("dtype", c_int), ("y_dtype", c_int),
+                ("y2", c_void_p), ("gamma2", c_void_p), ("beta2", c_void_p), ("eps2", c_float), ("mean2", c_void_p), ("rstd2", c_void_p)]
 
 
 class LayerNormBwdArgs(C.Structure):

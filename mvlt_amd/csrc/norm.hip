@@ -197,6 +197,39 @@ __global__ __launch_bounds__(NT) void ln_fwd_fixed_kernel(mvlt_layernorm_args p)
           for (int e = 0; e < VN; ++e) o[e] += ad[e];
         }
         Vec<TY>::store(yr + c0, o);
+        if (p.y2) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) v[u][it][e] = o[e];
+        }
+      }
+      if (p.y2) {
+        // chained second LayerNorm of the row just written (the first block's norm1 behind the patch / text embedding's LN + pos):
+        // the output row is still in registers, so that block needs no LayerNorm launch (and no re-read of the fp32 row) of its own
+        float s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITS; ++it)
+#pragma unroll
+          for (int e = 0; e < VN; ++e) s2 += v[u][it][e];
+        const float mean2 = group_sum<G>(s2) * inv_c;
+        float q2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITS; ++it)
+#pragma unroll
+          for (int e = 0; e < VN; ++e) { float d = v[u][it][e] - mean2; q2 += d * d; }
+        const float rstd2 = rsqrtf(group_sum<G>(q2) * inv_c + p.eps2);
+        const long prow = rowmap_base(ym, row);
+        if (gl == 0) { p.mean2[prow] = mean2; p.rstd2[prow] = rstd2; }
+        bf16* y2r = (bf16*)p.y2 + prow * p.ldy;
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const int c0 = (gl + it * G) * VN;
+          float ga[VN], be[VN], o[VN];
+          Vec<float>::load(p.gamma2 + c0, ga);
+          Vec<float>::load(p.beta2 + c0, be);
+#pragma unroll
+          for (int e = 0; e < VN; ++e) o[e] = (v[u][it][e] - mean2) * rstd2 * ga[e] + be[e];
+          Vec<bf16>::store(y2r + c0, o);
+        }
       }
     }
   }
@@ -365,9 +398,12 @@ template <typename T, typename TY, int G, int ITS, int RU> void launch_fwd_fixed
   hipLaunchKernelGGL((ln_fwd_fixed_kernel<T, TY, G, ITS, RU>), dim3((unsigned)grid), dim3(NT), 0, s, a);
 }
 
-template <typename T, typename TY> int launch_fwd(const mvlt_layernorm_args& a, hipStream_t s) {
+template <typename T, typename TY> int launch_fwd(const mvlt_layernorm_args& a_in, hipStream_t s) {
   // the widths of this model get an exact (lanes, chunks) split; everything else takes the power-of-two group kernel
   static const bool fixed_ok = !getenv("MVLT_LN_GENERIC");
+  const bool fixed_c = a_in.C == 64 || a_in.C == 128 || a_in.C == 320 || a_in.C == 512 || a_in.C == 768;
+  const mvlt_layernorm_args& a = a_in;
+  MVLT_REQUIRE(!a.y2 || (fixed_ok && fixed_c), "mvlt_layernorm_fwd: the chained second LayerNorm (y2) needs C in {64, 128, 320, 512, 768}, got %d", a.C);
   if (fixed_ok) {
     switch (a.C) {
       case 64: launch_fwd_fixed<T, TY, 8, 1, 2>(a, s); return mvlt_check_launch("mvlt_layernorm_fwd");

@@ -55,11 +55,21 @@ def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, co
     return C_out
 
 
+LN_CHAIN_WIDTHS = (64, 128, 320, 512, 768)     # widths with a fixed-geometry forward kernel: these can chain a second LayerNorm
+
+
 def layernorm_fwd(x, y, gamma, beta, rows, Cdim, ldx, ldy, eps, *, mean=None, rstd=None, add=None, add_rows=0,
-                  x_map=None, y_map=None):
+                  x_map=None, y_map=None, chain=None):
+    """chain = (gamma2, beta2, eps2, y2, mean2, rstd2): y2 (bf16, rows laid out like y) = LayerNorm(y) with the second parameter set,
+    from the same pass; mean2 / rstd2 are indexed by y's physical row.  Only for Cdim in LN_CHAIN_WIDTHS."""
     assert x.dtype in DT and y.dtype in DT and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    tail = (None, None, None, 0.0, None, None)
+    if chain is not None:
+        g2, b2, eps2, y2, m2, r2 = chain
+        assert Cdim in LN_CHAIN_WIDTHS and y2.dtype == torch.bfloat16 and g2.dtype == b2.dtype == m2.dtype == r2.dtype == torch.float32
+        tail = (ptr(y2), ptr(g2), ptr(b2), eps2, ptr(m2), ptr(r2))
     a = L.LayerNormArgs(ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(add), add_rows,
-                        rows, Cdim, ldx, ldy, x_map or _ID, y_map or _ID, eps, DT[x.dtype], DT[y.dtype])
+                        rows, Cdim, ldx, ldy, x_map or _ID, y_map or _ID, eps, DT[x.dtype], DT[y.dtype], *tail)
     check(L.lib.mvlt_layernorm_fwd(C.byref(a), stream_ptr()), "mvlt_layernorm_fwd")
     return y
 

@@ -25,6 +25,7 @@ def _empty(shape, dtype, dev):
 
 _LN_COPIES = not os.environ.get("MVLT_LN_NO_COPIES")      # A/B switch: LayerNorm parameter gradients by plain atomics
 _NO_DX2 = bool(os.environ.get("MVLT_NO_DX2"))      # A/B switch: DropPath-scaled gradient copy by a separate pass
+_NO_LN_CHAIN = bool(os.environ.get("MVLT_NO_LN_CHAIN")) or bool(os.environ.get("MVLT_LN_GENERIC"))   # A/B switch: first block's norm1 as its own launch
 _NO_LNB_FUSE = bool(os.environ.get("MVLT_NO_LNB_FUSE"))    # A/B switch: norm2's backward as its own launch behind the fused-MLP dx kernel
 _NO_POST_LN = bool(os.environ.get("MVLT_NO_POST_LN"))      # A/B switch: every block launches its own norm1
 _NO_OUT_OP = bool(os.environ.get("MVLT_NO_OUT_OP"))        # A/B switch: fp32 stage output + separate cast pass
@@ -211,8 +212,15 @@ class TrunkStep:
         x = _empty((B, N, C), self.rt, dev)
         pos = self._pos(i, self.f32(f"pos_embed{i+1}"))
         sv["pe_pre"], sv["pe_mean"], sv["pe_rstd"] = pe_pre, _empty((B * HW,), torch.float32, dev), _empty((B * HW,), torch.float32, dev)
+        # the first block's norm1 is chained onto the two embedding LayerNorms below (their output rows are in registers): that block
+        # launches no LayerNorm of its own and the fp32 rows are not read back
+        chain = None
+        if dt == torch.bfloat16 and C in ops.LN_CHAIN_WIDTHS and not _NO_LN_CHAIN:
+            p0 = Names.blk(i, 0)
+            self._pre_ln1 = (_empty((B, N, C), dt, dev), _empty((B * N,), torch.float32, dev), _empty((B * N,), torch.float32, dev))
+            chain = (self.f32(p0 + "norm1.weight"), self.f32(p0 + "norm1.bias"), EPS_BLOCK, *self._pre_ln1)
         ops.layernorm_fwd(pe_pre, x, self.f32(pe + "norm.weight"), self.f32(pe + "norm.bias"), B * HW, C, C, C, EPS_DEFAULT,
-                          mean=sv["pe_mean"], rstd=sv["pe_rstd"], add=pos, add_rows=HW, y_map=rowmap(HW, N, 0))
+                          mean=sv["pe_mean"], rstd=sv["pe_rstd"], add=pos, add_rows=HW, y_map=rowmap(HW, N, 0), chain=chain)
         # ---- text embed: Linear + LN(1e-5) + text pos-embed written into x[:, HW:]
         te_pre = _empty((B * T, C), dt, dev)
         if i == 0:
@@ -225,7 +233,7 @@ class TrunkStep:
         sv["te_pre"], sv["te_mean"], sv["te_rstd"] = te_pre, _empty((B * T,), torch.float32, dev), _empty((B * T,), torch.float32, dev)
         ops.layernorm_fwd(te_pre, x, self.f32(ten + "1.weight"), self.f32(ten + "1.bias"), B * T, C, C, C, EPS_DEFAULT,
                           mean=sv["te_mean"], rstd=sv["te_rstd"], add=self.f32(f"text_pos_embed{i+1}")[0], add_rows=T,
-                          y_map=rowmap(T, N, HW))
+                          y_map=rowmap(T, N, HW), chain=chain)
         sv["x_in_prev"] = xp
         sv["blocks"] = []
         self._mark()

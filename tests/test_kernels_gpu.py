@@ -226,6 +226,40 @@ def test_layernorm_fwd_bwd(ops, dtype, rows, Cdim, eps):
     assert maxrel(dx2.float(), xr.grad) < TOL[dtype]
 
 
+@pytest.mark.parametrize("Cdim", [64, 128, 320, 512])
+def test_layernorm_chained_second_norm(ops, Cdim):
+    """mvlt_layernorm_fwd with y2: the embedding LayerNorm (+ pos-embed, rows mapped into the token buffer) and the first block's norm1
+    of the row it just wrote, in one pass -- against two separate launches"""
+    bf = torch.bfloat16
+    B, HW, T = 3, 20, 7
+    N = HW + T
+    pre = rnd(B * HW, Cdim, dtype=bf)
+    g1, b1 = 1 + 0.2 * rnd(Cdim, dtype=torch.float32, seed=1), 0.1 * rnd(Cdim, dtype=torch.float32, seed=2)
+    g2, b2 = 1 + 0.2 * rnd(Cdim, dtype=torch.float32, seed=3), 0.1 * rnd(Cdim, dtype=torch.float32, seed=4)
+    pos = rnd(HW, Cdim, dtype=torch.float32, seed=5)
+    from mvlt_amd._lib import rowmap
+    ymap = rowmap(HW, N, 0)
+    x_ref = torch.zeros(B, N, Cdim, device=dev())
+    ops.layernorm_fwd(pre, x_ref, g1, b1, B * HW, Cdim, Cdim, Cdim, 1e-5, add=pos, add_rows=HW, y_map=ymap)
+    y2_ref = torch.zeros(B, N, Cdim, device=dev(), dtype=bf)
+    m_ref, r_ref = torch.zeros(B * N, device=dev()), torch.zeros(B * N, device=dev())
+    ops.layernorm_fwd(x_ref, y2_ref, g2, b2, B * N, Cdim, Cdim, Cdim, 1e-6, mean=m_ref, rstd=r_ref)
+    x = torch.zeros(B, N, Cdim, device=dev())
+    y2 = torch.zeros(B, N, Cdim, device=dev(), dtype=bf)
+    m2, r2 = torch.zeros(B * N, device=dev()), torch.zeros(B * N, device=dev())
+    mean, rstd = torch.empty(B * HW, device=dev()), torch.empty(B * HW, device=dev())
+    ops.layernorm_fwd(pre, x, g1, b1, B * HW, Cdim, Cdim, Cdim, 1e-5, mean=mean, rstd=rstd, add=pos, add_rows=HW, y_map=ymap,
+                      chain=(g2, b2, 1e-6, y2, m2, r2))
+    assert torch.equal(x, x_ref)
+    img = torch.zeros(B, N, dtype=torch.bool, device=dev())
+    img[:, :HW] = True
+    sel = img.view(-1)
+    assert maxrel(m2[sel], m_ref[sel]) < 1e-5 and maxrel(r2[sel], r_ref[sel]) < 1e-5
+    assert (m2[~sel] == 0).all() and (y2[:, HW:] == 0).all()                       # text rows belong to the other launch
+    d = (y2[:, :HW].float() - y2_ref[:, :HW].float()).abs().max().item()
+    assert d <= 2 ** -7 * y2_ref.float().abs().max().item()                        # at most one bf16 ulp apart
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_layernorm_into_concat_with_pos(ops, dtype):
     """LN + pos-embed add + write into the image-token range of the concatenated (B, HW+T, C) buffer."""
