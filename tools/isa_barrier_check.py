@@ -50,21 +50,27 @@ def scan(fn):
     return hits
 
 
+def check_file(args):
+    f, tmp = args
+    asm = os.path.join(tmp, f + ".s")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-S", "--cuda-device-only",
+                    os.path.join(SRC, f), "-o", asm], check=True, stderr=subprocess.DEVNULL)
+    out = []
+    for name, fn in functions(asm).items():
+        for i, j, k in scan(fn):
+            out.append(f"{f}: {name[:90]}: back-edge at +{i} reaches the barrier at +{j} with the LDS write at +{k} undrained")
+    return out
+
+
 def main():
-    bad = 0
-    with tempfile.TemporaryDirectory() as tmp:
-        for f in sorted(os.listdir(SRC)):
-            if not f.endswith(".hip"):
-                continue
-            asm = os.path.join(tmp, f + ".s")
-            subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-S", "--cuda-device-only",
-                            os.path.join(SRC, f), "-o", asm], check=True, stderr=subprocess.DEVNULL)
-            for name, fn in functions(asm).items():
-                for i, j, k in scan(fn):
-                    bad += 1
-                    print(f"{f}: {name[:90]}: back-edge at +{i} reaches the barrier at +{j} with the LDS write at +{k} undrained")
-    print("suspicious back-edges:", bad)
-    return 1 if bad else 0
+    from concurrent.futures import ThreadPoolExecutor
+    files = sorted((f for f in os.listdir(SRC) if f.endswith(".hip")), key=lambda f: -os.path.getsize(os.path.join(SRC, f)))
+    with tempfile.TemporaryDirectory() as tmp, ThreadPoolExecutor(max_workers=min(6, len(files))) as ex:     # one hipcc -S per source, in parallel
+        hits = [h for r in ex.map(check_file, [(f, tmp) for f in files]) for h in r]
+    for h in hits:
+        print(h)
+    print("suspicious back-edges:", len(hits))
+    return 1 if hits else 0
 
 
 if __name__ == "__main__":
