@@ -358,6 +358,14 @@ int mvlt_ew_mul3_bwd(const float* dy, int lddy, const float* a, const float* b, 
 int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, int C, int scale, void* out, int ldo, int out_dtype, int nchw, void* stream);
 int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int H, int W, int C, int scale, void* dx, int lddx, int accumulate, int dx_dtype,
                       void* stream);
+/* The MIM loss without the image-sized prediction (training): SmoothL1(beta 1, mean) between the x scale bilinear upsample
+ * (align_corners=True) of the score map x[B,H,W,C] (pixel-major fp32, row stride ldx) and the NCHW fp32 target [B,C,H*scale,W*scale]
+ * (reference libs/vl_heads.py:163-165 + engine_grid_masking.py:99).  fwd: *loss_sum += the SUM over all elements (the caller divides by
+ * their number); bwd: dx[B*H*W, lddx] (bf16 or fp32, columns 0..C-1) = d(mean loss)/d(x) * gscale[0], recomputing the prediction.
+ * Geometry of the final x8 upsample only: W <= 64, W*scale a multiple of 4 and <= 256. */
+int mvlt_upsample_l1_fwd(const float* x, int ldx, int B, int H, int W, int C, int scale, const float* target, float* loss_sum, void* stream);
+int mvlt_upsample_l1_bwd(const float* x, int ldx, int B, int H, int W, int C, int scale, const float* target, const float* gscale, void* dx, int lddx,
+                         int dx_dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -117,7 +117,8 @@ EXPORTS = ["mvlt_last_error", "mvlt_abi_version", "mvlt_sizeof", "mvlt_gemm_nt",
            "mvlt_transpose_cast", "mvlt_row_scale", "mvlt_weight_prep", "mvlt_col_stats", "mvlt_bn_finalize", "mvlt_bn_norm", "mvlt_bn_bwd_reduce", "mvlt_bn_bwd_apply", "mvlt_ew_mul3_bwd",
            "mvlt_ew_mul", "mvlt_upsample_fwd", "mvlt_upsample_bwd", "mvlt_mlp_fwd", "mvlt_mlp_bwd_dx", "mvlt_mlp_bwd_dw",
            "mvlt_grid_mask_flags", "mvlt_grid_mask_apply", "mvlt_token_mask", "mvlt_resize_bilinear_tokens", "mvlt_gelu_bwd",
-           "mvlt_keep_mask", "mvlt_droppath_scales", "mvlt_loss_compose", "mvlt_add_column_sums"]
+           "mvlt_keep_mask", "mvlt_droppath_scales", "mvlt_loss_compose", "mvlt_add_column_sums",
+           "mvlt_upsample_l1_fwd", "mvlt_upsample_l1_bwd"]
 
 DT = {torch.bfloat16: 0, torch.float32: 1}
 

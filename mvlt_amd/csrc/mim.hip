@@ -457,6 +457,121 @@ __global__ __launch_bounds__(NT) void upsample_bwd_nchw4_kernel(const float* dy,
   }
 }
 
+// ---- the MIM loss without the image-sized logits (training): SmoothL1(mean) of the x s bilinear upsample (align_corners=True) of the
+// low-resolution score map x[B,H,W,C] (pixel-major, row stride ldx) against the NCHW target -- the upsampled prediction (201 MB at
+// batch 256) is never written: the forward reduces the loss while it interpolates (same tiling as upsample_fwd_nchw4_kernel), the
+// backward recomputes the prediction of the <= 2s+1 output rows that touch a score row and folds clamp(pred - target) back onto the
+// score map in one pass (same tiling as upsample_bwd_nchw4_kernel).  Reference: libs/vl_heads.py:163-165 + engine_grid_masking.py:99.
+__global__ __launch_bounds__(NT) void upsample_l1_fwd_kernel(const float* x, int ldx, int H, int W, int C, int s, const float* target, int nrows,
+                                                             float* loss_sum) {
+  __shared__ float src[8][2][64];
+  __shared__ float s_wy[8];
+  __shared__ float s_w[NT / 64];
+  const int Ho = H * s, Wo = W * s;
+  const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const int q = threadIdx.x & 63, rsub = threadIdx.x >> 6;
+  float acc = 0.f;
+  // a workgroup walks several 8-row groups and ends with ONE atomic (24576 same-address atomics, one per row group, cost more than
+  // the whole interpolation)
+  for (int row_base = blockIdx.x * 8; row_base < nrows; row_base += gridDim.x * 8) {
+    __syncthreads();                                 // the previous group's reads of src are done
+    for (int i = threadIdx.x; i < 8 * 2 * W; i += NT) {
+      const int rr = i / (2 * W), rem = i - rr * 2 * W, yy = rem / W, xx = rem - yy * W;
+      const int row = row_base + rr;
+      if (row < nrows) {
+        const int oy = row % Ho, bc = row / Ho;
+        const int c = bc % C, b = bc / C;
+        const float fy = oy * ry;
+        const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+        src[rr][yy][xx] = x[((long)b * H * W + (long)(yy ? y1 : y0) * W + xx) * ldx + c];
+        if (rem == 0) s_wy[rr] = fy - y0;
+      }
+    }
+    __syncthreads();
+    if (q * 4 < Wo) {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int rr = pass * 4 + rsub, row = row_base + rr;
+        if (row >= nrows) continue;
+        const float wy = s_wy[rr];
+        const f32x4 t = *(const f32x4*)(target + (long)row * Wo + q * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ox = q * 4 + e;
+          const float fx = ox * rx;
+          const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+          const float wx = fx - x0;
+          const float o = (1.f - wy) * ((1.f - wx) * src[rr][0][x0] + wx * src[rr][0][x1]) + wy * ((1.f - wx) * src[rr][1][x0] + wx * src[rr][1][x1]);
+          const float d = fabsf(o - t[e]);
+          acc += d < 1.0f ? 0.5f * d * d : d - 0.5f;
+        }
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss_sum, s_w[0] + s_w[1] + s_w[2] + s_w[3]);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(NT) void upsample_l1_bwd_kernel(const float* x, int ldx, int H, int W, int C, int s, const float* target, const float* gscale,
+                                                             float inv_n, TO* dx, int lddx) {
+  __shared__ __attribute__((aligned(16))) float part[4][256];
+  __shared__ float lr[3][64];                      // score rows iy - 1, iy, iy + 1 (clamped) of channel c
+  const int Ho = H * s, Wo = W * s;
+  const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const int row = blockIdx.x;                      // (b * C + c) * H + iy
+  const int iy = row % H, bc = row / H;
+  const int c = bc % C, b = bc / C;
+  for (int i = threadIdx.x; i < 3 * W; i += NT) {
+    const int k = i / W, xx = i - k * W;
+    const int y = min(max(iy - 1 + k, 0), H - 1);
+    lr[k][xx] = x[((long)b * H * W + (long)y * W + xx) * ldx + c];
+  }
+  __syncthreads();
+  const int oy_lo = ry > 0.f ? max(0, (int)floorf((iy - 1) / ry)) : 0, oy_hi = ry > 0.f ? min(Ho - 1, (int)ceilf((iy + 1) / ry)) : Ho - 1;
+  const float* plane = target + (long)bc * Ho * Wo;
+  const int q = threadIdx.x & 63, g = threadIdx.x >> 6;
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  if (q * 4 < Wo) {
+    int x0[4]; float wx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float fx = (q * 4 + e) * rx; x0[e] = (int)fx; wx[e] = fx - x0[e]; }
+    for (int oy = oy_lo + g; oy <= oy_hi; oy += 4) {
+      const float fy = oy * ry;
+      const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+      const float wy = fy - y0;
+      const float wyi = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+      if (wyi == 0.f) continue;
+      const float* r0 = lr[y0 - iy + 1];           // y0, y1 are within iy - 1 .. iy + 1 whenever wyi != 0
+      const float* r1 = lr[y1 - iy + 1];
+      const f32x4 tg = *(const f32x4*)(plane + (long)oy * Wo + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int xa = x0[e], xb = min(xa + 1, W - 1);
+        const float o = (1.f - wy) * ((1.f - wx[e]) * r0[xa] + wx[e] * r0[xb]) + wy * ((1.f - wx[e]) * r1[xa] + wx[e] * r1[xb]);
+        t[e] += wyi * __builtin_amdgcn_fmed3f(o - tg[e], -1.0f, 1.0f);
+      }
+    }
+    *(f32x4*)(&part[g][q * 4]) = t;
+  }
+  __syncthreads();
+  const float sc = gscale[0] * inv_n;
+  for (int ix = threadIdx.x; ix < W; ix += NT) {
+    const int ox_lo = rx > 0.f ? max(0, (int)floorf((ix - 1) / rx)) : 0, ox_hi = rx > 0.f ? min(Wo - 1, (int)ceilf((ix + 1) / rx)) : Wo - 1;
+    float acc = 0.f;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      const float fx = ox * rx;
+      const int xa = (int)fx, xb = min(xa + 1, W - 1);
+      const float w = fx - xa;
+      const float wxi = (xa == ix ? 1.f - w : 0.f) + (xb == ix ? w : 0.f);
+      acc += wxi * (part[0][ox] + part[1][ox] + part[2][ox] + part[3][ox]);
+    }
+    dx[(((long)b * H + iy) * W + ix) * lddx + c] = from_f32<TO>(acc * sc);
+  }
+}
+
 inline int grid_for(long work, int cap = 8192) {
   long g = (work + NT - 1) / NT;
   if (g > cap) g = cap;
@@ -611,4 +726,25 @@ extern "C" int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int
   }
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, nchw, B, H, W, C, scale, dx, lddx, accumulate);
   return mvlt_check_launch("mvlt_upsample_bwd");
+}
+
+extern "C" int mvlt_upsample_l1_fwd(const float* x, int ldx, int B, int H, int W, int C, int scale, const float* target, float* loss_sum, void* stream) {
+  MVLT_REQUIRE(x && target && loss_sum && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1, "mvlt_upsample_l1_fwd: bad arguments");
+  MVLT_REQUIRE(W <= 64 && (W * scale) % 4 == 0 && W * scale <= 256 && ((uintptr_t)target & 15) == 0 && (long)B * C * H * scale < (1L << 31),
+               "mvlt_upsample_l1_fwd: needs W <= 64, W * scale a multiple of 4 and <= 256, 16-byte aligned target");
+  const int nrows = B * C * H * scale;
+  const int groups = (nrows + 7) / 8;
+  hipLaunchKernelGGL(upsample_l1_fwd_kernel, dim3((unsigned)(groups < 2048 ? groups : 2048)), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, target, nrows, loss_sum);
+  return mvlt_check_launch("mvlt_upsample_l1_fwd");
+}
+
+extern "C" int mvlt_upsample_l1_bwd(const float* x, int ldx, int B, int H, int W, int C, int scale, const float* target, const float* gscale, void* dx, int lddx,
+                                    int dx_dtype, void* stream) {
+  MVLT_REQUIRE(x && target && gscale && dx && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1 && (dx_dtype == 0 || dx_dtype == 1), "mvlt_upsample_l1_bwd: bad arguments");
+  MVLT_REQUIRE(W <= 64 && (W * scale) % 4 == 0 && W * scale <= 256 && ((uintptr_t)target & 15) == 0, "mvlt_upsample_l1_bwd: needs W <= 64, W * scale a multiple of 4 and <= 256");
+  const float inv_n = 1.0f / ((float)B * C * H * scale * W * scale);
+  const dim3 grid((unsigned)(B * C * H));
+  if (dx_dtype == 0) hipLaunchKernelGGL(upsample_l1_bwd_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, target, gscale, inv_n, (bf16*)dx, lddx);
+  else hipLaunchKernelGGL(upsample_l1_bwd_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, target, gscale, inv_n, (float*)dx, lddx);
+  return mvlt_check_launch("mvlt_upsample_l1_bwd");
 }

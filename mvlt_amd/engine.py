@@ -143,7 +143,9 @@ def compute_losses(outputs, images, mlm_labels, itm_labels, sup_cls_labels, sub_
         if outputs["sup_cls_logits"] is not None:
             ls["loss_sup_cls"] = cross_entropy(outputs["sup_cls_logits"].view(-1, 48).float(), sup_cls_labels.view(-1))
             ls["loss_sub_cls"] = cross_entropy(outputs["sub_cls_logits"].view(-1, 122).float(), sub_cls_labels.view(-1))
-        if outputs["t2i_logits"] is not None:
+        if outputs.get("t2i_loss") is not None:
+            ls["loss_t2i"] = outputs["t2i_loss"].float()
+        elif outputs["t2i_logits"] is not None:
             ls["loss_t2i"] = smooth_l1(outputs["t2i_logits"].float(), images)
         if any(v is not None for v in ls.values()):
             return _compose_hip(ls)
@@ -177,7 +179,7 @@ def train_step(model, batch, idx, t2i_on, fused=True):
     core = _core(model)
     if fused and hasattr(core, "store") and core.loss_type.get("mlm"):
         outputs = model(inp, batch["input_ids"], mlm_labels=batch["mlm_labels"], mlm_positions=batch.get("mlm_positions"),
-                        mlm_count=batch.get("mlm_count"))
+                        mlm_count=batch.get("mlm_count"), t2i_target=images if core.loss_type.get("t2i") else None)
     else:
         outputs = model(inp, batch["input_ids"])
     return compute_losses(outputs, images, batch["mlm_labels"], batch["itm_labels"], batch["sup_cls_labels"], batch["sub_cls_labels"])

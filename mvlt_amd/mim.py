@@ -81,7 +81,7 @@ class MimStep:
         return out
 
     # ------------------------------------------------------------------ forward
-    def forward(self):
+    def forward(self, target=None):
         S, dev, dt, B = self.S, self.dev, self.dt, self.B
         x2, x3, x4 = self.x
         s1, s2, s3, M1, M2, M3 = self.s1, self.s2, self.s3, self.M1, self.M2, self.M3
@@ -116,8 +116,16 @@ class MimStep:
         # score: conv1x1 (192 -> 3) + bias, then x8 bilinear to the image, written as NCHW fp32
         sc = _e((M1, 3), dev)
         ops.gemm_nt(e16, S.extra["t2i_head.score.0.weight::W"], sc, M1, 3, 3 * ch, 3 * ch, 3 * ch, 3, bias=S.master("t2i_head.score.0.bias"))
-        out = _e((B, 3, 8 * s1, 8 * s1), dev)
-        ops.upsample_fwd(sc, 3, B, s1, s1, 3, 8, out, 0, nchw=True)
+        if target is not None:
+            # training with the loss fused behind the decoder: SmoothL1 against the target image while interpolating, the (B, 3, S, S)
+            # prediction is never written (and the backward recomputes it from the score map)
+            acc = pool_zeros((1,), torch.float32, dev)
+            ops.upsample_l1_fwd(sc, 3, B, s1, s1, 3, 8, target, acc)
+            out = (acc / target.numel()).reshape(())
+            self.sc, self.target = sc, target
+        else:
+            out = _e((B, 3, 8 * s1, 8 * s1), dev)
+            ops.upsample_fwd(sc, 3, B, s1, s1, 3, 8, out, 0, nchw=True)
         if self.nbt:
             torch._foreach_add_(self.nbt, 1)
             self.nbt = []
@@ -155,10 +163,14 @@ class MimStep:
         s1, s2, s3, M1, M2, M3 = self.s1, self.s2, self.s3, self.M1, self.M2, self.M3
         ch = 64
         k = self.keep
-        dout = dout.contiguous().float()
         # score head
         dsc_p = _z((M1, 8), dev, dt)                     # [pixels][3 -> 8] in the compute dtype: the operand of the two GEMMs below
-        ops.upsample_bwd(dout, 0, True, B, s1, s1, 3, 8, dsc_p, 8)
+        if getattr(self, "target", None) is not None:    # fused loss: dout is the scalar gradient of the loss
+            ops.upsample_l1_bwd(self.sc, 3, B, s1, s1, 3, 8, self.target, dout.reshape(1).float().contiguous(), dsc_p, 8)
+            self.sc = self.target = None
+        else:
+            dout = dout.contiguous().float()
+            ops.upsample_bwd(dout, 0, True, B, s1, s1, 3, 8, dsc_p, 8)
         # weight gradient and, as the GEMM's column sum, the bias gradient (a torch sum over a [262144, 3] matrix took 92 us)
         ops.gemm_tn(dsc_p, k["e16"], S.grad("t2i_head.score.0.weight").view(3, 3 * ch), M1, 3, 3 * ch, 8, 3 * ch, 3 * ch,
                     colsum=S.grad("t2i_head.score.0.bias"))
@@ -205,9 +217,9 @@ class MimStep:
 
 class _MimFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2, x3, x4, model, sides, need_grad, sink=None):
+    def forward(ctx, x2, x3, x4, model, sides, need_grad, sink=None, target=None):
         step = MimStep(model, x2, x3, x4, sides, model.training, need_grad)
-        out = step.forward()
+        out = step.forward(target)
         ctx.step, ctx.sink = step, sink
         return out
 
@@ -219,8 +231,9 @@ class _MimFn(torch.autograd.Function):
         ctx.step = ctx.sink = None
         step.S.fold_copies()                          # the conv weight gradients leave the tap arena for G
         step.S.announce_prefix("t2i_head.")          # the decoder's gradients are final: reduce them under the trunk backward
-        return g2, g3, g4, None, None, None, None
+        return g2, g3, g4, None, None, None, None, None
 
 
-def mim_head(model, x2, x3, x4, sides, need_grad, sink=None):
-    return _MimFn.apply(x2, x3, x4, model, sides, need_grad, sink)
+def mim_head(model, x2, x3, x4, sides, need_grad, sink=None, target=None):
+    """-> t2i_logits (B, 3, S, S), or with `target` (fp32 NCHW image) the mean SmoothL1 loss against it as a 0-dim tensor"""
+    return _MimFn.apply(x2, x3, x4, model, sides, need_grad, sink, target)

@@ -301,6 +301,30 @@ def upsample_bwd(dy, lddy, nchw, B, H, W, Cdim, scale, dx, lddx, accumulate=Fals
                                   stream_ptr()), "mvlt_upsample_bwd")
 
 
+L.lib.mvlt_upsample_l1_fwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]
+L.lib.mvlt_upsample_l1_bwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]
+
+
+def upsample_l1_ok(W, scale):
+    """geometry the fused upsample + SmoothL1 kernels take (the final x8 upsample of the MIM decoder)"""
+    return W <= 64 and (W * scale) % 4 == 0 and W * scale <= 256
+
+
+def upsample_l1_fwd(x, ldx, B, H, W, Cdim, scale, target, loss_sum):
+    """loss_sum[0] += sum SmoothL1(upsample(x) - target); x: fp32 [B*H*W, ldx] pixel-major, target: fp32 NCHW [B, C, H*scale, W*scale]"""
+    _need_cuda(x, target, loss_sum)
+    assert x.dtype == target.dtype == loss_sum.dtype == torch.float32 and target.is_contiguous()
+    check(L.lib.mvlt_upsample_l1_fwd(_p(x), ldx, B, H, W, Cdim, scale, _p(target), _p(loss_sum), stream_ptr()), "mvlt_upsample_l1_fwd")
+
+
+def upsample_l1_bwd(x, ldx, B, H, W, Cdim, scale, target, gscale, dx, lddx):
+    """dx[:, :C] = d(mean SmoothL1) / d(x) * gscale[0] (dx bf16 or fp32, row stride lddx)"""
+    _need_cuda(x, target, dx)
+    assert x.dtype == target.dtype == gscale.dtype == torch.float32 and dx.dtype in DT and target.is_contiguous()
+    check(L.lib.mvlt_upsample_l1_bwd(_p(x), ldx, B, H, W, Cdim, scale, _p(target), _p(gscale), _p(dx), lddx, DT[dx.dtype], stream_ptr()),
+          "mvlt_upsample_l1_bwd")
+
+
 # ------------------------------------------------------------------ fused MLP (csrc/mlp.hip), bf16, C in {64, 128}
 def mlp_fwd(x, w1, b1, w2, b2, residual, out, M, Cdim, hid, *, row_scale=None, rows_per_scale=0, h_out=None, ln=None, out_op=None, post_ln=None):
     """ln = (gamma, beta, eps, y, mean, rstd): LayerNorm(residual) folded into the operand load -- `x` is then not read (may be None);

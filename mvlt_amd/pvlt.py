@@ -271,12 +271,12 @@ class PyramidVisionLanguageTransformer(nn.Module):
             self._store.P = None
 
     # ------------------------------------------------------------------ forward
-    def forward(self, input_images, input_ids, mlm_labels=None, mlm_positions=None, mlm_count=None):
+    def forward(self, input_images, input_ids, mlm_labels=None, mlm_positions=None, mlm_count=None, t2i_target=None):
         if not input_images.is_cuda:
             raise RuntimeError("mvlt_amd PVLT runs on MI355X only (HIP kernels); there is no CPU path. "
                                "Use oracle/pvlt_oracle.py for CPU checks.")
         from .schedule import run_forward
-        return run_forward(self, input_images, input_ids, mlm_labels, mlm_positions, mlm_count)
+        return run_forward(self, input_images, input_ids, mlm_labels, mlm_positions, mlm_count, t2i_target)
 
 
 def _cfg(url='', **kwargs):     # timm.models.vision_transformer._cfg metadata (stored as model.default_cfg, unused)

@@ -25,6 +25,7 @@ def _empty(shape, dtype, dev):
 
 _LN_COPIES = not os.environ.get("MVLT_LN_NO_COPIES")      # A/B switch: LayerNorm parameter gradients by plain atomics
 _NO_DX2 = bool(os.environ.get("MVLT_NO_DX2"))      # A/B switch: DropPath-scaled gradient copy by a separate pass
+_NO_T2I_FUSE = bool(os.environ.get("MVLT_NO_T2I_FUSE"))    # A/B switch: t2i_logits materialised, SmoothL1 as its own two passes
 _NO_LN_CHAIN = bool(os.environ.get("MVLT_NO_LN_CHAIN")) or bool(os.environ.get("MVLT_LN_GENERIC"))   # A/B switch: first block's norm1 as its own launch
 _NO_LNB_FUSE = bool(os.environ.get("MVLT_NO_LNB_FUSE"))    # A/B switch: norm2's backward as its own launch behind the fused-MLP dx kernel
 _NO_POST_LN = bool(os.environ.get("MVLT_NO_POST_LN"))      # A/B switch: every block launches its own norm1
@@ -808,8 +809,10 @@ class _HostCount:
         return int(self.pin[0])
 
 
-def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_count=None):
+def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_count=None, t2i_target=None):
     """mlm_labels: (B, T) int64 with -1 = not selected -> fused masked-row MLM head + loss (`mlm_loss`).
+    t2i_target: (B, 3, S, S) fp32 clean image -> the MIM decoder returns its SmoothL1 loss (`t2i_loss`) instead of `t2i_logits`
+    (training: the image-sized prediction is never materialised, engine_grid_masking.py:99 is fused behind vl_heads.py:163-165).
     mlm_positions: optional precomputed selection (ascending flat indices, int32, on the device).
     mlm_count: optional number of selected positions as a host int (the engine counts on the host when the loader hands it
     CPU labels; the device prefetcher brings it along) -- without it the count comes back through `_HostCount`."""
@@ -867,7 +870,12 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_cou
             if grad_on and not model.training:
                 raise NotImplementedError("MIM decoder backward with eval-mode BatchNorm is not scheduled (no reference config needs it)")
             sides = tuple(images.shape[2] // model.patch_size // (2 ** i) for i in (1, 2, 3))
-            out["t2i_logits"] = mim_head(model, x2, x3, x4, sides, grad_on, sink)
+            fuse_loss = (t2i_target is not None and t2i_target.dtype == torch.float32 and t2i_target.shape == (B, 3, 8 * sides[0], 8 * sides[0])
+                         and ops.upsample_l1_ok(sides[0], 8) and not _NO_T2I_FUSE)
+            if fuse_loss:
+                out["t2i_loss"] = mim_head(model, x2, x3, x4, sides, grad_on, sink, t2i_target.contiguous())
+            else:
+                out["t2i_logits"] = mim_head(model, x2, x3, x4, sides, grad_on, sink)
         else:
             out["t2i_logits"] = model.t2i_head.run(*feats, conv_dtype=model.compute_dtype)
     return out

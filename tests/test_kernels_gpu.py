@@ -660,6 +660,29 @@ def test_upsample_fwd_bwd(ops, B, H, C, s, nchw, out_dtype):
         assert (dx16[:, C:] == 0).all()
 
 
+@pytest.mark.parametrize("B,H,C,s,out_dtype", [(2, 32, 3, 8, torch.bfloat16), (3, 8, 3, 8, torch.float32), (1, 12, 3, 8, torch.float32), (2, 16, 6, 4, torch.bfloat16)])
+def test_upsample_smooth_l1_fused(ops, B, H, C, s, out_dtype):
+    """mvlt_upsample_l1_fwd / _bwd: SmoothL1(mean) of the bilinear x s upsample (align_corners=True) against an NCHW target without the
+    upsampled tensor (reference libs/vl_heads.py:163-165 + engine_grid_masking.py:99) -- against F.interpolate + F.smooth_l1_loss"""
+    x = rnd(B * H * H, C, dtype=torch.float32, scale=1.5)
+    Ho = H * s
+    target = rnd(B, C, Ho, Ho, dtype=torch.float32, seed=3)
+    xt = x.view(B, H, H, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    pred = F.interpolate(xt, scale_factor=s, mode="bilinear", align_corners=True)
+    ref = F.smooth_l1_loss(pred, target)
+    acc = torch.zeros(1, device=dev())
+    ops.upsample_l1_fwd(x, C, B, H, H, C, s, target, acc)
+    got = acc.item() / target.numel()
+    assert abs(got - ref.item()) <= 1e-5 * abs(ref.item())
+    (ref * 3.0).backward()
+    want = xt.grad.permute(0, 2, 3, 1).reshape(B * H * H, C)
+    ld = 8
+    dx = torch.zeros(B * H * H, ld, device=dev(), dtype=out_dtype)
+    ops.upsample_l1_bwd(x, C, B, H, H, C, s, target, torch.full((1,), 3.0, device=dev()), dx, ld)
+    assert maxrel(dx[:, :C].float(), want) < (1e-5 if out_dtype == torch.float32 else TOL[torch.bfloat16])
+    assert (dx[:, C:] == 0).all()
+
+
 # ------------------------------------------------------------------ train-mode BatchNorm over pixel-major matrices
 @pytest.mark.parametrize("M,C,lddy,off", [(5000, 64, 192, 0), (3001, 192, 192, 0), (2048, 128, 192, 64), (777, 6, 6, 0)])
 def test_batchnorm_fwd_bwd(ops, M, C, lddy, off):
