@@ -339,19 +339,21 @@ int mvlt_bn_finalize(const float* sum, const float* sumsq, int copies /* accumul
                      float* running_mean, float* running_var /* nullable pair: updated like nn.BatchNorm2d */, void* stream);
 int mvlt_bn_norm(const float* z, int ldz, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
                  float* y32, int ld32, void* y_op, int ld_op, int op_dtype /* dtype of y_op: the MFMA-operand copy */, void* stream);
-int mvlt_bn_bwd_reduce(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, long M, int C,
-                       float* s1 /* += sum dy = dbeta */, float* s2 /* += sum dy*xhat = dgamma */, void* stream);
-int mvlt_bn_bwd_apply(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, const float* gamma,
+/* dy (the gradient w.r.t. the BatchNorm output) is fp32 (dy_dtype 1) or bf16 (dy_dtype 0: what the decoder's first backward stages hand
+ * over -- a gradient tensor is read twice here and written once by its producer) */
+int mvlt_bn_bwd_reduce(const void* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, long M, int C,
+                       float* s1 /* += sum dy = dbeta */, float* s2 /* += sum dy*xhat = dgamma */, int dy_dtype, void* stream);
+int mvlt_bn_bwd_apply(const void* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, const float* gamma,
                       const float* s1, const float* s2, long M, int C, void* dz_op, int lddz,
                       float* g_beta, float* g_gamma /* nullable pair: += s1, += s2 (the BatchNorm parameter gradients) */,
-                      int op_dtype, void* stream);
+                      int op_dtype, int dy_dtype, void* stream);
 /* out (+)= a*b(*c) elementwise over [M, C] fp32 with row strides; optional operand-dtype copy of the result */
 int mvlt_ew_mul(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c, int ldc, long M, int C,
                 int accumulate, void* out_op, int ld_op, int op_dtype, void* stream);
 /* gradients of y = a*b*c (all [M, C] fp32, row stride ld; dy row stride lddy): da = dy*b*c, db = dy*a*c, dc = dy*a*b
  * (the three-way feature product of reference libs/vl_heads.py:152) */
-int mvlt_ew_mul3_bwd(const float* dy, int lddy, const float* a, const float* b, const float* c, int ld, float* da, float* db, float* dc,
-                     long M, int C, void* stream);
+int mvlt_ew_mul3_bwd(const void* dy /* fp32 or bf16 (dy_dtype) */, int lddy, const float* a, const float* b, const float* c, int ld, float* da, float* db,
+                     float* dc, long M, int C, int dy_dtype, void* stream);
 /* bilinear resize by an integer factor, align_corners=True.  x fp32 [B,H,W,C] (row stride ldx) -> [B,sH,sW,C] (bf16/fp32,
  * row stride ldo) or NCHW fp32 [B,C,sH,sW]; bwd is the exact adjoint in gather form (no atomics); its dx is fp32 (dx_dtype 1) or,
  * behind the NCHW upsample only, bf16 (dx_dtype 0: the [pixels][8]-padded operand of the score conv's gradient GEMMs). */

@@ -14,6 +14,14 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const f32x4& v
   *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 }
 template <> __device__ __forceinline__ void store4<float>(float* p, const f32x4& v) { *(f32x4*)p = v; }
+// four consecutive gradient values as fp32 from an fp32 or bf16 tensor (the decoder's first backward stages hand their activations'
+// gradients over in bf16: they are read twice by the BatchNorm backward and once by the producer)
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
+  const bf16x4 v = *(const bf16x4*)p;
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
 
 // ---- per-column sum / sum of squares (BatchNorm batch statistics) and the two backward reductions
 // mode 0: s1 += sum z, s2 += sum z^2          mode 1: s1 += sum dy, s2 += sum dy * xhat  (xhat = (z-mean)*rstd)
@@ -55,8 +63,8 @@ __global__ __launch_bounds__(NT) void col_reduce_kernel(const float* z, int ldz,
 
 // The same two reductions with 16-byte loads: C/4 lanes span a row, NT/(C/4) rows per pass, four passes in flight per thread
 // (the 4-byte form above keeps too few bytes in flight to reach HBM speed at C = 64).  C % 4 == 0, ld % 4 == 0, 16-byte aligned.
-template <int MODE, int NT>
-__global__ __launch_bounds__(NT) void col_reduce4_kernel(const float* z, int ldz, const float* dy, int lddy, const float* mean, const float* rstd,
+template <int MODE, int NT, typename TDY = float>
+__global__ __launch_bounds__(NT) void col_reduce4_kernel(const float* z, int ldz, const TDY* dy, int lddy, const float* mean, const float* rstd,
                                                          long M, int C, float* s1, float* s2, int rows_per_wg) {
   extern __shared__ float sm[];             // [2][C]
   for (int i = threadIdx.x; i < 2 * C; i += NT) sm[i] = 0.f;
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(NT) void col_reduce4_kernel(const float* z, int ldz
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         zv[u] = *(const f32x4*)(z + (r + (long)u * rpp) * ldz + tc);
-        if (MODE == 1) dv[u] = *(const f32x4*)(dy + (r + (long)u * rpp) * lddy + tc);
+        if (MODE == 1) dv[u] = load4<TDY>(dy + (r + (long)u * rpp) * lddy + tc);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(NT) void col_reduce4_kernel(const float* z, int ldz
     }
     for (; r < r1; r += rpp) {
       f32x4 zv = *(const f32x4*)(z + r * ldz + tc), dv = zv;
-      if (MODE == 1) dv = *(const f32x4*)(dy + r * lddy + tc);
+      if (MODE == 1) dv = load4<TDY>(dy + r * lddy + tc);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (MODE == 0) { a1[e] += zv[e]; a2[e] += zv[e] * zv[e]; }
@@ -136,8 +144,8 @@ __global__ __launch_bounds__(NT) void bn_norm_kernel(const float* z, int ldz, co
 }
 
 // dz = gamma * rstd * (dy - s1/M - xhat * s2/M)   (bf16: it is the A operand of the conv dgrad / wgrad GEMMs)
-template <typename TO>
-__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd,
+template <typename TO, typename TDY = float>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const TDY* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd,
                                                           const float* gamma, const float* s1, const float* s2, long M, int C, TO* dz, int lddz,
                                                           float* g_beta, float* g_gamma) {
   const int cq = C / 4;
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* dy, int l
     for (int c = threadIdx.x; c < C; c += NT) { g_beta[c] += s1[c]; g_gamma[c] += s2[c]; }
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
     long r = i / cq; int c = (int)(i - r * cq) * 4;
-    f32x4 d = *(const f32x4*)(dy + r * lddy + c), zv = *(const f32x4*)(z + r * ldz + c);
+    f32x4 d = load4<TDY>(dy + r * lddy + c), zv = *(const f32x4*)(z + r * ldz + c);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -185,12 +193,13 @@ __global__ __launch_bounds__(NT) void ew_mul_kernel(float* out, int ldo, const f
 
 // gradients of the three-way product y = a * b * c (reference libs/vl_heads.py:152: conv_upsample2(..) * conv_upsample3(..) * low):
 // da = dy b c, db = dy a c, dc = dy a b in one pass (three ew_mul launches read dy and two of the factors each)
-__global__ __launch_bounds__(NT) void ew_mul3_bwd_kernel(const float* dy, int lddy, const float* a, const float* b, const float* c, int ld,
+template <typename TDY>
+__global__ __launch_bounds__(NT) void ew_mul3_bwd_kernel(const TDY* dy, int lddy, const float* a, const float* b, const float* c, int ld,
                                                          float* da, float* db, float* dc, long M, int C) {
   const int cq = C / 4;
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
     long r = i / cq; int col = (int)(i - r * cq) * 4;
-    const f32x4 g = *(const f32x4*)(dy + r * lddy + col);
+    const f32x4 g = load4<TDY>(dy + r * lddy + col);
     const f32x4 va = *(const f32x4*)(a + r * ld + col), vb = *(const f32x4*)(b + r * ld + col), vc = *(const f32x4*)(c + r * ld + col);
     f32x4 oa, ob, oc;
 #pragma unroll
@@ -597,7 +606,7 @@ extern "C" int mvlt_col_stats(const float* z, int ldz, long M, int C, float* sum
   if (vec4_ok(z, ldz, C)) {
     int rows_per_wg = reduce_rows_per_wg(M, C, RNT, RWGS);
     int grid = (int)((M + rows_per_wg - 1) / rows_per_wg);
-    hipLaunchKernelGGL((col_reduce4_kernel<0, RNT>), dim3(grid), dim3(RNT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, nullptr, 0, nullptr, nullptr, M, C, sum, sumsq, rows_per_wg);
+    hipLaunchKernelGGL((col_reduce4_kernel<0, RNT>), dim3(grid), dim3(RNT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, (const float*)nullptr, 0, nullptr, nullptr, M, C, sum, sumsq, rows_per_wg);
     return mvlt_check_launch("mvlt_col_stats");
   }
   int grid = (int)((M + 63) / 64); if (grid > 2048) grid = 2048;
@@ -623,33 +632,48 @@ extern "C" int mvlt_bn_norm(const float* z, int ldz, const float* mean, const fl
   return mvlt_check_launch("mvlt_bn_norm");
 }
 
-extern "C" int mvlt_bn_bwd_reduce(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, long M, int C,
-                                  float* s1, float* s2, void* stream) {
-  MVLT_REQUIRE(dy && z && mean && rstd && s1 && s2 && C > 0 && C <= 256, "mvlt_bn_bwd_reduce: bad arguments (C <= 256)");
+extern "C" int mvlt_bn_bwd_reduce(const void* dy_, int lddy, const float* z, int ldz, const float* mean, const float* rstd, long M, int C,
+                                  float* s1, float* s2, int dy_dtype, void* stream) {
+  MVLT_REQUIRE(dy_ && z && mean && rstd && s1 && s2 && C > 0 && C <= 256 && (dy_dtype == 0 || dy_dtype == 1), "mvlt_bn_bwd_reduce: bad arguments (C <= 256)");
   if (M <= 0) return MVLT_OK;
-  if (vec4_ok(z, ldz, C) && vec4_ok(dy, lddy, C) && (((uintptr_t)mean | (uintptr_t)rstd) & 15) == 0) {
+  const float* dy = (const float*)dy_;
+  const bool dy_vec = dy_dtype == 1 ? vec4_ok(dy, lddy, C) : (C % 4 == 0 && C <= 256 && lddy % 4 == 0 && ((uintptr_t)dy_ & 7) == 0);
+  MVLT_REQUIRE(dy_dtype == 1 || (dy_vec && vec4_ok(z, ldz, C)), "mvlt_bn_bwd_reduce: bf16 dy needs C, ld multiples of 4 and aligned rows");
+  if (vec4_ok(z, ldz, C) && dy_vec && (((uintptr_t)mean | (uintptr_t)rstd) & 15) == 0) {
     // measured at M = 262144: C = 64 34.7 -> 30.6 us with 512 threads, C = 192 98.8 -> 80.0 us with 1024 (5.0 TB/s)
     const int nt = C <= 64 ? 512 : 1024;
     int rows_per_wg = reduce_rows_per_wg(M, C, nt, RWGS);
     int grid = (int)((M + rows_per_wg - 1) / rows_per_wg);
-    if (nt == 512) hipLaunchKernelGGL((col_reduce4_kernel<1, 512>), dim3(grid), dim3(512), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, M, C, s1, s2, rows_per_wg);
-    else hipLaunchKernelGGL((col_reduce4_kernel<1, 1024>), dim3(grid), dim3(1024), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, M, C, s1, s2, rows_per_wg);
+    const size_t lds = 2 * C * sizeof(float);
+    if (dy_dtype == 0) {
+      if (nt == 512) hipLaunchKernelGGL((col_reduce4_kernel<1, 512, bf16>), dim3(grid), dim3(512), lds, (hipStream_t)stream, z, ldz, (const bf16*)dy_, lddy, mean, rstd, M, C, s1, s2, rows_per_wg);
+      else hipLaunchKernelGGL((col_reduce4_kernel<1, 1024, bf16>), dim3(grid), dim3(1024), lds, (hipStream_t)stream, z, ldz, (const bf16*)dy_, lddy, mean, rstd, M, C, s1, s2, rows_per_wg);
+    } else {
+      if (nt == 512) hipLaunchKernelGGL((col_reduce4_kernel<1, 512>), dim3(grid), dim3(512), lds, (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, M, C, s1, s2, rows_per_wg);
+      else hipLaunchKernelGGL((col_reduce4_kernel<1, 1024>), dim3(grid), dim3(1024), lds, (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, M, C, s1, s2, rows_per_wg);
+    }
     return mvlt_check_launch("mvlt_bn_bwd_reduce");
   }
+  MVLT_REQUIRE(dy_dtype == 1, "mvlt_bn_bwd_reduce: bf16 dy needs the vectorised path (16-byte aligned mean / rstd)");
   int grid = (int)((M + 63) / 64); if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(grid), dim3(NT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, (int)M, C, s1, s2);
   return mvlt_check_launch("mvlt_bn_bwd_reduce");
 }
 
-extern "C" int mvlt_bn_bwd_apply(const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, const float* gamma,
+extern "C" int mvlt_bn_bwd_apply(const void* dy_, int lddy, const float* z, int ldz, const float* mean, const float* rstd, const float* gamma,
                                  const float* s1, const float* s2, long M, int C, void* dz_bf16, int lddz, float* g_beta, float* g_gamma,
-                                 int op_dtype, void* stream) {
-  MVLT_REQUIRE(dy && z && mean && rstd && gamma && s1 && s2 && dz_bf16 && C % 4 == 0 && lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0,
+                                 int op_dtype, int dy_dtype, void* stream) {
+  MVLT_REQUIRE(dy_ && z && mean && rstd && gamma && s1 && s2 && dz_bf16 && C % 4 == 0 && lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0 && (dy_dtype == 0 || dy_dtype == 1),
                "mvlt_bn_bwd_apply: bad arguments");
   MVLT_REQUIRE((g_beta == nullptr) == (g_gamma == nullptr), "mvlt_bn_bwd_apply: g_beta and g_gamma go together");
   if (M <= 0) return MVLT_OK;
-  if (op_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
-  else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (float*)dz_bf16, lddz, g_beta, g_gamma);
+  const dim3 grid(grid_for(M * (C / 4)));
+  const float* dy = (const float*)dy_;
+  const bf16* dyh = (const bf16*)dy_;
+  if (op_dtype == 0 && dy_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else if (op_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else if (dy_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (float*)dz_bf16, lddz, g_beta, g_gamma);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), grid, dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (float*)dz_bf16, lddz, g_beta, g_gamma);
   return mvlt_check_launch("mvlt_bn_bwd_apply");
 }
 
@@ -664,11 +688,12 @@ extern "C" int mvlt_ew_mul(float* out, int ldo, const float* a, int lda, const f
   return mvlt_check_launch("mvlt_ew_mul");
 }
 
-extern "C" int mvlt_ew_mul3_bwd(const float* dy, int lddy, const float* a, const float* b, const float* c, int ld, float* da, float* db, float* dc,
-                                long M, int C, void* stream) {
-  MVLT_REQUIRE(dy && a && b && c && da && db && dc && C % 4 == 0 && lddy % 4 == 0 && ld % 4 == 0 && ld >= C, "mvlt_ew_mul3_bwd: bad arguments");
+extern "C" int mvlt_ew_mul3_bwd(const void* dy, int lddy, const float* a, const float* b, const float* c, int ld, float* da, float* db, float* dc,
+                                long M, int C, int dy_dtype, void* stream) {
+  MVLT_REQUIRE(dy && a && b && c && da && db && dc && C % 4 == 0 && lddy % 4 == 0 && ld % 4 == 0 && ld >= C && (dy_dtype == 0 || dy_dtype == 1), "mvlt_ew_mul3_bwd: bad arguments");
   if (M <= 0) return MVLT_OK;
-  hipLaunchKernelGGL(ew_mul3_bwd_kernel, dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy, lddy, a, b, c, ld, da, db, dc, M, C);
+  if (dy_dtype == 0) hipLaunchKernelGGL(ew_mul3_bwd_kernel<bf16>, dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, lddy, a, b, c, ld, da, db, dc, M, C);
+  else hipLaunchKernelGGL(ew_mul3_bwd_kernel<float>, dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const float*)dy, lddy, a, b, c, ld, da, db, dc, M, C);
   return mvlt_check_launch("mvlt_ew_mul3_bwd");
 }
 

@@ -248,8 +248,8 @@ def transpose_cast(w, out, R, Ccols, ld_out):
 L.lib.mvlt_col_stats.argtypes = [_vp, _i, _l, _i, _vp, _vp, _vp]
 L.lib.mvlt_bn_finalize.argtypes = [_vp, _vp, _i, _l, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]
 L.lib.mvlt_bn_norm.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _i, _i, _vp]
-L.lib.mvlt_bn_bwd_reduce.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _l, _i, _vp, _vp, _vp]
-L.lib.mvlt_bn_bwd_apply.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _vp, _i, _vp]
+L.lib.mvlt_bn_bwd_reduce.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _vp]
+L.lib.mvlt_bn_bwd_apply.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _vp, _i, _i, _vp]
 L.lib.mvlt_ew_mul.argtypes = [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _l, _i, _i, _vp, _i, _i, _vp]
 L.lib.mvlt_upsample_fwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]
 L.lib.mvlt_upsample_bwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]
@@ -271,19 +271,22 @@ def bn_norm(z, ldz, mean, rstd, gamma, beta, M, Cdim, y32=None, ld32=0, y16=None
 
 
 def bn_bwd_reduce(dy, lddy, z, ldz, mean, rstd, M, Cdim, s1, s2):
-    check(L.lib.mvlt_bn_bwd_reduce(_p(dy), lddy, _p(z), ldz, _p(mean), _p(rstd), M, Cdim, _p(s1), _p(s2), stream_ptr()), "mvlt_bn_bwd_reduce")
+    assert dy.dtype in DT and z.dtype == torch.float32
+    check(L.lib.mvlt_bn_bwd_reduce(_p(dy), lddy, _p(z), ldz, _p(mean), _p(rstd), M, Cdim, _p(s1), _p(s2), DT[dy.dtype], stream_ptr()), "mvlt_bn_bwd_reduce")
 
 
 def bn_bwd_apply(dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, Cdim, dz16, lddz, g_beta=None, g_gamma=None):
+    assert dy.dtype in DT and z.dtype == torch.float32
     check(L.lib.mvlt_bn_bwd_apply(_p(dy), lddy, _p(z), ldz, _p(mean), _p(rstd), _p(gamma), _p(s1), _p(s2), M, Cdim, _p(dz16), lddz,
-                                  _p(g_beta), _p(g_gamma), DT[dz16.dtype], stream_ptr()), "mvlt_bn_bwd_apply")
+                                  _p(g_beta), _p(g_gamma), DT[dz16.dtype], DT[dy.dtype], stream_ptr()), "mvlt_bn_bwd_apply")
 
 
-L.lib.mvlt_ew_mul3_bwd.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _l, _i, _vp]
+L.lib.mvlt_ew_mul3_bwd.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _l, _i, _i, _vp]
 
 
 def ew_mul3_bwd(dy, lddy, a, b, c, ld, da, db, dc, M, Cdim):
-    check(L.lib.mvlt_ew_mul3_bwd(_p(dy), lddy, _p(a), _p(b), _p(c), ld, _p(da), _p(db), _p(dc), M, Cdim, stream_ptr()), "mvlt_ew_mul3_bwd")
+    assert dy.dtype in DT
+    check(L.lib.mvlt_ew_mul3_bwd(_p(dy), lddy, _p(a), _p(b), _p(c), ld, _p(da), _p(db), _p(dc), M, Cdim, DT[dy.dtype], stream_ptr()), "mvlt_ew_mul3_bwd")
 
 
 def ew_mul(out, ldo, a, lda, b, ldb, c=None, ldc=0, *, M, Cdim, accumulate=False, out16=None, ld16=0):

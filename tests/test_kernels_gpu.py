@@ -715,6 +715,18 @@ def test_batchnorm_fwd_bwd(ops, M, C, lddy, off):
         ops.bn_bwd_apply(dy, lddy, z, C, mean, rstd, gamma, red[0], red[1], M, C, dz, C, g_beta=gb, g_gamma=gg)
         assert maxrel(dz, zr.grad) < 1e-3
         assert maxrel(gb - 1.0, br.grad) < 1e-4 and maxrel(gg - 2.0, gr.grad) < 1e-4
+        # bf16 dy (what the MIM decoder's first backward stages hand over): same kernels reading half the bytes; checked against the fp32
+        # kernels fed the bf16-rounded gradient
+        dyh = dyw.to(torch.bfloat16)[:, off:off + C]
+        dyr = dyh.float()
+        r32, r16 = torch.zeros(2, C, device=dev()), torch.zeros(2, C, device=dev())
+        ops.bn_bwd_reduce(dyr.contiguous(), C, z, C, mean, rstd, M, C, r32[0], r32[1])
+        ops.bn_bwd_reduce(dyh, lddy, z, C, mean, rstd, M, C, r16[0], r16[1])
+        assert maxrel(r16, r32) < 1e-5
+        d32, d16 = torch.empty(M, C, device=dev()), torch.empty(M, C, device=dev())
+        ops.bn_bwd_apply(dyr.contiguous(), C, z, C, mean, rstd, gamma, r32[0], r32[1], M, C, d32, C)
+        ops.bn_bwd_apply(dyh, lddy, z, C, mean, rstd, gamma, r32[0], r32[1], M, C, d16, C)
+        assert torch.equal(d16, d32)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -750,6 +762,10 @@ def test_ew_mul3_bwd(ops):
     da, db, dc = (torch.empty(M, Cd, device=dev()) for _ in range(3))
     ops.ew_mul3_bwd(dyw, 3 * Cd, a, b, c, Cd, da, db, dc, M, Cd)
     dy = dyw[:, :Cd]
+    assert maxrel(da, dy * b * c) < 1e-6 and maxrel(db, dy * a * c) < 1e-6 and maxrel(dc, dy * a * b) < 1e-6
+    dyh = dyw.to(torch.bfloat16)
+    ops.ew_mul3_bwd(dyh, 3 * Cd, a, b, c, Cd, da, db, dc, M, Cd)
+    dy = dyh[:, :Cd].float()
     assert maxrel(da, dy * b * c) < 1e-6 and maxrel(db, dy * a * c) < 1e-6 and maxrel(dc, dy * a * b) < 1e-6
 
 
