@@ -352,8 +352,8 @@ int mvlt_ew_mul(float* out, int ldo, const float* a, int lda, const float* b, in
                 int accumulate, void* out_op, int ld_op, int op_dtype, void* stream);
 /* gradients of y = a*b*c (all [M, C] fp32, row stride ld; dy row stride lddy): da = dy*b*c, db = dy*a*c, dc = dy*a*b
  * (the three-way feature product of reference libs/vl_heads.py:152) */
-int mvlt_ew_mul3_bwd(const void* dy /* fp32 or bf16 (dy_dtype) */, int lddy, const float* a, const float* b, const float* c, int ld, float* da, float* db,
-                     float* dc, long M, int C, int dy_dtype, void* stream);
+int mvlt_ew_mul3_bwd(const void* dy /* fp32 or bf16 (dy_dtype) */, int lddy, const float* a, const float* b, const float* c, int ld,
+                     void* da, void* db, void* dc /* dy's dtype */, long M, int C, int dy_dtype, void* stream);
 /* bilinear resize by an integer factor, align_corners=True.  x fp32 [B,H,W,C] (row stride ldx) -> [B,sH,sW,C] (bf16/fp32,
  * row stride ldo) or NCHW fp32 [B,C,sH,sW]; bwd is the exact adjoint in gather form (no atomics); its dx is fp32 (dx_dtype 1) or,
  * behind the NCHW upsample only, bf16 (dx_dtype 0: the [pixels][8]-padded operand of the score conv's gradient GEMMs). */

@@ -193,9 +193,9 @@ __global__ __launch_bounds__(NT) void ew_mul_kernel(float* out, int ldo, const f
 
 // gradients of the three-way product y = a * b * c (reference libs/vl_heads.py:152: conv_upsample2(..) * conv_upsample3(..) * low):
 // da = dy b c, db = dy a c, dc = dy a b in one pass (three ew_mul launches read dy and two of the factors each)
-template <typename TDY>
+template <typename TDY, typename TO>
 __global__ __launch_bounds__(NT) void ew_mul3_bwd_kernel(const TDY* dy, int lddy, const float* a, const float* b, const float* c, int ld,
-                                                         float* da, float* db, float* dc, long M, int C) {
+                                                         TO* da, TO* db, TO* dc, long M, int C) {
   const int cq = C / 4;
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
     long r = i / cq; int col = (int)(i - r * cq) * 4;
@@ -204,9 +204,9 @@ __global__ __launch_bounds__(NT) void ew_mul3_bwd_kernel(const TDY* dy, int lddy
     f32x4 oa, ob, oc;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { oa[e] = g[e] * vb[e] * vc[e]; ob[e] = g[e] * va[e] * vc[e]; oc[e] = g[e] * va[e] * vb[e]; }
-    *(f32x4*)(da + r * ld + col) = oa;
-    *(f32x4*)(db + r * ld + col) = ob;
-    *(f32x4*)(dc + r * ld + col) = oc;
+    store4<TO>(da + r * ld + col, oa);
+    store4<TO>(db + r * ld + col, ob);
+    store4<TO>(dc + r * ld + col, oc);
   }
 }
 
@@ -688,12 +688,13 @@ extern "C" int mvlt_ew_mul(float* out, int ldo, const float* a, int lda, const f
   return mvlt_check_launch("mvlt_ew_mul");
 }
 
-extern "C" int mvlt_ew_mul3_bwd(const void* dy, int lddy, const float* a, const float* b, const float* c, int ld, float* da, float* db, float* dc,
+extern "C" int mvlt_ew_mul3_bwd(const void* dy, int lddy, const float* a, const float* b, const float* c, int ld, void* da, void* db, void* dc,
                                 long M, int C, int dy_dtype, void* stream) {
+  /* da / db / dc take dy's dtype */
   MVLT_REQUIRE(dy && a && b && c && da && db && dc && C % 4 == 0 && lddy % 4 == 0 && ld % 4 == 0 && ld >= C && (dy_dtype == 0 || dy_dtype == 1), "mvlt_ew_mul3_bwd: bad arguments");
   if (M <= 0) return MVLT_OK;
-  if (dy_dtype == 0) hipLaunchKernelGGL(ew_mul3_bwd_kernel<bf16>, dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, lddy, a, b, c, ld, da, db, dc, M, C);
-  else hipLaunchKernelGGL(ew_mul3_bwd_kernel<float>, dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const float*)dy, lddy, a, b, c, ld, da, db, dc, M, C);
+  if (dy_dtype == 0) hipLaunchKernelGGL((ew_mul3_bwd_kernel<bf16, bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, lddy, a, b, c, ld, (bf16*)da, (bf16*)db, (bf16*)dc, M, C);
+  else hipLaunchKernelGGL((ew_mul3_bwd_kernel<float, float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const float*)dy, lddy, a, b, c, ld, (float*)da, (float*)db, (float*)dc, M, C);
   return mvlt_check_launch("mvlt_ew_mul3_bwd");
 }
 

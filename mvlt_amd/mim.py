@@ -191,7 +191,7 @@ class MimStep:
         ops.upsample_bwd(dupc, 2 * ch, False, B, s2, s2, 2 * ch, 2, dc, 2 * ch)
         # b = cu2o * cu3o * low
         db = dcat3                                                                  # columns [0, 64), row stride 192
-        dcu2o, dcu3o, dlow = _e((M1, ch), dev), _e((M1, ch), dev), _e((M1, ch), dev)
+        dcu2o, dcu3o, dlow = _e((M1, ch), dev, gd), _e((M1, ch), dev, gd), _e((M1, ch), dev, gd)
         ops.ew_mul3_bwd(db, 3 * ch, k["cu2o"], k["cu3o"], k["low"], ch, dcu2o, dcu3o, dlow, M1, ch)
         # gradient of cat2 = [a | cu4 out]: starts with the path a -> up -> cu3
         dcat2 = _z((M2, 2 * ch), dev)

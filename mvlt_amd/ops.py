@@ -285,7 +285,7 @@ L.lib.mvlt_ew_mul3_bwd.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _l
 
 
 def ew_mul3_bwd(dy, lddy, a, b, c, ld, da, db, dc, M, Cdim):
-    assert dy.dtype in DT
+    assert dy.dtype in DT and da.dtype == db.dtype == dc.dtype == dy.dtype
     check(L.lib.mvlt_ew_mul3_bwd(_p(dy), lddy, _p(a), _p(b), _p(c), ld, _p(da), _p(db), _p(dc), M, Cdim, DT[dy.dtype], stream_ptr()), "mvlt_ew_mul3_bwd")
 
 

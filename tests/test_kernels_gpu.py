@@ -764,9 +764,10 @@ def test_ew_mul3_bwd(ops):
     dy = dyw[:, :Cd]
     assert maxrel(da, dy * b * c) < 1e-6 and maxrel(db, dy * a * c) < 1e-6 and maxrel(dc, dy * a * b) < 1e-6
     dyh = dyw.to(torch.bfloat16)
-    ops.ew_mul3_bwd(dyh, 3 * Cd, a, b, c, Cd, da, db, dc, M, Cd)
+    dah, dbh, dch = (torch.empty(M, Cd, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    ops.ew_mul3_bwd(dyh, 3 * Cd, a, b, c, Cd, dah, dbh, dch, M, Cd)
     dy = dyh[:, :Cd].float()
-    assert maxrel(da, dy * b * c) < 1e-6 and maxrel(db, dy * a * c) < 1e-6 and maxrel(dc, dy * a * b) < 1e-6
+    assert torch.equal(dah, (dy * b * c).to(torch.bfloat16)) and torch.equal(dbh, (dy * a * c).to(torch.bfloat16)) and torch.equal(dch, (dy * a * b).to(torch.bfloat16))
 
 
 # ------------------------------------------------------------------ round 2 additions
