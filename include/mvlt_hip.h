@@ -358,8 +358,8 @@ int mvlt_ew_mul3_bwd(const void* dy /* fp32 or bf16 (dy_dtype) */, int lddy, con
  * row stride ldo) or NCHW fp32 [B,C,sH,sW]; bwd is the exact adjoint in gather form (no atomics); its dx is fp32 (dx_dtype 1) or,
  * behind the NCHW upsample only, bf16 (dx_dtype 0: the [pixels][8]-padded operand of the score conv's gradient GEMMs). */
 int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, int C, int scale, void* out, int ldo, int out_dtype, int nchw, void* stream);
-int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int H, int W, int C, int scale, void* dx, int lddx, int accumulate, int dx_dtype,
-                      void* stream);
+int mvlt_upsample_bwd(const void* dy /* fp32; bf16 (dy_dtype 0) for the pixel-major resizes */, int lddy, int nchw, int B, int H, int W, int C, int scale, void* dx,
+                      int lddx, int accumulate, int dx_dtype, int dy_dtype, void* stream);
 /* The MIM loss without the image-sized prediction (training): SmoothL1(beta 1, mean) between the x scale bilinear upsample
  * (align_corners=True) of the score map x[B,H,W,C] (pixel-major fp32, row stride ldx) and the NCHW fp32 target [B,C,H*scale,W*scale]
  * (reference libs/vl_heads.py:163-165 + engine_grid_masking.py:99).  fwd: *loss_sum += the SUM over all elements (the caller divides by

@@ -356,7 +356,8 @@ __global__ __launch_bounds__(NT) void upsample_fwd_nchw4_kernel(const float* x, 
   }
 }
 // backward, pixel-major dy: workgroup = input row (b, iy), threads = (ix, 4-channel group)
-__global__ __launch_bounds__(NT) void upsample_bwd_row_kernel(const float* dy, int lddy, int H, int W, int C, int s, float* dx, int lddx, int accumulate, int chunks) {
+template <typename TDY>
+__global__ __launch_bounds__(NT) void upsample_bwd_row_kernel(const TDY* dy, int lddy, int H, int W, int C, int s, float* dx, int lddx, int accumulate, int chunks) {
   const int Ho = H * s, Wo = W * s;
   const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
   const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
@@ -374,14 +375,14 @@ __global__ __launch_bounds__(NT) void upsample_bwd_row_kernel(const float* dy, i
     const float wy = fy - y0;
     const float wyi = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
     if (wyi == 0.f) continue;
-    const float* drow = dy + ((long)b * Ho + oy) * Wo * lddy + c;
+    const TDY* drow = dy + ((long)b * Ho + oy) * Wo * lddy + c;
     for (int ox = ox_lo; ox <= ox_hi; ++ox) {
       const float fx = ox * rx;
       const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
       const float wx = fx - x0;
       const float wxi = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
       if (wxi == 0.f) continue;
-      acc += (wyi * wxi) * *(const f32x4*)(drow + (long)ox * lddy);
+      acc += (wyi * wxi) * load4<TDY>(drow + (long)ox * lddy);
     }
   }
   float* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
@@ -724,9 +725,19 @@ extern "C" int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, i
   return mvlt_check_launch("mvlt_upsample_fwd");
 }
 
-extern "C" int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int H, int W, int C, int scale, void* dx_, int lddx, int accumulate, int dx_dtype,
-                                 void* stream) {
-  MVLT_REQUIRE(dy && dx_ && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1, "mvlt_upsample_bwd: bad arguments");
+extern "C" int mvlt_upsample_bwd(const void* dy_, int lddy, int nchw, int B, int H, int W, int C, int scale, void* dx_, int lddx, int accumulate, int dx_dtype,
+                                 int dy_dtype, void* stream) {
+  MVLT_REQUIRE(dy_ && dx_ && B > 0 && H > 0 && W > 0 && C > 0 && scale >= 1 && (dy_dtype == 0 || dy_dtype == 1), "mvlt_upsample_bwd: bad arguments");
+  const float* dy = (const float*)dy_;
+  if (dy_dtype == 0) {
+    // bf16 dy: the pixel-major x2 resizes inside the decoder (their dy is a conv input gradient in the operand dtype)
+    MVLT_REQUIRE(!nchw && dx_dtype == 1 && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy_ & 7) == 0 && ((uintptr_t)dx_ & 15) == 0,
+                 "mvlt_upsample_bwd: bf16 dy needs the pixel-major layout, fp32 dx, C / ld multiples of 4");
+    const int chunks = (W * (C / 4) + NT - 1) / NT;
+    hipLaunchKernelGGL(upsample_bwd_row_kernel<bf16>, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy_, lddy, H, W, C, scale,
+                       (float*)dx_, lddx, accumulate, chunks);
+    return mvlt_check_launch("mvlt_upsample_bwd");
+  }
   MVLT_REQUIRE(dx_dtype == 1 || (dx_dtype == 0 && nchw), "mvlt_upsample_bwd: bf16 dx only behind the NCHW (final x8) upsample");
   float* dx = (float*)dx_;
   long total = (long)B * H * W * C;
@@ -746,7 +757,7 @@ extern "C" int mvlt_upsample_bwd(const float* dy, int lddy, int nchw, int B, int
   MVLT_REQUIRE(dx_dtype == 1, "mvlt_upsample_bwd: bf16 dx needs the row-buffered NCHW path (W * scale * 4 <= 64 KB)");
   if (!nchw && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0) {
     const int chunks = (W * (C / 4) + NT - 1) / NT;
-    hipLaunchKernelGGL(upsample_bwd_row_kernel, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, H, W, C, scale, dx, lddx,
+    hipLaunchKernelGGL(upsample_bwd_row_kernel<float>, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, H, W, C, scale, dx, lddx,
                        accumulate, chunks);
     return mvlt_check_launch("mvlt_upsample_bwd");
   }

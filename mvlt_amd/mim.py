@@ -186,7 +186,7 @@ class MimStep:
         ops.gemm_nt(dsc_p, S.extra["t2i_head.score.0.weight::T"], de, M1, 3 * ch, 8, 8, 8, 3 * ch)
         dd = self.bn_conv_bwd("conv4", de, 3 * ch, dx_dtype=gd)
         dcat3 = self.bn_conv_bwd("conv_concat3", dd, 3 * ch, dx_dtype=gd)          # [:, :64] = db, [:, 64:] = d(cu5 out)
-        dupc = self.bn_conv_bwd("conv_upsample5", dcat3[:, ch:], 3 * ch)
+        dupc = self.bn_conv_bwd("conv_upsample5", dcat3[:, ch:], 3 * ch, dx_dtype=gd)
         dc = _e((M2, 2 * ch), dev)
         ops.upsample_bwd(dupc, 2 * ch, False, B, s2, s2, 2 * ch, 2, dc, 2 * ch)
         # b = cu2o * cu3o * low
@@ -195,9 +195,9 @@ class MimStep:
         ops.ew_mul3_bwd(db, 3 * ch, k["cu2o"], k["cu3o"], k["low"], ch, dcu2o, dcu3o, dlow, M1, ch)
         # gradient of cat2 = [a | cu4 out]: starts with the path a -> up -> cu3
         dcat2 = _z((M2, 2 * ch), dev)
-        dupa = self.bn_conv_bwd("conv_upsample3", dcu3o, ch)
+        dupa = self.bn_conv_bwd("conv_upsample3", dcu3o, ch, dx_dtype=gd)
         ops.upsample_bwd(dupa, ch, False, B, s2, s2, ch, 2, dcat2, 2 * ch, accumulate=True)
-        dupm = self.bn_conv_bwd("conv_upsample2", dcu2o, ch)
+        dupm = self.bn_conv_bwd("conv_upsample2", dcu2o, ch, dx_dtype=gd)
         dmid = _e((M2, ch), dev)
         ops.upsample_bwd(dupm, ch, False, B, s2, s2, ch, 2, dmid, ch)
         self.bn_conv_bwd("conv_concat2", dc, 2 * ch, dx=dcat2, lddx=2 * ch, accumulate=True)

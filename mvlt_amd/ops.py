@@ -252,7 +252,7 @@ L.lib.mvlt_bn_bwd_reduce.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _l, _i, _vp, _v
 L.lib.mvlt_bn_bwd_apply.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _vp, _i, _i, _vp]
 L.lib.mvlt_ew_mul.argtypes = [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _l, _i, _i, _vp, _i, _i, _vp]
 L.lib.mvlt_upsample_fwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]
-L.lib.mvlt_upsample_bwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]
+L.lib.mvlt_upsample_bwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]
 
 
 def col_stats(z, ldz, M, Cdim, s, ss):
@@ -299,9 +299,9 @@ def upsample_fwd(x, ldx, B, H, W, Cdim, scale, out, ldo, nchw=False):
 
 
 def upsample_bwd(dy, lddy, nchw, B, H, W, Cdim, scale, dx, lddx, accumulate=False):
-    assert dy.dtype == torch.float32 and dx.dtype in DT
+    assert dy.dtype in DT and dx.dtype in DT
     check(L.lib.mvlt_upsample_bwd(_p(dy), lddy, 1 if nchw else 0, B, H, W, Cdim, scale, _p(dx), lddx, 1 if accumulate else 0, DT[dx.dtype],
-                                  stream_ptr()), "mvlt_upsample_bwd")
+                                  DT[dy.dtype], stream_ptr()), "mvlt_upsample_bwd")
 
 
 L.lib.mvlt_upsample_l1_fwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]

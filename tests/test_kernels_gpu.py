@@ -653,6 +653,12 @@ def test_upsample_fwd_bwd(ops, B, H, C, s, nchw, out_dtype):
     ops.upsample_bwd(dy, 0 if nchw else C, nchw, B, H, H, C, s, dx, C, accumulate=True)
     want = base + xt.grad.permute(0, 2, 3, 1).reshape(B * H * H, C)
     assert maxrel(dx, want) < 1e-5
+    if not nchw and C % 4 == 0:  # bf16 dy (a conv input gradient in the operand dtype): same adjoint on the rounded values
+        dyh = dy.to(torch.bfloat16)
+        dxa, dxb = torch.zeros(B * H * H, C, device=dev()), torch.zeros(B * H * H, C, device=dev())
+        ops.upsample_bwd(dyh, C, False, B, H, H, C, s, dxa, C)
+        ops.upsample_bwd(dyh.float(), C, False, B, H, H, C, s, dxb, C)
+        assert torch.equal(dxa, dxb)
     if nchw:                     # bf16 dx, rows padded to 8 (the score conv's gradient operand, mim.py): pad columns stay untouched
         dx16 = torch.zeros(B * H * H, 8, device=dev(), dtype=torch.bfloat16)
         ops.upsample_bwd(dy, 0, True, B, H, H, C, s, dx16, 8)
