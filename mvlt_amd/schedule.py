@@ -478,7 +478,10 @@ class TrunkStep:
                 ops.mlp_bwd_dx(bs["xn2"], dx, w1, self.wT(p + "mlp.fc1.weight"), w2t, self.f32(p + "mlp.fc1.bias"), dxn2, M, C, hid,
                                row_scale=bs["s2"], rows_per_scale=N)
         else:
-            dy2 = self._scaled(dx, bs["s2"], N)
+            dy2 = getattr(self, "_dy2_pre", None)                # written by the block above's norm1 backward when there is one
+            self._dy2_pre = None
+            if dy2 is None:
+                dy2 = self._scaled(dx, bs["s2"], N)
             ops.gemm_tn(dy2, bs["gact"], self.g(p + "mlp.fc2.weight"), M, C, hid, C, hid, hid, colsum=self.g(p + "mlp.fc2.bias"))
             dh = _empty((M, hid), dt, dev)
             ops.gemm_nt(dy2, self.wT(p + "mlp.fc2.weight"), dh, M, hid, C, C, C, hid, act=2, H=bs["hpre"])
@@ -535,8 +538,14 @@ class TrunkStep:
         else:
             ops.gemm_tn(dkv, bs["xn1"], gkvw, M, 2 * C, C, 2 * C, C, C, colsum=gkvb)
             ops.gemm_nt(dkv, wkvT, dxn1, M, C, 2 * C, 2 * C, 2 * C, C, R=dxn1)
+        # the block below (processed next) scales this gradient by its own MLP-branch DropPath factor first thing when its MLP is not the
+        # fused kernel (stages 3-4): norm1's backward writes that scaled copy in the same pass
+        prev = self.saved[i]["blocks"][j - 1] if j > 0 else None
+        pre = prev is not None and not prev.get("fused_mlp", True) and prev.get("s2") is not None and not _NO_DX2
+        self._dy2_pre = _empty((M, C), dx.dtype, dev) if pre else None
         ops.layernorm_bwd(dxn1, bs["x"], dx, self.f32(p + "norm1.weight"), bs["m1"], bs["r1"], M, C, C, C, C,
-                          dgamma=self.gl(p + "norm1.weight"), dbeta=self.gl(p + "norm1.bias"), **self.lnk(), accumulate=True)
+                          dgamma=self.gl(p + "norm1.weight"), dbeta=self.gl(p + "norm1.bias"), **self.lnk(), accumulate=True,
+                          dx2=self._dy2_pre, dx2_scale=prev["s2"] if pre else None, dx2_rows_per_scale=N if pre else 0, lddx2=C if pre else 0)
         bs.clear()
         return dx
 
