@@ -173,6 +173,31 @@ def time_dominant_kernel(model, B, device):
                                        algorithmic_bytes=bytes2, traffic=traffic2))
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one, which has not touched the GPU
+    (no HIP call, no torch.cuda.is_available(); a process that has must never exec another program on this pool), the way the
+    reference is started (scripts_dws/dws_mvlt_exp21.sh:13-16: torch.distributed.launch --nproc_per_node=8 main_vl.py), and leave
+    with the launcher's exit code.  Rank 0's JSON line goes to this process's stdout unchanged."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()                      # counts devices without initialising the runtime on this image
+    if have < n:
+        print(f"bench.py: --gpus {n} but this node exposes {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    if n == 1:
+        env["MVLT_DP_FORCE_COLLECTIVES"] = "1"            # world size 1 through the launcher = the RCCL code path of N > 1
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,7 +210,11 @@ def main():
                     help="pretrain = {mlm,itm,t2i} (BASELINE configs 2-4); finetune = {cls} only (config 5, dws_mvlt_ft_exp48)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--spawn", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1 (RCCL path at world size 1)")
     args = ap.parse_args()
+
+    if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -238,10 +267,13 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.time() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    per_rank = [dt]
+    if use_pg:
+        t = torch.zeros(world, device=device, dtype=torch.float64)
+        t[rank] = dt
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)          # every rank's own time; the job's time is the slowest rank's
+        per_rank = t.tolist()
+        dt = max(per_rank)
     pairs_s = B * world * args.steps / dt
 
     # blocks-only GPU time (SRAttention + MLP Blocks incl. their LayerNorms): two more iterations with HIP events around the
@@ -259,6 +291,8 @@ def main():
             else f"image-text pairs/sec/node, {args.model} MVLT {args.task} step", "value": round(pairs_s, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "ranks_seen": dist.get_world_size() if use_pg else 1,
+            "per_rank_pairs_s": [round(B * args.steps / t, 1) for t in per_rank],
             "config": {"workload": f"{args.model} MVLT " + ("pre-train (MLM+MIM+ITM)" if args.task == "pretrain" else "fine-tune (CLS heads)") + f", {args.img}x{args.img} RGB + 128 tokens, "
                                    f"batch {B}/GPU (global {B * world}), train_one_epoch_vl: fwd+loss+bwd+allreduce+AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "fused AdamW (fp32 master)",

@@ -92,11 +92,13 @@ __global__ __launch_bounds__(NT) void token_mask_kernel(const long* ori, long* i
 }
 // ---- train-mode masks of the step itself (nn.Dropout inside BertEmbeddings, timm DropPath per block; reference libs/pvlt.py:135,233),
 // from the same counter-based generator: one launch each instead of ATen's rand / compare / cast / divide chains.
-// keep[i] = draw_i >= drop_p on 16-bit draws (eight per Philox call, one 8-byte store per thread); counter = (i / 8, call, 2, call >> 32).
+// keep[i] = draw_i >= drop_p on 16-bit draws (eight per Philox call, one 8-byte store per thread); counter = (i / 8, call, 4, call >> 32)
+// (streams 0-2 belong to the per-sample dataset masks; a stream of its own keeps the dropout draws of call n apart from the token-masking
+// draws of sample id n when both generators run under the same seed).
 __global__ __launch_bounds__(NT) void keep_mask_kernel(uint8_t* keep, long n, uint32_t thr16, uint64_t seed, uint64_t call) {
   const long g = (long)blockIdx.x * NT + threadIdx.x;
   if (g * 8 >= n) return;
-  const u4 d = draws(seed, call, (uint32_t)g, 2);
+  const u4 d = draws(seed, call, (uint32_t)g, 4);
   const uint32_t w[4] = {d.x, d.y, d.z, d.w};
   uint8_t k[8];
 #pragma unroll
@@ -111,13 +113,13 @@ __global__ __launch_bounds__(NT) void keep_mask_kernel(uint8_t* keep, long n, ui
   }
 }
 // out[r][j] = (draw >= rate[r]) / (1 - rate[r]) on 24-bit draws: DropPath's per-sample keep factor (timm drop_path: x / keep_prob * mask);
-// counter = (r * per + j, call, 3, call >> 32)
+// counter = (r * per + j, call, 5, call >> 32)
 __global__ __launch_bounds__(NT) void droppath_scales_kernel(float* out, const float* rates, int nrate, int per, uint64_t seed, uint64_t call) {
   const int i = blockIdx.x * NT + threadIdx.x;
   if (i >= nrate * per) return;
   const float rate = rates[i / per];
   const uint32_t thr = (uint32_t)(rate * 16777216.0f);
-  const uint32_t d = draws(seed, call, (uint32_t)i, 3).x >> 8;
+  const uint32_t d = draws(seed, call, (uint32_t)i, 5).x >> 8;
   out[i] = d >= thr ? 1.0f / (1.0f - rate) : 0.0f;
 }
 

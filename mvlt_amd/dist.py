@@ -36,6 +36,7 @@ class DataParallel(nn.Module):
         self._synced_init = False
         module.store.on_backward_done = self._finish
         module.store.on_range_ready = self._range_ready
+        module.store.on_pass_aborted = self._aborted
 
     # parameters start identical on every rank (DDP broadcasts rank 0's at construction)
     def _sync_init(self):
@@ -67,6 +68,15 @@ class DataParallel(nn.Module):
         except (AttributeError, RuntimeError):
             for b in bufs:
                 dist.broadcast(b, 0, group=self.pg)
+
+    def _aborted(self, store):
+        """a backward pass raised after announcing ranges: wait for what is in flight and forget it (the next pass starts clean)"""
+        for w in self._works:
+            try:
+                w.wait()
+            except RuntimeError:
+                pass
+        self._works = []
 
     def _range_ready(self, store, lo, hi):
         """called by the backward schedule when G[lo:hi] is final on the compute stream"""

@@ -268,17 +268,28 @@ class BF16Scaler:
         self._scaler = None
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False):
-        loss.backward(create_graph=create_graph)
-        # main_vl.py passes --clip-grad (default None = no clipping).  timm's NativeScaler tests `is not None`, so the engine's
-        # own default max_norm=0 would scale every gradient to zero there; here 0 means "no clipping" as well.
-        if clip_grad:
-            assert parameters is not None
-            parameters = list(parameters)
-            store = getattr(getattr(optimizer, "model", None), "store", None)
+        # The data-parallel mean's 1/world may ride in the fused AdamW kernel instead of being a pass over G -- but only HERE, where
+        # the next reader of the gradients is known to be that kernel (or the clipping below, which settles the factor first).  Any
+        # other loop (timm's NativeScaler, a user's clip_grad_norm_ / logging / stock optimizer) gets final gradients.
+        from .optim import FusedAdamW
+        store = optimizer.model.store if isinstance(optimizer, FusedAdamW) else None
+        if store is not None:
+            store.scale_in_optimizer = True
+        try:
+            loss.backward(create_graph=create_graph)
+            # main_vl.py passes --clip-grad (default None = no clipping).  timm's NativeScaler tests `is not None`, so the engine's
+            # own default max_norm=0 would scale every gradient to zero there; here 0 means "no clipping" as well.
+            if clip_grad:
+                assert parameters is not None
+                parameters = list(parameters)
+                if store is not None:
+                    store.apply_pending_scale()                                # clipping reads the gradients: they must be final
+                torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
+            optimizer.step()
+        finally:
             if store is not None:
-                store.apply_pending_scale()                                    # clipping reads the gradients: they must be final
-            torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
-        optimizer.step()
+                store.scale_in_optimizer = False
+                store.apply_pending_scale()                                    # nothing owed outside this call (a step that raised)
 
     def state_dict(self):
         return {}

@@ -31,7 +31,6 @@ class FusedAdamW(torch.optim.Optimizer):
         self._m = self._v = self._wd_mask = None
         self._hp = None
         self._pending = None                  # (m, v) of a checkpoint loaded before the flat store exists
-        model.store.scale_in_optimizer = True   # a data-parallel wrapper may leave its 1/world factor to this optimizer's kernel
 
     def _ensure(self):
         S = self.model.store

@@ -136,8 +136,9 @@ class FlatStore:
         self.fn_params = []
         self.on_backward_done = None      # optional callable(store): data-parallel gradient exchange hook
         self.on_range_ready = None        # optional callable(store, lo, hi): G[lo:hi] is final (overlapped all-reduce)
+        self.on_pass_aborted = None       # optional callable(store): a backward pass died before its final callback (see new_pass)
         self._ranges_done = []
-        self.scale_in_optimizer = False   # set by FusedAdamW: its kernel multiplies the gradient by `pending_grad_scale`
+        self.scale_in_optimizer = False   # set by engine.BF16Scaler around backward + FusedAdamW.step: that kernel applies `pending_grad_scale`
         self.pending_grad_scale = 1.0     # factor still owed to G (1/world after a data-parallel SUM all-reduce)
 
     # ------------------------------------------------------------------ layout
@@ -155,9 +156,8 @@ class FlatStore:
             self.params[name] = p
             off += (n + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
-        # parameters whose gradients the HIP schedule writes itself (everything but the torch-autograd MIM decoder)
-        hip_mim = getattr(self.module, "mim_impl", "hip") == "hip"
-        self.fn_params = [(n, p) for n, p in self.params.items() if hip_mim or not n.startswith("t2i_head.")]
+        # parameters whose gradients the HIP schedule writes itself: all of them
+        self.fn_params = list(self.params.items())
 
     def is_current(self):
         if self.P is None:
@@ -303,17 +303,23 @@ class FlatStore:
         return to those), the running sum when they alias G (accumulation over several backward passes without zero_grad;
         zero_grad(set_to_none=False) zeroes G through the alias).  Deciding here and not in the forward is what makes the
         second and later optimizer steps correct: during the forward `.grad` still aliases G from the previous step."""
-        name, first = next(iter(self.fn_params))
-        if first.grad is None or first.grad.data_ptr() != self.grad(name).data_ptr():
+        # accumulate only if a trainable parameter's .grad aliases its slice of G; frozen parameters (requires_grad=False, .grad stays
+        # None for ever) and parameters the optimizer's zero_grad does not cover say nothing about the caller's intent (ADVICE r2)
+        live = [(n, q) for n, q in self.fn_params if q.requires_grad]
+        alias = [q.grad is not None and q.grad.data_ptr() == self.grad(n).data_ptr() for n, q in live]
+        if not any(alias):
             self.G.zero_()
             self.pending_grad_scale = 1.0
-        else:
+        else:                                                # any-alias: a parameter the last pass produced no gradient for has .grad None
             self.apply_pending_scale()
         self._ranges_done = []
         self._own = set()
         if getattr(self, "_tap_lo", None) is not None:       # a backward that died between a conv weight-gradient GEMM and its fold
             self._tap_arena.zero_()
             self._tap_lo = self._tap_hi = None
+        if getattr(self, "_ln_lo", None) is not None:        # same for the LayerNorm accumulator copies of a pass that never folded
+            self._ln_arena[:, self._ln_lo:self._ln_hi].zero_()
+            self._ln_lo = self._ln_hi = None
 
     def own(self, t):
         """register a gradient tensor a backward node of this pass created itself: later nodes of the same pass may then accumulate
@@ -323,6 +329,17 @@ class FlatStore:
 
     def owns(self, t):
         return t is not None and t.data_ptr() in getattr(self, "_own", ())
+
+    def new_pass(self):
+        """Called by every grad-enabled forward.  `_finalize_queued` is cleared by the autograd engine's final callback; a backward
+        that raised (OOM, a kernel check, KeyboardInterrupt) drops its queued callbacks, and the flag would stay set for the life of
+        the store: every later backward would then skip `begin_backward` (G never zeroed, ranges never reset) and `_finalize` (no
+        fold, no data-parallel exchange).  No forward runs inside a backward pass, so a set flag here IS a dead pass."""
+        if self._finalize_queued:
+            self._finalize_queued = False
+            self._ranges_done = []
+            if self.on_pass_aborted is not None:
+                self.on_pass_aborted(self)
 
     def queue_finalize(self):
         """Called at the top of every HIP-scheduled backward node: the first call of a backward pass prepares G

@@ -17,7 +17,6 @@ from functools import partial
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from ._lib import patchmap, rowmap
@@ -103,9 +102,8 @@ def _conv_bn(cin, cout):
 
 
 class _ITGHead(nn.Module):
-    """MIM decoder parameters (reference libs/vl_heads.py:107-134).  The product path evaluates them with the HIP
-    schedule in mvlt_amd/mim.py; `run` below is the same graph on PyTorch-ROCm ops, used only as an A/B reference
-    in tests (model.mim_impl = "torch")."""
+    """MIM decoder parameters (reference libs/vl_heads.py:107-134), evaluated by the HIP schedule in mvlt_amd/mim.py (the same graph
+    on PyTorch-ROCm ops, the A/B reference of the HIP-vs-torch test, lives in tests/mim_twin.py)."""
 
     def __init__(self, dims, ch=64):
         super().__init__()
@@ -121,23 +119,6 @@ class _ITGHead(nn.Module):
         self.conv_concat3 = _conv_bn(3 * ch, 3 * ch)
         self.conv4 = _conv_bn(3 * ch, 3 * ch)
         self.score = nn.Sequential(nn.Conv2d(3 * ch, 3, 1))
-
-    def run(self, f1, f2, f3, conv_dtype):
-        """conv3x3 operands in `conv_dtype` (bf16 MFMA on MIOpen), everything else -- BatchNorm statistics and
-        normalisation, the align_corners bilinear resizes, the three-way feature products -- in fp32."""
-        def cb(seq, t):
-            y = F.conv2d(t.to(conv_dtype), seq[0].weight.to(conv_dtype), None, padding=1).float()
-            return seq[1](y)
-        up = lambda t, s=2: F.interpolate(t, scale_factor=s, mode="bilinear", align_corners=True)
-        low, mid, high = cb(self.reduction1, f1), cb(self.reduction2, f2), cb(self.reduction3, f3)
-        a = cb(self.conv_upsample1, up(high)) * mid
-        b = cb(self.conv_upsample2, up(mid)) * cb(self.conv_upsample3, up(a)) * low
-        c = cb(self.conv_concat2, torch.cat((a, cb(self.conv_upsample4, up(high))), 1))
-        d = cb(self.conv_concat3, torch.cat((b, cb(self.conv_upsample5, up(c))), 1))
-        e = cb(self.conv4, d)
-        sc = self.score[0]
-        s = F.conv2d(e.to(conv_dtype), sc.weight.to(conv_dtype), None).float() + sc.bias.view(1, -1, 1, 1)
-        return up(s, 8)
 
 
 # =============================================================================================== the model
@@ -199,9 +180,6 @@ class PyramidVisionLanguageTransformer(nn.Module):
         self._init_weights()
         self.register_load_state_dict_pre_hook(self._drop_legacy_keys)
 
-        # "hip": the MIM decoder runs as the explicit kernel schedule of mvlt_amd/mim.py (default).  "torch": its
-        # PyTorch-ROCm twin (_ITGHead.run, MIOpen convs under autograd) -- kept as the A/B reference for tests only.
-        self.mim_impl = "hip"
         self._store = FlatStore(self, compute_dtype)
         self._anchor = None
         self._transposed, self._conv_perm = self._operand_lists()
@@ -277,6 +255,24 @@ class PyramidVisionLanguageTransformer(nn.Module):
                                "Use oracle/pvlt_oracle.py for CPU checks.")
         from .schedule import run_forward
         return run_forward(self, input_images, input_ids, mlm_labels, mlm_positions, mlm_count, t2i_target)
+
+
+    def forward_pyramid_features_vl(self, x, y):
+        """(img_feats, text_feats) of the four stages like the reference method of the same name (libs/pvlt.py:322-356): image
+        features (B, C_i, H_i, W_i) contiguous, text features (B, T, C_i).  The stage outputs are the trunk's token buffers; the
+        two views per stage are made by ATen (this is an API-shape adapter for callers outside the hot path -- `forward` hands the
+        token buffers to the heads directly)."""
+        if not x.is_cuda:
+            raise RuntimeError("mvlt_amd PVLT runs on MI355X only (HIP kernels); there is no CPU path.")
+        from .schedule import run_trunk
+        outs = run_trunk(self, x, y)
+        B, side = x.shape[0], x.shape[2] // self.patch_size
+        img_feats, text_feats = [], []
+        for i, t in enumerate(outs):
+            s_i = side // (2 ** i)
+            img_feats.append(t[:, : s_i * s_i, :].reshape(B, s_i, s_i, -1).permute(0, 3, 1, 2).contiguous())
+            text_feats.append(t[:, s_i * s_i:, :])
+        return img_feats, text_feats
 
 
 def _cfg(url='', **kwargs):     # timm.models.vision_transformer._cfg metadata (stored as model.default_cfg, unused)

@@ -827,9 +827,7 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_cou
     CPU labels; the device prefetcher brings it along) -- without it the count comes back through `_HostCount`."""
     S = model.store
     dev = images.device
-    S.ensure(dev)
-    grad_on = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
-    model._pool_token = ZeroPool.of(dev).reset(grad_on)           # one fill for all of this step's zero-initialised scratch
+    grad_on = _begin_pass(model, dev)
     lt = model.loss_type
     sel = None
     if lt['mlm'] and mlm_labels is not None and mlm_positions is None:
@@ -840,7 +838,7 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_cou
         cnt = pool_zeros((1,), torch.int32, dev)
         ops.masked_select(flat, idx, cnt)
         sel = (idx, mlm_count if mlm_count is not None else _HostCount(cnt))
-    S.refresh(model._transposed, model._conv_perm, model._conv3 if model.mim_impl == "hip" else ())
+    S.refresh(model._transposed, model._conv_perm, model._conv3)
     x1, x2, x3, x4 = _TrunkFn.apply(model, images, ids, grad_on, *[p for _, p in S.fn_params])
     sink = _GradSink(S) if grad_on else None            # the heads' common gradient buffer for x4
     B = images.shape[0]
@@ -869,22 +867,34 @@ def run_forward(model, images, ids, mlm_labels=None, mlm_positions=None, mlm_cou
         out["sup_cls_logits"] = _ClsHeadFn.apply(x4, model, "sup_cls", HW4, sink)
         out["sub_cls_logits"] = _ClsHeadFn.apply(x4, model, "sub_cls", HW4, sink)
     if lt['t2i']:
-        feats = []
-        for x, i in ((x2, 1), (x3, 2), (x4, 3)):
-            side = images.shape[2] // model.patch_size // (2 ** i)
-            f = x[:, : side * side, :].reshape(B, side, side, model.dims[i]).permute(0, 3, 1, 2)
-            feats.append(f)
-        if model.mim_impl == "hip":
-            from .mim import mim_head
-            if grad_on and not model.training:
-                raise NotImplementedError("MIM decoder backward with eval-mode BatchNorm is not scheduled (no reference config needs it)")
-            sides = tuple(images.shape[2] // model.patch_size // (2 ** i) for i in (1, 2, 3))
-            fuse_loss = (t2i_target is not None and t2i_target.dtype == torch.float32 and t2i_target.shape == (B, 3, 8 * sides[0], 8 * sides[0])
-                         and ops.upsample_l1_ok(sides[0], 8) and not _NO_T2I_FUSE)
-            if fuse_loss:
-                out["t2i_loss"] = mim_head(model, x2, x3, x4, sides, grad_on, sink, t2i_target.contiguous())
-            else:
-                out["t2i_logits"] = mim_head(model, x2, x3, x4, sides, grad_on, sink)
+        from .mim import mim_head
+        if grad_on and not model.training:
+            raise NotImplementedError("MIM decoder backward with eval-mode BatchNorm is not scheduled (no reference config needs it)")
+        sides = tuple(images.shape[2] // model.patch_size // (2 ** i) for i in (1, 2, 3))
+        fuse_loss = (t2i_target is not None and t2i_target.dtype == torch.float32 and t2i_target.shape == (B, 3, 8 * sides[0], 8 * sides[0])
+                     and ops.upsample_l1_ok(sides[0], 8) and not _NO_T2I_FUSE)
+        if fuse_loss:
+            out["t2i_loss"] = mim_head(model, x2, x3, x4, sides, grad_on, sink, t2i_target.contiguous())
         else:
-            out["t2i_logits"] = model.t2i_head.run(*feats, conv_dtype=model.compute_dtype)
+            out["t2i_logits"] = mim_head(model, x2, x3, x4, sides, grad_on, sink)
     return out
+
+
+def _begin_pass(model, dev):
+    """common head of every forward entry: flat store on the device, one fill for all of this step's zero-initialised scratch"""
+    S = model.store
+    S.ensure(dev)
+    grad_on = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+    model._pool_token = ZeroPool.of(dev).reset(grad_on)
+    if grad_on:
+        S.new_pass()                                              # a backward that raised must not poison this pass (FlatStore.new_pass)
+    return grad_on
+
+
+def run_trunk(model, images, ids):
+    """The trunk alone, behind `forward_pyramid_features_vl` (reference libs/pvlt.py:322-356): the four stage outputs as
+    (B, HW_i + T, C_i) token buffers, image tokens first (differentiable: one autograd node, like in `run_forward`)."""
+    S = model.store
+    grad_on = _begin_pass(model, images.device)
+    S.refresh(model._transposed, model._conv_perm, model._conv3)
+    return _TrunkFn.apply(model, images, ids, grad_on, *[p for _, p in S.fn_params])

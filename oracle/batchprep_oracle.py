@@ -26,6 +26,7 @@ W0, W1 = 0x9E3779B9, 0xBB67AE85
 MASK32 = np.uint64(0xFFFFFFFF)
 
 STREAM_GRID, STREAM_ROW, STREAM_TOKEN = 0, 1, 2
+STREAM_DROPOUT, STREAM_DROPPATH = 4, 5
 TOK_CLS, TOK_SEP, TOK_MASK, TOK_PAD, VOCAB = 101, 102, 103, 0, 30522
 # integer thresholds on 24-bit draws: r < T  <=>  r / 2^24 < p  for p in {0.15, 0.8, 0.9}
 T15, T80, T90 = 2516583, 13421773, 15099495
@@ -125,13 +126,14 @@ def prepare_batch(seed, sample0, images, ori_ids, num_mask, mode, patch=16):
     return dict(masked_images=masked, patch_flags=flags, input_ids=input_ids, mlm_labels=labels, mlm_positions=positions)
 
 
-# ---- train-mode masks of the step (mvlt_keep_mask / mvlt_droppath_scales): same generator, streams 2 / 3, counted by the caller's
+# ---- train-mode masks of the step (mvlt_keep_mask / mvlt_droppath_scales): same generator, streams 4 / 5 (their own: stream 2 is the
+# token masking's, and with equal seeds call n would otherwise reuse the draws of sample id n), counted by the caller's
 # running draw count `call` in the place of the sample id
 def keep_mask(seed, call, n, drop_p):
     """n uint8 keep flags, Bernoulli(1 - drop_p) on 16-bit draws: nn.Dropout(drop_p) of BertEmbeddings (reference libs/pvlt.py:232-233
     via transformers' BertEmbeddings.dropout); element i uses half (i % 2) of word (i % 8) // 2 of Philox call i // 8"""
     groups = (n + 7) // 8
-    w = np.stack(draws(seed, call, np.arange(groups), 2), axis=1)                 # (groups, 4) uint32
+    w = np.stack(draws(seed, call, np.arange(groups), STREAM_DROPOUT), axis=1)                 # (groups, 4) uint32
     lo, hi = w & np.uint32(0xFFFF), w >> np.uint32(16)
     d16 = np.stack([lo, hi], axis=2).reshape(groups, 8)                          # e -> word e >> 1, half e & 1
     thr = np.uint32(int(np.float32(drop_p) * np.float32(65536.0)))
@@ -143,7 +145,7 @@ def droppath_scales(seed, call, rates, per):
     (reference libs/pvlt.py:135,141-142: x / keep_prob * floor(keep_prob + U))"""
     rates = np.asarray(rates, dtype=np.float32)
     n = rates.shape[0] * per
-    d = draws(seed, call, np.arange(n), 3)[0] >> np.uint32(8)
+    d = draws(seed, call, np.arange(n), STREAM_DROPPATH)[0] >> np.uint32(8)
     r = np.repeat(rates, per)
     thr = (r * np.float32(16777216.0)).astype(np.uint32)
     return np.where(d >= thr, np.float32(1.0) / (np.float32(1.0) - r), np.float32(0.0)).astype(np.float32).reshape(rates.shape[0], per)

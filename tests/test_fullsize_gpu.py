@@ -1,0 +1,107 @@
+"""GPU: BASELINE configuration #2 at its FULL size (pvlt_tiny, 256x256 + 128 tokens, batch 256, bf16 operands) -- the shapes
+bench.py times.  The golden fixtures pin this configuration at B = 4 (the CPU reference needs minutes per step beyond that), so
+at B = 256 the checks are the size-independent ones (reference engine_grid_masking.py:69-102):
+  * one iteration of `train_one_epoch_vl`: every loss finite, and the MLM / ITM losses equal to what the same 256 pairs give when
+    they go through the eval-mode model as 64 independent batches of 4 (the configuration the fixtures DO pin);
+  * the masked-index selection over the 32768 labels bit-equal to torch.nonzero;
+  * the same step (same batch, same draws) repeated with freed memory poisoned in between: every gradient equal to the first run's
+    up to fp32 atomic-order noise (a race or an uninitialised read shows up here)."""
+import argparse
+import contextlib
+import io
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import bench
+
+pytestmark = pytest.mark.gpu
+B, IMG, T = 256, 256, 128
+LT = dict(mlm=1, itm=1, t2i=1, cls=0)
+
+
+def _model():
+    from mvlt_amd import pvlt
+    torch.manual_seed(77)
+    m = pvlt.pvlt_tiny(pretrained=False, token_hidden_size=768, num_text_tokens=T, loss_type=LT, pretrained_pth=None,
+                       drop_path_rate=0.1, drop_rate=0.0, num_classes=1000, in_chans=3)
+    return m.cuda()
+
+
+def test_masked_select_equals_nonzero_at_full_size():
+    from mvlt_amd import ops
+    dev = torch.device("cuda:0")
+    labels = bench.synth_batch(B, 32, T, dev, 5)["mlm_labels"].reshape(-1).contiguous()
+    assert labels.numel() == 32768
+    idx = torch.empty(labels.numel(), device=dev, dtype=torch.int32)
+    cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+    ops.masked_select(labels, idx, cnt)
+    want = torch.nonzero(labels != -1).flatten().to(torch.int32)
+    n = int(cnt.item())
+    assert n == want.numel() and n > 1000
+    assert torch.equal(idx[:n], want)
+
+
+def test_full_batch_engine_iteration_matches_chunked_eval(parity):
+    import engine_grid_masking as E
+    from mvlt_amd.engine import BF16Scaler
+    from mvlt_amd.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    model = _model()
+    batch = bench.synth_batch(B, IMG, T, dev, 4321)
+    # the same 256 pairs as 64 eval-mode batches of 4: full (4, 128, 30522) MLM logits, the reference's CrossEntropyLoss(ignore_index=-1)
+    model.eval()
+    ce_sum, n_sel, itm_sum = 0.0, 0, 0.0
+    with torch.no_grad():
+        for c in range(0, B, 4):
+            out = model(batch["image"][c:c + 4], batch["input_ids"][c:c + 4])
+            lab = batch["mlm_labels"][c:c + 4].reshape(-1)
+            ce_sum += F.cross_entropy(out["mlm_logits"].reshape(-1, 30522).float(), lab, ignore_index=-1, reduction="sum").item()
+            n_sel += int((lab != -1).sum())
+            itm_sum += F.cross_entropy(out["itm_logits"].reshape(-1, 2).float(), batch["itm_labels"][c:c + 4].reshape(-1), reduction="sum").item()
+    want_mlm, want_itm = ce_sum / n_sel, itm_sum / B
+    # one engine iteration at full size; DropPath / dropout draws replaced by ones so that train mode == eval mode for MLM / ITM
+    # (BatchNorm, the only other train / eval difference, lives in the MIM decoder alone)
+    model.injected_masks = dict(bert=torch.ones(B, T, 768), droppath=[torch.ones(B)] * 8, droppath2=[torch.ones(B)] * 8)
+    opt = FusedAdamW(model, lr=1e-5, weight_decay=0.01)
+    with contextlib.redirect_stdout(io.StringIO()):
+        stats = E.train_one_epoch_vl(model, None, [batch], opt, dev, 0, BF16Scaler(), None, None, None, True, False,
+                                     argparse.Namespace(loss_type=LT))
+    torch.cuda.synchronize()
+    for k in ("total_loss", "loss_mlm", "loss_itm", "loss_t2i"):
+        assert stats[k] == stats[k] and abs(stats[k]) < 1e4, (k, stats[k])
+    assert parity("full256/loss_mlm vs 64 eval chunks", abs(stats["loss_mlm"] - want_mlm) / want_mlm, 2e-2), (stats["loss_mlm"], want_mlm)
+    assert parity("full256/loss_itm vs 64 eval chunks", abs(stats["loss_itm"] - want_itm) / want_itm, 2e-2), (stats["loss_itm"], want_itm)
+    assert abs(stats["total_loss"] - (stats["loss_mlm"] + stats["loss_itm"] + stats["loss_t2i"])) <= 1e-3 * abs(stats["total_loss"])
+    assert all(torch.isfinite(p).all() for p in model.parameters())          # the AdamW step of that iteration
+
+
+def test_full_batch_step_is_repeatable(parity):
+    from mvlt_amd.engine import train_step
+    dev = torch.device("cuda:0")
+    model = _model()
+    model.train()
+    batch = bench.synth_batch(B, IMG, T, dev, 1)
+    ref, worst = None, (0.0, "")
+    for it in range(3):
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(1234)
+        torch.cuda.manual_seed(1234)
+        junk = [torch.full((1 << 26,), float("nan"), device=dev) for _ in range(8)]          # poison freed memory (2 GB)
+        del junk
+        total, _ = train_step(model, batch, 1, True)
+        total.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(total)
+        cur = {k: p.grad.detach().float().clone() for k, p in model.named_parameters() if p.grad is not None}
+        if ref is None:
+            ref = cur
+            assert len(ref) > 150
+            continue
+        for k, v in ref.items():
+            d = (cur[k] - v).norm().item() / max(v.norm().item(), 1e-20)
+            assert d == d, k
+            worst = max(worst, (d, k))
+    assert parity(f"full256/repeat-step worst gradient deviation ({worst[1]})", worst[0], 1e-3), worst

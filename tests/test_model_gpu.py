@@ -147,7 +147,17 @@ def test_eval_forward_parity(golden_dir, parity, name, dtype):
                 e = head_prob_err(out[key].float().cpu().numpy(), g[k])
                 if not parity(f"full/{key}(prob)", e, TOL[dtype]):
                     bad[k + "(prob)"] = e
-                parity(f"full-logits-info/{key}", err_metric(out[key].float().cpu().numpy(), g[k], dtype), 1.0)
+                # ... and the logits themselves: 2e-2 like every other output wherever the reference's OWN bf16
+                # autocast run stays under 2e-2 on them (stored by make_golden.py as eval/bf16_floor/itm_logits: 3 of the 6 cases);
+                # where the reference's own floor is above the bar (3.7e-2 .. 4.6e-2 on the B x 2 logits of the tiny 224 / 256 cases)
+                # the probability bound above is the gate and the logits error is on record only
+                floor = float(g["eval/bf16_floor/itm_logits"]) if "eval/bf16_floor/itm_logits" in g.files else 1.0
+                el = err_metric(out[key].float().cpu().numpy(), g[k], dtype)
+                if floor <= TOL[dtype]:
+                    if not parity(f"full/{key}(logits)", el, TOL[dtype]):
+                        bad[k + "(logits)"] = el
+                else:
+                    parity(f"full-logits-info/{key} (reference bf16 floor {floor:.1e})", el, 1.0)
                 continue
             e = err_metric(out[key].float().cpu().numpy(), g[k], dtype)
             if not parity(f"full/{key}", e, tol_for(g, key, dtype)):
@@ -280,10 +290,12 @@ def test_missing_gpu_path_is_loud():
 @pytest.mark.parametrize("img,B", [(96, 3), (256, 2)])
 def test_mim_decoder_hip_vs_torch_twin(dtype, tol, img, B):
     """The HIP schedule of the MIM decoder (mvlt_amd/mim.py: conv3x3 as 3x3-gather GEMMs, batch-stat BatchNorm, bilinear
-    resizes, products) against the same graph on PyTorch-ROCm ops: output, BN running stats and every gradient
-    (the twin itself is pinned to the reference by the golden tests when mim_impl='torch')."""
+    resizes, products) against the same graph on PyTorch-ROCm ops (tests/mim_twin.py, fed by the product's own
+    `forward_pyramid_features_vl`): output, BN running stats, every decoder gradient and -- through the trunk's backward -- every
+    trunk gradient.  The product has one backend; the twin lives in tests/."""
     import torch.nn.functional as F
     from mvlt_amd import pvlt
+    from tests.mim_twin import MimTwin
     lt = dict(mlm=0, itm=0, t2i=1, cls=0)
     T = 16
     cfg = O.Cfg("pvlt_tiny", lt, 224, 768, T, 0.0)
@@ -294,22 +306,34 @@ def test_mim_decoder_hip_vs_torch_twin(dtype, tol, img, B):
     for impl in ("torch", "hip"):
         m = pvlt.pvlt_tiny(pretrained=False, token_hidden_size=768, num_text_tokens=T, loss_type=lt, pretrained_pth=None,
                            drop_path_rate=0.0, compute_dtype=dtype)
-        m.mim_impl = impl
         m.load_state_dict(sd, strict=True)
         m.cuda().train()
         m.injected_masks = dict(bert=torch.ones(B, T, 768), droppath=[torch.ones(B)] * 8, droppath2=[torch.ones(B)] * 8)
-        out = m(batch["masked_images"].to(dev), batch["input_ids"].to(dev))["t2i_logits"]
+        if impl == "hip":
+            out = m(batch["masked_images"].to(dev), batch["input_ids"].to(dev))["t2i_logits"]
+            dec = m.t2i_head
+        else:
+            dec = MimTwin(m.dims).to(dev).train()
+            dec.load_state_dict({k[len("t2i_head."):]: v for k, v in sd.items() if k.startswith("t2i_head.")}, strict=True)
+            img_feats, text_feats = m.forward_pyramid_features_vl(batch["masked_images"].to(dev), batch["input_ids"].to(dev))
+            assert [tuple(f.shape) for f in img_feats] == [(B, c, img // (4 << i), img // (4 << i)) for i, c in enumerate(m.dims)]
+            assert [tuple(f.shape) for f in text_feats] == [(B, T, c) for c in m.dims]
+            out = dec(img_feats[1], img_feats[2], img_feats[3], conv_dtype=dtype)
         loss = 10 * F.smooth_l1_loss(out.float(), batch["image"].to(dev))
         loss.backward()
         torch.cuda.synchronize()
-        res[impl] = (out.detach().float().cpu(), {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if p.grad is not None},
-                     {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items() if "running_" in k})
+        grads = {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if p.grad is not None and not k.startswith("t2i_head.")}
+        grads.update({"t2i_head." + k: p.grad.detach().float().cpu().clone() for k, p in dec.named_parameters() if p.grad is not None})
+        res[impl] = (out.detach().float().cpu(), grads,
+                     {"t2i_head." + k: v.detach().float().cpu().clone() for k, v in dec.state_dict().items() if "running_" in k})
     o_t, g_t, r_t = res["torch"]
     o_h, g_h, r_h = res["hip"]
     assert tuple(o_h.shape) == (B, 3, img, img)
     assert ((o_h - o_t).norm() / o_t.norm()).item() < tol
+    assert len(r_t) == 22 and set(r_t) == set(r_h)
     for k, v in r_t.items():
         assert ((r_h[k] - v).norm() / v.norm().clamp_min(1e-12)).item() < max(tol, 1e-3), k
+    assert any(k.startswith("t2i_head.") for k in g_t) and any(k.startswith("block1.") for k in g_t)
     bad = {}
     for k, v in g_t.items():
         if v.norm().item() < 1e-8:
