@@ -89,6 +89,7 @@ def test_full_batch_step_is_repeatable(parity):
             p.grad = None
         torch.manual_seed(1234)
         torch.cuda.manual_seed(1234)
+        model._rng_calls = 0                    # the step's own Philox draws (BERT dropout, DropPath) restart with the seed
         junk = [torch.full((1 << 26,), float("nan"), device=dev) for _ in range(8)]          # poison freed memory (2 GB)
         del junk
         total, _ = train_step(model, batch, 1, True)

@@ -18,7 +18,7 @@ for it in range(N):
     model.store.G.zero_() if getattr(model, "store", None) is not None and model.store.G is not None else None
     for p in model.parameters():
         if p.grad is not None: p.grad.zero_()
-    torch.manual_seed(1234); torch.cuda.manual_seed(1234)
+    torch.manual_seed(1234); torch.cuda.manual_seed(1234); model._rng_calls = 0
     junk = [torch.full((1 << 24,), float("nan"), device=dev) for _ in range(6)]; del junk       # poison freed memory
     total, _ = train_step(model, batch, 1, True)
     total.backward()
