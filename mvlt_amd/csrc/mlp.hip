@@ -17,6 +17,7 @@
 // four consecutive hidden units of one token: one 8-byte LDS store into the consumer's A-operand tile.
 #include "common.h"
 #include "../../include/mvlt_hip.h"
+#include <type_traits>
 
 namespace {
 
@@ -33,34 +34,14 @@ template <int K> __device__ __forceinline__ int toff(int row, int k) {
 
 __device__ __forceinline__ bf16x8 ldfrag(const bf16* tile_base_elem) { return *(const bf16x8*)tile_base_elem; }
 
+// ---- B-operand fragments of a wave's 32 token rows (x, and dy for the backward): 8 consecutive channels of token fr per lane, straight
+// from global memory (used by every hidden chunk, never re-read: no LDS copy); forward: optionally with Block.norm2 folded in
 template <int C, int MODE>
-__global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
-  constexpr int JC = MlpGeo<C>::JC;
-  constexpr int BM = 128;                    // token rows per workgroup
-  constexpr int WR = BM / 4;                 // token rows per wave: each wave is self-contained (producer AND consumer of its rows)
-  constexpr int MT = WR / 16;                // 16-token tiles per wave
-  constexpr int CT = C / 16;                 // 16-col output tiles (all of C)
-  constexpr int KS_C = C / 32;               // k32 steps over C
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* sWa = (bf16*)smem;                                   // [2][JC][C]   W1 chunk
-  bf16* sWb = sWa + 2 * JC * C;                              // [2][C][JC]   W2[:, chunk] (mode 0) / W1^T[:, chunk] (mode 1)
-  bf16* sWc = sWb + 2 * C * JC;                              // [2][JC][C]   W2^T chunk   (mode 1 only)
-  float* sB1 = (float*)(sWc + (MODE == 1 ? 2 * JC * C : 0)); // [hid]        fc1 bias: a global load inside the chunk loop would
-                                                             //              wait (vmcnt is in-order) for the weight prefetch too
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 15, fg = lane >> 4;
-  const int m0 = blockIdx.x * BM;
+__device__ __forceinline__ void mlp_load_rows(const mvlt_mlp_args& p, int m0, int wave, int fr, int fg, bf16x8 (&xfr)[2][C / 32],
+                                              bf16x8 (&yfr)[MODE == 1 ? 2 : 1][C / 32]) {
+  constexpr int MT = 2, WR = 32, KS_C = C / 32;
   const bf16* X = (const bf16*)p.x;
   const bf16* DY = (const bf16*)p.dy;
-  const bf16* Wa = (const bf16*)p.w1;        // [hid][C]
-  const bf16* Wb = (const bf16*)p.wb;        // [C][hid]
-  const bf16* Wc = (const bf16*)p.wc;        // [hid][C]
-  const int hid = p.hid;
-
-  for (int u = tid; u < p.hid; u += NT) sB1[u] = p.b1[u];
-  // ---- B-operand fragments of this wave's tokens (x, and dy for the backward): 8 consecutive channels of token fr per
-  // lane, straight from global memory (used by every hidden chunk, never re-read: no LDS copy)
-  bf16x8 xfr[MT][KS_C], yfr[MODE == 1 ? MT : 1][KS_C];
   if (MODE == 0 && p.ln_x) {
     // LayerNorm folded into the operand load (Block.norm2): the four fg-lanes of a token hold its whole fp32 row (KS_C x 8 channels
     // each), so the row statistics are two xor-shuffles away; the normalised row is this wave's fc1 operand AND is stored for the
@@ -123,110 +104,14 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
       if (MODE == 1) yfr[mt][ks] = __builtin_bit_cast(bf16x8, w);
     }
   }
-  // ---- weight-chunk staging (global -> registers -> LDS), double buffered
-  constexpr int WA_IT = JC * (C / 8) / NT;   // 2 (C=64) / 4 (C=128)
-  constexpr int WB_IT = C * (JC / 8) / NT;   // 2 / 4
-  u32x4 ra[WA_IT], rb[WB_IT], rc[MODE == 1 ? WA_IT : 1];
-  auto wload = [&](int jc) {
-#pragma unroll
-    for (int it = 0; it < WA_IT; ++it) {
-      int u = tid + it * NT, r = u / (C / 8), ch = u % (C / 8);
-      ra[it] = *(const u32x4*)(Wa + (long)(jc * JC + r) * C + ch * 8);
-      if (MODE == 1) rc[it] = *(const u32x4*)(Wc + (long)(jc * JC + r) * C + ch * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < WB_IT; ++it) {
-      int u = tid + it * NT, r = u / (JC / 8), ch = u % (JC / 8);
-      rb[it] = *(const u32x4*)(Wb + (long)r * hid + jc * JC + ch * 8);
-    }
-  };
-  auto wstore = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < WA_IT; ++it) {
-      int u = tid + it * NT, r = u / (C / 8), ch = u % (C / 8);
-      *(u32x4*)(sWa + buf * JC * C + toff<C>(r, ch * 8)) = ra[it];
-      if (MODE == 1) *(u32x4*)(sWc + buf * JC * C + toff<C>(r, ch * 8)) = rc[it];
-    }
-#pragma unroll
-    for (int it = 0; it < WB_IT; ++it) {
-      int u = tid + it * NT, r = u / (JC / 8), ch = u % (JC / 8);
-      *(u32x4*)(sWb + buf * C * JC + toff<JC>(r, ch * 8)) = rb[it];
-    }
-  };
-  wload(0);
-  wstore(0);
-  __syncthreads();
+}
 
-  f32x4 oacc[MT][CT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < CT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nchunks = hid / JC;
-  for (int jc = 0; jc < nchunks; ++jc) {
-    const int buf = jc & 1;
-    if (jc + 1 < nchunks) wload(jc + 1);
-    // ---- producers, transposed: tile (jt, mt): rows = hidden units 16 jt.. of the chunk, cols = this wave's tokens 16 mt..
-    // A lane ends up with hidden units 16 jt + 4 fg + r of token fr.  Two hidden tiles (jt = 2 pair, 2 pair + 1) give it 8
-    // values of one token = one A-operand fragment of the consumer MFMA, with k-slot (fg, jj) <-> hidden unit
-    // 32 pair + 16 (jj >> 2) + 4 fg + (jj & 3); the consumer's B operand is read from the W chunk in the same order
-    // (two 8-byte LDS reads), so the activation goes from accumulator to operand without touching LDS.
-    const bf16* wa = sWa + buf * JC * C;
-    const bf16* wc = sWc + buf * JC * C;
-    bf16x8 gfrag[JC / 32][MT];
-#pragma unroll
-    for (int jt = 0; jt < JC / 16; ++jt) {
-      const int jrow = jt * 16 + fr;                   // A-operand row (hidden unit inside the chunk)
-      bf16x8 af[KS_C], cf[MODE == 1 ? KS_C : 1];
-#pragma unroll
-      for (int ks = 0; ks < KS_C; ++ks) {
-        af[ks] = ldfrag(wa + toff<C>(jrow, ks * 32 + fg * 8));
-        if (MODE == 1) cf[ks] = ldfrag(wc + toff<C>(jrow, ks * 32 + fg * 8));
-      }
-      const int jl = jt * 16 + 4 * fg;                 // the four hidden units this lane ends up with: jl + r
-      f32x4 b1v = *(const f32x4*)(sB1 + jc * JC + jl);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int mrow = wave * WR + mt * 16 + fr;     // token (column fr of the tile)
-        f32x4 h = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS_C; ++ks) {
-          h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], xfr[mt][ks], h, 0, 0, 0);
-          if (MODE == 1) dg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[ks], yfr[mt][ks], dg, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-          const f32x2 hv = f32x2{h[r], h[r + 1]} + f32x2{b1v[r], b1v[r + 1]};
-          const f32x2 gv = (MODE == 0) ? gelu_fast2(hv) : f32x2{dg[r], dg[r + 1]} * gelu_fast_grad2(hv);
-          gfrag[jt >> 1][mt][(jt & 1) * 4 + r] = (bf16)gv[0];
-          gfrag[jt >> 1][mt][(jt & 1) * 4 + r + 1] = (bf16)gv[1];
-          h[r] = hv[0]; h[r + 1] = hv[1];
-        }
-        if (MODE == 0 && p.h_out && m0 + mrow < p.M) {
-          bf16x4 h4 = {(bf16)h[0], (bf16)h[1], (bf16)h[2], (bf16)h[3]};
-          *(bf16x4*)((bf16*)p.h_out + (long)(m0 + mrow) * hid + jc * JC + jl) = h4;
-        }
-      }
-    }
-    // ---- consumer: out[this wave's tokens][C] += G[tokens][64] . Wb[C][64]^T
-    const bf16* wb = sWb + buf * C * JC;
-#pragma unroll
-    for (int pair = 0; pair < JC / 32; ++pair) {
-#pragma unroll
-      for (int j = 0; j < CT; ++j) {
-        const bf16x4 b0 = *(const bf16x4*)(wb + toff<JC>(j * 16 + fr, pair * 32 + 4 * fg));
-        const bf16x4 b1 = *(const bf16x4*)(wb + toff<JC>(j * 16 + fr, pair * 32 + 16 + 4 * fg));
-        const bf16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-#pragma unroll
-        for (int i = 0; i < MT; ++i) oacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfrag[pair][i], bfr, oacc[i][j], 0, 0, 0);
-      }
-    }
-    if (jc + 1 < nchunks) wstore(buf ^ 1);
-    __syncthreads();                                   // weight double buffer: next chunk visible, this one free next time
-  }
-
-  // ---- epilogue: oacc[i][j][r] = out[token wave*WR + 16 i + 4 fg + r][c = 16 j + fr]
+// ---- epilogue shared by the fused kernels: oacc[i][j][r] = out[token wave*32 + 16 i + 4 fg + r][c = 16 j + fr]
+template <int C, int MODE>
+__device__ __forceinline__ void mlp_epilogue(const mvlt_mlp_args& p, char* smem, int m0, int tid, f32x4 (&oacc)[2][C / 16]) {
+  constexpr int MT = 2, WR = 32, CT = C / 16;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
   // staged per wave through LDS (the operand tiles are dead) so that global traffic is 16-byte, row-contiguous
   // (one 16-token tile at a time: 4 waves x 16 rows x (C+4) floats)
   constexpr int LDW = C + 4, CPR = C / 8, RPI = 64 / CPR;
@@ -362,6 +247,367 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
     for (int c = tid; c < 2 * C; c += NT)
       p.lnb_partials[(long)blockIdx.x * 2 * C + c] = part[c] + part[2 * C + c] + part[4 * C + c] + part[6 * C + c];
   }
+}
+
+template <int C, int MODE>
+__global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
+  constexpr int JC = MlpGeo<C>::JC;
+  constexpr int BM = 128;                    // token rows per workgroup
+  constexpr int WR = BM / 4;                 // token rows per wave: each wave is self-contained (producer AND consumer of its rows)
+  constexpr int MT = WR / 16;                // 16-token tiles per wave
+  constexpr int CT = C / 16;                 // 16-col output tiles (all of C)
+  constexpr int KS_C = C / 32;               // k32 steps over C
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sWa = (bf16*)smem;                                   // [2][JC][C]   W1 chunk
+  bf16* sWb = sWa + 2 * JC * C;                              // [2][C][JC]   W2[:, chunk] (mode 0) / W1^T[:, chunk] (mode 1)
+  bf16* sWc = sWb + 2 * C * JC;                              // [2][JC][C]   W2^T chunk   (mode 1 only)
+  float* sB1 = (float*)(sWc + (MODE == 1 ? 2 * JC * C : 0)); // [hid]        fc1 bias: a global load inside the chunk loop would
+                                                             //              wait (vmcnt is in-order) for the weight prefetch too
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int m0 = blockIdx.x * BM;
+  const bf16* X = (const bf16*)p.x;
+  const bf16* DY = (const bf16*)p.dy;
+  const bf16* Wa = (const bf16*)p.w1;        // [hid][C]
+  const bf16* Wb = (const bf16*)p.wb;        // [C][hid]
+  const bf16* Wc = (const bf16*)p.wc;        // [hid][C]
+  const int hid = p.hid;
+
+  for (int u = tid; u < p.hid; u += NT) sB1[u] = p.b1[u];
+  // ---- B-operand fragments of this wave's tokens (x, and dy for the backward): 8 consecutive channels of token fr per
+  // lane, straight from global memory (used by every hidden chunk, never re-read: no LDS copy)
+  bf16x8 xfr[MT][KS_C], yfr[MODE == 1 ? MT : 1][KS_C];
+  mlp_load_rows<C, MODE>(p, m0, wave, fr, fg, xfr, yfr);
+  // ---- weight-chunk staging (global -> registers -> LDS), double buffered
+  constexpr int WA_IT = JC * (C / 8) / NT;   // 2 (C=64) / 4 (C=128)
+  constexpr int WB_IT = C * (JC / 8) / NT;   // 2 / 4
+  u32x4 ra[WA_IT], rb[WB_IT], rc[MODE == 1 ? WA_IT : 1];
+  auto wload = [&](int jc) {
+#pragma unroll
+    for (int it = 0; it < WA_IT; ++it) {
+      int u = tid + it * NT, r = u / (C / 8), ch = u % (C / 8);
+      ra[it] = *(const u32x4*)(Wa + (long)(jc * JC + r) * C + ch * 8);
+      if (MODE == 1) rc[it] = *(const u32x4*)(Wc + (long)(jc * JC + r) * C + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < WB_IT; ++it) {
+      int u = tid + it * NT, r = u / (JC / 8), ch = u % (JC / 8);
+      rb[it] = *(const u32x4*)(Wb + (long)r * hid + jc * JC + ch * 8);
+    }
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < WA_IT; ++it) {
+      int u = tid + it * NT, r = u / (C / 8), ch = u % (C / 8);
+      *(u32x4*)(sWa + buf * JC * C + toff<C>(r, ch * 8)) = ra[it];
+      if (MODE == 1) *(u32x4*)(sWc + buf * JC * C + toff<C>(r, ch * 8)) = rc[it];
+    }
+#pragma unroll
+    for (int it = 0; it < WB_IT; ++it) {
+      int u = tid + it * NT, r = u / (JC / 8), ch = u % (JC / 8);
+      *(u32x4*)(sWb + buf * C * JC + toff<JC>(r, ch * 8)) = rb[it];
+    }
+  };
+  wload(0);
+  wstore(0);
+  __syncthreads();
+
+  f32x4 oacc[MT][CT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = hid / JC;
+  for (int jc = 0; jc < nchunks; ++jc) {
+    const int buf = jc & 1;
+    if (jc + 1 < nchunks) wload(jc + 1);
+    // ---- producers, transposed: tile (jt, mt): rows = hidden units 16 jt.. of the chunk, cols = this wave's tokens 16 mt..
+    // A lane ends up with hidden units 16 jt + 4 fg + r of token fr.  Two hidden tiles (jt = 2 pair, 2 pair + 1) give it 8
+    // values of one token = one A-operand fragment of the consumer MFMA, with k-slot (fg, jj) <-> hidden unit
+    // 32 pair + 16 (jj >> 2) + 4 fg + (jj & 3); the consumer's B operand is read from the W chunk in the same order
+    // (two 8-byte LDS reads), so the activation goes from accumulator to operand without touching LDS.
+    const bf16* wa = sWa + buf * JC * C;
+    const bf16* wc = sWc + buf * JC * C;
+    bf16x8 gfrag[JC / 32][MT];
+#pragma unroll
+    for (int jt = 0; jt < JC / 16; ++jt) {
+      const int jrow = jt * 16 + fr;                   // A-operand row (hidden unit inside the chunk)
+      bf16x8 af[KS_C], cf[MODE == 1 ? KS_C : 1];
+#pragma unroll
+      for (int ks = 0; ks < KS_C; ++ks) {
+        af[ks] = ldfrag(wa + toff<C>(jrow, ks * 32 + fg * 8));
+        if (MODE == 1) cf[ks] = ldfrag(wc + toff<C>(jrow, ks * 32 + fg * 8));
+      }
+      const int jl = jt * 16 + 4 * fg;                 // the four hidden units this lane ends up with: jl + r
+      f32x4 b1v = *(const f32x4*)(sB1 + jc * JC + jl);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int mrow = wave * WR + mt * 16 + fr;     // token (column fr of the tile)
+        f32x4 h = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS_C; ++ks) {
+          h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], xfr[mt][ks], h, 0, 0, 0);
+          if (MODE == 1) dg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[ks], yfr[mt][ks], dg, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 hv = f32x2{h[r], h[r + 1]} + f32x2{b1v[r], b1v[r + 1]};
+          const f32x2 gv = (MODE == 0) ? gelu_fast2(hv) : f32x2{dg[r], dg[r + 1]} * gelu_fast_grad2(hv);
+          gfrag[jt >> 1][mt][(jt & 1) * 4 + r] = (bf16)gv[0];
+          gfrag[jt >> 1][mt][(jt & 1) * 4 + r + 1] = (bf16)gv[1];
+          h[r] = hv[0]; h[r + 1] = hv[1];
+        }
+        if (MODE == 0 && p.h_out && m0 + mrow < p.M) {
+          bf16x4 h4 = {(bf16)h[0], (bf16)h[1], (bf16)h[2], (bf16)h[3]};
+          *(bf16x4*)((bf16*)p.h_out + (long)(m0 + mrow) * hid + jc * JC + jl) = h4;
+        }
+      }
+    }
+    // ---- consumer: out[this wave's tokens][C] += G[tokens][64] . Wb[C][64]^T
+    const bf16* wb = sWb + buf * C * JC;
+#pragma unroll
+    for (int pair = 0; pair < JC / 32; ++pair) {
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const bf16x4 b0 = *(const bf16x4*)(wb + toff<JC>(j * 16 + fr, pair * 32 + 4 * fg));
+        const bf16x4 b1 = *(const bf16x4*)(wb + toff<JC>(j * 16 + fr, pair * 32 + 16 + 4 * fg));
+        const bf16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+        for (int i = 0; i < MT; ++i) oacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfrag[pair][i], bfr, oacc[i][j], 0, 0, 0);
+      }
+    }
+    if (jc + 1 < nchunks) wstore(buf ^ 1);
+    __syncthreads();                                   // weight double buffer: next chunk visible, this one free next time
+  }
+
+  mlp_epilogue<C, MODE>(p, smem, m0, tid, oacc);
+}
+
+// ------------------------------------------------------------------------------------------------ software-pipelined fused MLP
+// Round 3.  The kernel above runs, per wave and hidden chunk, 16 producer MFMAs, then ~270 VALU instructions of GELU, then 16 consumer
+// MFMAs -- strictly one after the other (ISA: tools/isa_mix.py), so the matrix pipe idles through every activation block and the VALU
+// through every MFMA block unless ANOTHER wave of the SIMD happens to be in the opposite phase (counters: MFMA busy 0.20-0.28 of SIMD
+// cycles, VALU active ~0.25 per wave).  Here the three stages of a 32-hidden-unit slice u are spread over three loop iterations of ONE
+// wave -- iteration i issues the producer MFMAs of slice i+1, the activation of slice i and the consumer MFMAs of slice i-1, which are
+// independent instruction streams the scheduler may interleave (MFMAs issue asynchronously: the VALU work of a wave runs in the shadow
+// of its own matrix instructions):
+//
+//     P(i+1): H = W1[slice] x^T + b1      (+ dG = W2^T[slice] dy^T)     -> hacc[(i+1)&1]      [MFMA]
+//     G(i)  : g = gelu(H)                 (dH = dG * gelu'(H))          -> gfrag[i&1] (bf16)  [VALU]
+//     C(i-1): out += g W2[:, slice]^T     (dx += dH W1^T[:, slice])                            [MFMA]
+//
+// Producer tiles are transposed (rows = hidden units, columns = tokens) and the hidden unit of tile row rho is chosen as
+// 32 u + 8 (rho >> 2) + 4 h + (rho & 3) for the two tiles h = 0, 1 of a slice: lane (fr, fg) then ends up with the EIGHT CONSECUTIVE
+// hidden units 32 u + 8 fg .. + 7 of token fr = one A-operand fragment of the consumer MFMA in natural k order, and the consumer's B
+// fragment is ONE 16-byte LDS read (the kernel above pairs tiles 16 apart: two 8-byte reads that hipcc fuses into ds_read2st64_b64,
+// which is 2-way bank conflicted: lds_conflict_frac 0.25-0.31).  fc1's bias is the producer's accumulator initialiser (no VALU add).
+// Weight slices arrive by LDS-DMA (no staging registers, no ds_write), two small rings of two slots: the producer side (W1 [, W2^T]
+// rows of slice i+2) and the consumer side (Wb columns of slice i) are fetched in iteration i, one barrier per iteration.
+template <int C> __device__ __forceinline__ int pipe_fP(int rho) {       // 16-B slot swizzle of a producer-tile row (row = hidden unit in slice)
+  return C == 64 ? (((rho >> 1) & 1) | (((rho >> 3) & 3) << 1)) : ((rho & 3) | (((rho >> 3) & 3) << 2));
+}
+__device__ __forceinline__ int pipe_gC(int n) { return (0 - (n >> 2)) & 3; }   // same for a consumer-tile row (row = channel, 64-B rows)
+
+__device__ __forceinline__ float gelu_fast1(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
+  const float x2 = xc * xc;
+  const float t = xc * __builtin_fmaf(__builtin_fmaf(x2, -MVLT_LOG2E * MVLT_GP2, -MVLT_LOG2E * MVLT_GP1), x2, -MVLT_LOG2E * MVLT_GP0);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return x * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+__device__ __forceinline__ float gelu_fast_grad1(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
+  const float x2 = xc * xc;
+  const float t = xc * __builtin_fmaf(__builtin_fmaf(x2, -MVLT_LOG2E * MVLT_GP2, -MVLT_LOG2E * MVLT_GP1), x2, -MVLT_LOG2E * MVLT_GP0);
+  const float e = __builtin_amdgcn_exp2f(t);
+  const float sg = __builtin_amdgcn_rcpf(e + 1.0f);
+  const float up = __builtin_fmaf(__builtin_fmaf(x2, 5.0f * MVLT_GP2, 3.0f * MVLT_GP1), x2, MVLT_GP0);
+  return __builtin_fmaf(x * up, sg * sg * e, sg);
+}
+
+template <int C, int MODE>
+__global__ __launch_bounds__(NT, 2) void mlp_pipe_kernel(mvlt_mlp_args p) {
+  constexpr int MT = 2, CT = C / 16, KS_C = C / 32;
+  constexpr int NP = MODE == 1 ? 2 : 1;          // producer-side tiles per slice: W1 (, W2^T)
+  constexpr int RB = 2 * C;                      // bytes per producer-tile row
+  constexpr int SPR = RB / 16;                   // 16-B slots per row: 8 / 16
+  constexpr int RPI = 64 / SPR;                  // rows per DMA instruction: 8 / 4
+  constexpr int IPW = 32 / RPI / 4;              // DMA instructions per wave per producer tile: 1 / 2
+  constexpr int PB = 32 * RB;                    // producer tile bytes: 4 / 8 KB
+  constexpr int CB = C * 64;                     // consumer tile [C][32] bytes: 4 / 8 KB
+  constexpr int IPWC = C / 16 / 4;               // DMA instructions per wave per consumer tile: 1 / 2
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [2][NP][PB] producer ring | [2][CB] consumer ring | b1 [hid] floats
+  char* const sP = smem;
+  char* const sC = smem + 2 * NP * PB;
+  float* const sB1 = (float*)(sC + 2 * CB);
+  const unsigned sP_lds = (unsigned)(uintptr_t)sP, sC_lds = (unsigned)(uintptr_t)sC;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int m0 = blockIdx.x * 128;
+  const int hid = p.hid, NU = hid / 32;
+
+  // ---- DMA geometry: per-lane source pointers of slice 0, advanced by a wave-uniform slice offset
+  const char* srcP[NP][IPW];
+  const char* srcC[IPWC];
+#pragma unroll
+  for (int it = 0; it < IPW; ++it) {
+    const int q = wave + 4 * it, row = q * RPI + lane / SPR, slot = lane % SPR;
+    const long off = (long)row * RB + ((slot ^ pipe_fP<C>(row)) << 4);
+    srcP[0][it] = (const char*)p.w1 + off;
+    if (MODE == 1) srcP[NP - 1][it] = (const char*)p.wc + off;
+  }
+#pragma unroll
+  for (int it = 0; it < IPWC; ++it) {
+    const int q = wave + 4 * it, n = q * 16 + (lane >> 2), slot = lane & 3;
+    srcC[it] = (const char*)p.wb + (long)n * hid * 2 + ((slot ^ pipe_gC(n)) << 4);
+  }
+  auto dmaP = [&](int u, int ring) {             // producer tile(s) of slice u -> ring slot
+    const long so = (long)u * PB;
+#pragma unroll
+    for (int t = 0; t < NP; ++t)
+#pragma unroll
+      for (int it = 0; it < IPW; ++it)
+        glds16(srcP[t][it] + so, __builtin_amdgcn_readfirstlane(sP_lds + (ring * NP + t) * PB + (wave + 4 * it) * 1024));
+  };
+  auto dmaC = [&](int u, int ring) {
+#pragma unroll
+    for (int it = 0; it < IPWC; ++it)
+      glds16(srcC[it] + u * 64, __builtin_amdgcn_readfirstlane(sC_lds + ring * CB + (wave + 4 * it) * 1024));
+  };
+  dmaP(0, 0);
+  if (NU > 1) dmaP(1, 1);
+  for (int u = tid; u < hid; u += NT) sB1[u] = p.b1[u];
+
+  bf16x8 xfr[MT][KS_C], yfr[MODE == 1 ? MT : 1][KS_C];
+  mlp_load_rows<C, MODE>(p, m0, wave, fr, fg, xfr, yfr);
+
+  // ---- fragment geometry (byte offsets inside a tile)
+  const int rho0 = 8 * (fr >> 2) + (fr & 3);                         // tile h: row rho0 + 4 h
+  int poff[KS_C];
+#pragma unroll
+  for (int ks = 0; ks < KS_C; ++ks) poff[ks] = rho0 * RB + (((ks * 4 + fg) ^ pipe_fP<C>(rho0)) << 4);
+  const int coff = fr * 64 + ((fg ^ pipe_gC(fr)) << 4);             // tile j: + j * 16 * 64
+
+  f32x4 oacc[MT][CT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 hacc[2][2][MT], dgacc[MODE == 1 ? 2 : 1][2][MT];
+  u32x4 gfrag[2][MT];                            // bf16 pairs: word 2 h + (r >> 1) of token tile mt = hidden units 8 fg + 4 h + r
+
+  // One iteration = NSLOT slots of {a few MFMAs, two activations per lane}, pinned apart by sched_barrier(0): hipcc otherwise emits an
+  // iteration's MFMAs as one block and its ~150 VALU instructions as another (checked in the ISA; sched_group_barrier requests did
+  // not change that), which is exactly the serialisation this kernel exists to remove.  Inside a slot the MFMAs come first, so the
+  // activation's VALU / transcendental instructions issue while the matrix pipe works.
+  //   PAR = parity of the slice being ACTIVATED (i): hacc[PAR] -> gfrag[PAR]; producers write hacc[PAR ^ 1] (slice i + 1) from producer
+  //   ring slot PAR ^ 1; consumers read gfrag[PAR ^ 1] (slice i - 1) and consumer ring slot PAR ^ 1.
+  constexpr int NSLOT = 8;
+  constexpr int PK = KS_C / 2;                   // producer k-steps per slot (a tile takes two slots)
+  constexpr int CPS = CT * MT / NSLOT;           // consumer MFMAs per slot: 1 / 2
+  auto iteration = [&](auto parc, auto dopc, auto docc, auto dogc, int u_next) {
+    constexpr int PAR = decltype(parc)::value;
+    constexpr bool DO_P = decltype(dopc)::value, DO_C = decltype(docc)::value, DO_G = decltype(dogc)::value;
+    const char* tp = sP + (PAR ^ 1) * NP * PB;
+    const char* tc = sC + (PAR ^ 1) * CB;
+    // operand fragments of slot sl are read one slot ahead into set sl & 1 (only slot 0's reads wait for LDS in front of their MFMAs)
+    bf16x8 af[2][PK], cf[MODE == 1 ? 2 : 1][PK], bfr[2][CPS];
+    f32x4 b1v;
+    auto read_frags = [&](auto slc) {
+      constexpr int sl = decltype(slc)::value, t = sl >> 1, half = sl & 1, h = t >> 1;
+      if (DO_P) {
+#pragma unroll
+        for (int k = 0; k < PK; ++k) {
+          af[sl & 1][k] = *(const bf16x8*)(tp + h * 4 * RB + poff[half * PK + k]);
+          if (MODE == 1) cf[sl & 1][k] = *(const bf16x8*)(tp + PB + h * 4 * RB + poff[half * PK + k]);
+        }
+        if ((sl & 3) == 0) b1v = *(const f32x4*)(sB1 + u_next * 32 + 8 * fg + 4 * h);       // first slot of the two tiles sharing h
+      }
+      if (DO_C) {
+#pragma unroll
+        for (int k = 0; k < CPS; ++k) bfr[sl & 1][k] = *(const bf16x8*)(tc + ((sl * CPS + k) / MT) * 16 * 64 + coff);
+      }
+    };
+    read_frags(std::integral_constant<int, 0>{});
+    auto slot = [&](auto slc) {
+      constexpr int sl = decltype(slc)::value;
+      constexpr int t = sl >> 1, half = sl & 1;  // producer tile (h, mt) = (t >> 1, t & 1) and activation group: same order
+      constexpr int h = t >> 1, mt = t & 1;
+      if constexpr (sl + 1 < NSLOT) read_frags(std::integral_constant<int, sl + 1>{});
+      if (DO_P) {
+        f32x4 hh = half == 0 ? b1v : hacc[PAR ^ 1][h][mt];
+        f32x4 dg = half == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : dgacc[MODE == 1 ? (PAR ^ 1) : 0][h][mt];
+#pragma unroll
+        for (int k = 0; k < PK; ++k) {
+          hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[sl & 1][k], xfr[mt][half * PK + k], hh, 0, 0, 0);
+          if (MODE == 1) dg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[sl & 1][k], yfr[mt][half * PK + k], dg, 0, 0, 0);
+        }
+        hacc[PAR ^ 1][h][mt] = hh;
+        if (MODE == 1) dgacc[PAR ^ 1][h][mt] = dg;
+      }
+      if (DO_C) {
+#pragma unroll
+        for (int k = 0; k < CPS; ++k) {
+          constexpr int c0 = sl * CPS;
+          const int c = c0 + k, j = c / MT, i = c % MT;
+          oacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gfrag[PAR ^ 1][i]), bfr[sl & 1][k], oacc[i][j], 0, 0, 0);
+        }
+      }
+      if (DO_G) {
+        const float h0 = hacc[PAR][h][mt][2 * half], h1 = hacc[PAR][h][mt][2 * half + 1];
+        float g0, g1;
+        if (MODE == 0) { g0 = gelu_fast1(h0); g1 = gelu_fast1(h1); }
+        else {
+          g0 = dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half] * gelu_fast_grad1(h0);
+          g1 = dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half + 1] * gelu_fast_grad1(h1);
+        }
+        gfrag[PAR][mt][2 * h + half] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{g0, g1}, bf16x2));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    slot(std::integral_constant<int, 0>{}); slot(std::integral_constant<int, 1>{}); slot(std::integral_constant<int, 2>{});
+    slot(std::integral_constant<int, 3>{}); slot(std::integral_constant<int, 4>{}); slot(std::integral_constant<int, 5>{});
+    slot(std::integral_constant<int, 6>{}); slot(std::integral_constant<int, 7>{});
+  };
+  auto fence = [&]() {                           // this iteration's DMAs have landed for every wave; its LDS reads are done
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using Y = std::true_type;
+  using N = std::false_type;
+
+  fence();                                       // slices 0, 1 of the producer side and the bias are in LDS
+  iteration(P1{}, Y{}, N{}, N{}, 0);             // "iteration -1": producers of slice 0 (ring slot 0) -> hacc[0]
+  fence();                                       // ring slot 0 may be refilled
+  // iteration 0: P(1), G(0)
+  dmaP(min(2, NU - 1), 0);
+  dmaC(0, 0);
+  iteration(P0{}, Y{}, N{}, Y{}, 1);
+  fence();
+  // steady state, two iterations per trip: i odd, then i + 1 even (NU is even and >= 4: hid % 64 == 0, hid >= 128)
+  for (int i = 1; i + 1 < NU - 1; i += 2) {
+    dmaP(min(i + 2, NU - 1), 1);
+    dmaC(i, 1);
+    iteration(P1{}, Y{}, Y{}, Y{}, i + 1);
+    fence();
+    dmaP(min(i + 3, NU - 1), 0);
+    dmaC(i + 1, 0);
+    iteration(P0{}, Y{}, Y{}, Y{}, i + 2);
+    fence();
+  }
+  // last iteration i = NU - 1 (odd): G(NU-1), C(NU-2); then the consumers of the last slice alone
+  dmaC(NU - 1, 1);
+  iteration(P1{}, N{}, Y{}, Y{}, 0);
+  fence();
+  iteration(P0{}, N{}, Y{}, N{}, 0);
+  __syncthreads();                               // the epilogue stages through the same LDS
+  mlp_epilogue<C, MODE>(p, smem, m0, tid, oacc);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients
@@ -612,6 +858,15 @@ template <int C, int MODE> int launch(const mvlt_mlp_args& a, hipStream_t s) {
   size_t lds = (size_t)(2 * JC * C * (MODE == 1 ? 2 : 1) + 2 * C * JC) * 2 + (size_t)a.hid * 4;
   const size_t stage = (size_t)4 * 16 * (C + 4) * 4;       // epilogue staging (4 waves x 16 rows) reuses the weight buffers
   if (lds < stage) lds = stage;
+  static const bool legacy = getenv("MVLT_MLP_LEGACY") != nullptr;
+  static const bool force128 = getenv("MVLT_MLP_PIPE128") != nullptr;
+  if (!legacy && !a.h_out && a.hid >= 128 && !(C == 128 && MODE == 1 && !force128)) {      // the software-pipelined kernel (no pre-activation store: nothing in the step asks for one)
+    size_t l2 = (size_t)2 * (MODE == 1 ? 2 : 1) * 32 * 2 * C + (size_t)2 * C * 64 + (size_t)a.hid * 4;
+    if (l2 < stage) l2 = stage;
+    hipFuncSetAttribute((const void*)mlp_pipe_kernel<C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+    hipLaunchKernelGGL((mlp_pipe_kernel<C, MODE>), dim3((a.M + BM - 1) / BM), dim3(NT), l2, s, a);
+    return mvlt_check_launch(MODE == 0 ? "mvlt_mlp_fwd" : "mvlt_mlp_bwd_dx");
+  }
   hipFuncSetAttribute((const void*)mlp_fused_kernel<C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((mlp_fused_kernel<C, MODE>), dim3((a.M + BM - 1) / BM), dim3(NT), lds, s, a);
   return mvlt_check_launch(MODE == 0 ? "mvlt_mlp_fwd" : "mvlt_mlp_bwd_dx");

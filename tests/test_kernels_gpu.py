@@ -572,6 +572,10 @@ def test_fused_mlp(ops, Cdim, hid, M, Bsz):
     ref = branch + res
     assert maxrel(hbuf.float(), h) < 2e-2
     assert maxrel(out - res, branch) < 2e-2
+    # without the pre-activation store the forward is the software-pipelined kernel (mlp_pipe_kernel): the launch the step makes
+    out2 = torch.full((M, Cdim), float("nan"), device=dev())
+    ops.mlp_fwd(x, w1, b1, w2, b2, res, out2, M, Cdim, hid, row_scale=scale, rows_per_scale=rps)
+    assert maxrel(out2 - res, branch) < 2e-2
     dy = rnd(M, Cdim, dtype=bf, seed=7)
     ref.backward(dy.float())
     dx = torch.empty(M, Cdim, device=dev(), dtype=bf)
