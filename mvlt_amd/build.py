@@ -13,6 +13,10 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libmvlt_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+# mlp.hip: the software-pipelined kernels interleave scalar-f32 activation code with MFMAs; hipcc's SLP vectoriser would pair it into
+# v_pk_*_f32 again, and packed fp32 VALU does not overlap with MFMA on gfx950 (tools/probes/valu_rates.hip: 16 x {mfma + 4 v_pk_fma} runs
+# at exactly the sum of the two, 16 x {mfma + 8 v_fma} hides half of the MFMA time)
+EXTRA = {"mlp.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():
@@ -30,7 +34,7 @@ def _compile(src, force, verbose):
     o = os.path.join(OBJ, src[:-4] + ".o")
     if not force and os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), _deps_mtime()):
         return o
-    cmd = ["hipcc", *FLAGS, "-c", s, "-o", o]
+    cmd = ["hipcc", *FLAGS, *EXTRA.get(src, []), "-c", s, "-o", o]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -837,6 +837,263 @@ __global__ __launch_bounds__(NT, C == 64 ? 2 : 1) void mlp_wgrad_kernel(mvlt_mlp
   }
 }
 
+// ---- round 3: the same computation with (a) the activation's VALU work of token sub-tile mt issued in the shadow of sub-tile mt + 1's
+// producer MFMAs and of the weight-gradient MFMAs (slots pinned by sched_barrier(0), as in mlp_pipe_kernel), (b) the per-sample
+// DropPath factor taken per 64-token TILE (the launch takes this path when rows_per_scale % 64 == 0: a tile then never straddles two
+// samples): one scalar per tile instead of sixteen compare / select pairs, and a tile whose factor is 0 -- the sample's branch was
+// dropped -- is skipped altogether, (c) fc1's bias as the producers' accumulator initialiser and db1 = dh^T 1 as one more MFMA column
+// block instead of VALU adds, (d) NW = 8 waves of ONE 16-unit hidden tile each at C = 128, where the four-wave form needs 446 registers
+// per lane (one wave per SIMD: a VALU-bound loop then issues one instruction per ~7 cycles instead of one per ~3).
+__device__ __forceinline__ void gelu_fast_both1(float x, float& g, float& dg) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
+  const float x2 = xc * xc;
+  const float t = xc * __builtin_fmaf(__builtin_fmaf(x2, -MVLT_LOG2E * MVLT_GP2, -MVLT_LOG2E * MVLT_GP1), x2, -MVLT_LOG2E * MVLT_GP0);
+  const float e = __builtin_amdgcn_exp2f(t);
+  const float sg = __builtin_amdgcn_rcpf(e + 1.0f);
+  const float up = __builtin_fmaf(__builtin_fmaf(x2, 5.0f * MVLT_GP2, 3.0f * MVLT_GP1), x2, MVLT_GP0);
+  g = x * sg;
+  dg = __builtin_fmaf(x * up, __builtin_fmaf(-sg, sg, sg), sg);          // s + x u' s (1 - s)
+}
+
+template <int C, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void mlp_wgrad2_kernel(mvlt_mlp_args p, int m_per_split, int splits, int ny) {
+  constexpr int NTH = NW * 64;
+  constexpr int JT = 8 / NW;                   // 16-unit hidden tiles per wave: 2 (4 waves) / 1 (8 waves)
+  constexpr int KS_C = C / 32, CT16 = C / 16;
+  constexpr int ROWB = 2 * C;                  // bytes per token row
+  constexpr int CH = C / 8;                    // 16-B slots per row
+  constexpr int RPP = NTH / CH;                // rows per pass of the whole workgroup
+  constexpr int IT = 64 / RPP;                 // passes per tile
+  constexpr int TILE = 64 * ROWB;
+  constexpr int STAGE = 2 * TILE;              // x tile | dy tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sW1 = (bf16*)smem;                     // [128][C]
+  bf16* sW2T = sW1 + 128 * C;                  // [128][C]
+  char* sT = smem + 2 * 128 * C * 2;           // [2][x tile | dy tile]
+  const unsigned sT_lds = (unsigned)(uintptr_t)sT;
+
+  // one token split (all its ny hidden blocks) per XCD: x / dy rows come through that L2 once
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int zq = kq / ny, by = kq - zq * ny;
+  const int bz = zq * 8 + xcd;
+  if (bz >= splits) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int j0 = by * 128, jw = wave * 16 * JT;                   // this wave's hidden units: j0 + jw + 16 jt + (column)
+  const int m_begin = bz * m_per_split, m_end = min(p.M, m_begin + m_per_split);
+
+  // ---- DMA geometry (same image as mlp_wgrad_kernel)
+  const int l_row0 = tid / CH;
+  const int l_chunk = (tid % CH) ^ (wg_hs<C>(l_row0) << 1);
+  const char* xsrc = (const char*)p.x + l_chunk * 16;
+  const char* ysrc = (const char*)p.dy + l_chunk * 16;
+  const char* zsrc = (const char*)g_zero_page + ((tid * 16 + (blockIdx.x & 15) * 4096) & 65535);
+  auto issue = [&](int mt, int slot) {
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int m = mt + j * RPP + l_row0;
+      const bool ok = m < m_end;
+      const unsigned long long off = (unsigned long long)(unsigned)m * ROWB;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(sT_lds + slot * STAGE + (j * NTH + wave * 64) * 16);
+      glds16(ok ? xsrc + off : zsrc, dst);
+      glds16(ok ? ysrc + off : zsrc, dst + TILE);
+    }
+  };
+  issue(m_begin, 0);
+
+  for (int u = tid; u < 128 * (C / 8); u += NTH) {
+    int r = u / (C / 8), ch = u % (C / 8);
+    *(u32x4*)(sW1 + toff<C>(r, ch * 8)) = *(const u32x4*)((const bf16*)p.w1 + (long)(j0 + r) * C + ch * 8);
+    *(u32x4*)(sW2T + toff<C>(r, ch * 8)) = *(const u32x4*)((const bf16*)p.wc + (long)(j0 + r) * C + ch * 8);
+  }
+  float b1v[JT];
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) b1v[jt] = p.b1[j0 + jw + jt * 16 + fr];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();                             // weights visible (and tile 0 has landed)
+
+  // ---- fragment geometry
+  const int hs_row = wg_hs<C>(fr);                                   // producers: token row 16 mt + fr
+  int xoff[KS_C];
+#pragma unroll
+  for (int ks = 0; ks < KS_C; ++ks) xoff[ks] = fr * ROWB + (((ks * 4 + fg) ^ (hs_row << 1)) << 4);
+  const int L = lane & 15;
+  const int trow = 4 * fg + (L >> 2);                                // transposed reads: token row 32 pair + trow (+16)
+  const int hs_t = wg_hs<C>(trow);
+  int toffs[CT16];
+#pragma unroll
+  for (int ct = 0; ct < CT16; ++ct) toffs[ct] = trow * ROWB + ((ct ^ hs_t) << 5) + ((L & 3) << 3);
+
+  // the hidden-unit operands of the producers stay in registers: 2 JT KS_C fragments (32 registers at either geometry)
+  bf16x8 w1f[JT][KS_C], w2f[JT][KS_C];
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+    for (int ks = 0; ks < KS_C; ++ks) {
+      w1f[jt][ks] = ldfrag(sW1 + toff<C>(jw + jt * 16 + fr, ks * 32 + fg * 8));
+      w2f[jt][ks] = ldfrag(sW2T + toff<C>(jw + jt * 16 + fr, ks * 32 + fg * 8));
+    }
+
+  f32x4 dw1[JT][CT16], dw2[CT16][JT], db1m[JT];
+#pragma unroll
+  for (int a = 0; a < JT; ++a) {
+    db1m[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < CT16; ++b) { dw1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; dw2[b][a] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  // db2[c] = sum_m s_m dy[m][c]: wave w owns channel tile w (CT16 == NW at both geometries) and adds one MFMA against a ones fragment per
+  // token-tile pair -- every column of that product holds the row sums.  Every workgroup computes it (two MFMAs per tile, no branch in
+  // the loop); the by == 0 ones flush it.
+  // The per-sample factor s never touches the per-element path: the accumulators hold UNSCALED sums under the invariant
+  // true sum = run_sc x accumulator.  Tiles of dropped samples (s = 0) are skipped; when a tile's factor differs from run_sc (DropPath
+  // hands out one non-zero value per block, so in practice never) the accumulators are rescaled by run_sc / s first.  The flush multiplies
+  // by run_sc.
+  static_assert(CT16 == NW, "one channel tile of dy per wave");
+  f32x4 db2m = {0.f, 0.f, 0.f, 0.f};
+  float run_sc = 0.0f;                         // 0: nothing accumulated yet
+  const int toff_own = trow * ROWB + ((wave ^ hs_t) << 5) + ((L & 3) << 3);
+  const bool do_db2 = by == 0;
+  const bool scaled = p.row_scale != nullptr;
+  const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+
+  int slot = 0;
+  for (int mt0 = m_begin; mt0 < m_end; mt0 += 64, slot ^= 1) {
+    if (mt0 != m_begin) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // tile mt0 landed for every wave; the other slot is free again
+      asm volatile("" ::: "memory");
+    }
+    if (mt0 + 64 < m_end) issue(mt0 + 64, slot ^ 1);
+    // DropPath factor of this tile's sample (wave-uniform); a dropped sample contributes nothing to any of the four gradients
+    float sc = 1.0f;
+    if (scaled) {
+      sc = sload_f32(p.row_scale + __builtin_amdgcn_readfirstlane(mt0 / p.rows_per_scale));
+      if (sc == 0.0f) continue;
+    }
+    if (sc != run_sc) {
+      if (run_sc != 0.0f) {
+        const float f = run_sc / sc;
+#pragma unroll
+        for (int a = 0; a < JT; ++a) {
+          db1m[a] *= f;
+#pragma unroll
+          for (int b = 0; b < CT16; ++b) { dw1[a][b] *= f; dw2[b][a] *= f; }
+        }
+        db2m *= f;
+      }
+      run_sc = sc;
+    }
+    const char* tX = sT + slot * STAGE;
+    const char* tY = tX + TILE;
+
+    f32x4 hd[2][JT][2];                        // [sub-tile parity][hidden tile][h | dg]
+    u32x4 gfrag[JT][2], dhfrag[JT][2];         // [hidden tile][token-tile pair]: k-slot (fg, jj) <-> token 32 pair + 16 (jj>>2) + 4 fg + (jj&3)
+    auto produce = [&](auto mtc) {
+      constexpr int mt = decltype(mtc)::value;
+      bf16x8 xf[KS_C], yf[KS_C];
+#pragma unroll
+      for (int ks = 0; ks < KS_C; ++ks) {
+        xf[ks] = *(const bf16x8*)(tX + mt * 16 * ROWB + xoff[ks]);
+        yf[ks] = *(const bf16x8*)(tY + mt * 16 * ROWB + xoff[ks]);
+      }
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt) {
+        f32x4 h = {b1v[jt], b1v[jt], b1v[jt], b1v[jt]}, dg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS_C; ++ks) {
+          h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ks], w1f[jt][ks], h, 0, 0, 0);
+          dg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[ks], w2f[jt][ks], dg, 0, 0, 0);
+        }
+        hd[mt & 1][jt][0] = h;
+        hd[mt & 1][jt][1] = dg;
+      }
+    };
+    auto activate = [&](auto mtc) {
+      constexpr int mt = decltype(mtc)::value;
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          float g0, g1, d0, d1;
+          gelu_fast_both1(hd[mt & 1][jt][0][r], g0, d0);
+          gelu_fast_both1(hd[mt & 1][jt][0][r + 1], g1, d1);
+          const float q0 = hd[mt & 1][jt][1][r], q1 = hd[mt & 1][jt][1][r + 1];
+          gfrag[jt][mt >> 1][(mt & 1) * 2 + (r >> 1)] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{g0, g1}, bf16x2));
+          dhfrag[jt][mt >> 1][(mt & 1) * 2 + (r >> 1)] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0 * d0, q1 * d1}, bf16x2));
+        }
+    };
+    auto consume = [&](auto pairc, auto ct0c, auto ct1c) {       // weight-gradient products of token-tile pair `pair`, channel tiles [ct0, ct1)
+      constexpr int pair = decltype(pairc)::value, ct0 = decltype(ct0c)::value, ct1 = decltype(ct1c)::value;
+#pragma unroll
+      for (int ct = ct0; ct < ct1; ++ct) {
+        typedef __attribute__((address_space(3))) s16x4* lptr;
+        const char* ax = tX + pair * 32 * ROWB + toffs[ct];
+        const char* ay = tY + pair * 32 * ROWB + toffs[ct];
+        s16x4 xa = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)ax), xb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(ax + 16 * ROWB));
+        s16x4 ya = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)ay), yb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(ay + 16 * ROWB));
+        const unsigned long long xl = __builtin_bit_cast(unsigned long long, xa), xh = __builtin_bit_cast(unsigned long long, xb);
+        const unsigned long long yl = __builtin_bit_cast(unsigned long long, ya), yh = __builtin_bit_cast(unsigned long long, yb);
+        const bf16x8 xt = __builtin_bit_cast(bf16x8, u32x4{(unsigned)xl, (unsigned)(xl >> 32), (unsigned)xh, (unsigned)(xh >> 32)});
+        const bf16x8 yt = __builtin_bit_cast(bf16x8, u32x4{(unsigned)yl, (unsigned)(yl >> 32), (unsigned)yh, (unsigned)(yh >> 32)});
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+          dw1[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, dhfrag[jt][pair]), xt, dw1[jt][ct], 0, 0, 0);   // rows j, cols c
+          dw2[ct][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yt, __builtin_bit_cast(bf16x8, gfrag[jt][pair]), dw2[ct][jt], 0, 0, 0);    // rows c, cols j
+        }
+      }
+      if (ct0 == 0) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)        // db1[j] += sum over the pair's 32 tokens of dh: one more column block, against ones
+          db1m[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, dhfrag[jt][pair]), ones, db1m[jt], 0, 0, 0);
+        typedef __attribute__((address_space(3))) s16x4* lptr;
+        const char* ay = tY + pair * 32 * ROWB + toff_own;
+        s16x4 ya = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)ay), yb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(ay + 16 * ROWB));
+        const unsigned long long yl = __builtin_bit_cast(unsigned long long, ya), yh = __builtin_bit_cast(unsigned long long, yb);
+        const bf16x8 yo = __builtin_bit_cast(bf16x8, u32x4{(unsigned)yl, (unsigned)(yl >> 32), (unsigned)yh, (unsigned)(yh >> 32)});
+        db2m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yo, ones, db2m, 0, 0, 0);
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using IH = std::integral_constant<int, CT16 / 2>;
+    using IF = std::integral_constant<int, CT16>;
+    produce(I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    produce(I1{}); activate(I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    produce(I2{}); activate(I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    produce(I3{}); consume(I0{}, I0{}, IH{}); activate(I2{});
+    __builtin_amdgcn_sched_barrier(0);
+    consume(I0{}, IH{}, IF{}); activate(I3{});
+    __builtin_amdgcn_sched_barrier(0);
+    consume(I1{}, I0{}, IF{});
+  }
+  // ---- flush (true sums = run_sc x accumulators)
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) {
+    const int jb = j0 + jw + jt * 16;
+#pragma unroll
+    for (int ct = 0; ct < CT16; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        atomicAdd(&p.dw1[(long)(jb + 4 * fg + r) * C + ct * 16 + fr], dw1[jt][ct][r] * run_sc);
+        atomicAdd(&p.dw2[(long)(ct * 16 + 4 * fg + r) * p.hid + jb + fr], dw2[ct][jt][r] * run_sc);
+      }
+    if (fr == 0) {                             // every column of the ones-product holds the same sums: column 0 adds them
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&p.db1[jb + 4 * fg + r], db1m[jt][r] * run_sc);
+    }
+  }
+  if (do_db2 && fr == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(&p.db2[wave * 16 + 4 * fg + r], db2m[r] * run_sc);
+  }
+}
+
 template <int C> int launch_wgrad(const mvlt_mlp_args& a, hipStream_t s) {
   const size_t lds = (size_t)2 * 128 * C * 2 + (size_t)2 * 2 * 64 * 2 * C;      // weights + 2 x (x tile | dy tile)
   const int ny = a.hid / 128;
@@ -848,6 +1105,13 @@ template <int C> int launch_wgrad(const mvlt_mlp_args& a, hipStream_t s) {
   if (splits < 1) splits = 1;
   const int m_per_split = ((mtiles + splits - 1) / splits) * 64;
   splits = (a.M + m_per_split - 1) / m_per_split;
+  static const bool legacy = getenv("MVLT_MLP_LEGACY") != nullptr || getenv("MVLT_MLP_WGRAD_LEGACY") != nullptr;
+  if (!legacy && (!a.row_scale || a.rows_per_scale % 64 == 0)) {      // tile-uniform DropPath factor: the round-3 kernel
+    constexpr int NW = C == 64 ? 4 : 8;
+    hipFuncSetAttribute((const void*)mlp_wgrad2_kernel<C, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mlp_wgrad2_kernel<C, NW>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NW * 64), lds, s, a, m_per_split, splits, ny);
+    return mvlt_check_launch("mvlt_mlp_bwd_dw");
+  }
   hipFuncSetAttribute((const void*)mlp_wgrad_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((mlp_wgrad_kernel<C>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NT), lds, s, a, m_per_split, splits, ny);
   return mvlt_check_launch("mvlt_mlp_bwd_dw");

@@ -551,14 +551,18 @@ def test_transpose_cast(ops, dtype):
 
 
 # ------------------------------------------------------------------ fused MLP (stages 1 / 2)
-@pytest.mark.parametrize("Cdim,hid,M,Bsz", [(64, 512, 3 * 400, 3), (128, 1024, 2 * 333, 2), (64, 512, 130, 1)])
+@pytest.mark.parametrize("Cdim,hid,M,Bsz", [(64, 512, 3 * 400, 3), (128, 1024, 2 * 333, 2), (64, 512, 130, 1),
+                                            # samples of whole 64-token tiles (what the model's stages give: 4224 / 1152 rows per sample): the
+                                            # round-3 weight-gradient kernel (tile-uniform DropPath factor, dropped samples skipped); the last
+                                            # case has two DIFFERENT non-zero factors (the accumulator-rescale branch)
+                                            (64, 512, 3 * 448, 3), (128, 1024, 3 * 320, 3), (64, 512, 4 * 192, 4)])
 def test_fused_mlp(ops, Cdim, hid, M, Bsz):
     bf = torch.bfloat16
     x = rnd(M, Cdim, dtype=bf)
     w1, w2 = rnd(hid, Cdim, dtype=bf, seed=1, scale=Cdim ** -0.5), rnd(Cdim, hid, dtype=bf, seed=2, scale=hid ** -0.5)
     b1, b2 = 0.1 * rnd(hid, dtype=torch.float32, seed=3), 0.1 * rnd(Cdim, dtype=torch.float32, seed=4)
     res = rnd(M, Cdim, dtype=torch.float32, seed=5)
-    scale = torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.9][:Bsz], device=dev())
+    scale = torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.9, 1.0 / 0.75][:Bsz], device=dev())
     rps = M // Bsz
     out = torch.empty(M, Cdim, device=dev())
     hbuf = torch.empty(M, hid, device=dev(), dtype=bf)
