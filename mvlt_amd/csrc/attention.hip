@@ -8,6 +8,7 @@
 // and feeds P^T straight back as the B operand of O^T = V^T P^T.  Nothing but Q, K, V, O and the log-sum-exp
 // touches HBM.  fp32 instantiation (exact-f32 MFMA 32x32x2) serves the 1e-3 parity bar.
 #include "common.h"
+#include <type_traits>
 #include "../../include/mvlt_hip.h"
 
 namespace {
@@ -275,6 +276,344 @@ template <typename T> int launch_fwd(const mvlt_attn_args& a, hipStream_t s) {
     case 8: return launch_fwd_n<T, 8>(a, s);
     case 9: return launch_fwd_n<T, 9>(a, s);
     case 10: return launch_fwd_n<T, 10>(a, s);
+    default: break;
+  }
+  mvlt_set_error("mvlt_sr_attention_fwd: M=%d keys exceeds the 320-key LDS-resident design", a.M);
+  return MVLT_ERR_UNSUPPORTED;
+}
+
+
+// ------------------------------------------------------------------------------------------------ forward, round 3 (bf16)
+// Same math as attn_fwd_kernel, re-organised around what tools/probes/valu_rates.hip measured on gfx950: a wave issues one VALU instruction
+// per ~3.5 ns on its own, the SIMD retires one per ~1.55 ns (exp: 3.6 ns), a 32x32x16 MFMA occupies the matrix pipe for 16 ns, and the
+// two only overlap when their instructions are interleaved in the stream.  A 32-query tile needs 48 MFMAs (0.77 us) and, at best, ~4
+// VALU + 1 exp per score (96 scores per lane: ~0.85 us); the kernel above spends ~4 us per tile and SIMD (counters: 47 % of the wave
+// cycles parked at waits, 27 % issuing).  Changes:
+//  * the keys are cut into two blocks; the block-1 score MFMAs run under block 0's exponentials, block 0's P V MFMAs under block 1's, and
+//    the NEXT tile's first score MFMAs under this tile's normalise-and-store (slots pinned with sched_barrier(0));
+//  * the row maximum used as the exponent's reference is block 0's; block 1 only forces the usual rescale when its maximum is more than
+//    2^24 above it (a wave-uniform branch that LayerNorm-ed inputs never take) -- no multiply pass over the O accumulators;
+//  * a workgroup keeps K / V^T of its (batch, head) in LDS for a whole chunk of several hundred queries (a wave walks 4 - 9 tiles) and
+//    fetches the next tile's Q rows while the current tile computes;
+//  * V^T rows are stored with the keys of a 32-key tile permuted so that an MFMA A fragment is ONE 16-byte read (was two 8-byte reads,
+//    29 % bank conflicts), rows padded to a stride of 16 B mod 256 B (conflict-free for the 16-lane groups of ds_read_b128);
+//  * accumulators start from an inline zero (128 v_mov per tile in the kernel above), no masking code unless keys are padded.
+template <int NKT, bool PADDED>
+__global__ __launch_bounds__(NT, 2) void attn_fwd2_kernel(mvlt_attn_args p, int nq_chunks, int q_per_wg) {
+  typedef bf16 T;
+  constexpr int MP = NKT * 32;
+  constexpr int BT0 = (NKT + 1) / 2, BT1 = NKT - BT0;
+  constexpr int VPAD = 8;
+  constexpr int VS = MP + VPAD;               // V^T row stride (elements): 64 NKT + 16 bytes = an odd multiple of 16 B, so 16 consecutive rows
+                                              // at one column fall on 16 different 16-byte slots of the 256-byte bank window
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sK = (T*)smem;                           // [MP][64] swizzled
+  T* sVt = sK + MP * HD;                      // [64][VS], keys permuted inside each 32-key tile
+  char* sQ = (char*)(sVt + HD * VS);          // [4 waves][32 rows][128 B]: a wave's next Q tile, 16-B chunks XOR-swizzled by (row >> 1) & 7
+  char* sO = sQ + 4 * 4096;                   // [4 waves][16 rows][144 B]: O staging, half a tile at a time
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5, l31 = lane & 31;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, j = bid >> 3;
+  const int gidx = xcd + 8 * (j / nq_chunks);
+  const int chunk_id = j % nq_chunks;
+  if (gidx >= p.B * p.H) return;
+  const int b = gidx / p.H, h = gidx % p.H;
+
+  const T* Qg = (const T*)p.Q + (long)b * p.N * p.ldq + h * HD;
+  const T* Kg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.k_off + h * HD;
+  const T* Vg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.v_off + h * HD;
+  T* Og = (T*)p.O + (long)b * p.N * p.ldo + h * HD;
+
+  const int q_begin = chunk_id * q_per_wg;
+  const int q_end = min(p.N, q_begin + q_per_wg);
+  // Q rows and O rows go through LDS in full 128-byte lines: a row-per-lane access (each lane its own row, 16 or 8 bytes per instruction)
+  // makes every wave instruction touch 64 different lines -- with the stores and loads in that form the kernel ran 107 us on the stage-1
+  // shape, 68 us without the stores, 83 us with the loads served from cache (ablations, one box).  Q: four LDS-DMA instructions of eight
+  // rows each per tile, issued one tile ahead into the wave's own buffer; O: through a 16-row staging tile, 16 bytes per lane, eight
+  // lanes per row.
+  char* const myQ = sQ + wave * 4096;
+  char* const myO = sO + wave * 2304;
+  const unsigned myQ_lds = (unsigned)(uintptr_t)myQ;
+  const int qd_row = lane >> 3, qd_chunk = lane & 7;
+  const char* zsrc = (const char*)g_zero_page + ((lane * 16 + wave * 1024) & 65535);
+  auto dma_q = [&](int q0) {
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int row = 8 * k4 + qd_row, q = q0 + row;
+      const char* src = (const char*)(Qg + (long)q * p.ldq) + ((qd_chunk ^ ((row >> 1) & 7)) << 4);
+      glds16(q < q_end ? src : zsrc, __builtin_amdgcn_readfirstlane(myQ_lds + k4 * 1024));
+    }
+  };
+  dma_q(q_begin + wave * 32);
+  for (int u = tid; u < MP * 8; u += NT) {
+    const int r = u >> 3, c = u & 7;
+    u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+    if (r < p.M) {
+      kv = *(const u32x4*)(Kg + (long)r * p.ldkv + c * 8);
+      vv = *(const u32x4*)(Vg + (long)r * p.ldkv + c * 8);
+    }
+    *(u32x4*)(sK + Lds<T>::off(r, c * 8)) = kv;
+    // key r = 32 t + 16 s2 + 8 hi + 4 gg + lo  ->  column 32 t + 16 s2 + 8 gg + 4 hi + lo
+    const int col = (r & ~15) | (((r >> 2) & 1) << 3) | (((r >> 3) & 1) << 2) | (r & 3);
+    T ve[8];
+    *(u32x4*)ve = vv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sVt[(c * 8 + e) * VS + col] = ve[e];
+  }
+  __syncthreads();
+
+  const float sl2 = p.scale * 1.44269504088896340736f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 accA[BT0], accB[BT1 > 0 ? BT1 : 1], oacc[2];
+  bf16x8 qf[4];
+  // Operand fragments of one 4-MFMA step (a key tile of K, or a key tile of V^T for both halves of d) are read ONE STEP AHEAD into a
+  // two-deep register ring: a read issued right in front of its MFMA puts a full LDS latency in front of each of the 48 MFMAs of a tile.
+  // A tile is 2 NKT steps (block-1 scores, block-0 P V, block-1 P V, next tile's block-0 scores), so the ring parity is static.
+  bf16x8 fr[2][4];
+  auto readK = [&](auto parc, int t) {
+    constexpr int par = decltype(parc)::value;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fr[par][s] = *(const bf16x8*)(sK + Lds<T>::off(t * 32 + l31, 16 * s + 8 * g));
+  };
+  auto readV = [&](auto parc, int t) {
+    constexpr int par = decltype(parc)::value;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) fr[par][2 * s2 + dt] = *(const bf16x8*)(sVt + (32 * dt + l31) * VS + 32 * t + 16 * s2 + 8 * g);
+  };
+  auto mmaS = [&](auto parc, f32x16& acc) {                       // acc = K tile . Q^T   (rows = keys, cols = queries)
+    constexpr int par = decltype(parc)::value;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[par][s], qf[s], s == 0 ? zero16 : acc, 0, 0, 0);
+  };
+  auto mmaPV = [&](auto parc, const f32x16& pa, bool first) {     // O^T += V^T[:, key tile] . P^T, P from the tile's score accumulators
+    constexpr int par = decltype(parc)::value;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 pf;                             // B operand: P^T, k-slot (g, jj) <-> key 32 t + 16 s2 + 4 g + 8 (jj >> 2) + (jj & 3)
+#pragma unroll
+      for (int jj = 0; jj < 8; jj += 2) {
+        const bf16x2 pr = __builtin_convertvector(f32x2{pa[8 * s2 + jj], pa[8 * s2 + jj + 1]}, bf16x2);
+        pf[jj] = pr[0]; pf[jj + 1] = pr[1];
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[par][2 * s2 + dt], pf, (first && s2 == 0) ? zero16 : oacc[dt], 0, 0, 0);
+    }
+  };
+  auto mask = [&](f32x16& acc, int t) {                           // padded keys (>= M) score -inf; only instantiated when M < MP
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
+      if (key >= p.M) acc[r] = -INFINITY;
+    }
+  };
+  auto rowmax = [&](const f32x16* acc, int nt) {
+    float m = acc[0][0];
+#pragma unroll
+    for (int ti = 0; ti < BT0; ++ti) {
+      if (ti < nt) {
+#pragma unroll
+        for (int r = (ti == 0 ? 1 : 0); r < 16; r += 2)
+          m = (r + 1 < 16) ? __builtin_fmaxf(__builtin_fmaxf(m, acc[ti][r]), acc[ti][r + 1]) : __builtin_fmaxf(m, acc[ti][r]);
+      }
+    }
+    return fmaxf(m, __shfl_xor(m, 32));
+  };
+  float mneg, sum, mref;
+  auto expo = [&](f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], sl2, mneg));
+      acc[r] = e;
+      sum += e;
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  // step index -> ring parity: steps of a tile run [0, BT1) block-1 scores, [BT1, NKT) block-0 P V, [NKT, NKT + BT1) block-1 P V,
+  // [NKT + BT1, 2 NKT) next tile's block-0 scores; the fragments of step n sit in ring slot n & 1
+#define ATTN_PAR(n) std::integral_constant<int, ((n) & 1)>{}
+
+  auto take_q = [&](int q_after) {              // the landed tile -> fragments; then the buffer is free for the tile after it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(myQ + l31 * 128 + (((2 * s + g) ^ ((l31 >> 1) & 7)) << 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (q_after < q_end) dma_q(q_after);
+  };
+  int q0 = q_begin + wave * 32;
+  if (q0 < q_end) {
+    take_q(q0 + 4 * 32);
+    // the first tile's block-0 scores, un-overlapped (ring parity as in the steady state: step NKT + BT1 + k)
+    readK(ATTN_PAR(NKT + BT1), 0);
+#pragma unroll
+    for (int k = 0; k < BT0; ++k) {
+      if (k + 1 < BT0) { if ((NKT + BT1 + k + 1) & 1) readK(P1{}, k + 1); else readK(P0{}, k + 1); }
+      else if (BT1 > 0) readK(P0{}, BT0);              // step 0 of the steady state: parity 0
+      else readV(P0{}, 0);
+      if ((NKT + BT1 + k) & 1) mmaS(P1{}, accA[k]); else mmaS(P0{}, accA[k]);
+    }
+  }
+  for (; q0 < q_end; q0 += 4 * 32) {
+    const int q = q0 + l31;
+    const bool has_next = q0 + 4 * 32 < q_end;
+    // ---- block-1 scores (MFMA)  ||  block-0 numerators relative to block 0's row maximum (VALU)
+    if (PADDED) {
+#pragma unroll
+      for (int ti = 0; ti < BT0; ++ti) mask(accA[ti], ti);
+    }
+    const float m0 = rowmax(accA, BT0);
+    mneg = -m0 * sl2;
+    sum = 0.f;
+    mref = m0;
+#pragma unroll
+    for (int k = 0; k < BT1; ++k) {
+      if (k + 1 < BT1) { if ((k + 1) & 1) readK(P1{}, BT0 + k + 1); else readK(P0{}, BT0 + k + 1); }
+      else { if (BT1 & 1) readV(P1{}, 0); else readV(P0{}, 0); }
+      if (k & 1) mmaS(P1{}, accB[k]); else mmaS(P0{}, accB[k]);
+      // block-0 tiles spread over the BT1 steps (the last step takes what is left)
+#pragma unroll
+      for (int ti = 0; ti < BT0; ++ti)
+        if (ti == k || (k == BT1 - 1 && ti > k)) expo(accA[ti]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (BT1 == 0) {
+#pragma unroll
+      for (int ti = 0; ti < BT0; ++ti) expo(accA[ti]);
+    }
+    // ---- block-0 P V (MFMA)  ||  block-1 numerators (VALU)
+#pragma unroll
+    for (int k = 0; k < BT0; ++k) {
+      const int n = BT1 + k;
+      if (k + 1 < BT0) { if ((n + 1) & 1) readV(P1{}, k + 1); else readV(P0{}, k + 1); }
+      else if (BT1 > 0) { if ((n + 1) & 1) readV(P1{}, BT0); else readV(P0{}, BT0); }
+      else { if ((n + 1) & 1) readK(P1{}, 0); else readK(P0{}, 0); }
+      if (n & 1) mmaPV(P1{}, accA[k], k == 0); else mmaPV(P0{}, accA[k], k == 0);
+      if (BT1 > 0) {
+        if (k == 0) {
+          if (PADDED) {
+#pragma unroll
+            for (int ti = 0; ti < BT1; ++ti) mask(accB[ti], BT0 + ti);
+          }
+          const float m1 = rowmax(accB, BT1);
+          // block 0's maximum stays the reference unless block 1 tops it by more than 2^24 (exp2 arguments up to 24 lose nothing in
+          // fp32 and are far from bf16's range end); otherwise the standard rescale of what block 0 has left behind -- after its P V
+          // MFMAs of this very step have been accounted for: the branch sits behind them in program order
+          const bool far = (m1 - m0) * sl2 > 24.0f;
+          if (__builtin_amdgcn_ballot_w64(far) != 0) {
+            const float alpha = far ? __builtin_amdgcn_exp2f((m0 - m1) * sl2) : 1.0f;
+            mref = far ? m1 : m0;
+            mneg = -mref * sl2;
+            sum *= alpha;
+            // the remaining block-0 numerators (tiles 1 .. BT0-1 are still to be multiplied into O) and what tile 0 already added
+#pragma unroll
+            for (int ti = 1; ti < BT0; ++ti)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) accA[ti][r] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+          }
+        }
+#pragma unroll
+        for (int ti = 0; ti < BT1; ++ti)
+          if (ti == k || (k == BT0 - 1 && ti > k)) expo(accB[ti]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- block-1 P V
+#pragma unroll
+    for (int k = 0; k < BT1; ++k) {
+      const int n = NKT + k;
+      if (k + 1 < BT1) { if ((n + 1) & 1) readV(P1{}, BT0 + k + 1); else readV(P0{}, BT0 + k + 1); }
+      else { if ((n + 1) & 1) readK(P1{}, 0); else readK(P0{}, 0); }
+      if (n & 1) mmaPV(P1{}, accB[k], false); else mmaPV(P0{}, accB[k], false);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- the next tile's block-0 scores (MFMA)  ||  normalise and store this tile (VALU)
+    if (has_next) take_q(q0 + 8 * 32);
+#pragma unroll
+    for (int k = 0; k < BT0; ++k) {
+      const int n = NKT + BT1 + k;
+      if (k + 1 < BT0) { if ((n + 1) & 1) readK(P1{}, k + 1); else readK(P0{}, k + 1); }
+      else if (BT1 > 0) readK(P0{}, BT0);
+      else readV(P0{}, 0);
+      if (has_next) { if (n & 1) mmaS(P1{}, accA[k]); else mmaS(P0{}, accA[k]); }
+      if (k == 0) {
+        sum += __shfl_xor(sum, 32);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        // oacc[dt][r] = O[q = l31][d = 32 dt + (r&3) + 8 (r>>2) + 4 g]: sixteen rows at a time into the staging tile (8-byte pieces), back out
+        // as 16 bytes per lane with eight lanes per row, stored as whole 128-byte lines
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          if ((l31 >> 4) == pass) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+              for (int rq = 0; rq < 4; ++rq) {
+                const bf16x2 a = __builtin_convertvector(f32x2{oacc[dt][4 * rq] * inv, oacc[dt][4 * rq + 1] * inv}, bf16x2);
+                const bf16x2 c = __builtin_convertvector(f32x2{oacc[dt][4 * rq + 2] * inv, oacc[dt][4 * rq + 3] * inv}, bf16x2);
+                *(u32x2*)(myO + (l31 & 15) * 144 + (32 * dt + 8 * rq + 4 * g) * 2) = u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, c)};
+              }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int row = 8 * hh + (lane >> 3), qq = q0 + 16 * pass + row;
+            const u32x4 v = *(const u32x4*)(myO + row * 144 + (lane & 7) * 16);
+            if (qq < q_end) *(u32x4*)(Og + (long)qq * p.ldo + (lane & 7) * 8) = v;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (q < q_end && g == 0 && p.lse) p.lse[((long)b * p.H + h) * p.N + q] = mref * p.scale + __logf(sum);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef ATTN_PAR
+}
+
+template <int NKT> int launch_fwd2_n(const mvlt_attn_args& a, hipStream_t s) {
+  constexpr int MP = NKT * 32;
+  constexpr int VPAD = 8;
+  const size_t lds = (size_t)(MP * HD + HD * (MP + VPAD)) * 2 + 4 * 4096 + 4 * 2304;
+  const int groups = a.B * a.H;
+  // a workgroup's four waves walk its query chunk in 32-query tiles; chunks as long as the grid allows (K / V staging is per chunk):
+  // at least ~1024 workgroups (two per CU, two rounds) when the problem has them
+  int nq = 1;
+  while (nq < 8 && groups * nq < 1024 && (a.N + nq) / (nq + 1) >= 512) ++nq;
+  int q_per_wg = ((a.N + nq - 1) / nq + 127) / 128 * 128;
+  nq = (a.N + q_per_wg - 1) / q_per_wg;
+  const int grid = 8 * ((groups + 7) / 8) * nq;
+  if (a.M == MP) {
+    hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_fwd2_kernel<NKT, false>), dim3(grid), dim3(NT), lds, s, a, nq, q_per_wg);
+  } else {
+    hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_fwd2_kernel<NKT, true>), dim3(grid), dim3(NT), lds, s, a, nq, q_per_wg);
+  }
+  return mvlt_check_launch("mvlt_sr_attention_fwd");
+}
+
+int launch_fwd2(const mvlt_attn_args& a, hipStream_t s) {
+  switch ((a.M + 31) / 32) {
+    case 1: return launch_fwd2_n<1>(a, s);
+    case 2: return launch_fwd2_n<2>(a, s);
+    case 3: return launch_fwd2_n<3>(a, s);
+    case 4: return launch_fwd2_n<4>(a, s);
+    case 5: return launch_fwd2_n<5>(a, s);
+    case 6: return launch_fwd2_n<6>(a, s);
+    case 7: return launch_fwd2_n<7>(a, s);
+    case 8: return launch_fwd2_n<8>(a, s);
+    case 9: return launch_fwd2_n<9>(a, s);
+    case 10: return launch_fwd2_n<10>(a, s);
     default: break;
   }
   mvlt_set_error("mvlt_sr_attention_fwd: M=%d keys exceeds the 320-key LDS-resident design", a.M);
@@ -798,6 +1137,8 @@ extern "C" int mvlt_sr_attention_fwd(const mvlt_attn_args* a, void* stream) {
   const int pc = a->dtype == 0 ? 8 : 4;
   MVLT_REQUIRE(a->ldq % pc == 0 && a->ldkv % pc == 0 && a->ldo % pc == 0 && a->k_off % pc == 0 && a->v_off % pc == 0,
                "mvlt_sr_attention_fwd: strides/offsets must be multiples of %d elements", pc);
+  static const bool legacy = getenv("MVLT_ATTN_FWD_LEGACY") != nullptr;
+  if (a->dtype == 0 && !legacy) return launch_fwd2(*a, (hipStream_t)stream);
   return a->dtype == 0 ? launch_fwd<bf16>(*a, (hipStream_t)stream) : launch_fwd<float>(*a, (hipStream_t)stream);
 }
 
