@@ -143,34 +143,67 @@ def roofline_cases(B, device):
     w2 = (torch.randn(64, 64, device=device) * 0.125).to(bf)
     b2 = torch.randn(64, device=device)
     o2 = torch.empty(M2, 64, device=device, dtype=bf)
+    # the single largest launch of the step (profiles/r03_kernel_stats.csv): the fused-MLP weight gradients of a stage-1 block,
+    # dW1 / db1 / dW2 / db2 from x and dy with the hidden activation recomputed on chip (M = B*4224 tokens, C = 64, hidden 512), with the
+    # per-sample DropPath factors of the step (one sample in ten dropped)
+    hid = 512
+    xm = torch.randn(M2, 64, device=device).to(bf)
+    dym = torch.randn(M2, 64, device=device).to(bf)
+    w1 = (torch.randn(hid, 64, device=device) * 0.125).to(bf)
+    w2t = (torch.randn(hid, 64, device=device) * hid ** -0.5).to(bf)
+    b1 = torch.randn(hid, device=device) * 0.1
+    dw1, db1, dw2, db2 = (torch.zeros(hid, 64, device=device), torch.zeros(hid, device=device), torch.zeros(64, hid, device=device),
+                          torch.zeros(64, device=device))
+    rs = torch.full((B,), 1.0 / 0.9, device=device)
+    rs[::10] = 0.0
     return [("conv192", lambda: ops.gemm_nt(x, w, out, M, C, 9 * C, C, 9 * C, C, a_map=amap), 2.0 * M * C * 9 * C),
-            ("proj64", lambda: ops.gemm_nt(x2, w2, o2, M2, 64, 64, 64, 64, 64, bias=b2), 2.0 * (2 * M2 * 64 + 64 * 64))]
+            ("proj64", lambda: ops.gemm_nt(x2, w2, o2, M2, 64, 64, 64, 64, 64, bias=b2), 2.0 * (2 * M2 * 64 + 64 * 64)),
+            ("mlp_dw64", lambda: ops.mlp_bwd_dw(xm, dym, w1, w2t, b1, dw1, db1, dw2, db2, M2, 64, hid, row_scale=rs, rows_per_scale=4224),
+             2.0 * 2 * M2 * 64 * hid)]
 
 
 def time_dominant_kernel(model, B, device):
-    """Roofline of the dominant kernel family of the step, the NT GEMMs on LDS-DMA rings (~30 % of GPU time in profiles/): the
-    largest in-step launch is the MIM decoder's 192->192 conv3x3 at 32x32 (conv4 / conv_concat3 forward and their
-    input gradients) = a gathered-row GEMM with M = B*1024, N = 192, K = 9*192, MFMA-bound (AI ~ 575 F/B), run by
-    `conv3_nt_kernel` (the family's loop with the 3x3-gathered operand on a channel-sliced LDS halo).  Timed
-    with HIP events on torch's current stream, which is the stream mvlt_gemm_nt launches on.  `traffic` = HBM bytes
-    per launch from the committed PMC passes (profiles/*_roofline_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, collected
-    offline because counters cannot be read inside this process).  Also reported: the HBM-bound K=64 shape
-    (stage-1 q/proj-like projection) of the same kernel family."""
-    (_, f1, flops), (_, f2, bytes2) = roofline_cases(B, device)
-    ms, ms2 = _time_launch(f1), _time_launch(f2)
-    tf = flops / (ms * 1e-3) / 1e12
-    traffic = traffic2 = None
+    """`roofline` = the launch with the largest share of the step (profiles/r03_kernel_stats.csv: the fused-MLP weight gradients of the two
+    stage-1 blocks, ~0.45 ms each), timed alone with HIP events on torch's current stream = the stream the C ABI launches on.
+    Its ALGORITHMIC work is the two weight-gradient products dW1 = dh^T x and dW2 = dy^T g: 2 x 2*M*C*hid FLOP (M = B*4224, C = 64, hid = 512)
+    over 2 x M*C bf16 operand bytes; the kernel EXECUTES twice that (h = x W1^T and dg = dy W2 are recomputed on chip so that nothing of
+    size M x hid touches HBM) plus ~18 VALU instructions per hidden element and token for GELU / GELU', which is what bounds it
+    (VALU / MFMA issue rates measured by tools/probes/valu_rates.hip).  `bound` is "mfma" in the contract's
+    vocabulary: the fraction says how far the launch is from doing its algorithmic FLOPs at matrix-pipe speed.
+    `siblings`: round 2's roofline launch (the MIM decoder's 192->192 conv3x3 as a gathered GEMM, MFMA-bound) and the HBM-bound K = 64
+    projection of the same GEMM family.  `traffic` = HBM bytes per launch from the committed PMC passes
+    (profiles/*_roofline_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, collected offline: counters cannot be read inside this process)."""
+    (_, f1, flops1), (_, f2, bytes2), (_, f3, flops3) = roofline_cases(B, device)
+    ms, ms2, ms3 = _time_launch(f1), _time_launch(f2), _time_launch(f3)
     tj = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_roofline_traffic.json")) if B == 256 else []
-    if tj:
-        t = json.load(open(os.path.join(ROOT, "profiles", tj[-1])))
-        traffic, traffic2 = t.get("conv192", {}).get("hbm_bytes"), t.get("proj64", {}).get("hbm_bytes")
-    return dict(kernel="conv3_nt_kernel<32, 192, 1> (bf16, 128x192 tile, 3x3-gather A from an LDS halo, plain epilogue): MIM conv3x3 192->192 @32x32 as GEMM (M=B*1024, N=192, K=1728)",
-                bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_BF16_TFLOPS, 4),
-                traffic=traffic, ms_per_launch=round(ms, 4), algorithmic_flops=flops,
-                hbm_bound_sibling=dict(kernel="gemm_nt_dma_kernel<64, 0, 1, 64, 128> (bf16, 128x64 tile): K=64 N=64 projection, M=B*4224", bound="hbm",
-                                       achieved=round(bytes2 / (ms2 * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                                       frac=round(bytes2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), ms_per_launch=round(ms2, 4),
-                                       algorithmic_bytes=bytes2, traffic=traffic2))
+    t = json.load(open(os.path.join(ROOT, "profiles", tj[-1]))) if tj else {}
+    tr = lambda k: t.get(k, {}).get("hbm_bytes")
+    tf1, tf3 = flops1 / (ms * 1e-3) / 1e12, flops3 / (ms3 * 1e-3) / 1e12
+    M2 = B * 4224
+    return dict(kernel="mlp_wgrad2_kernel<64, 4> (bf16): fused-MLP weight gradients of a stage-1 block, M = B*4224 tokens, C = 64, hidden 512 "
+                       "(dW1, db1, dW2, db2; h / dg / GELU / GELU' recomputed on chip; DropPath factors per sample, dropped samples skipped)",
+                share_of_step="largest single launch: 2 x ~0.45 ms of a ~23.5 ms step (profiles/r03_kernel_stats.csv)",
+                bound="mfma", achieved=round(tf3, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf3 / PEAK_BF16_TFLOPS, 4),
+                traffic=tr("mlp_dw64"), ms_per_launch=round(ms3, 4), algorithmic_flops=flops3, executed_flops=2 * flops3,
+                algorithmic_bytes=2.0 * 2 * M2 * 64,
+                limiter="VALU: ~18 instructions per (token, hidden unit) for GELU and GELU' against 4 x 64 MACs on the matrix pipe",
+                siblings=[
+                    dict(kernel="conv3_nt_kernel<32, 192, 1> (bf16, 128x192 tile, 3x3-gather A from an LDS halo): MIM conv3x3 192->192 @32x32 as GEMM "
+                                "(M=B*1024, N=192, K=1728) -- round 2's roofline launch", bound="mfma", achieved=round(tf1, 1), peak=PEAK_BF16_TFLOPS,
+                         unit="TFLOP/s", frac=round(tf1 / PEAK_BF16_TFLOPS, 4), traffic=tr("conv192"), ms_per_launch=round(ms, 4), algorithmic_flops=flops1),
+                    dict(kernel="gemm_nt_dma_kernel<64, 0, 1, 64, 128> (bf16, 128x64 tile): K=64 N=64 projection, M=B*4224", bound="hbm",
+                         achieved=round(bytes2 / (ms2 * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                         frac=round(bytes2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), ms_per_launch=round(ms2, 4), algorithmic_bytes=bytes2, traffic=tr("proj64"))])
+
+
+def step_traffic():
+    """HBM GB per step of the committed FETCH_SIZE / WRITE_SIZE passes over whole steps (tools/step_traffic.sh -> profiles/rNN_step_traffic.txt)"""
+    import re
+    fs = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_step_traffic.txt"))
+    if not fs:
+        return None, None
+    m = re.search(r"([0-9.]+) GB", open(os.path.join(ROOT, "profiles", fs[-1])).readline())
+    return (float(m.group(1)) if m else None), fs[-1]
 
 
 def spawn_ranks(n):
@@ -324,6 +357,9 @@ def main():
                                 "target": 0.40},
             }
             line["roofline"] = time_dominant_kernel(core, B, device)
+            gb, src = step_traffic()
+            line["step"] = {"executed_tflops": round(per_gpu * executed / 1e12, 1), "ms": round(ms_step, 3),
+                            "hbm_gb_per_step": gb, "hbm_tb_per_s": round(gb / ms_step, 2) if gb else None, "hbm_source": src}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)

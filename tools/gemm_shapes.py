@@ -66,6 +66,10 @@ def main():
     for nm in ("mlp_fwd", "mlp_bwd_dx", "mlp_bwd_dw"):
         if hasattr(ops, nm):
             wrap(nm, lambda a, k: tuple(x for x in a if isinstance(x, int))[:3])
+    # SR attention: key = (B, heads, queries, keys)
+    for nm in ("sr_attention_fwd", "sr_attention_bwd"):
+        if hasattr(ops, nm):
+            wrap(nm, lambda a, k: tuple(x for x in a if isinstance(x, int))[:4])
     step(3)
     torch.cuda.synchronize()
     for nm, f in orig.items():

@@ -43,7 +43,8 @@ def main():
         wc = m.get("SQ_WAVE_CYCLES", 0)
         gui = m.get("GRBM_GUI_ACTIVE", 0)
         d = [us,
-             m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * 256 * 4) if gui else "",           # busy cycles summed over SIMDs / (cycles x 1024 SIMDs)
+             m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui / 8.0 * 256 * 4) if gui else "",     # busy cycles summed over the 1024 SIMDs / (shader cycles x 1024);
+                                                                                               # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs (was 8x too small)
              m.get("SQ_WAIT_ANY", 0) / wc if wc else "", m.get("SQ_WAIT_INST_ANY", 0) / wc if wc else "",
              m.get("SQ_ACTIVE_INST_ANY", 0) / wc if wc else "", m.get("SQ_ACTIVE_INST_VALU", 0) / wc if wc else "",
              m.get("SQ_LDS_BANK_CONFLICT", 0) / m["SQ_LDS_IDX_ACTIVE"] if m.get("SQ_LDS_IDX_ACTIVE") else ""]

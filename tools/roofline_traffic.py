@@ -16,7 +16,7 @@ import json
 import sys
 from collections import defaultdict
 
-CASE = {"conv3_nt_kernel<32, 192": "conv192", "gemm_nt_dma_kernel<192": "conv192", "gemm_nt_dma_kernel<128": "conv192", "gemm_nt_dma_kernel<64": "proj64", "gemm_nt_kernelIDF16bLi128": "conv192",
+CASE = {"mlp_wgrad2_kernel<64": "mlp_dw64", "mlp_wgrad_kernel<64": "mlp_dw64", "conv3_nt_kernel<32, 192": "conv192", "gemm_nt_dma_kernel<192": "conv192", "gemm_nt_dma_kernel<128": "conv192", "gemm_nt_dma_kernel<64": "proj64", "gemm_nt_kernelIDF16bLi128": "conv192",
         "gemm_nt_kernelIDF16bLi64": "proj64", "bfloat16_copy_kernel": "calib_cast"}
 
 
