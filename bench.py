@@ -242,6 +242,7 @@ def main():
     ap.add_argument("--task", default="pretrain", choices=["pretrain", "finetune"],
                     help="pretrain = {mlm,itm,t2i} (BASELINE configs 2-4); finetune = {cls} only (config 5, dws_mvlt_ft_exp48)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the isolated roofline launches (whole-step counter passes: tools/step_traffic.sh)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--spawn", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1 (RCCL path at world size 1)")
     args = ap.parse_args()
@@ -356,7 +357,8 @@ def main():
                                 "mfma_frac": round(3 * FWD_BLOCKS * B / (blocks_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                 "target": 0.40},
             }
-            line["roofline"] = time_dominant_kernel(core, B, device)
+            if not args.no_roofline:
+                line["roofline"] = time_dominant_kernel(core, B, device)
             gb, src = step_traffic()
             line["step"] = {"executed_tflops": round(per_gpu * executed / 1e12, 1), "ms": round(ms_step, 3),
                             "hbm_gb_per_step": gb, "hbm_tb_per_s": round(gb / ms_step, 2) if gb else None, "hbm_source": src}

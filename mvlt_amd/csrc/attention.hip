@@ -298,9 +298,10 @@ template <typename T> int launch_fwd(const mvlt_attn_args& a, hipStream_t s) {
 //  * V^T rows are stored with the keys of a 32-key tile permuted so that an MFMA A fragment is ONE 16-byte read (was two 8-byte reads,
 //    29 % bank conflicts), rows padded to a stride of 16 B mod 256 B (conflict-free for the 16-lane groups of ds_read_b128);
 //  * accumulators start from an inline zero (128 v_mov per tile in the kernel above), no masking code unless keys are padded.
-template <int NKT, bool PADDED>
-__global__ __launch_bounds__(NT, 2) void attn_fwd2_kernel(mvlt_attn_args p, int nq_chunks, int q_per_wg) {
+template <int NKT, bool PADDED, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd2_kernel(mvlt_attn_args p, int nq_chunks, int q_per_wg) {
   typedef bf16 T;
+  constexpr int NTH = NW * 64;       // 4 waves while two workgroups fit a CU (M <= 192 keys), 8 waves in one workgroup per CU beyond
   constexpr int MP = NKT * 32;
   constexpr int BT0 = (NKT + 1) / 2, BT1 = NKT - BT0;
   constexpr int VPAD = 8;
@@ -309,8 +310,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd2_kernel(mvlt_attn_args p, int 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sK = (T*)smem;                           // [MP][64] swizzled
   T* sVt = sK + MP * HD;                      // [64][VS], keys permuted inside each 32-key tile
-  char* sQ = (char*)(sVt + HD * VS);          // [4 waves][32 rows][128 B]: a wave's next Q tile, 16-B chunks XOR-swizzled by (row >> 1) & 7
-  char* sO = sQ + 4 * 4096;                   // [4 waves][16 rows][144 B]: O staging, half a tile at a time
+  char* sQ = (char*)(sVt + HD * VS);          // [NW waves][32 rows][128 B]: a wave's next Q tile, 16-B chunks XOR-swizzled by (row >> 1) & 7
+  char* sO = sQ + NW * 4096;                  // [NW waves][16 rows][144 B]: O staging, half a tile at a time
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 5, l31 = lane & 31;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd2_kernel(mvlt_attn_args p, int 
     }
   };
   dma_q(q_begin + wave * 32);
-  for (int u = tid; u < MP * 8; u += NT) {
+  for (int u = tid; u < MP * 8; u += NTH) {
     const int r = u >> 3, c = u & 7;
     u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
     if (r < p.M) {
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd2_kernel(mvlt_attn_args p, int 
   };
   int q0 = q_begin + wave * 32;
   if (q0 < q_end) {
-    take_q(q0 + 4 * 32);
+    take_q(q0 + NW * 32);
     // the first tile's block-0 scores, un-overlapped (ring parity as in the steady state: step NKT + BT1 + k)
     readK(ATTN_PAR(NKT + BT1), 0);
 #pragma unroll
@@ -457,9 +458,9 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd2_kernel(mvlt_attn_args p, int 
       if ((NKT + BT1 + k) & 1) mmaS(P1{}, accA[k]); else mmaS(P0{}, accA[k]);
     }
   }
-  for (; q0 < q_end; q0 += 4 * 32) {
+  for (; q0 < q_end; q0 += NW * 32) {
     const int q = q0 + l31;
-    const bool has_next = q0 + 4 * 32 < q_end;
+    const bool has_next = q0 + NW * 32 < q_end;
     // ---- block-1 scores (MFMA)  ||  block-0 numerators relative to block 0's row maximum (VALU)
     if (PADDED) {
 #pragma unroll
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd2_kernel(mvlt_attn_args p, int 
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- the next tile's block-0 scores (MFMA)  ||  normalise and store this tile (VALU)
-    if (has_next) take_q(q0 + 8 * 32);
+    if (has_next) take_q(q0 + 2 * NW * 32);
 #pragma unroll
     for (int k = 0; k < BT0; ++k) {
       const int n = NKT + BT1 + k;
@@ -580,26 +581,32 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd2_kernel(mvlt_attn_args p, int 
 #undef ATTN_PAR
 }
 
-template <int NKT> int launch_fwd2_n(const mvlt_attn_args& a, hipStream_t s) {
+template <int NKT, int NW> int launch_fwd2_nw(const mvlt_attn_args& a, hipStream_t s) {
   constexpr int MP = NKT * 32;
   constexpr int VPAD = 8;
-  const size_t lds = (size_t)(MP * HD + HD * (MP + VPAD)) * 2 + 4 * 4096 + 4 * 2304;
+  const size_t lds = (size_t)(MP * HD + HD * (MP + VPAD)) * 2 + NW * 4096 + NW * 2304;
   const int groups = a.B * a.H;
-  // a workgroup's four waves walk its query chunk in 32-query tiles; chunks as long as the grid allows (K / V staging is per chunk):
+  // a workgroup's waves walk its query chunk in 32-query tiles; chunks as long as the grid allows (K / V staging is per chunk):
   // at least ~1024 workgroups (two per CU, two rounds) when the problem has them
   int nq = 1;
   while (nq < 8 && groups * nq < 1024 && (a.N + nq) / (nq + 1) >= 512) ++nq;
-  int q_per_wg = ((a.N + nq - 1) / nq + 127) / 128 * 128;
+  int q_per_wg = ((a.N + nq - 1) / nq + 32 * NW - 1) / (32 * NW) * (32 * NW);
   nq = (a.N + q_per_wg - 1) / q_per_wg;
   const int grid = 8 * ((groups + 7) / 8) * nq;
   if (a.M == MP) {
-    hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_fwd2_kernel<NKT, false>), dim3(grid), dim3(NT), lds, s, a, nq, q_per_wg);
+    hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKT, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_fwd2_kernel<NKT, false, NW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
   } else {
-    hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_fwd2_kernel<NKT, true>), dim3(grid), dim3(NT), lds, s, a, nq, q_per_wg);
+    hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKT, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_fwd2_kernel<NKT, true, NW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
   }
   return mvlt_check_launch("mvlt_sr_attention_fwd");
+}
+// four waves while two workgroups fit the 160 KB of a CU (up to 192 keys: 75.8 KB each), eight waves in ONE workgroup beyond (272 keys at
+// 384 px: 100 KB with four waves would leave one wave per SIMD)
+template <int NKT> int launch_fwd2_n(const mvlt_attn_args& a, hipStream_t s) {
+  if constexpr (NKT <= 6) return launch_fwd2_nw<NKT, 4>(a, s);
+  else return launch_fwd2_nw<NKT, 8>(a, s);
 }
 
 int launch_fwd2(const mvlt_attn_args& a, hipStream_t s) {
@@ -610,13 +617,9 @@ int launch_fwd2(const mvlt_attn_args& a, hipStream_t s) {
     case 4: return launch_fwd2_n<4>(a, s);
     case 5: return launch_fwd2_n<5>(a, s);
     case 6: return launch_fwd2_n<6>(a, s);
-    case 7: return launch_fwd2_n<7>(a, s);
-    case 8: return launch_fwd2_n<8>(a, s);
-    case 9: return launch_fwd2_n<9>(a, s);
-    case 10: return launch_fwd2_n<10>(a, s);
     default: break;
   }
-  mvlt_set_error("mvlt_sr_attention_fwd: M=%d keys exceeds the 320-key LDS-resident design", a.M);
+  mvlt_set_error("mvlt_sr_attention_fwd: the round-3 kernel takes M <= 192 keys, got %d", a.M);
   return MVLT_ERR_UNSUPPORTED;
 }
 
@@ -1137,8 +1140,10 @@ extern "C" int mvlt_sr_attention_fwd(const mvlt_attn_args* a, void* stream) {
   const int pc = a->dtype == 0 ? 8 : 4;
   MVLT_REQUIRE(a->ldq % pc == 0 && a->ldkv % pc == 0 && a->ldo % pc == 0 && a->k_off % pc == 0 && a->v_off % pc == 0,
                "mvlt_sr_attention_fwd: strides/offsets must be multiples of %d elements", pc);
+  // round-3 kernel up to 192 keys (every 256-px configuration); beyond (272 keys at 384 px) its two score blocks no longer fit the
+  // register budget of two waves per SIMD next to the O accumulators (144 + 32 of 256), and the round-2 kernel is the faster one
   static const bool legacy = getenv("MVLT_ATTN_FWD_LEGACY") != nullptr;
-  if (a->dtype == 0 && !legacy) return launch_fwd2(*a, (hipStream_t)stream);
+  if (a->dtype == 0 && !legacy && a->M <= 192) return launch_fwd2(*a, (hipStream_t)stream);
   return a->dtype == 0 ? launch_fwd<bf16>(*a, (hipStream_t)stream) : launch_fwd<float>(*a, (hipStream_t)stream);
 }
 
