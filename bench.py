@@ -3,8 +3,9 @@
 forward + loss + backward + gradient all-reduce + AdamW) on N MI355X of one node.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # starts its own N ranks (child processes, before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # or under a launcher (RANK / LOCAL_RANK / WORLD_SIZE from the environment)
 
 Workload = BASELINE.json configs[1]: pvlt_tiny, 256x256 RGB + 128 BERT tokens, batch 256 per GPU, bf16 MFMA
 operands with fp32 accumulation / residual stream / master weights, synthetic data generated on device
@@ -12,8 +13,9 @@ operands with fp32 accumulation / residual stream / master weights, synthetic da
 engine_grid_masking.py:40-143): clean image on even steps, grid-masked image on odd steps.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline      the dominant kernel timed live with HIP events on its launch stream (see DESIGN.md for the
-                algorithmic FLOP count used)
+  roofline      the largest single launch of the step (fused-MLP weight gradients of a stage-1 block) timed live with HIP events on
+                its launch stream: algorithmic vs executed FLOPs, PMC traffic; round 2's MFMA- and HBM-bound launches as `siblings`
+  step          executed TFLOP/s and HBM GB per step (committed whole-step counter passes) over ms per step
   cpu_baseline  the CPU oracle (oracle/pvlt_oracle.py, kind "port") timed on this box's host cores at config #1
                 shapes (4 pairs), N=1 only: full train step (fwd+loss+bwd+AdamW) = `value`, forward+loss beside it
   flops         reference-equivalent and EXECUTED FLOPs per pair, and the blocks-only (SRAttention + MLP) MFMA utilisation
