@@ -293,7 +293,10 @@ def attn_ref(q, kv, H, scale):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("B,H,N,M", [(2, 1, 4224, 192), (2, 2, 1152, 192), (1, 5, 384, 192), (3, 8, 192, 192),
-                                     (1, 1, 9344, 272), (2, 8, 272, 272), (2, 2, 29, 29), (1, 1, 596, 29), (1, 3, 100, 320)])
+                                     (1, 1, 9344, 272), (2, 8, 272, 272), (2, 2, 29, 29), (1, 1, 596, 29), (1, 3, 100, 320),
+                                     # round-3 forward (<= 192 keys): padded keys inside the second block, an odd number of key tiles
+                                     # (3 + 2), two tiles (1 + 1), and a query count that leaves partial tiles in several chunks
+                                     (2, 2, 700, 100), (1, 3, 333, 150), (2, 1, 1500, 64), (1, 2, 260, 40)])
 def test_sr_attention_fwd(ops, dtype, B, H, N, M):
     if dtype == torch.float32 and M > 288:
         pytest.skip("fp32 K/V^T of 320 keys exceed 160 KB LDS")
@@ -327,6 +330,28 @@ def test_sr_attention_bwd(ops, dtype, B, H, N, M):
     tol = 3e-2 if dtype == torch.bfloat16 else 2e-3
     assert maxrel(dq.float(), qr.grad) < tol
     assert maxrel(dkv, kvr.grad) < tol
+
+
+def test_sr_attention_fwd_late_maximum(ops):
+    """The round-3 forward takes the FIRST key block's row maximum as the exponent reference and rescales only when the second block tops it
+    by more than 2^24.  Random data never takes that branch (cdna guide rule 26: a rare data-dependent branch needs an input that forces
+    it): here one key of the second block is aligned with every query so that its score exceeds everything in the first block by far more
+    than the threshold -- for half of the queries only (the branch is wave-uniform, the factor per lane), and once within the threshold."""
+    bf = torch.bfloat16
+    B, H, N, M = 2, 1, 320, 192
+    for boost in (60.0, 3.0):                              # 60 / 0.125-scaled: ~2^80 above block 0 (rescale); 3: inside the threshold
+        q = rnd(B, N, 64, dtype=bf)
+        kv = rnd(B, M, 128, dtype=bf, seed=1)
+        kv[:, 150, :64] = 0
+        kv[:, 150, :8] = boost                             # key 150 (second block): score = boost * sum(q[:8]) * scale
+        q[:, ::2, :8] = q[:, ::2, :8].abs() + 2.0          # every other query: large positive score on that key
+        o = torch.empty_like(q)
+        lse = torch.empty(B, H, N, device=dev())
+        ops.sr_attention_fwd(q, kv, o, lse, B, H, N, M, 64, 128, 64, 0, 64, 0.125)
+        ref, ref_lse = attn_ref(q, kv, H, 0.125)
+        assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+        assert maxrel(o.float(), ref) < TOL[bf], boost
+        assert ((lse - ref_lse).abs() / ref_lse.abs().clamp_min(1.0)).max().item() < 2e-2, boost
 
 
 def test_sr_attention_bwd_bf16_dkv(ops):
