@@ -127,6 +127,34 @@ __device__ __forceinline__ void mlp_epilogue(const mvlt_mlp_args& p, char* smem,
   float lgam[8], accg[8], accb[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { lgam[e] = lnb ? p.lnb_gamma[nc + e] : 0.f; accg[e] = 0.f; accb[e] = 0.f; }
+  // Everything the row passes below read from HBM -- the fp32 residual rows (forward), or the LayerNorm input rows, their statistics and
+  // the gradient stream's current rows (backward with lnb_x) -- is requested HERE for all of the wave's 32 rows, before the first staging
+  // pass: read inside the passes, each of the 2 x NIT row groups paid its own HBM round trip behind the previous group's stores (the
+  // epilogue was 52 of 280 us of the stage-1 forward and ~120 of 530 us of the stage-1 input-gradient launch, by ablation)
+  constexpr int NIT = 16 / RPI;
+  f32x4 pre_a[MT][NIT][2];       // forward: residual row chunk; backward: LayerNorm input row chunk
+  u32x4 pre_o[MT][NIT];          // backward: current gradient-stream row chunk (bf16 x 8)
+  float pre_mean[MT][NIT], pre_rstd[MT][NIT], pre_rs[MT][NIT], pre_sc[MT][NIT];
+  if (MODE == 0 || lnb) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = m0 + wave * WR + i * 16 + it * RPI + lane / CPR;
+        const bool ok = m < p.M;
+        const long idx = (long)(ok ? m : 0) * C + nc;
+        const float* src = (MODE == 0) ? (const float*)p.residual + idx : p.lnb_x + idx;
+        pre_a[i][it][0] = *(const f32x4*)src;
+        pre_a[i][it][1] = *(const f32x4*)(src + 4);
+        pre_rs[i][it] = p.row_scale ? p.row_scale[(ok ? m : 0) / p.rows_per_scale] : 1.0f;
+        if (MODE == 1) {
+          pre_o[i][it] = *(const u32x4*)((const bf16*)p.lnb_dx + idx);
+          pre_mean[i][it] = p.lnb_mean[ok ? m : 0];
+          pre_rstd[i][it] = p.lnb_rstd[ok ? m : 0];
+          pre_sc[i][it] = p.lnb_dx2 ? p.lnb_dx2_scale[(ok ? m : 0) / p.lnb_dx2_rows_per_scale] : 0.f;
+        }
+      }
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -145,11 +173,10 @@ __device__ __forceinline__ void mlp_epilogue(const mvlt_mlp_args& p, char* smem,
       if (m >= p.M) continue;
       f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      const float rs = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+      const float rs = (MODE == 0 || lnb) ? pre_rs[i][it] : (p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.0f);
       const long idx = (long)m * C + nc;
       if (MODE == 0) {
-        const float* R = (const float*)p.residual + idx;
-        f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
+        const f32x4 r0 = pre_a[i][it][0], r1 = pre_a[i][it][1];
         float rr[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (v[e] + b2v[e]) * rs + rr[e];
@@ -197,11 +224,10 @@ __device__ __forceinline__ void mlp_epilogue(const mvlt_mlp_args& p, char* smem,
         *(bf16x8*)((bf16*)p.out + idx) = o;
       } else {
         // dx (+)= LayerNorm backward of d(LN output) = v * rs; optional second output dx2 = dx * DropPath factor of the other branch
-        const float* xr = p.lnb_x + idx;
-        const f32x4 x0 = *(const f32x4*)xr, x1 = *(const f32x4*)(xr + 4);
-        const bf16x8 old = *(const bf16x8*)((const bf16*)p.lnb_dx + idx);
+        const f32x4 x0 = pre_a[i][it][0], x1 = pre_a[i][it][1];
+        const bf16x8 old = __builtin_bit_cast(bf16x8, pre_o[i][it]);
         const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        const float mean = p.lnb_mean[m], rstd = p.lnb_rstd[m];
+        const float mean = pre_mean[i][it], rstd = pre_rstd[i][it];
         float g[8], xh[8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -221,7 +247,7 @@ __device__ __forceinline__ void mlp_epilogue(const mvlt_mlp_args& p, char* smem,
         for (int e = 0; e < 8; ++e) { dxv[e] = rstd * (g[e] - s1 - xh[e] * s2) + (float)old[e]; o1[e] = (bf16)dxv[e]; }
         *(bf16x8*)((bf16*)p.lnb_dx + idx) = o1;
         if (p.lnb_dx2) {
-          const float sc = p.lnb_dx2_scale[m / p.lnb_dx2_rows_per_scale];
+          const float sc = pre_sc[i][it];
           bf16x8 o2;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o2[e] = (bf16)(dxv[e] * sc);
