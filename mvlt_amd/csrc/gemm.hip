@@ -1378,7 +1378,10 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
   constexpr int LPT = A_ITERS + B_ITERS;
   constexpr int STAGE = (BMT + BN) * ROWB;
   // chunk swizzle by row: 16 consecutive rows x one logical chunk must spread over all 64 banks
-  auto swzk = [](int row, int chunk) { return CH == 8 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3)); };
+  // (four chunks per row, BK = 32: a ds_read_b128 lane group holds rows {r, r+12} at one chunk and {r+4, r+8} at the next for each r & 3 --
+  // the mask must differ between those four row quads in a way that keeps chunk ^ mask distinct: (-(row >> 2)) & 3 does, (row >> 2) & 3, round
+  // 2's choice, maps them onto two slots: 43 % LDS bank conflicts in the stage-3 fc1 + GELU launch)
+  auto swzk = [](int row, int chunk) { return CH == 8 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((0 - (row >> 2)) & 3)); };
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
