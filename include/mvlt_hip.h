@@ -145,7 +145,9 @@ int mvlt_batch_sum(const void* in, float* out, int B, int R, int C, long batch_s
 /* Spatial-reduction attention core: O = softmax(Q K^T * scale) V per (batch, head), head_dim = 64,
  * M <= 320 keys (whole K/V of a head stays in LDS; single-pass softmax).  No mask (reference
  * libs/pvlt.py:113-117 applies none).  Q: (B,N,ldq) with head h at columns [64h,64h+64); K,V: (B,M,ldkv)
- * rows, head h at columns k_off+64h / v_off+64h of the kv buffer; O like Q.  lse[B,H,N] fp32 saved for bwd. */
+ * rows, head h at columns k_off+64h / v_off+64h of the kv buffer; O like Q.  lse[B,H,N] fp32 saved for bwd.
+ * lse = ref * scale + log(sum of exp((s - ref) * scale)) where ref is a row maximum of the scores (bf16, M <= 192: the maximum over the
+ * first half of the keys unless the second half tops it by 2^24 -- the value of lse does not depend on which). */
 typedef struct mvlt_attn_args {
   const void* Q; const void* KV; void* O; float* lse;
   int B, H, N, M;
@@ -288,7 +290,10 @@ int mvlt_weight_prep(const mvlt_prep_desc* descs /* device */, const int* blk_st
  *   mvlt_mlp_bwd_dx : out[M,C] (bf16) = ((dy W2) * gelu'(x W1^T + b1)) W1 * row_scale
  *                     w1 = W1 [hid,C], wb = W1^T [C,hid], wc = W2^T [hid,C]
  *   mvlt_mlp_bwd_dw : dW1[hid,C] += dh^T x, db1 += colsum dh, dW2[C,hid] += (dy*row_scale)^T gelu(h), db2 += colsum dy*row_scale
- *                     (fp32 atomics into caller-zeroed buffers; dh, h recomputed on chip)  w1 = W1, wc = W2^T */
+ *                     (fp32 atomics into caller-zeroed buffers; dh, h recomputed on chip)  w1 = W1, wc = W2^T
+ * Kernel selection (same results either way, tests/test_kernels_gpu.py::test_fused_mlp): without h_out the forward and the input gradient run
+ * the software-pipelined kernel (hid >= 128); rows_per_scale % 64 == 0 (or no row_scale) lets the weight gradients take the per-tile
+ * DropPath factor path -- a 64-token tile then never straddles two samples, tiles of samples whose factor is 0 are skipped. */
 typedef struct mvlt_mlp_args {
   const void* x; const void* dy;
   const void* w1; const void* wb; const void* wc;
