@@ -249,6 +249,57 @@ def test_gradients_do_not_accumulate_across_engine_order_steps():
     assert all(float(p.grad.max()) == 4.0 and float(p.grad.min()) == 4.0 for p in m.parameters())      # (alignment gaps of G excepted)
 
 
+class _RaisingFn(torch.autograd.Function):
+    """a backward node that dies after the HIP-scheduled part of the pass has started"""
+
+    @staticmethod
+    def forward(ctx, x, S):
+        ctx.S = S
+        return x * 1.0
+
+    @staticmethod
+    def backward(ctx, dy):
+        ctx.S.queue_finalize()
+        ctx.S.G.add_(100.0)
+        raise RuntimeError("kernel check failed")
+
+
+def test_a_backward_that_raises_does_not_poison_the_next_pass():
+    """`_finalize_queued` is cleared by the autograd engine's final callback; a backward that raises drops the
+    callback, and without a reset every later pass would skip begin_backward (G never zeroed) and _finalize (no fold, no gradient
+    exchange).  run_forward calls FlatStore.new_pass() in every grad-enabled forward."""
+    m = _toy_store()
+    S = m.store
+    aborted = []
+    S.on_pass_aborted = lambda st: aborted.append(1)
+    done = []
+    S.on_backward_done = lambda st: done.append(1)
+    x = torch.ones(2, requires_grad=True)
+    with pytest.raises(RuntimeError, match="kernel check failed"):
+        _RaisingFn.apply(x, S).sum().backward()
+    assert S._finalize_queued and float(S.G.max()) == 100.0           # the state the dead pass leaves behind
+    S.new_pass()                                                      # what the next forward does
+    assert not S._finalize_queued and aborted == [1]
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    y = _SideEffectFn.apply(x, S, 2.0, *[p for _, p in S.fn_params])
+    opt.zero_grad()
+    y.sum().backward()
+    assert float(S.G.max()) == 2.0 and float(S.G.min()) == 2.0 and done == [1]      # zeroed again, finalised again
+
+
+def test_gradient_accumulation_survives_a_frozen_first_parameter():
+    """the zero-or-accumulate decision of begin_backward looked at the FIRST parameter only; a frozen one
+    (requires_grad=False: .grad stays None for ever) made every pass zero G."""
+    m = _toy_store()
+    S = m.store
+    next(iter(m.parameters())).requires_grad_(False)
+    x = torch.ones(2, requires_grad=True)
+    for _ in range(2):                                                # two passes without zero_grad must add up
+        y = _SideEffectFn.apply(x, S, 3.0, *[p for _, p in S.fn_params])
+        y.sum().backward()
+    assert float(S.G.max()) == 6.0
+
+
 def test_deferred_data_parallel_scale_is_applied_once():
     m = _toy_store()
     S = m.store
