@@ -67,18 +67,30 @@ def _worker(rank, world, port, kind, q):
         from mvlt_amd.optim import FusedAdamW
         core = _model(seed=9 + rank)                 # different start weights: the wrapper must broadcast rank 0's
         p_init = _model(seed=9).state_dict()
-        if kind == "ours":
+        if kind in ("ours", "ours_scaler"):
             model = DataParallel(core)
         else:
             model = torch.nn.parallel.DistributedDataParallel(core, device_ids=[0])
         opt = FusedAdamW(core, lr=1e-3, weight_decay=0.05)
         batch = _batch(rank)
-        _grads(model, batch)
         S = core.store
-        S.sync_grads()
-        scale = S.pending_grad_scale                 # 1/world still owed to the fused optimizer's kernel (DataParallel only)
-        g_mine = (S.G * scale).cpu()
-        opt.step()
+        if kind == "ours_scaler":
+            # the engine's own path: BF16Scaler runs backward + FusedAdamW.step with the 1/world factor riding in the optimizer kernel
+            # (G keeps the rank SUM; nothing may be owed once the call returns)
+            from mvlt_amd.engine import BF16Scaler, train_step
+            total, _ = train_step(model, batch, 1, True)
+            for p_ in model.parameters():
+                p_.grad = None
+            BF16Scaler()(total, opt)
+            assert S.pending_grad_scale == 1.0 and not S.scale_in_optimizer
+            g_mine = (S.G / world).cpu()
+        else:
+            _grads(model, batch)
+            S.sync_grads()
+            scale = S.pending_grad_scale             # 1.0: outside the engine's scaler the wrapper hands out final (mean) gradients
+            assert scale == 1.0
+            g_mine = (S.G * scale).cpu()
+            opt.step()
         torch.cuda.synchronize()
         # single-process reference, computed by every rank for itself: both batches through a plain model with rank 0's weights,
         # gradients averaged, one FusedAdamW step on the mean
@@ -104,7 +116,7 @@ def _worker(rank, world, port, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["ours", "torch_ddp"])
+@pytest.mark.parametrize("kind", ["ours", "ours_scaler", "torch_ddp"])
 def test_two_ranks_average_gradients_like_ddp(kind, parity):
     world = 2
     ctx = mp.get_context("spawn")
