@@ -568,7 +568,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd2_kernel(mvl
           for (int hh = 0; hh < 2; ++hh) {
             const int row = 8 * hh + (lane >> 3), qq = q0 + 16 * pass + row;
             const u32x4 v = *(const u32x4*)(myO + row * 144 + (lane & 7) * 16);
-            if (qq < q_end) *(u32x4*)(Og + (long)qq * p.ldo + (lane & 7) * 8) = v;
+            if (qq < q_end) st_g<MVLT_NT_ATTN>((u32x4*)(Og + (long)qq * p.ldo + (lane & 7) * 8), v);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
     __syncthreads();                                   // (A) tile q0 landed; previous tile's dS / dQ tiles are complete
     if (q_prev >= 0 && tid < 256) {                    // deferred dQ store of the previous tile: 16 B per thread
       const int r = tid >> 3, c = tid & 7;
-      if (q_prev + r < q_end) *(u32x4*)(dQg + (long)(q_prev + r) * p.ldq + c * 8) = *(const u32x4*)(sdQ + r * HD + c * 8);
+      if (q_prev + r < q_end) st_g<MVLT_NT_ATTN>((u32x4*)(dQg + (long)(q_prev + r) * p.ldq + c * 8), *(const u32x4*)(sdQ + r * HD + c * 8));
     }
     const float lse_now = lse_cur;
     if (q0 + 32 < q_end) {
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
   __syncthreads();
   if (q_prev >= 0 && tid < 256) {
     const int r = tid >> 3, c = tid & 7;
-    if (q_prev + r < q_end) *(u32x4*)(dQg + (long)(q_prev + r) * p.ldq + c * 8) = *(const u32x4*)(sdQ + r * HD + c * 8);
+    if (q_prev + r < q_end) st_g<MVLT_NT_ATTN>((u32x4*)(dQg + (long)(q_prev + r) * p.ldq + c * 8), *(const u32x4*)(sdQ + r * HD + c * 8));
   }
   // ---- flush dK / dV
 #pragma unroll

@@ -15,6 +15,39 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// Streaming global accesses (`global_store_* ... nt`, `global_load_* ... nt`).  An activation or gradient tensor written by a GEMM epilogue
+// is read back by a LATER launch, long after it would have left the 4 MB L2 of an XCD; written the normal way (write-back, line allocated)
+// it pushes the operand tiles the running workgroups share -- the weights, the A rows of the n-tiles of one m-tile -- out of that L2.
+// Measured (tools/ubench_mlpgemm.py, MI355X): stage-3 fc1 + GELU 212 -> 180 us, stage-4 190 -> 155 us, stage-4 gelu'-dgrad 224 -> 188 us,
+// stage-3 fc1 dgrad 130 -> 110 us; whole step 23.05 -> 22.75 ms with the GEMM epilogues alone (bits 0 and 6).  The same hint on the pure
+// streaming kernels is a LOSS: LayerNorm outputs (norm.hip) +0.27 ms -- their consumer is the next launch and the 256 MB Infinity Cache
+// serves part of it, which `nt` gives up; the MIM decoder's BatchNorm / upsample kernels +0.05 ms; the fused-MLP and attention epilogues
+// are neutral.  MVLT_NT_MASK selects the groups (A/B builds: tools/build_alt.sh ... -DMVLT_NT_MASK=0x..); the default is what measured best.
+#ifndef MVLT_NT_MASK
+#define MVLT_NT_MASK 0x41
+#endif
+#define MVLT_NT_GEMM ((MVLT_NT_MASK >> 0) & 1)
+#define MVLT_NT_NORM ((MVLT_NT_MASK >> 1) & 1)
+#define MVLT_NT_MLP ((MVLT_NT_MASK >> 2) & 1)
+#define MVLT_NT_ATTN ((MVLT_NT_MASK >> 3) & 1)
+#define MVLT_NT_EW ((MVLT_NT_MASK >> 4) & 1)
+#define MVLT_NT_MIM ((MVLT_NT_MASK >> 5) & 1)
+#define MVLT_NT_LD ((MVLT_NT_MASK >> 6) & 1)       // read-once operands of epilogues / streaming kernels
+template <bool NTF, typename V> __device__ __forceinline__ void st_g(V* p, const V& v) {
+  if constexpr (!NTF) *p = v;
+  else if constexpr (sizeof(V) == 16) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), (u32x4*)p);
+  else if constexpr (sizeof(V) == 8) __builtin_nontemporal_store(__builtin_bit_cast(u32x2, v), (u32x2*)p);
+  else if constexpr (sizeof(V) == 4) __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, v), (uint32_t*)p);
+  else { static_assert(sizeof(V) == 2, "st_g: 2 / 4 / 8 / 16-byte values"); __builtin_nontemporal_store(__builtin_bit_cast(uint16_t, v), (uint16_t*)p); }
+}
+template <bool NTF, typename V> __device__ __forceinline__ V ld_g(const V* p) {
+  if constexpr (!NTF) return *p;
+  else if constexpr (sizeof(V) == 16) return __builtin_bit_cast(V, __builtin_nontemporal_load((const u32x4*)p));
+  else if constexpr (sizeof(V) == 8) return __builtin_bit_cast(V, __builtin_nontemporal_load((const u32x2*)p));
+  else if constexpr (sizeof(V) == 4) return __builtin_bit_cast(V, __builtin_nontemporal_load((const uint32_t*)p));
+  else { static_assert(sizeof(V) == 2, "ld_g: 2 / 4 / 8 / 16-byte values"); return __builtin_bit_cast(V, __builtin_nontemporal_load((const uint16_t*)p)); }
+}
+
 #define MVLT_OK 0
 #define MVLT_ERR_ARG -1
 #define MVLT_ERR_LAUNCH -2

@@ -158,13 +158,13 @@ __device__ __forceinline__ void nt_epilogue(const mvlt_gemm_nt_args& p, f32x4 (&
         };
         auto store8 = [&](void* base, const float* o) {
           if (ofp32) {
-            *(f32x4*)((float*)base + idx) = f32x4{o[0], o[1], o[2], o[3]};
-            *(f32x4*)((float*)base + idx + 4) = f32x4{o[4], o[5], o[6], o[7]};
+            st_g<MVLT_NT_GEMM>((f32x4*)((float*)base + idx), f32x4{o[0], o[1], o[2], o[3]});
+            st_g<MVLT_NT_GEMM>((f32x4*)((float*)base + idx + 4), f32x4{o[4], o[5], o[6], o[7]});
           } else {
             bf16x8 a;
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = (bf16)o[e];
-            *(bf16x8*)((bf16*)base + idx) = a;
+            st_g<MVLT_NT_GEMM>((bf16x8*)((bf16*)base + idx), a);
           }
         };
         if (p.act == 1) {
@@ -271,6 +271,11 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fg = lane >> 4;
   const int ofp32 = p.out_dtype;
+#ifdef MVLT_NT_REUSE_ONLY
+  const bool nts = p.N > BN || p.K > 128;
+#else
+  const bool nts = true;
+#endif
   float* stage = (float*)smem + wave * 32 * LDW;
   const int ch = lane % CPR;
   const int nc = n0 + wn * WN + ch * 8;
@@ -337,8 +342,8 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       if (EPI == 2 && p.row_scale) rs[sl][it] = p.row_scale[fdiv24(mm, p.rows_per_scale, inv_rps)];
       if ((EPI == 2 || EPI == 4) && ok[sl][it]) {
         const void* src = (EPI == 2) ? p.R : p.H;
-        if (ofp32) { raw[sl][it][0] = *(const u32x4*)((const float*)src + idx[sl][it]); raw[sl][it][1] = *(const u32x4*)((const float*)src + idx[sl][it] + 4); }
-        else raw[sl][it][0] = *(const u32x4*)((const bf16*)src + idx[sl][it]);
+        if (ofp32) { raw[sl][it][0] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)src + idx[sl][it])); raw[sl][it][1] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)src + idx[sl][it] + 4)); }
+        else raw[sl][it][0] = ld_g<MVLT_NT_LD>((const u32x4*)((const bf16*)src + idx[sl][it]));
       }
     }
   };
@@ -369,13 +374,19 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       const long ix = idx[sl][it];
       auto store8 = [&](void* base, const float* o) {
         if (ofp32) {
-          *(f32x4*)((float*)base + ix) = f32x4{o[0], o[1], o[2], o[3]};
-          *(f32x4*)((float*)base + ix + 4) = f32x4{o[4], o[5], o[6], o[7]};
+          if (nts) {
+            st_g<MVLT_NT_GEMM>((f32x4*)((float*)base + ix), f32x4{o[0], o[1], o[2], o[3]});
+            st_g<MVLT_NT_GEMM>((f32x4*)((float*)base + ix + 4), f32x4{o[4], o[5], o[6], o[7]});
+          } else {
+            st_g<false>((f32x4*)((float*)base + ix), f32x4{o[0], o[1], o[2], o[3]});
+            st_g<false>((f32x4*)((float*)base + ix + 4), f32x4{o[4], o[5], o[6], o[7]});
+          }
         } else {
           bf16x8 a;
 #pragma unroll
           for (int e = 0; e < 8; ++e) a[e] = (bf16)o[e];
-          *(bf16x8*)((bf16*)base + ix) = a;
+          if (nts) st_g<MVLT_NT_GEMM>((bf16x8*)((bf16*)base + ix), a);
+          else st_g<false>((bf16x8*)((bf16*)base + ix), a);
         }
       };
       float o8[8];
@@ -501,13 +512,13 @@ __device__ __forceinline__ void nt_epilogue_192(const mvlt_gemm_nt_args& p, f32x
         }
         const long ix = phys * p.ldc + nc;
         if (ofp32) {
-          *(f32x4*)((float*)p.C + ix) = f32x4{v[0], v[1], v[2], v[3]};
-          *(f32x4*)((float*)p.C + ix + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          st_g<MVLT_NT_GEMM>((f32x4*)((float*)p.C + ix), f32x4{v[0], v[1], v[2], v[3]});
+          st_g<MVLT_NT_GEMM>((f32x4*)((float*)p.C + ix + 4), f32x4{v[4], v[5], v[6], v[7]});
         } else {
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-          *(bf16x8*)((bf16*)p.C + ix) = o;
+          st_g<MVLT_NT_GEMM>((bf16x8*)((bf16*)p.C + ix), o);
         }
       }
     }

@@ -11,9 +11,9 @@ constexpr int NT = 256;
 
 template <typename TO> __device__ __forceinline__ void store4(TO* p, const f32x4& v);
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const f32x4& v) {
-  *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  st_g<MVLT_NT_MIM>((bf16x4*)p, bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]});
 }
-template <> __device__ __forceinline__ void store4<float>(float* p, const f32x4& v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void store4<float>(float* p, const f32x4& v) { st_g<MVLT_NT_MIM>((f32x4*)p, v); }
 // four consecutive gradient values as fp32 from an fp32 or bf16 tensor (the decoder's first backward stages hand their activations'
 // gradients over in bf16: they are read twice by the BatchNorm backward and once by the producer)
 template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NT) void bn_norm_kernel(const float* z, int ldz, co
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean[c + e]) * rstd[c + e] * gamma[c + e] + beta[c + e];
-    if (y32) *(f32x4*)(y32 + r * ld32 + c) = o;
+    if (y32) st_g<MVLT_NT_MIM>((f32x4*)(y32 + r * ld32 + c), o);
     if (y16) store4<TO>(y16 + r * ld16 + c, o);
   }
 }
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NT) void ew_mul_kernel(float* out, int ldo, const f
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += o[e];
     }
-    if (out) *(f32x4*)(out + r * ldo + c) = v;
+    if (out) st_g<MVLT_NT_MIM>((f32x4*)(out + r * ldo + c), v);
     if (o16) store4<TO>(o16 + r * ld16 + c, v);
   }
 }
@@ -288,8 +288,8 @@ __global__ __launch_bounds__(NT) void upsample_fwd_row_kernel(const float* x, in
   const f32x4 v10 = *(const f32x4*)(xb + ((long)y1 * W + x0) * ldx), v11 = *(const f32x4*)(xb + ((long)y1 * W + x1) * ldx);
   const f32x4 v = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
   TO* o = out + (((long)b * Ho + oy) * Wo + ox) * ldo + c;
-  if constexpr (sizeof(TO) == 4) *(f32x4*)o = v;
-  else *(bf16x4*)o = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  if constexpr (sizeof(TO) == 4) st_g<MVLT_NT_MIM>((f32x4*)o, v);
+  else st_g<MVLT_NT_MIM>((bf16x4*)o, bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]});
 }
 // NCHW fp32 output: workgroup = (b, c, oy) plane row, threads = ox
 __global__ __launch_bounds__(NT) void upsample_fwd_nchw_kernel(const float* x, int ldx, int H, int W, int C, int s, float* out, int nrows) {
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NT) void upsample_fwd_nchw4_kernel(const float* x, 
       const float wx = fx - x0;
       o[e] = (1.f - wy) * ((1.f - wx) * src[rr][0][x0] + wx * src[rr][0][x1]) + wy * ((1.f - wx) * src[rr][1][x0] + wx * src[rr][1][x1]);
     }
-    *(f32x4*)(out + (long)row * Wo + q * 4) = o;
+    st_g<MVLT_NT_MIM>((f32x4*)(out + (long)row * Wo + q * 4), o);
   }
 }
 // backward, pixel-major dy: workgroup = input row (b, iy), threads = (ix, 4-channel group)
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NT) void upsample_bwd_row_kernel(const TDY* dy, int
   }
   float* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
   if (accumulate) acc += *(const f32x4*)d;
-  *(f32x4*)d = acc;
+  st_g<MVLT_NT_MIM>((f32x4*)d, acc);
 }
 // backward, NCHW dy (final x8 upsample, C = 3): workgroup = (b, c, iy).  Pass 1: thread ox folds its output column over
 // the rows that touch iy (coalesced plane-row reads) into LDS; pass 2: thread ix folds the <= 2s+1 columns that touch it.

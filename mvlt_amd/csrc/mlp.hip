@@ -86,7 +86,7 @@ __device__ __forceinline__ void mlp_load_rows(const mvlt_mlp_args& p, int m0, in
         }
         if (!ok) o = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         xfr[mt][ks] = o;
-        if (ok) *(bf16x8*)((bf16*)p.ln_y + (long)m * C + ks * 32 + fg * 8) = o;
+        if (ok) st_g<MVLT_NT_MLP>((bf16x8*)((bf16*)p.ln_y + (long)m * C + ks * 32 + fg * 8), o);
       }
     }
   } else {
@@ -144,11 +144,11 @@ __device__ __forceinline__ void mlp_epilogue(const mvlt_mlp_args& p, char* smem,
         const bool ok = m < p.M;
         const long idx = (long)(ok ? m : 0) * C + nc;
         const float* src = (MODE == 0) ? (const float*)p.residual + idx : p.lnb_x + idx;
-        pre_a[i][it][0] = *(const f32x4*)src;
-        pre_a[i][it][1] = *(const f32x4*)(src + 4);
+        pre_a[i][it][0] = ld_g<MVLT_NT_LD && MVLT_NT_MLP>((const f32x4*)src);
+        pre_a[i][it][1] = ld_g<MVLT_NT_LD && MVLT_NT_MLP>((const f32x4*)(src + 4));
         pre_rs[i][it] = p.row_scale ? p.row_scale[(ok ? m : 0) / p.rows_per_scale] : 1.0f;
         if (MODE == 1) {
-          pre_o[i][it] = *(const u32x4*)((const bf16*)p.lnb_dx + idx);
+          pre_o[i][it] = ld_g<MVLT_NT_LD && MVLT_NT_MLP>((const u32x4*)((const bf16*)p.lnb_dx + idx));
           pre_mean[i][it] = p.lnb_mean[ok ? m : 0];
           pre_rstd[i][it] = p.lnb_rstd[ok ? m : 0];
           pre_sc[i][it] = p.lnb_dx2 ? p.lnb_dx2_scale[(ok ? m : 0) / p.lnb_dx2_rows_per_scale] : 0.f;
@@ -182,14 +182,14 @@ __device__ __forceinline__ void mlp_epilogue(const mvlt_mlp_args& p, char* smem,
         for (int e = 0; e < 8; ++e) v[e] = (v[e] + b2v[e]) * rs + rr[e];
         if (p.out) {
           float* O = (float*)p.out + idx;
-          *(f32x4*)O = f32x4{v[0], v[1], v[2], v[3]};
-          *(f32x4*)(O + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          st_g<MVLT_NT_MLP>((f32x4*)O, f32x4{v[0], v[1], v[2], v[3]});
+          st_g<MVLT_NT_MLP>((f32x4*)(O + 4), f32x4{v[4], v[5], v[6], v[7]});
         }
         if (p.out_op) {                  // MFMA-operand copy of the block output (the last block of a stage writes only this one)
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-          *(bf16x8*)((bf16*)p.out_op + idx) = o;
+          st_g<MVLT_NT_MLP>((bf16x8*)((bf16*)p.out_op + idx), o);
         }
         if (p.post_y) {
           // LayerNorm of the OUTPUT row (the next block's norm1, reference libs/pvlt.py:141) while the row is here: its CPR lanes hold
@@ -215,13 +215,13 @@ __device__ __forceinline__ void mlp_epilogue(const mvlt_mlp_args& p, char* smem,
             o[e] = (bf16)((v[e] - mean) * rstd * g0[e] + be0[e]);
             o[4 + e] = (bf16)((v[4 + e] - mean) * rstd * g1[e] + be1[e]);
           }
-          *(bf16x8*)((bf16*)p.post_y + idx) = o;
+          st_g<MVLT_NT_MLP>((bf16x8*)((bf16*)p.post_y + idx), o);
         }
       } else if (!lnb) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)(v[e] * rs);
-        *(bf16x8*)((bf16*)p.out + idx) = o;
+        st_g<MVLT_NT_MLP>((bf16x8*)((bf16*)p.out + idx), o);
       } else {
         // dx (+)= LayerNorm backward of d(LN output) = v * rs; optional second output dx2 = dx * DropPath factor of the other branch
         const f32x4 x0 = pre_a[i][it][0], x1 = pre_a[i][it][1];
@@ -245,13 +245,13 @@ __device__ __forceinline__ void mlp_epilogue(const mvlt_mlp_args& p, char* smem,
         bf16x8 o1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { dxv[e] = rstd * (g[e] - s1 - xh[e] * s2) + (float)old[e]; o1[e] = (bf16)dxv[e]; }
-        *(bf16x8*)((bf16*)p.lnb_dx + idx) = o1;
+        st_g<MVLT_NT_MLP>((bf16x8*)((bf16*)p.lnb_dx + idx), o1);
         if (p.lnb_dx2) {
           const float sc = pre_sc[i][it];
           bf16x8 o2;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o2[e] = (bf16)(dxv[e] * sc);
-          *(bf16x8*)((bf16*)p.lnb_dx2 + idx) = o2;
+          st_g<MVLT_NT_MLP>((bf16x8*)((bf16*)p.lnb_dx2 + idx), o2);
         }
       }
     }
@@ -452,8 +452,16 @@ __device__ __forceinline__ float gelu_fast_grad1(float x) {
   return __builtin_fmaf(x * up, sg * sg * e, sg);
 }
 
+// Waves per SIMD the register allocation is held to: two.  The C = 64 input-gradient kernel needs 174 registers left alone; held to 168
+// (three waves per SIMD, 16 B of scratch per lane) the bare launch goes 420 -> 384 us (tools/ubench_mlp2.py; a VALU-bound body gains from
+// the third wave: tools/probes/valu_rates.hip, 16 x {MFMA + 8 v_fma} takes 38.8 / 27.5 / 21.5 ticks per SIMD at 2 / 3 / 4 waves) -- but the
+// step's launches run the LayerNorm-backward epilogue, whose prefetched rows then spill: +0.5 ms per step (same-box A/B 23.90 vs 23.38 ms).
+// Four waves (128 registers) spill 328 B per lane: 1778 us.  C = 128 forward at three waves: 260 B of scratch, 213 -> 390 us.
+#ifndef MVLT_PIPE_WAVES_64_1
+#define MVLT_PIPE_WAVES_64_1 2
+#endif
 template <int C, int MODE>
-__global__ __launch_bounds__(NT, 2) void mlp_pipe_kernel(mvlt_mlp_args p) {
+__global__ __launch_bounds__(NT, (C == 64 && MODE == 1) ? MVLT_PIPE_WAVES_64_1 : 2) void mlp_pipe_kernel(mvlt_mlp_args p) {
   constexpr int MT = 2, CT = C / 16, KS_C = C / 32;
   constexpr int NP = MODE == 1 ? 2 : 1;          // producer-side tiles per slice: W1 (, W2^T)
   constexpr int RB = 2 * C;                      // bytes per producer-tile row

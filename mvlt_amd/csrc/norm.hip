@@ -30,11 +30,16 @@ template <> struct Vec<bf16> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
   }
+  static __device__ __forceinline__ void load_s(const bf16* p, float* f) {        // streaming: a row read once by this launch
+    bf16x8 v = ld_g<MVLT_NT_LD && MVLT_NT_NORM>((const bf16x8*)p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+  }
   static __device__ __forceinline__ void store(bf16* p, const float* f) {
     bf16x8 v;
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
-    *(bf16x8*)p = v;
+    st_g<MVLT_NT_NORM>((bf16x8*)p, v);
   }
 };
 template <> struct Vec<float> {
@@ -44,10 +49,15 @@ template <> struct Vec<float> {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
   }
+  static __device__ __forceinline__ void load_s(const float* p, float* f) {
+    f32x4 a = ld_g<MVLT_NT_LD && MVLT_NT_NORM>((const f32x4*)p), b = ld_g<MVLT_NT_LD && MVLT_NT_NORM>((const f32x4*)(p + 4));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+  }
   static __device__ __forceinline__ void store(float* p, const float* f) {
     f32x4 a = {f[0], f[1], f[2], f[3]}, b = {f[4], f[5], f[6], f[7]};
-    *(f32x4*)p = a;
-    *(f32x4*)(p + 4) = b;
+    st_g<MVLT_NT_NORM>((f32x4*)p, a);
+    st_g<MVLT_NT_NORM>((f32x4*)(p + 4), b);
   }
 };
 
@@ -79,7 +89,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(mvlt_layernorm_args p) {
     for (int it = 0; it < MAXIT; ++it) {
       int c = gl + it * G;
       if (c < nchunk) {
-        Vec<T>::load(xr + c * VN, v[it]);
+        Vec<T>::load_s(xr + c * VN, v[it]);
 #pragma unroll
         for (int e = 0; e < VN; ++e) s += v[it][e];
       }
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_fixed_kernel(mvlt_layernorm_args p)
       if (live[u]) {
         const T* xr = (const T*)p.x + rowmap_base(xm, row) * p.ldx;
 #pragma unroll
-        for (int it = 0; it < ITS; ++it) Vec<T>::load(xr + (gl + it * G) * VN, v[u][it]);
+        for (int it = 0; it < ITS; ++it) Vec<T>::load_s(xr + (gl + it * G) * VN, v[u][it]);
       }
     }
 #pragma unroll
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_fixed_kernel(mvlt_layernorm_args p)
         for (int e = 0; e < VN; ++e) o[e] = (v[u][it][e] - mean) * rstd * ga[e] + be[e];
         if (addr) {                                  // "+ pos_embed": two 16-byte loads instead of eight scalar ones
           float ad[VN];
-          Vec<float>::load(addr + c0, ad);
+          Vec<float>::load_s(addr + c0, ad);
 #pragma unroll
           for (int e = 0; e < VN; ++e) o[e] += ad[e];
         }
@@ -268,8 +278,8 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
       int c = gl + it * G;
       if (c < nchunk) {
         float dyv[VN], xv[VN];
-        Vec<T>::load(dyr + c * VN, dyv);
-        Vec<TX>::load(xr + c * VN, xv);
+        Vec<T>::load_s(dyr + c * VN, dyv);
+        Vec<TX>::load_s(xr + c * VN, xv);
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
           float h = (xv[e] - mean) * rstd;
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
         for (int e = 0; e < VN; ++e) o[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
         if (p.dx_accumulate) {
           float old[VN];
-          Vec<TDX>::load(dxr + c * VN, old);
+          Vec<TDX>::load_s(dxr + c * VN, old);
 #pragma unroll
           for (int e = 0; e < VN; ++e) o[e] += old[e];
         }
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(NT) void batch_sum_kernel(const T* in, float* out, 
     r = (int)(i / nchunk); c = (int)(i - (long)r * nchunk);
     for (int b = bs; b < B; b += 16) {
       float v[VN];
-      Vec<T>::load(in + ((long)b * batch_stride + r) * ld + c * VN, v);
+      Vec<T>::load_s(in + ((long)b * batch_stride + r) * ld + c * VN, v);
 #pragma unroll
       for (int e = 0; e < VN; ++e) acc[e] += v[e];
     }
