@@ -32,7 +32,8 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define MVLT_NT_ATTN ((MVLT_NT_MASK >> 3) & 1)
 #define MVLT_NT_EW ((MVLT_NT_MASK >> 4) & 1)
 #define MVLT_NT_MIM ((MVLT_NT_MASK >> 5) & 1)
-#define MVLT_NT_LD ((MVLT_NT_MASK >> 6) & 1)       // read-once operands of epilogues / streaming kernels
+#define MVLT_NT_LD ((MVLT_NT_MASK >> 6) & 1)       // read-once operands of epilogues
+#define MVLT_NT_NORM_LD ((MVLT_NT_MASK >> 7) & 1)  // rows a LayerNorm launch reads once
 template <bool NTF, typename V> __device__ __forceinline__ void st_g(V* p, const V& v) {
   if constexpr (!NTF) *p = v;
   else if constexpr (sizeof(V) == 16) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), (u32x4*)p);

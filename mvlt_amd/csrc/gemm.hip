@@ -271,11 +271,6 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fg = lane >> 4;
   const int ofp32 = p.out_dtype;
-#ifdef MVLT_NT_REUSE_ONLY
-  const bool nts = p.N > BN || p.K > 128;
-#else
-  const bool nts = true;
-#endif
   float* stage = (float*)smem + wave * 32 * LDW;
   const int ch = lane % CPR;
   const int nc = n0 + wn * WN + ch * 8;
@@ -374,19 +369,13 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       const long ix = idx[sl][it];
       auto store8 = [&](void* base, const float* o) {
         if (ofp32) {
-          if (nts) {
-            st_g<MVLT_NT_GEMM>((f32x4*)((float*)base + ix), f32x4{o[0], o[1], o[2], o[3]});
-            st_g<MVLT_NT_GEMM>((f32x4*)((float*)base + ix + 4), f32x4{o[4], o[5], o[6], o[7]});
-          } else {
-            st_g<false>((f32x4*)((float*)base + ix), f32x4{o[0], o[1], o[2], o[3]});
-            st_g<false>((f32x4*)((float*)base + ix + 4), f32x4{o[4], o[5], o[6], o[7]});
-          }
+          st_g<MVLT_NT_GEMM>((f32x4*)((float*)base + ix), f32x4{o[0], o[1], o[2], o[3]});
+          st_g<MVLT_NT_GEMM>((f32x4*)((float*)base + ix + 4), f32x4{o[4], o[5], o[6], o[7]});
         } else {
           bf16x8 a;
 #pragma unroll
           for (int e = 0; e < 8; ++e) a[e] = (bf16)o[e];
-          if (nts) st_g<MVLT_NT_GEMM>((bf16x8*)((bf16*)base + ix), a);
-          else st_g<false>((bf16x8*)((bf16*)base + ix), a);
+          st_g<MVLT_NT_GEMM>((bf16x8*)((bf16*)base + ix), a);
         }
       };
       float o8[8];

@@ -31,7 +31,7 @@ template <> struct Vec<bf16> {
     for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
   }
   static __device__ __forceinline__ void load_s(const bf16* p, float* f) {        // streaming: a row read once by this launch
-    bf16x8 v = ld_g<MVLT_NT_LD && MVLT_NT_NORM>((const bf16x8*)p);
+    bf16x8 v = ld_g<MVLT_NT_NORM_LD>((const bf16x8*)p);
 #pragma unroll
     for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
   }
@@ -50,7 +50,7 @@ template <> struct Vec<float> {
     for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
   }
   static __device__ __forceinline__ void load_s(const float* p, float* f) {
-    f32x4 a = ld_g<MVLT_NT_LD && MVLT_NT_NORM>((const f32x4*)p), b = ld_g<MVLT_NT_LD && MVLT_NT_NORM>((const f32x4*)(p + 4));
+    f32x4 a = ld_g<MVLT_NT_NORM_LD>((const f32x4*)p), b = ld_g<MVLT_NT_NORM_LD>((const f32x4*)(p + 4));
 #pragma unroll
     for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
   }
