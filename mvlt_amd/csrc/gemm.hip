@@ -270,7 +270,9 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
   constexpr int NIT = 32 / RPI;
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fg = lane >> 4;
-  const int ofp32 = p.out_dtype;
+  // the GELU / GELU' epilogues write (and read) operand-dtype tensors only -- the host dispatch guarantees it -- so their fp32 store / load
+  // paths and the second half of every prefetch slot are not compiled in (EPI 4: 119 -> fewer registers, a third workgroup per CU)
+  const int ofp32 = (EPI == 3 || EPI == 4) ? 0 : p.out_dtype;
   float* stage = (float*)smem + wave * 32 * LDW;
   const int ch = lane % CPR;
   const int nc = n0 + wn * WN + ch * 8;
@@ -1744,8 +1746,8 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
       if (a->act == 0 && !a->col_sum && !a->R && !a->row_scale) epi = 6;
       else if (a->act == 0 && !a->col_sum && a->R) epi = 7;
     } else if (lean_ok) {
-      if (a->act == 1 && !a->R && !a->row_scale && !a->col_sum) epi = 3;
-      else if (a->act == 2 && !a->R && !a->row_scale && !a->col_sum) epi = 4;
+      if (a->act == 1 && !a->R && !a->row_scale && !a->col_sum && a->out_dtype == 0) epi = 3;
+      else if (a->act == 2 && !a->R && !a->row_scale && !a->col_sum && a->out_dtype == 0) epi = 4;
       else if (a->act == 0 && a->R && !a->col_sum) epi = 2;
       else if (a->act == 0 && !a->R && !a->row_scale && a->col_sum) epi = 5;
       else if (a->act == 0 && !a->R && !a->row_scale && !a->col_sum) epi = 1;
@@ -1756,7 +1758,7 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     // workgroup fits per CU and covers it (98304x1280x320: 240 -> 220 us, 49152x2048x512: 234 -> 201 us).  Long K loses to the
     // doubled barrier count (K = 2048: 103 -> 125 us), other epilogues are neutral; EPI 4 prefers its two-half H prefetch,
     // whose registers allow two workgroups per CU either way (220 / 213 us against 227 / 217 us).
-    const int bkd = (!narrow && a->a_map.mode == 0 && epi == 3 && a->K <= 512 && !getenv("MVLT_NT_BK64")) ? 32 : 64;
+    const int bkd = (!narrow && a->a_map.mode == 0 && (epi == 3 || (epi == 4 && !getenv("MVLT_NT_EPI4_BK64"))) && a->K <= 512 && !getenv("MVLT_NT_BK64")) ? 32 : 64;
     const int nkd = bkd == 32 ? (a->K + 31) / 32 : nk;
     int ns = nkd < 2 ? nkd : 2;
     if (const char* e = getenv("MVLT_NT_NS")) { ns = atoi(e); if (ns > nkd) ns = nkd; if (ns < 2) ns = nkd < 2 ? nkd : 2; if (ns > 6) ns = 6; }
@@ -1805,7 +1807,8 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
       else if (epi == 1) hipLaunchKernelGGL((gemm_nt_dma_kernel<192, 2, 1, 64>), grid192, block, lds3, s, *a, ns);
       else hipLaunchKernelGGL((gemm_nt_dma_kernel<192, 2, 5, 64>), grid192, block, lds3, s, *a, ns);
     } else if (narrow) MVLT_NT_LAUNCH(64, 64);
-    else if (bkd == 32) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 0, 3, 32>), grid, block, lds2, s, *a, ns);
+    else if (bkd == 32 && epi == 3) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 0, 3, 32>), grid, block, lds2, s, *a, ns);
+    else if (bkd == 32) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 0, 4, 32>), grid, block, lds2, s, *a, ns);
     else MVLT_NT_LAUNCH(128, 64);
 #undef MVLT_NT_LAUNCH_E
 #undef MVLT_NT_LAUNCH
