@@ -7,6 +7,8 @@ get weight_decay 0, everything else args.weight_decay.  It is a torch.optim.Opti
 lr schedulers (`param_groups[i]['lr']`) and state_dict()/load_state_dict() keep working; `param_groups[0]` is the
 no-decay group and `[1]` the decay group, like timm's add_weight_decay.
 """
+import os
+
 import torch
 
 from . import ops
@@ -29,7 +31,8 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._step = 0
         self._m = self._v = self._wd_mask = None
-        self._hp = None
+        self._hp = self._hp_pin = None
+        self._hp_ev = [None] * 4
         self._pending = None                  # (m, v) of a checkpoint loaded before the flat store exists
 
     def _ensure(self):
@@ -47,6 +50,11 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._v.copy_(pv)
                 self._pending = None
             self._hp = torch.zeros(8, device=S.P.device)
+            # the step's scalars reach the device through a ring of PINNED rows: from a pageable source hipMemcpyAsync stages the copy on
+            # the host and the call returns only when the stream has drained -- the host then enqueues the optimizer kernel and the whole
+            # next forward behind an idle GPU (1.3 ms per fine-tune step, tools/host_time.py).  An event per row guards its reuse.
+            self._hp_pin = torch.zeros(4, 8).pin_memory() if S.P.is_cuda and not os.environ.get("MVLT_HP_PAGEABLE") else None
+            self._hp_ev = [None] * 4
             # one byte per parameter: 1 = weight decay applies (timm's split: not for 1-D tensors / biases)
             ids_nd = {id(p) for p in self.param_groups[0]["params"]}
             mask = torch.zeros(S.total, dtype=torch.uint8)
@@ -68,7 +76,16 @@ class FusedAdamW(torch.optim.Optimizer):
         assert g0["lr"] == g1["lr"], "FusedAdamW steps both param groups with one learning rate (as timm's scheduler sets them)"
         gscale, S.pending_grad_scale = S.pending_grad_scale, 1.0      # 1/world of the data-parallel mean, applied in the kernel
         row = [g0["lr"], b1, b2, g0["eps"], g1["weight_decay"], 1 - b1 ** self._step, 1 - b2 ** self._step, gscale]
-        self._hp.copy_(torch.tensor(row, dtype=torch.float32), non_blocking=True)
+        if self._hp_pin is None:
+            self._hp.copy_(torch.tensor(row, dtype=torch.float32))
+        else:
+            k = self._step % 4
+            if self._hp_ev[k] is not None:
+                self._hp_ev[k].synchronize()              # the copy that last used this row has run (four steps ago: a no-op wait)
+            self._hp_pin[k].copy_(torch.tensor(row, dtype=torch.float32))
+            self._hp.copy_(self._hp_pin[k], non_blocking=True)
+            ev = self._hp_ev[k] = self._hp_ev[k] or torch.cuda.Event()
+            ev.record()
         ops.adamw_step(S.P, S.G, self._m, self._v, S.C, S.total, self._hp, self._wd_mask)
         # W^T / permuted conv operand copies are refreshed by the next forward; the plain bf16 copy S.C is already current,
         # which holds as long as nothing else writes the parameters before that forward (FlatStore.versions() notices)
