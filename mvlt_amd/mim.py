@@ -23,6 +23,7 @@ CONVS = ("reduction1", "reduction2", "reduction3", "conv_upsample1", "conv_upsam
 
 
 _FP32_DY = bool(os.environ.get("MVLT_MIM_FP32_DY"))      # A/B switch: every gradient map of the decoder's backward in fp32
+_NO_BN_FOLD = bool(os.environ.get("MVLT_MIM_NO_BN_FOLD"))   # A/B switch: eval mode keeps the separate BatchNorm pass over an fp32 z
 
 
 def _z(shape, dev, dtype=torch.float32):
@@ -52,8 +53,14 @@ class MimStep:
         S, dev = self.S, self.dev
         p = f"t2i_head.{name}"
         amap = conv3map(side, side, tokens_in, cin)
-        z = _e((M, cout), dev)
         bn = getattr(self.m.t2i_head, name)[1]
+        if not self.training and not self.need_grad and not _NO_BN_FOLD:
+            # inference: BatchNorm on its running statistics is an affine map per output channel -- folded into the conv (`norm` launches it
+            # with the destination it is given): no fp32 z, no normalisation pass, eleven launches fewer per forward
+            r = dict(name=name, p=p, fold=self._folded(name, p, bn, cin, cout), xin=xin, ld_in=ld_in, amap=amap, cin=cin, cout=cout, M=M)
+            self.rec[name] = r
+            return r
+        z = _e((M, cout), dev)
         st = _z((2, STAT_COPIES, cout), dev) if self.training else (None, None)   # batch statistics ride on the conv's epilogue
         if _SEPARATE_STATS and self.training:
             ops.gemm_nt(xin, S.extra[p + ".0.weight::K"], z, M, cout, 9 * cin, ld_in, 9 * cin, cout, a_map=amap)
@@ -73,8 +80,29 @@ class MimStep:
         self.rec[name] = r
         return r
 
+    def _folded(self, name, p, bn, cin, cout):
+        """-> (W', b'): W' = W * gamma * rsqrt(running_var + eps) per output channel, taken from the fp32 masters in the gather's
+        [out][kh][kw][cin] order and rounded to the operand dtype ONCE; b' = beta - running_mean * gamma * rsqrt(...).  Cached on the model
+        until the parameters' derived copies are refreshed again or the BatchNorm buffers are written."""
+        S, m = self.S, self.m
+        key = (S.refresh_count, bn.running_mean._version, bn.running_var._version, bn.num_batches_tracked._version, self.dt)
+        cache = m.__dict__.setdefault("_mim_fold", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            scale = S.master(p + ".1.weight") * torch.rsqrt(bn.running_var.float() + BN_EPS)
+            shift = (S.master(p + ".1.bias") - bn.running_mean.float() * scale).contiguous()
+            wk = (S.master(p + ".0.weight").permute(0, 2, 3, 1).reshape(cout, 9 * cin) * scale[:, None]).to(self.dt).contiguous()
+            hit = cache[name] = (key, wk, shift)
+        return hit[1], hit[2]
+
     def norm(self, r, y32=None, ld32=0, y16=None, ld16=0):
         S = self.S
+        if "fold" in r:
+            wk, shift = r["fold"]
+            for y, ld in ((y32, ld32), (y16, ld16)):
+                if y is not None:
+                    ops.gemm_nt(r["xin"], wk, y, r["M"], r["cout"], 9 * r["cin"], r["ld_in"], 9 * r["cin"], ld, a_map=r["amap"], bias=shift)
+            return
         ops.bn_norm(r["z"], r["cout"], r["mean"], r["rstd"], S.master(r["p"] + ".1.weight"), S.master(r["p"] + ".1.bias"), r["M"], r["cout"],
                     y32, ld32, y16, ld16)
 

@@ -129,6 +129,7 @@ class FlatStore:
         self.params = OrderedDict()       # name -> Parameter (unique)
         self.total = 0
         self._cast_version = -1
+        self.refresh_count = 0                   # bumped whenever refresh() rebuilds the derived copies
         self._c_fresh_version = None
         self.extra = {}                   # derived operand copies: name -> tensor
         self._finalize_queued = False
@@ -235,6 +236,7 @@ class FlatStore:
             ops.weight_prep(self._prep_desc, self._prep_blk, self._prep_n, self._prep_blocks, self.compute_dtype)
         self._cast_version = ver
         self.force_dirty = False
+        self.refresh_count += 1      # consumers that cache their own derived copies key on this
 
     def _build_prep(self, transposed, conv_perm, conv3):
         """Descriptor table of every derived weight copy (one mvlt_weight_prep launch per step refreshes them all).

@@ -105,3 +105,37 @@ def test_evaluate_recognition_matches_reference(golden_dir, parity, dtype):
             ref_m = g[f"recog/{tag}_metrics"]
             got_m = [res[f"{tag}_{k}"] for k in ("accuracy", "macro_f1", "micro_f1", "weighted_f1")]
             assert np.allclose(got_m, ref_m, atol=1e-9), (tag, got_m, ref_m)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_eval_decoder_with_folded_batchnorm_tracks_the_unfolded_one(golden_dir, parity, monkeypatch, dtype):
+    """Inference mode folds each BatchNorm of the MIM decoder into its conv (mvlt_amd/mim.py:MimStep._folded, reference
+    libs/vl_heads.py:147-152 under model.eval()).  The folded forward must equal the pass that keeps z and normalises it -- and keep
+    doing so after the running statistics and the weights have moved (the folded copies are cached)."""
+    from mvlt_amd import mim
+    from mvlt_amd.engine import train_step
+    from mvlt_amd.optim import FusedAdamW
+    model, g, seed, B, img, T, nb, nq, nc = _setup(golden_dir, dtype)
+    b = {k: v.cuda() for k, v in O.to_torch_batch(filler.make_batch(seed + 7, B, img, T)).items()}
+    tol = 1e-5 if dtype == torch.float32 else 1.5e-2
+
+    def both():
+        model.eval()
+        with torch.no_grad():
+            monkeypatch.setattr(mim, "_NO_BN_FOLD", False)
+            a = model(b["image"], b["input_ids"])["t2i_logits"].float()
+            monkeypatch.setattr(mim, "_NO_BN_FOLD", True)
+            c = model(b["image"], b["input_ids"])["t2i_logits"].float()
+        return a, c
+
+    a0, c0 = both()
+    assert parity("bn-fold/initial", ((a0 - c0).norm() / c0.norm()).item(), tol)
+    # one training step: batch statistics move the running buffers (through the C ABI, no torch version bump), AdamW moves the weights
+    model.train()
+    opt = FusedAdamW(model, lr=1e-2, weight_decay=0.0)
+    total, _ = train_step(model, b, 0, True)
+    total.backward()
+    opt.step()
+    a1, c1 = both()
+    assert ((c1 - c0).norm() / c0.norm()).item() > 10 * tol            # the step did change the decoder's output ...
+    assert parity("bn-fold/after-step", ((a1 - c1).norm() / c1.norm()).item(), tol)      # ... and the folded copies followed
