@@ -124,6 +124,53 @@ __device__ __forceinline__ void gelu_erf_both2(f32x2 x, f32x2& g, f32x2& dg) {
 #define MVLT_GP1 0.07397063459225359f
 #define MVLT_GP2 -0.0006933278070537189f
 #define MVLT_LOG2E 1.4426950408889634f
+// Transcendental-free forms (MVLT_GELU_POLY bit 0: GELU' of the input-gradient kernels, bit 1: GELU of the forward, bit 2: the pair of the
+// weight-gradient kernels).  Phi(x) - 1/2 and GELU'(x) - 1/2 are odd: x * P(x^2) on |x| <= 4, clamped beyond (Phi(4) = 1 - 3.2e-5,
+// GELU'(4) = 1 + 5.0e-4), near-minimax fits (the fitting recipe is in DESIGN 6.0).  v_exp_f32 / v_rcp_f32 cost 2.3 plain VALU
+// instructions each on gfx950 (profiles/r03_valu_rates.txt): GELU' is 10 plain instructions here against 15 + 2 transcendentals
+// (19.6 units) above.  |GELU' error| <= 2.8e-4 + the 5e-4 tail, |Phi error| <= 1.0e-4 absolute (fp32 Horner).
+#ifndef MVLT_GELU_POLY
+#define MVLT_GELU_POLY 3
+#endif
+__device__ __forceinline__ float gelu_poly_phi_s(float xc, float s) {          // Phi(xc) for |xc| <= 4, s = xc^2
+  float r = 2.816099979e-08f;
+  r = __builtin_fmaf(r, s, -1.891889492e-06f);
+  r = __builtin_fmaf(r, s, 5.419039730e-05f);
+  r = __builtin_fmaf(r, s, -8.789809206e-04f);
+  r = __builtin_fmaf(r, s, 9.112951399e-03f);
+  r = __builtin_fmaf(r, s, -6.538835501e-02f);
+  r = __builtin_fmaf(r, s, 3.985269119e-01f);
+  return __builtin_fmaf(xc, r, 0.5f);
+}
+__device__ __forceinline__ float gelu_poly_dg_s(float xc, float s) {           // GELU'(xc) for |xc| <= 4
+  float r = -1.641974535e-08f;
+  r = __builtin_fmaf(r, s, 1.213803683e-06f);
+  r = __builtin_fmaf(r, s, -3.845951304e-05f);
+  r = __builtin_fmaf(r, s, 6.876447493e-04f);
+  r = __builtin_fmaf(r, s, -7.687437410e-03f);
+  r = __builtin_fmaf(r, s, 5.591481231e-02f);
+  r = __builtin_fmaf(r, s, -2.620298260e-01f);
+  r = __builtin_fmaf(r, s, 7.967216338e-01f);
+  return __builtin_fmaf(xc, r, 0.5f);
+}
+__device__ __forceinline__ float gelu_poly1(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
+  return x * gelu_poly_phi_s(xc, xc * xc);
+}
+__device__ __forceinline__ float gelu_poly_grad1(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
+  return gelu_poly_dg_s(xc, xc * xc);
+}
+// GELU and GELU' together: Phi by the polynomial, the Gaussian term by one exponential (12 plain + 1 transcendental against 12 + 2)
+__device__ __forceinline__ void gelu_poly_both1(float x, float& g, float& dg) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
+  const float s = xc * xc;
+  const float ph = gelu_poly_phi_s(xc, s);
+  const float e = __builtin_amdgcn_exp2f(s * (-0.5f * MVLT_LOG2E));
+  g = x * ph;
+  dg = __builtin_fmaf(xc * 0.39894228040143267794f, e, ph);
+}
+
 __device__ __forceinline__ void gelu_fast_parts2(f32x2 x, f32x2& xc2, f32x2& e, f32x2& sg) {
   const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -7.0f, 7.0f), __builtin_amdgcn_fmed3f(x[1], -7.0f, 7.0f)};
   xc2 = xc * xc;
@@ -133,11 +180,32 @@ __device__ __forceinline__ void gelu_fast_parts2(f32x2 x, f32x2& xc2, f32x2& e, 
   sg = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};             // sigmoid(u) ~ Phi(x)
 }
 __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+#if MVLT_GELU_POLY & 2
+  return f32x2{gelu_poly1(x[0]), gelu_poly1(x[1])};
+#endif
   f32x2 s2, e, sg;
   gelu_fast_parts2(x, s2, e, sg);
   return x * sg;
 }
 __device__ __forceinline__ void gelu_fast_both2(f32x2 x, f32x2& g, f32x2& dg) {
+#if MVLT_GELU_POLY & 4
+  {                                            // the polynomial form on the packed-f32 ops: 16 instructions per PAIR of activations
+    const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x[1], -4.0f, 4.0f)};
+    const f32x2 s = xc * xc;
+    f32x2 r = s * 2.816099979e-08f + -1.891889492e-06f;
+    r = r * s + 5.419039730e-05f;
+    r = r * s + -8.789809206e-04f;
+    r = r * s + 9.112951399e-03f;
+    r = r * s + -6.538835501e-02f;
+    r = r * s + 3.985269119e-01f;
+    const f32x2 ph = xc * r + 0.5f;
+    const f32x2 a = s * (-0.5f * MVLT_LOG2E);
+    const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    g = x * ph;
+    dg = (xc * 0.39894228040143267794f) * e + ph;
+    return;
+  }
+#endif
   f32x2 s2, e, sg;
   gelu_fast_parts2(x, s2, e, sg);
   g = x * sg;
@@ -145,6 +213,9 @@ __device__ __forceinline__ void gelu_fast_both2(f32x2 x, f32x2& g, f32x2& dg) {
   dg = (x * up) * (sg * sg * e) + sg;
 }
 __device__ __forceinline__ f32x2 gelu_fast_grad2(f32x2 x) {
+#if MVLT_GELU_POLY & 1
+  return f32x2{gelu_poly_grad1(x[0]), gelu_poly_grad1(x[1])};
+#endif
   f32x2 g, dg;
   gelu_fast_both2(x, g, dg);
   return dg;

@@ -10,6 +10,9 @@
 // v_mfma_f32_16x16x32_bf16 (bf16) or 8 x v_mfma_f32_16x16x4_f32 (fp32: exact-f32 path for the 1e-3 parity bar).
 // LDS rows are 128 B (64 bf16 / 32 fp32 of K) = 8 x 16-B chunks, XOR-swizzled by row so the ds_read_b128
 // fragment reads are conflict-free; global->register->LDS staging is double-buffered (one barrier per K tile).
+#ifndef MVLT_GELU_POLY
+#define MVLT_GELU_POLY 0     // the GELU / GELU' GEMM epilogues keep the sigmoid form: the polynomial one measured no gain here (HBM-bound launches; same-box A/B 22.60 / 22.73 against 22.63 / 22.67 ms)
+#endif
 #include "common.h"
 #include "../../include/mvlt_hip.h"
 
@@ -1397,6 +1400,16 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
   const int m0 = tile_m * BMT, n0 = tile_n * BN;
   const RowMap amap = to_rowmap(p.a_map);
   const unsigned smem_lds = (unsigned)(uintptr_t)smem;
+#ifdef MVLT_NT_STAGGER
+  // experiment: the workgroups of the first round that share a CU start a quarter of a tile time apart, so that their store phases
+  // do not coincide (MVLT_NT_STAGGER = shift that picks the co-resident index out of the block id, 3 or 8)
+  if constexpr (EPI == 3 || EPI == 4) {
+    if (bid < 1024) {
+      const int phase = (bid >> MVLT_NT_STAGGER) & 3;
+      for (int q = 0; q < phase; ++q) __builtin_amdgcn_s_sleep(127);
+    }
+  }
+#endif
 
   const int row_in = tid / CH;                                  // 0..RPL-1 (+RPL i)
   const int chunk = swzk(row_in, tid % CH);                     // source chunk of this thread's LDS slot: swz is an involution

@@ -389,6 +389,47 @@ __global__ __launch_bounds__(NT) void upsample_bwd_row_kernel(const TDY* dy, int
   if (accumulate) acc += *(const f32x4*)d;
   st_g<MVLT_NT_MIM>((f32x4*)d, acc);
 }
+// the same with the scale a template parameter: an input pixel is touched by at most 2 S + 1 output rows / columns, so the two tap-weight
+// vectors are computed ONCE per thread into registers (the generic kernel recomputes the column weights inside the row loop: ~500 VALU
+// instructions per thread for 25 taps of which ~9-16 are non-zero -- the x2 resizes of the decoder were VALU-bound at ~2 TB/s)
+template <typename TDY, int S>
+__global__ __launch_bounds__(NT) void upsample_bwd_row_s_kernel(const TDY* dy, int lddy, int H, int W, int C, float* dx, int lddx, int accumulate, int chunks) {
+  constexpr int T = 2 * S + 1;
+  const int Ho = H * S, Wo = W * S;
+  const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
+  const int b = row / H, iy = row - b * H;
+  const int C4 = C >> 2;
+  const int idx = chunk * NT + threadIdx.x;
+  if (idx >= W * C4) return;
+  const int ix = idx / C4, c = (idx - ix * C4) << 2;
+  const int oy_lo = ry > 0.f ? max(0, (int)floorf((iy - 1) / ry)) : 0, ox_lo = rx > 0.f ? max(0, (int)floorf((ix - 1) / rx)) : 0;
+  float wyv[T], wxv[T];
+#pragma unroll
+  for (int k = 0; k < T; ++k) {
+    const int oy = oy_lo + k, ox = ox_lo + k;
+    const float fy = oy * ry, fx = ox * rx;
+    const int y0 = (int)fy, y1 = min(y0 + 1, H - 1), x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+    const float wy = fy - y0, wx = fx - x0;
+    wyv[k] = oy < Ho ? (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f) : 0.f;
+    wxv[k] = ox < Wo ? (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f) : 0.f;
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const TDY* base = dy + (((long)b * Ho + oy_lo) * Wo + ox_lo) * lddy + c;
+#pragma unroll
+  for (int ky = 0; ky < T; ++ky) {
+    if (wyv[ky] == 0.f) continue;
+    const TDY* drow = base + (long)ky * Wo * lddy;
+#pragma unroll
+    for (int kx = 0; kx < T; ++kx) {
+      if (wxv[kx] == 0.f) continue;
+      acc += (wyv[ky] * wxv[kx]) * load4<TDY>(drow + (long)kx * lddy);
+    }
+  }
+  float* d = dx + (((long)b * H + iy) * W + ix) * lddx + c;
+  if (accumulate) acc += *(const f32x4*)d;
+  st_g<MVLT_NT_MIM>((f32x4*)d, acc);
+}
 // backward, NCHW dy (final x8 upsample, C = 3): workgroup = (b, c, iy).  Pass 1: thread ox folds its output column over
 // the rows that touch iy (coalesced plane-row reads) into LDS; pass 2: thread ix folds the <= 2s+1 columns that touch it.
 template <typename TO>
@@ -734,8 +775,10 @@ extern "C" int mvlt_upsample_bwd(const void* dy_, int lddy, int nchw, int B, int
     MVLT_REQUIRE(!nchw && dx_dtype == 1 && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy_ & 7) == 0 && ((uintptr_t)dx_ & 15) == 0,
                  "mvlt_upsample_bwd: bf16 dy needs the pixel-major layout, fp32 dx, C / ld multiples of 4");
     const int chunks = (W * (C / 4) + NT - 1) / NT;
-    hipLaunchKernelGGL(upsample_bwd_row_kernel<bf16>, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy_, lddy, H, W, C, scale,
-                       (float*)dx_, lddx, accumulate, chunks);
+    if (scale == 2) hipLaunchKernelGGL((upsample_bwd_row_s_kernel<bf16, 2>), dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy_, lddy, H, W,
+                                       C, (float*)dx_, lddx, accumulate, chunks);
+    else hipLaunchKernelGGL(upsample_bwd_row_kernel<bf16>, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy_, lddy, H, W, C, scale,
+                            (float*)dx_, lddx, accumulate, chunks);
     return mvlt_check_launch("mvlt_upsample_bwd");
   }
   MVLT_REQUIRE(dx_dtype == 1 || (dx_dtype == 0 && nchw), "mvlt_upsample_bwd: bf16 dx only behind the NCHW (final x8) upsample");
@@ -757,8 +800,10 @@ extern "C" int mvlt_upsample_bwd(const void* dy_, int lddy, int nchw, int B, int
   MVLT_REQUIRE(dx_dtype == 1, "mvlt_upsample_bwd: bf16 dx needs the row-buffered NCHW path (W * scale * 4 <= 64 KB)");
   if (!nchw && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0) {
     const int chunks = (W * (C / 4) + NT - 1) / NT;
-    hipLaunchKernelGGL(upsample_bwd_row_kernel<float>, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, H, W, C, scale, dx, lddx,
-                       accumulate, chunks);
+    if (scale == 2) hipLaunchKernelGGL((upsample_bwd_row_s_kernel<float, 2>), dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, H, W, C, dx, lddx,
+                                       accumulate, chunks);
+    else hipLaunchKernelGGL(upsample_bwd_row_kernel<float>, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, H, W, C, scale, dx, lddx,
+                            accumulate, chunks);
     return mvlt_check_launch("mvlt_upsample_bwd");
   }
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, nchw, B, H, W, C, scale, dx, lddx, accumulate);

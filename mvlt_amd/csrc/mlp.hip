@@ -107,7 +107,7 @@ __device__ __forceinline__ void mlp_load_rows(const mvlt_mlp_args& p, int m0, in
 }
 
 // ---- epilogue shared by the fused kernels: oacc[i][j][r] = out[token wave*32 + 16 i + 4 fg + r][c = 16 j + fr]
-template <int C, int MODE>
+template <int C, int MODE, bool PFALL = true>
 __device__ __forceinline__ void mlp_epilogue(const mvlt_mlp_args& p, char* smem, int m0, int tid, f32x4 (&oacc)[2][C / 16]) {
   constexpr int MT = 2, WR = 32, CT = C / 16;
   const int lane = tid & 63, wave = tid >> 6;
@@ -135,28 +135,32 @@ __device__ __forceinline__ void mlp_epilogue(const mvlt_mlp_args& p, char* smem,
   f32x4 pre_a[MT][NIT][2];       // forward: residual row chunk; backward: LayerNorm input row chunk
   u32x4 pre_o[MT][NIT];          // backward: current gradient-stream row chunk (bf16 x 8)
   float pre_mean[MT][NIT], pre_rstd[MT][NIT], pre_rs[MT][NIT], pre_sc[MT][NIT];
-  if (MODE == 0 || lnb) {
+  // PFALL = false (three waves per SIMD: the other waves cover the round trip) requests one 16-row tile at a time: half the registers
+  auto prefetch = [&](int i) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int m = m0 + wave * WR + i * 16 + it * RPI + lane / CPR;
-        const bool ok = m < p.M;
-        const long idx = (long)(ok ? m : 0) * C + nc;
-        const float* src = (MODE == 0) ? (const float*)p.residual + idx : p.lnb_x + idx;
-        pre_a[i][it][0] = ld_g<MVLT_NT_LD && MVLT_NT_MLP>((const f32x4*)src);
-        pre_a[i][it][1] = ld_g<MVLT_NT_LD && MVLT_NT_MLP>((const f32x4*)(src + 4));
-        pre_rs[i][it] = p.row_scale ? p.row_scale[(ok ? m : 0) / p.rows_per_scale] : 1.0f;
-        if (MODE == 1) {
-          pre_o[i][it] = ld_g<MVLT_NT_LD && MVLT_NT_MLP>((const u32x4*)((const bf16*)p.lnb_dx + idx));
-          pre_mean[i][it] = p.lnb_mean[ok ? m : 0];
-          pre_rstd[i][it] = p.lnb_rstd[ok ? m : 0];
-          pre_sc[i][it] = p.lnb_dx2 ? p.lnb_dx2_scale[(ok ? m : 0) / p.lnb_dx2_rows_per_scale] : 0.f;
-        }
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + wave * WR + i * 16 + it * RPI + lane / CPR;
+      const bool ok = m < p.M;
+      const long idx = (long)(ok ? m : 0) * C + nc;
+      const float* src = (MODE == 0) ? (const float*)p.residual + idx : p.lnb_x + idx;
+      pre_a[i][it][0] = ld_g<MVLT_NT_LD && MVLT_NT_MLP>((const f32x4*)src);
+      pre_a[i][it][1] = ld_g<MVLT_NT_LD && MVLT_NT_MLP>((const f32x4*)(src + 4));
+      pre_rs[i][it] = p.row_scale ? p.row_scale[(ok ? m : 0) / p.rows_per_scale] : 1.0f;
+      if (MODE == 1) {
+        pre_o[i][it] = ld_g<MVLT_NT_LD && MVLT_NT_MLP>((const u32x4*)((const bf16*)p.lnb_dx + idx));
+        pre_mean[i][it] = p.lnb_mean[ok ? m : 0];
+        pre_rstd[i][it] = p.lnb_rstd[ok ? m : 0];
+        pre_sc[i][it] = p.lnb_dx2 ? p.lnb_dx2_scale[(ok ? m : 0) / p.lnb_dx2_rows_per_scale] : 0.f;
       }
+    }
+  };
+  if (PFALL && (MODE == 0 || lnb)) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) prefetch(i);
   }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
+    if (!PFALL && (MODE == 0 || lnb)) prefetch(i);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();               // previous tile's reads are done before it is overwritten
 #pragma unroll
@@ -436,6 +440,9 @@ template <int C> __device__ __forceinline__ int pipe_fP(int rho) {       // 16-B
 __device__ __forceinline__ int pipe_gC(int n) { return (0 - (n >> 2)) & 3; }   // same for a consumer-tile row (row = channel, 64-B rows)
 
 __device__ __forceinline__ float gelu_fast1(float x) {
+#if MVLT_GELU_POLY & 2
+  return gelu_poly1(x);
+#endif
   const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
   const float x2 = xc * xc;
   const float t = xc * __builtin_fmaf(__builtin_fmaf(x2, -MVLT_LOG2E * MVLT_GP2, -MVLT_LOG2E * MVLT_GP1), x2, -MVLT_LOG2E * MVLT_GP0);
@@ -443,6 +450,9 @@ __device__ __forceinline__ float gelu_fast1(float x) {
   return x * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 __device__ __forceinline__ float gelu_fast_grad1(float x) {
+#if MVLT_GELU_POLY & 1
+  return gelu_poly_grad1(x);
+#endif
   const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
   const float x2 = xc * xc;
   const float t = xc * __builtin_fmaf(__builtin_fmaf(x2, -MVLT_LOG2E * MVLT_GP2, -MVLT_LOG2E * MVLT_GP1), x2, -MVLT_LOG2E * MVLT_GP0);
@@ -452,13 +462,16 @@ __device__ __forceinline__ float gelu_fast_grad1(float x) {
   return __builtin_fmaf(x * up, sg * sg * e, sg);
 }
 
-// Waves per SIMD the register allocation is held to: two.  The C = 64 input-gradient kernel needs 174 registers left alone; held to 168
-// (three waves per SIMD, 16 B of scratch per lane) the bare launch goes 420 -> 384 us (tools/ubench_mlp2.py; a VALU-bound body gains from
-// the third wave: tools/probes/valu_rates.hip, 16 x {MFMA + 8 v_fma} takes 38.8 / 27.5 / 21.5 ticks per SIMD at 2 / 3 / 4 waves) -- but the
-// step's launches run the LayerNorm-backward epilogue, whose prefetched rows then spill: +0.5 ms per step (same-box A/B 23.90 vs 23.38 ms).
-// Four waves (128 registers) spill 328 B per lane: 1778 us.  C = 128 forward at three waves: 260 B of scratch, 213 -> 390 us.
+// Waves per SIMD the register allocation is held to.  A wave of these kernels issues one VALU instruction per ~3.5 ns however few waves share
+// its SIMD (tools/probes/valu_rates.hip: 16 x {MFMA + 8 v_fma} takes 38.8 / 27.5 / 21.5 ticks per SIMD at 2 / 3 / 4 waves), so occupancy is
+// throughput here.  The C = 64 input-gradient kernel needs 171 registers with the polynomial GELU' (174 with the sigmoid form); held to 168
+// = THREE waves per SIMD it spills two dwords outside the slice loop (8 B of scratch per lane, none in the loop) and its epilogue requests
+// the LayerNorm-backward operands one 16-row tile at a time (PFALL = false in mlp_epilogue: half the registers; the third wave covers the
+// round trip): bare launch 359 -> 326 us, step -0.1 ms (same-box A/B).  The sigmoid form at three waves with the all-rows prefetch spilled
+// inside the epilogue: +0.5 ms per step.  Four waves (128 registers) spill 328 B per lane: 1778 us.  C = 128 forward at three waves: 260 B
+// of scratch, 213 -> 390 us.
 #ifndef MVLT_PIPE_WAVES_64_1
-#define MVLT_PIPE_WAVES_64_1 2
+#define MVLT_PIPE_WAVES_64_1 3
 #endif
 template <int C, int MODE>
 __global__ __launch_bounds__(NT, (C == 64 && MODE == 1) ? MVLT_PIPE_WAVES_64_1 : 2) void mlp_pipe_kernel(mvlt_mlp_args p) {
@@ -641,7 +654,7 @@ __global__ __launch_bounds__(NT, (C == 64 && MODE == 1) ? MVLT_PIPE_WAVES_64_1 :
   fence();
   iteration(P0{}, N{}, Y{}, N{}, 0);
   __syncthreads();                               // the epilogue stages through the same LDS
-  mlp_epilogue<C, MODE>(p, smem, m0, tid, oacc);
+  mlp_epilogue<C, MODE, !(C == 64 && MODE == 1 && MVLT_PIPE_WAVES_64_1 >= 3)>(p, smem, m0, tid, oacc);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients
@@ -879,6 +892,10 @@ __global__ __launch_bounds__(NT, C == 64 ? 2 : 1) void mlp_wgrad_kernel(mvlt_mlp
 // block instead of VALU adds, (d) NW = 8 waves of ONE 16-unit hidden tile each at C = 128, where the four-wave form needs 446 registers
 // per lane (one wave per SIMD: a VALU-bound loop then issues one instruction per ~7 cycles instead of one per ~3).
 __device__ __forceinline__ void gelu_fast_both1(float x, float& g, float& dg) {
+#if MVLT_GELU_POLY & 4
+  gelu_poly_both1(x, g, dg);
+  return;
+#endif
   const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
   const float x2 = xc * xc;
   const float t = xc * __builtin_fmaf(__builtin_fmaf(x2, -MVLT_LOG2E * MVLT_GP2, -MVLT_LOG2E * MVLT_GP1), x2, -MVLT_LOG2E * MVLT_GP0);

@@ -12,7 +12,9 @@ from collections import Counter
 
 def main():
     src, flt = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
-    asm = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-S", "--cuda-device-only", src, "-o", "-"],
+    import os
+    extra = os.environ.get("MVLT_ISA_FLAGS", "").split() + (["-fno-slp-vectorize"] if src.endswith("mlp.hip") else [])    # the build's own flags
+    asm = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", *extra, "-S", "--cuda-device-only", src, "-o", "-"],
                          capture_output=True, text=True).stdout
     lines = asm.split("\n")
     starts = [(i, m.group(1)) for i, l in enumerate(lines) for m in [re.match(r"^(_Z\w+):\s*(;.*)?$", l)] if m]
