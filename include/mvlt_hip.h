@@ -70,6 +70,13 @@ typedef struct mvlt_gemm_nt_args {
                                 tiles into the fp32, caller-zeroed C with atomics (few output tiles, long K: the input
                                 gradient of the tied 30522-word MLM decoder, reference libs/vl_heads.py:31-36).  bf16
                                 operands, plain epilogue (bias allowed), identity row maps */
+  /* optional LayerNorm of the finished output row while it is on chip (bf16 operands, R given, N == 64 or 128 so that one tile holds
+   * whole rows, identity row maps): post_y[M, post_ld] (bf16) = LN(C row; post_gamma, post_beta, post_eps), statistics to post_mean /
+   * post_rstd [M].  attn.proj + DropPath + residual followed by Block.norm2 (reference libs/pvlt.py:140-142): the fused MLP then reads
+   * its operand in bf16 instead of normalising the fp32 mid stream itself. */
+  void* post_y; int post_ld;
+  const float* post_gamma; const float* post_beta; float post_eps;
+  float* post_mean; float* post_rstd;
 } mvlt_gemm_nt_args;
 int mvlt_gemm_nt(const mvlt_gemm_nt_args* args, void* stream);
 

@@ -36,7 +36,9 @@ class GemmNTArgs(C.Structure):
                 ("a_map", RowMap), ("c_map", RowMap),
                 ("bias", c_void_p), ("act", c_int), ("H", c_void_p),
                 ("row_scale", c_void_p), ("rows_per_scale", c_int), ("R", c_void_p),
-                ("col_sum", c_void_p), ("col_sumsq", c_void_p), ("col_copies", c_int), ("split_k", c_int)]
+                ("col_sum", c_void_p), ("col_sumsq", c_void_p), ("col_copies", c_int), ("split_k", c_int),
+                ("post_y", c_void_p), ("post_ld", c_int), ("post_gamma", c_void_p), ("post_beta", c_void_p), ("post_eps", C.c_float),
+                ("post_mean", c_void_p), ("post_rstd", c_void_p)]
 
 
 class PrepDesc(C.Structure):

@@ -255,6 +255,9 @@ __device__ __forceinline__ void nt_epilogue(const mvlt_gemm_nt_args& p, f32x4 (&
 //   EPI 1: C = AB^T (+bias)                      EPI 2: C = (AB^T + bias) * row_scale + R
 //   EPI 3: H = AB^T + bias ; C = gelu(H)         EPI 4: C = AB^T * gelu'(H)          EPI 5: EPI 1 + column sum / sum of squares
 //   EPI 6 / 7: EPI 1 / 2 written through a patch-scatter c_map (dgrad of the kernel==stride convs)
+//   EPI 8: EPI 2 + LayerNorm of the finished row (N == BN: the tile holds whole rows, split over the two waves of a row pair):
+//          post_y = LN(C row; post_gamma, post_beta, post_eps) in bf16 + the row statistics -- Block.norm2 behind attn.proj
+//          (reference libs/pvlt.py:140-142) without a pass of its own over the fp32 mid stream
 __device__ __forceinline__ int fdiv24(int m, int d, float inv) {      // exact m / d for 0 <= m < 2^24, inv = 1.0f / d
   int q = (int)((float)m * inv);
   int r = m - q * d;
@@ -264,7 +267,8 @@ template <int BN, int EPIX, int TM = 4>
 __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32x4 (&acc)[TM][BN / 32], char* smem, int m0, int n0,
                                                  int wave, int lane) {
   constexpr bool SCAT = (EPIX == 6 || EPIX == 7);     // EPI 6 / 7 = EPI 1 / 2 with a patch-scatter c_map (mode 1)
-  constexpr int EPI = EPIX == 6 ? 1 : EPIX == 7 ? 2 : EPIX;
+  constexpr bool POST = EPIX == 8;                    // EPI 8 = EPI 2 + LayerNorm of the output row
+  constexpr int EPI = EPIX == 6 ? 1 : (EPIX == 7 || EPIX == 8) ? 2 : EPIX;
   constexpr int WN = BN / 2;
   constexpr int TN_ = WN / 16;
   constexpr int LDW = WN + 4;
@@ -349,6 +353,12 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
   };
   constexpr bool PREFETCH = (EPI == 2 || EPI == 4);
   if (PREFETCH) { request(0); request(1); }
+  float pgam[8], pbet[8];
+  float* const xch = (float*)smem + 4 * 32 * LDW;    // POST: [128 rows][2 column halves] row sums | the same for the squared deviations
+  if constexpr (POST) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pgam[e] = p.post_gamma[nc + e]; pbet[e] = p.post_beta[nc + e]; }
+  }
 #pragma unroll
   for (int half = 0; half < NH; ++half) {
     const int sl = half & 1;
@@ -363,6 +373,76 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (POST) {
+      // the row's other half lives in the partner wave (wn ^ 1): two-pass statistics with one LDS exchange + workgroup barrier per pass
+      const float inv_n = 1.0f / (float)p.N;
+      float keep[NIT][8];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int rl = it * RPI + lane / CPR;
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) keep[it][e] = 0.f;
+        if (ok[sl][it]) {
+          const f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          float o8[8];
+          if (ofp32) {
+            const f32x4 a = __builtin_bit_cast(f32x4, raw[sl][it][0]), b = __builtin_bit_cast(f32x4, raw[sl][it][1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o8[e] = a[e]; o8[4 + e] = b[e]; }
+          } else {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, raw[sl][it][0]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] = (float)a[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[e] = (v[e] + bias8[e]) * rs[sl][it] + o8[e]; keep[it][e] = v[e]; sum += v[e]; }
+          const long ix = idx[sl][it];
+          if (ofp32) {
+            st_g<MVLT_NT_GEMM>((f32x4*)((float*)p.C + ix), f32x4{v[0], v[1], v[2], v[3]});
+            st_g<MVLT_NT_GEMM>((f32x4*)((float*)p.C + ix + 4), f32x4{v[4], v[5], v[6], v[7]});
+          } else {
+            bf16x8 a;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = (bf16)v[e];
+            st_g<MVLT_NT_GEMM>((bf16x8*)((bf16*)p.C + ix), a);
+          }
+        }
+#pragma unroll
+        for (int o = 1; o < CPR; o <<= 1) sum += __shfl_xor(sum, o);
+        if (ch == 0) xch[((wm * 2 + half) * 32 + rl) * 2 + wn] = sum;
+      }
+      __syncthreads();
+      float mean[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = (wm * 2 + half) * 32 + it * RPI + lane / CPR;
+        mean[it] = (xch[row * 2] + xch[row * 2 + 1]) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { keep[it][e] -= mean[it]; q += keep[it][e] * keep[it][e]; }
+#pragma unroll
+        for (int o = 1; o < CPR; o <<= 1) q += __shfl_xor(q, o);
+        if (ch == 0) xch[256 + row * 2 + wn] = q;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (!ok[sl][it]) continue;
+        const int rl = it * RPI + lane / CPR;
+        const int row = (wm * 2 + half) * 32 + rl;
+        const int m = m_first + half * 32 + it * RPI;
+        const float rstd = rsqrtf((xch[256 + row * 2] + xch[256 + row * 2 + 1]) * inv_n + p.post_eps);
+        bf16x8 y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = (bf16)(keep[it][e] * rstd * pgam[e] + pbet[e]);
+        st_g<MVLT_NT_GEMM>((bf16x8*)((bf16*)p.post_y + (long)m * p.post_ld + nc), y);
+        if (wn == 0 && ch == 0) { p.post_mean[m] = mean[it]; p.post_rstd[m] = rstd; }
+      }
+      if (PREFETCH && half + 2 < NH) request(half + 2);
+      continue;
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       if (!ok[sl][it]) continue;
@@ -1777,6 +1857,15 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     if (const char* e = getenv("MVLT_NT_NS")) { ns = atoi(e); if (ns > nkd) ns = nkd; if (ns < 2) ns = nkd < 2 ? nkd : 2; if (ns > 6) ns = 6; }
     size_t lds2 = (size_t)ns * (BM + bn) * (bkd * 2);
     if (lds2 < stage) lds2 = stage;
+    if (a->post_y) {                            // EPI 8: attn.proj + residual + Block.norm2 (whole rows in one tile)
+      MVLT_REQUIRE(epi == 2 && a->N == bn && a->a_map.mode == 0 && a->c_map.mode == 0 && a->c_map.rows_per_batch == 0 && a->post_gamma && a->post_beta &&
+                   a->post_mean && a->post_rstd && a->post_ld % 8 == 0 && ((uintptr_t)a->post_y & 15) == 0 && ((uintptr_t)a->post_gamma & 15) == 0,
+                   "mvlt_gemm_nt: post_y needs bf16 operands, a residual (R), N == 64 or 128, identity row maps, 16-byte aligned outputs");
+      if (lds2 < stage + 2048) lds2 = stage + 2048;
+      if (narrow) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 0, 8, 64>), grid, block, lds2, s, *a, ns);
+      else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 0, 8, 64>), grid, block, lds2, s, *a, ns);
+      return mvlt_check_launch("mvlt_gemm_nt");
+    }
 #define MVLT_NT_LAUNCH_E(BN_, AM_, BK_)                                                                                 \
   do {                                                                                                               \
     switch (epi) {                                                                                                   \

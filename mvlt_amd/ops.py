@@ -12,8 +12,9 @@ _ID = rowmap()
 
 
 def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias=None, act=0, H=None,
-            row_scale=None, rows_per_scale=0, R=None, col_sum=None, col_sumsq=None, col_copies=0, split_k=0):
-    """C[M,N] = epi(A[M,K] @ B[N,K]^T); see mvlt_gemm_nt in include/mvlt_hip.h."""
+            row_scale=None, rows_per_scale=0, R=None, col_sum=None, col_sumsq=None, col_copies=0, split_k=0, post_ln=None):
+    """C[M,N] = epi(A[M,K] @ B[N,K]^T); see mvlt_gemm_nt in include/mvlt_hip.h.  post_ln = (gamma, beta, eps, y, mean, rstd): LayerNorm of the
+    finished output rows rides on the epilogue (N == 64 / 128, bf16 operands, R given)."""
     assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype in DT
     if bias is not None:
         assert bias.dtype == torch.float32
@@ -28,6 +29,10 @@ def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias
     a = L.GemmNTArgs(ptr(A), ptr(B), ptr(C_out), M, N, K, lda, ldb, ldc, DT[A.dtype], DT[C_out.dtype],
                      a_map or _ID, c_map or _ID, ptr(bias), act, ptr(H), ptr(row_scale), rows_per_scale, ptr(R),
                      ptr(col_sum), ptr(col_sumsq), col_copies, split_k)
+    if post_ln is not None:
+        g, b, eps, y, mean, rstd = post_ln
+        assert g.dtype == b.dtype == mean.dtype == rstd.dtype == torch.float32 and y.dtype == torch.bfloat16 and y.is_contiguous()
+        a.post_y, a.post_ld, a.post_gamma, a.post_beta, a.post_eps, a.post_mean, a.post_rstd = ptr(y), y.shape[-1], ptr(g), ptr(b), eps, ptr(mean), ptr(rstd)
     check(L.lib.mvlt_gemm_nt(C.byref(a), stream_ptr()), "mvlt_gemm_nt")
     return C_out
 

@@ -30,6 +30,7 @@ _NO_LN_CHAIN = bool(os.environ.get("MVLT_NO_LN_CHAIN")) or bool(os.environ.get("
 _NO_LNB_FUSE = bool(os.environ.get("MVLT_NO_LNB_FUSE"))    # A/B switch: norm2's backward as its own launch behind the fused-MLP dx kernel
 _NO_POST_LN = bool(os.environ.get("MVLT_NO_POST_LN"))      # A/B switch: every block launches its own norm1
 _NO_OUT_OP = bool(os.environ.get("MVLT_NO_OUT_OP"))        # A/B switch: fp32 stage output + separate cast pass
+_NO_PROJ_LN = bool(os.environ.get("MVLT_NO_PROJ_LN"))      # A/B switch: LN2 folded into the fused MLP's operand load (round 2) instead of the proj epilogue
 _NO_LN_FOLD = bool(os.environ.get("MVLT_NO_LN_FOLD"))      # A/B switch: LN2 as its own launch in front of the fused MLP
 # A/B switches: conv weight gradients accumulated straight into the [out][cin][kh][kw] layout by the wgrad epilogue (strided atomics),
 # or through a pooled [out][kh][kw][cin] buffer + one permuted ATen add per convolution, instead of the store's tap arena
@@ -311,14 +312,18 @@ class TrunkStep:
         bs["ao"], bs["lse"] = ao, lse
         # proj + DropPath + residual
         xm = _empty((B, N, C), self.rt, dev)
-        ops.gemm_nt(ao, self.w(p + "attn.proj.weight"), xm, M, C, C, C, C, C, bias=self.f32(p + "attn.proj.bias"),
-                    row_scale=s1, rows_per_scale=N, R=x)
-        bs["xm"] = xm
-        # LN2 + MLP (fc1 + exact GELU, fc2) + DropPath + residual
         xn2 = _empty((B, N, C), dt, dev)
         bs["m2"], bs["r2"] = _empty((M,), f32, dev), _empty((M,), f32, dev)
         bs["xn2"] = xn2
         bs["fused_mlp"] = fused = (dt == torch.bfloat16 and C in (64, 128))
+        # stages 1-2 (one tile of the projection holds whole rows): Block.norm2 rides on the projection's epilogue -- the fused MLP then reads
+        # its operand in bf16 and the fp32 mid stream only once (as the residual), instead of normalising the fp32 rows itself
+        proj_ln = fused and not _NO_PROJ_LN and not _NO_LN_FOLD
+        ops.gemm_nt(ao, self.w(p + "attn.proj.weight"), xm, M, C, C, C, C, C, bias=self.f32(p + "attn.proj.bias"),
+                    row_scale=s1, rows_per_scale=N, R=x,
+                    post_ln=(self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), EPS_BLOCK, xn2.view(M, C), bs["m2"], bs["r2"]) if proj_ln else None)
+        bs["xm"] = xm
+        # LN2 + MLP (fc1 + exact GELU, fc2) + DropPath + residual
         # the last block of a stage has no fp32 consumer (its output feeds the next stage's patch embedding and the heads, which read
         # the MFMA-operand copy): the fused MLP then writes that copy itself and no fp32 stream -- no separate cast pass
         last_op = fused and j == m.depths[i] - 1 and self.dt != self.rt and not _NO_OUT_OP
@@ -327,8 +332,8 @@ class TrunkStep:
             # stages 1-2: LN2 -> fc1 -> GELU -> fc2 -> DropPath -> +residual in ONE kernel.  The (tokens x hidden) activation stays on
             # chip and is recomputed by the fused backward kernels; LN2 is folded into the operand load (the kernel reads the fp32
             # mid stream once for both the normalisation and the residual, and stores LN2's output + statistics for the backward)
-            ln = None if _NO_LN_FOLD else (self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), EPS_BLOCK, xn2, bs["m2"], bs["r2"])
-            if ln is None:
+            ln = None if (_NO_LN_FOLD or proj_ln) else (self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), EPS_BLOCK, xn2, bs["m2"], bs["r2"])
+            if ln is None and not proj_ln:
                 ops.layernorm_fwd(xm, xn2, self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), M, C, C, C, EPS_BLOCK, mean=bs["m2"], rstd=bs["r2"])
             post = None
             if j + 1 < m.depths[i] and not _NO_POST_LN:

@@ -83,6 +83,31 @@ def test_gemm_nt_epilogues(ops, dtype, N):
     assert maxrel(out4, ref_pre) < TOL[dtype]
 
 
+@pytest.mark.parametrize("N,K,M,out_dtype", [(64, 64, 8448, torch.float32), (128, 128, 1000, torch.float32), (64, 64, 200, torch.bfloat16)])
+def test_gemm_nt_layernorm_epilogue(ops, N, K, M, out_dtype):
+    """attn.proj + DropPath + residual with Block.norm2 of the finished row on the epilogue (reference libs/pvlt.py:140-142):
+    C as without the LayerNorm (bit-identical to the plain residual epilogue), post_y = LN(C) of the fp32 row, statistics saved."""
+    dt = torch.bfloat16
+    Bsz = 8 if M % 8 == 0 else 1
+    A, W = rnd(M, K, dtype=dt), rnd(N, K, dtype=dt, seed=1, scale=0.3)
+    bias = rnd(N, dtype=torch.float32, seed=2)
+    R = rnd(M, N, dtype=out_dtype, seed=3, scale=2.0)
+    scale = (torch.arange(Bsz, device=dev()) % 3 != 0).float() / 0.9
+    g, b = rnd(N, dtype=torch.float32, seed=4) + 1.0, rnd(N, dtype=torch.float32, seed=5)
+    plain = torch.empty(M, N, device=dev(), dtype=out_dtype)
+    ops.gemm_nt(A, W, plain, M, N, K, K, K, N, bias=bias, row_scale=scale, rows_per_scale=M // Bsz, R=R)
+    out = torch.empty_like(plain)
+    y = torch.full((M, N), float("nan"), device=dev(), dtype=dt)
+    mean, rstd = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    ops.gemm_nt(A, W, out, M, N, K, K, K, N, bias=bias, row_scale=scale, rows_per_scale=M // Bsz, R=R, post_ln=(g, b, 1e-6, y, mean, rstd))
+    assert torch.equal(out, plain)
+    x = (A.float() @ W.float().t() + bias) * scale.repeat_interleave(M // Bsz)[:, None] + R.float()      # the fp32 row the kernel normalises
+    ref = F.layer_norm(x, (N,), g, b, 1e-6)
+    assert torch.isfinite(y.float()).all()
+    assert maxrel(y.float(), ref) < TOL[dt]
+    assert maxrel(mean, x.mean(1)) < 2e-3 and maxrel(rstd, (x.var(1, unbiased=False) + 1e-6).rsqrt()) < 2e-3
+
+
 @pytest.mark.parametrize("M,N,K,S", [(1490, 768, 30528, 16), (130, 100, 1000, 4), (64, 64, 64, 8)])
 def test_gemm_nt_split_k(ops, M, N, K, S):
     """K cut over S workgroups per tile, fp32 atomics into a zeroed C (input gradient of the tied MLM decoder)."""
