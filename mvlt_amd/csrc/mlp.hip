@@ -21,6 +21,44 @@
 
 namespace {
 
+// Activation by table (MVLT_GELU_LUT bit 0: the weight-gradient kernels, bit 1: the input-gradient kernels, bit 2: the forward): the
+// pre-activation is rounded to bf16 -- what the stage 3-4 path stores and what torch autocast hands nn.GELU -- and { Phi - 1/2, GELU' - 1/2 }
+// of its magnitude comes out of a 13 KB LDS copy of g_gelu_lut (tools/gen_gelu_lut.py); the sign is applied by one FMA each: 9.5 VALU
+// instructions + one ds_read_b64 per hidden activation in the weight-gradient kernels instead of 17, 7 + one ds_read_b32 instead of 11-12 in the others
+// Measured (same box, tools/ubench_mlp2.py / ab_bench_libs.sh): weight gradients 470 -> 363 us (C = 64) and 381 -> 358 us (C = 128), step -0.24 ms;
+// input gradients 325 -> 324 / 301 -> 306 us and forward 265 -> 283 / 204 -> 210 us (three to four waves per SIMD already hide the polynomial;
+// the gather's LDS latency is not hidden): bits 1 and 2 stay off.
+#ifndef MVLT_GELU_LUT
+#define MVLT_GELU_LUT 1
+#endif
+#include "gelu_lut.inc"
+constexpr int GELU_LUT_BYTES = MVLT_GELU_LUT_PAD * 8;          // whole 1 KB LDS-DMA instructions
+// the table into LDS by LDS-DMA, 1 KB per wave instruction, dealt round-robin to the NWV waves (lands with the kernel's first vmcnt(0) + barrier)
+template <int NWV> __device__ __forceinline__ void gelu_lut_dma(unsigned lds_base, int wave, int lane) {
+  for (int k = wave; k < GELU_LUT_BYTES / 1024; k += NWV)
+    glds16((const char*)&g_gelu_lut[0][0] + k * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds_base + k * 1024));
+}
+// index of a bf16 magnitude (15 bits) as a byte offset from lut0 = table base - 8 * MVLT_GELU_LUT_BASE
+__device__ __forceinline__ unsigned gelu_lut_off(unsigned u) {
+  return min(max(u, (unsigned)MVLT_GELU_LUT_BASE), (unsigned)MVLT_GELU_LUT_TOP) << 3;
+}
+__device__ __forceinline__ float gelu_lut_sign(float h) { return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, h) & 0x80000000u) | 0x3f800000u); }
+// one of the two functions alone (WHICH = 0: Phi, 1: GELU') of two pre-activations
+template <int WHICH> __device__ __forceinline__ void gelu_lut_one2(const char* lut0, float h0, float h1, float& r0, float& r1) {
+  const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{h0, h1}, bf16x2));
+  const float t0 = *(const float*)(lut0 + gelu_lut_off(pk & 0x7fffu) + 4 * WHICH), t1 = *(const float*)(lut0 + gelu_lut_off((pk >> 16) & 0x7fffu) + 4 * WHICH);
+  r0 = __builtin_fmaf(gelu_lut_sign(h0), t0, 0.5f);
+  r1 = __builtin_fmaf(gelu_lut_sign(h1), t1, 0.5f);
+}
+// Phi(h) and GELU'(h) of two pre-activations; lut0 = LDS table base - 8 * MVLT_GELU_LUT_BASE
+__device__ __forceinline__ void gelu_lut_both2(const char* lut0, float h0, float h1, float& ph0, float& d0, float& ph1, float& d1) {
+  const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{h0, h1}, bf16x2));
+  const f32x2 t0 = *(const f32x2*)(lut0 + gelu_lut_off(pk & 0x7fffu)), t1 = *(const f32x2*)(lut0 + gelu_lut_off((pk >> 16) & 0x7fffu));
+  const float s0 = gelu_lut_sign(h0), s1 = gelu_lut_sign(h1);
+  ph0 = __builtin_fmaf(s0, t0[0], 0.5f); d0 = __builtin_fmaf(s0, t0[1], 0.5f);
+  ph1 = __builtin_fmaf(s1, t1[0], 0.5f); d1 = __builtin_fmaf(s1, t1[1], 0.5f);
+}
+
 constexpr int NT = 256;
 template <int C> struct MlpGeo { static constexpr int JC = (C == 64) ? 64 : 32; };   // hidden units per chunk: C*JC = 4096 MACs per token either way
 
@@ -304,6 +342,11 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
   const int hid = p.hid;
 
   for (int u = tid; u < p.hid; u += NT) sB1[u] = p.b1[u];
+  constexpr bool LUT = MODE == 1 && ((MVLT_GELU_LUT >> 1) & 1);     // GELU' by table (the launch sizes the LDS for it): visible after the first barrier below
+  float* const sLut = sB1 + hid;
+  const char* const lut0 = (const char*)sLut - 8 * MVLT_GELU_LUT_BASE;
+  if (LUT)
+    for (int u = tid; u < MVLT_GELU_LUT_N * 2; u += NT) sLut[u] = (&g_gelu_lut[0][0])[u];
   // ---- B-operand fragments of this wave's tokens (x, and dy for the backward): 8 consecutive channels of token fr per
   // lane, straight from global memory (used by every hidden chunk, never re-read: no LDS copy)
   bf16x8 xfr[MT][KS_C], yfr[MODE == 1 ? MT : 1][KS_C];
@@ -383,7 +426,12 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(mvlt_mlp_args p) {
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
           const f32x2 hv = f32x2{h[r], h[r + 1]} + f32x2{b1v[r], b1v[r + 1]};
-          const f32x2 gv = (MODE == 0) ? gelu_fast2(hv) : f32x2{dg[r], dg[r + 1]} * gelu_fast_grad2(hv);
+          f32x2 gv;
+          if (LUT) {
+            float d0, d1;
+            gelu_lut_one2<1>(lut0, hv[0], hv[1], d0, d1);
+            gv = f32x2{dg[r] * d0, dg[r + 1] * d1};
+          } else gv = (MODE == 0) ? gelu_fast2(hv) : f32x2{dg[r], dg[r + 1]} * gelu_fast_grad2(hv);
           gfrag[jt >> 1][mt][(jt & 1) * 4 + r] = (bf16)gv[0];
           gfrag[jt >> 1][mt][(jt & 1) * 4 + r + 1] = (bf16)gv[1];
           h[r] = hv[0]; h[r + 1] = hv[1];
@@ -489,6 +537,7 @@ __global__ __launch_bounds__(NT, (C == 64 && MODE == 1) ? MVLT_PIPE_WAVES_64_1 :
   char* const sP = smem;
   char* const sC = smem + 2 * NP * PB;
   float* const sB1 = (float*)(sC + 2 * CB);
+  constexpr bool LUT = (MVLT_GELU_LUT >> (MODE == 1 ? 1 : 2)) & 1;
   const unsigned sP_lds = (unsigned)(uintptr_t)sP, sC_lds = (unsigned)(uintptr_t)sC;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -526,6 +575,8 @@ __global__ __launch_bounds__(NT, (C == 64 && MODE == 1) ? MVLT_PIPE_WAVES_64_1 :
   };
   dmaP(0, 0);
   if (NU > 1) dmaP(1, 1);
+  const char* const lut0 = (const char*)(sB1 + hid) - 8 * MVLT_GELU_LUT_BASE;      // activation table behind the bias (the launch sizes the LDS for it)
+  if (LUT) gelu_lut_dma<4>((unsigned)(uintptr_t)(sB1 + hid), wave, lane);
   for (int u = tid; u < hid; u += NT) sB1[u] = p.b1[u];
 
   bf16x8 xfr[MT][KS_C], yfr[MODE == 1 ? MT : 1][KS_C];
@@ -606,7 +657,12 @@ __global__ __launch_bounds__(NT, (C == 64 && MODE == 1) ? MVLT_PIPE_WAVES_64_1 :
       if (DO_G) {
         const float h0 = hacc[PAR][h][mt][2 * half], h1 = hacc[PAR][h][mt][2 * half + 1];
         float g0, g1;
-        if (MODE == 0) { g0 = gelu_fast1(h0); g1 = gelu_fast1(h1); }
+        if (LUT) {
+          float a0, a1;
+          gelu_lut_one2<MODE>(lut0, h0, h1, a0, a1);
+          g0 = (MODE == 0 ? h0 : dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half]) * a0;
+          g1 = (MODE == 0 ? h1 : dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half + 1]) * a1;
+        } else if (MODE == 0) { g0 = gelu_fast1(h0); g1 = gelu_fast1(h1); }
         else {
           g0 = dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half] * gelu_fast_grad1(h0);
           g1 = dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half + 1] * gelu_fast_grad1(h1);
@@ -921,6 +977,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void mlp_wgrad2_kernel(mv
   bf16* sW1 = (bf16*)smem;                     // [128][C]
   bf16* sW2T = sW1 + 128 * C;                  // [128][C]
   char* sT = smem + 2 * 128 * C * 2;           // [2][x tile | dy tile]
+  constexpr int TILE_ = 64 * 2 * C;
+  float* sLut = (float*)(sT + 2 * 2 * TILE_);  // activation table (MVLT_GELU_LUT)
+  const char* const lut0 = (const char*)sLut - 8 * MVLT_GELU_LUT_BASE;
   const unsigned sT_lds = (unsigned)(uintptr_t)sT;
 
   // one token split (all its ny hidden blocks) per XCD: x / dy rows come through that L2 once
@@ -958,6 +1017,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void mlp_wgrad2_kernel(mv
     *(u32x4*)(sW1 + toff<C>(r, ch * 8)) = *(const u32x4*)((const bf16*)p.w1 + (long)(j0 + r) * C + ch * 8);
     *(u32x4*)(sW2T + toff<C>(r, ch * 8)) = *(const u32x4*)((const bf16*)p.wc + (long)(j0 + r) * C + ch * 8);
   }
+  if (MVLT_GELU_LUT & 1) gelu_lut_dma<NW>((unsigned)(uintptr_t)sLut, wave, lane);
   float b1v[JT];
 #pragma unroll
   for (int jt = 0; jt < JT; ++jt) b1v[jt] = p.b1[j0 + jw + jt * 16 + fr];
@@ -1067,8 +1127,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void mlp_wgrad2_kernel(mv
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
           float g0, g1, d0, d1;
-          gelu_fast_both1(hd[mt & 1][jt][0][r], g0, d0);
-          gelu_fast_both1(hd[mt & 1][jt][0][r + 1], g1, d1);
+          if (MVLT_GELU_LUT & 1) {
+            const float h0 = hd[mt & 1][jt][0][r], h1 = hd[mt & 1][jt][0][r + 1];
+            float ph0, ph1;
+            gelu_lut_both2(lut0, h0, h1, ph0, d0, ph1, d1);
+            g0 = h0 * ph0; g1 = h1 * ph1;
+          } else {
+            gelu_fast_both1(hd[mt & 1][jt][0][r], g0, d0);
+            gelu_fast_both1(hd[mt & 1][jt][0][r + 1], g1, d1);
+          }
           const float q0 = hd[mt & 1][jt][1][r], q1 = hd[mt & 1][jt][1][r + 1];
           gfrag[jt][mt >> 1][(mt & 1) * 2 + (r >> 1)] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{g0, g1}, bf16x2));
           dhfrag[jt][mt >> 1][(mt & 1) * 2 + (r >> 1)] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0 * d0, q1 * d1}, bf16x2));
@@ -1159,8 +1226,9 @@ template <int C> int launch_wgrad(const mvlt_mlp_args& a, hipStream_t s) {
   static const bool legacy = getenv("MVLT_MLP_LEGACY") != nullptr || getenv("MVLT_MLP_WGRAD_LEGACY") != nullptr;
   if (!legacy && (!a.row_scale || a.rows_per_scale % 64 == 0)) {      // tile-uniform DropPath factor: the round-3 kernel
     constexpr int NW = C == 64 ? 4 : 8;
-    hipFuncSetAttribute((const void*)mlp_wgrad2_kernel<C, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((mlp_wgrad2_kernel<C, NW>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NW * 64), lds, s, a, m_per_split, splits, ny);
+    const size_t lds_t = lds + ((MVLT_GELU_LUT & 1) ? GELU_LUT_BYTES : 0);
+    hipFuncSetAttribute((const void*)mlp_wgrad2_kernel<C, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+    hipLaunchKernelGGL((mlp_wgrad2_kernel<C, NW>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NW * 64), lds_t, s, a, m_per_split, splits, ny);
     return mvlt_check_launch("mvlt_mlp_bwd_dw");
   }
   hipFuncSetAttribute((const void*)mlp_wgrad_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1171,12 +1239,14 @@ template <int C> int launch_wgrad(const mvlt_mlp_args& a, hipStream_t s) {
 template <int C, int MODE> int launch(const mvlt_mlp_args& a, hipStream_t s) {
   constexpr int BM = 128, JC = MlpGeo<C>::JC;
   size_t lds = (size_t)(2 * JC * C * (MODE == 1 ? 2 : 1) + 2 * C * JC) * 2 + (size_t)a.hid * 4;
+  if (MODE == 1 && ((MVLT_GELU_LUT >> 1) & 1)) lds += GELU_LUT_BYTES;
   const size_t stage = (size_t)4 * 16 * (C + 4) * 4;       // epilogue staging (4 waves x 16 rows) reuses the weight buffers
   if (lds < stage) lds = stage;
   static const bool legacy = getenv("MVLT_MLP_LEGACY") != nullptr;
   static const bool force128 = getenv("MVLT_MLP_PIPE128") != nullptr;
   if (!legacy && !a.h_out && a.hid >= 128 && !(C == 128 && MODE == 1 && !force128)) {      // the software-pipelined kernel (no pre-activation store: nothing in the step asks for one)
     size_t l2 = (size_t)2 * (MODE == 1 ? 2 : 1) * 32 * 2 * C + (size_t)2 * C * 64 + (size_t)a.hid * 4;
+    if ((MVLT_GELU_LUT >> (MODE == 1 ? 1 : 2)) & 1) l2 += GELU_LUT_BYTES;
     if (l2 < stage) l2 = stage;
     hipFuncSetAttribute((const void*)mlp_pipe_kernel<C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
     hipLaunchKernelGGL((mlp_pipe_kernel<C, MODE>), dim3((a.M + BM - 1) / BM), dim3(NT), l2, s, a);
