@@ -166,11 +166,12 @@ def roofline_cases(B, device):
 
 def time_dominant_kernel(model, B, device):
     """`roofline` = the launch with the largest share of the step (profiles/r03_kernel_stats.csv: the fused-MLP weight gradients of the two
-    stage-1 blocks, ~0.45 ms each), timed alone with HIP events on torch's current stream = the stream the C ABI launches on.
+    stage-1 blocks, ~0.35 ms each since their activation comes from a table; the other three fused-MLP backward launches of stages 1-2 are
+    within 5 % of it), timed alone with HIP events on torch's current stream = the stream the C ABI launches on.
     Its ALGORITHMIC work is the two weight-gradient products dW1 = dh^T x and dW2 = dy^T g: 2 x 2*M*C*hid FLOP (M = B*4224, C = 64, hid = 512)
     over 2 x M*C bf16 operand bytes; the kernel EXECUTES twice that (h = x W1^T and dg = dy W2 are recomputed on chip so that nothing of
-    size M x hid touches HBM) plus ~18 VALU instructions per hidden element and token for GELU / GELU', which is what bounds it
-    (VALU / MFMA issue rates measured by tools/probes/valu_rates.hip).  `bound` is "mfma" in the contract's
+    size M x hid touches HBM) plus 9.5 VALU instructions and one 8-byte LDS gather per hidden element and token for GELU / GELU' (17 VALU
+    until the end of round 3); VALU and MFMA time ADD in this kernel (issue rates measured by tools/probes/valu_rates.hip).  `bound` is "mfma" in the contract's
     vocabulary: the fraction says how far the launch is from doing its algorithmic FLOPs at matrix-pipe speed.
     `siblings`: round 2's roofline launch (the MIM decoder's 192->192 conv3x3 as a gathered GEMM, MFMA-bound) and the HBM-bound K = 64
     projection of the same GEMM family.  `traffic` = HBM bytes per launch from the committed PMC passes
@@ -184,11 +185,13 @@ def time_dominant_kernel(model, B, device):
     M2 = B * 4224
     return dict(kernel="mlp_wgrad2_kernel<64, 4> (bf16): fused-MLP weight gradients of a stage-1 block, M = B*4224 tokens, C = 64, hidden 512 "
                        "(dW1, db1, dW2, db2; h / dg / GELU / GELU' recomputed on chip; DropPath factors per sample, dropped samples skipped)",
-                share_of_step="largest single launch: 2 x ~0.45 ms of a ~23.5 ms step (profiles/r03_kernel_stats.csv)",
+                share_of_step="largest kernel of the step by total time: 2 x ~0.35 ms of a ~22 ms step; the three other fused-MLP backward launches "
+                              "of stages 1-2 take 0.34-0.36 ms each, two per step each (profiles/r03_kernel_stats.csv)",
                 bound="mfma", achieved=round(tf3, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf3 / PEAK_BF16_TFLOPS, 4),
                 traffic=tr("mlp_dw64"), ms_per_launch=round(ms3, 4), algorithmic_flops=flops3, executed_flops=2 * flops3,
                 algorithmic_bytes=2.0 * 2 * M2 * 64,
-                limiter="VALU: ~18 instructions per (token, hidden unit) for GELU and GELU' against 4 x 64 MACs on the matrix pipe",
+                limiter="VALU + MFMA time add up: 9.5 VALU instructions + one LDS gather per (token, hidden unit) for GELU and GELU' (table over the "
+                        "bf16 pre-activation) next to 4 x 64 MACs on the matrix pipe, at two waves per SIMD (216 registers)",
                 siblings=[
                     dict(kernel="conv3_nt_kernel<32, 192, 1> (bf16, 128x192 tile, 3x3-gather A from an LDS halo): MIM conv3x3 192->192 @32x32 as GEMM "
                                 "(M=B*1024, N=192, K=1728) -- round 2's roofline launch", bound="mfma", achieved=round(tf1, 1), peak=PEAK_BF16_TFLOPS,

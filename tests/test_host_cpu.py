@@ -516,3 +516,34 @@ def test_bench_self_launch_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 2 and "--gpus 64" in r.stderr, (r.returncode, r.stderr[-500:])
+
+
+def test_gelu_table_matches_exact_erf_gelu_and_its_generator():
+    """csrc/gelu_lut.inc (the activation table of the fused-MLP weight-gradient kernels) holds { Phi(v) - 1/2, GELU'(v) - 1/2 } of the exact-erf
+    GELU (reference libs/pvlt.py:62 nn.GELU) at every bf16 value 2^-9 <= v <= 8, and is what tools/gen_gelu_lut.py writes."""
+    import re, math, subprocess, sys, tempfile, shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "mvlt_amd", "csrc", "gelu_lut.inc")
+    text = open(inc).read()
+    base, top, n = (int(re.search(r"#define MVLT_GELU_LUT_%s (\d+)" % k, text).group(1)) for k in ("BASE", "TOP", "N"))
+    assert top - base + 1 == n == 1537
+    rows = re.findall(r"\{([-+0-9.e]+)f, ([-+0-9.e]+)f\}", text)
+    assert len(rows) == n
+    bits = torch.arange(base, top + 1, dtype=torch.int32)
+    v = (bits << 16).view(torch.float32).double()
+    assert v[0].item() == 2.0 ** -9 and v[-1].item() == 8.0
+    x = v.clone().requires_grad_(True)
+    g = torch.nn.functional.gelu(x)                 # exact (erf) form
+    g.sum().backward()
+    want_phi, want_dg = (g / x).detach() - 0.5, x.grad - 0.5
+    got = torch.tensor([[float(a), float(b)] for a, b in rows], dtype=torch.float64)
+    assert (got[:, 0] - want_phi).abs().max().item() < 1e-7 and (got[:, 1] - want_dg).abs().max().item() < 1e-7
+    # the generator reproduces the committed file byte for byte
+    tmp = tempfile.mkdtemp()
+    try:
+        os.makedirs(os.path.join(tmp, "tools")); os.makedirs(os.path.join(tmp, "mvlt_amd", "csrc"))
+        shutil.copy(os.path.join(root, "tools", "gen_gelu_lut.py"), os.path.join(tmp, "tools"))
+        subprocess.run([sys.executable, os.path.join(tmp, "tools", "gen_gelu_lut.py")], check=True, capture_output=True)
+        assert open(os.path.join(tmp, "mvlt_amd", "csrc", "gelu_lut.inc")).read() == text
+    finally:
+        shutil.rmtree(tmp)
