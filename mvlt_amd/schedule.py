@@ -318,7 +318,7 @@ class TrunkStep:
         bs["fused_mlp"] = fused = (dt == torch.bfloat16 and C in (64, 128))
         # stages 1-2 (one tile of the projection holds whole rows): Block.norm2 rides on the projection's epilogue -- the fused MLP then reads
         # its operand in bf16 and the fp32 mid stream only once (as the residual), instead of normalising the fp32 rows itself
-        proj_ln = fused and not _NO_PROJ_LN and not _NO_LN_FOLD
+        proj_ln = fused and not _NO_PROJ_LN and not _NO_LN_FOLD and M < (1 << 24)      # (the lean GEMM epilogues index rows in 24 bits)
         ops.gemm_nt(ao, self.w(p + "attn.proj.weight"), xm, M, C, C, C, C, C, bias=self.f32(p + "attn.proj.bias"),
                     row_scale=s1, rows_per_scale=N, R=x,
                     post_ln=(self.f32(p + "norm2.weight"), self.f32(p + "norm2.bias"), EPS_BLOCK, xn2.view(M, C), bs["m2"], bs["r2"]) if proj_ln else None)
