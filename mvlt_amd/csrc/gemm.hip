@@ -14,6 +14,12 @@
 #define MVLT_GELU_POLY 0     // the GELU / GELU' GEMM epilogues keep the sigmoid form: the polynomial one measured no gain here (HBM-bound launches; same-box A/B 22.60 / 22.73 against 22.63 / 22.67 ms)
 #endif
 #include "common.h"
+#ifndef MVLT_NT_EARLY_DEFAULT
+#define MVLT_NT_EARLY_DEFAULT 0x100  // early slot release in the NT K-loop: logits GEMM 172 -> 163 us, step -0.16 ms (same-box A/B, MVLT_NT_EARLY=0 / 1)
+#endif
+#ifndef MVLT_TN_EARLY
+#define MVLT_TN_EARLY 0
+#endif
 #include "../../include/mvlt_hip.h"
 
 namespace {
@@ -1202,28 +1208,49 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_a
   // NS-deep ring: tile t+NS-1 is issued while tile t is consumed; the wait leaves the NS-2 younger tiles in flight.
   // Near the end fewer tiles are in flight than the count assumes, so the wait falls back to vmcnt(0) there; nothing
   // is issued past the last tile, so no DMA is outstanding when the epilogue reuses the LDS.
+  // MVLT_TN_EARLY (early slot release, as in gemm_nt_dma_kernel): all fragments of a tile are read up front, a second barrier frees its slot and
+  // the refill (tile t + NS) is issued in front of the MFMAs: NS tiles in flight per workgroup instead of NS - 1
+  constexpr bool EARLY = MVLT_TN_EARLY != 0;
 #pragma unroll
-  for (int st = 0; st < NS - 1; ++st)
+  for (int st = 0; st < (EARLY ? NS : NS - 1); ++st)
     if (m_begin + st * TBK < m_end) issue(m_begin + st * TBK, st);
-  int slot = 0, islot = NS - 1;
+  int slot = 0, islot = EARLY ? 0 : NS - 1;
   for (int mt = m_begin; mt < m_end; mt += TBK) {
-    if (NS > 2 && mt + (NS - 2) * TBK < m_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPT * (NS - 2)) : "memory");
+    constexpr int YOUNG = EARLY ? NS - 1 : NS - 2;       // younger tiles that may still be in flight when tile `mt` is needed
+    if (YOUNG > 0 && mt + YOUNG * TBK < m_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPT * (YOUNG > 0 ? YOUNG : 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();    // tile `mt` has landed for every wave; everyone is done reading the slot refilled next
     asm volatile("" ::: "memory");
-    if (mt + (NS - 1) * TBK < m_end) issue(mt + (NS - 1) * TBK, islot);
-    islot = islot + 1 == NS ? 0 : islot + 1;
+    if (!EARLY) {
+      if (mt + (NS - 1) * TBK < m_end) issue(mt + (NS - 1) * TBK, islot);
+      islot = islot + 1 == NS ? 0 : islot + 1;
+    }
     const char* sA = smem + slot * STAGE;
     const char* sB = sA + TA::BYTES;
     slot = slot + 1 == NS ? 0 : slot + 1;
     const int cs_turn = ((mt - m_begin) / TBK) % (do_colsum ? t2 : t1);
+    u32x4 fa_all[TBK / 32][TM_], fb_all[TBK / 32][TN_];
+    if (EARLY) {
+#pragma unroll
+      for (int ks = 0; ks < TBK / 32; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM_; ++i) fa_all[ks][i] = tr_frag(sA + aoff[i] + ks * 32 * TA::ROWB, TA::ROWB);
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) fb_all[ks][j] = tr_frag(sB + boff[j] + ks * 32 * TB::ROWB, TB::ROWB);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave holds its fragments: the slot may be refilled
+      asm volatile("" ::: "memory");
+      if (mt + NS * TBK < m_end) issue(mt + NS * TBK, islot);
+      islot = islot + 1 == NS ? 0 : islot + 1;
+    }
 #pragma unroll
     for (int ks = 0; ks < TBK / 32; ++ks) {
       u32x4 fa[TM_], fb[TN_];
 #pragma unroll
-      for (int i = 0; i < TM_; ++i) fa[i] = tr_frag(sA + aoff[i] + ks * 32 * TA::ROWB, TA::ROWB);
+      for (int i = 0; i < TM_; ++i) fa[i] = EARLY ? fa_all[ks][i] : tr_frag(sA + aoff[i] + ks * 32 * TA::ROWB, TA::ROWB);
 #pragma unroll
-      for (int j = 0; j < TN_; ++j) fb[j] = tr_frag(sB + boff[j] + ks * 32 * TB::ROWB, TB::ROWB);
+      for (int j = 0; j < TN_; ++j) fb[j] = EARLY ? fb_all[ks][j] : tr_frag(sB + boff[j] + ks * 32 * TB::ROWB, TB::ROWB);
 #pragma unroll
       for (int i = 0; i < TM_; ++i)
 #pragma unroll
@@ -1450,7 +1477,9 @@ template <int W> int launch_conv3_wgrad(const mvlt_gemm_tn_args& a, hipStream_t 
 // LDS image is the same (128-B rows of 64 k, 16-B chunks XOR-swizzled by row); because the DMA writes lane-linear the
 // swizzle is applied to the source chunk each lane fetches.  ns-deep ring with a counted vmcnt wait, as in the TN kernel.
 template <int BN, int AMODE, int EPI, int BK, int BMT = BM>
-__global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kernel(mvlt_gemm_nt_args p, int ns) {
+__global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kernel(mvlt_gemm_nt_args p, int ns_flags) {
+  const int ns = ns_flags & 0xff;                   // ring depth
+  const bool early = (ns_flags & 0x100) != 0;       // early slot release (below)
   constexpr int ROWB = BK * 2;                      // LDS row: BK k-values of one tile row
   constexpr int CH = BK / 8;                        // 16-B chunks per row (8 or 4)
   constexpr int RPL = NTHREADS / CH;                // tile rows one DMA instruction of the workgroup covers
@@ -1562,12 +1591,16 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
   const int nk = min(kt_per, nk_all - kt0);
   if (nk <= 0) return;
   const int fr = lane & 15, fg = lane >> 4;
-  for (int st = 0; st < ns - 1 && st < nk; ++st) issue(st);
-  if (ns == 1) issue(0);
-  int slot = 0, islot = ns - 1;
+  // Early slot release: every fragment of a stage is read into registers before its first MFMA, so the stage's slot is free as soon as all
+  // four waves have done those reads -- a second barrier right behind them -- and the refill (stage kt + ns) is issued THERE, in front of
+  // the MFMAs, instead of behind the barrier of the next k-step: ns stages in flight per workgroup instead of ns - 1.  With the
+  // two-slot ring the K-loop otherwise runs at one LDS-DMA latency per k-step (Little's law with the LDS as the window).
+  for (int st = 0; st < (early ? ns : ns - 1) && st < nk; ++st) issue(st);
+  if (ns == 1 && !early) issue(0);
+  int slot = 0, islot = early ? 0 : ns - 1;
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt must have landed; up to ns - 2 later tiles may still be in flight (none near the tail)
-    const int ahead = min(nk - 1 - kt, ns - 2);
+    // tile kt must have landed; up to ns - 2 (early: ns - 1) later tiles may still be in flight (none near the tail)
+    const int ahead = min(nk - 1 - kt, early ? ns - 1 : ns - 2);
     if (ahead >= 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * LPT) : "memory");
     else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * LPT) : "memory");
     else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LPT) : "memory");
@@ -1575,8 +1608,10 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (ns > 1 && kt + ns - 1 < nk) issue(islot);
-    islot = islot + 1 >= ns ? 0 : islot + 1;
+    if (!early) {
+      if (ns > 1 && kt + ns - 1 < nk) issue(islot);
+      islot = islot + 1 >= ns ? 0 : islot + 1;
+    }
     const char* a_s = smem + slot * STAGE + (wm * WM) * ROWB;
     const char* b_s = smem + slot * STAGE + BMT * ROWB + (wn * WN) * ROWB;
     slot = slot + 1 >= ns ? 0 : slot + 1;
@@ -1596,6 +1631,13 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
         int r = j * 16 + fr;
         fb[ks][j] = *(const u32x4*)(b_s + r * ROWB + swzk(wn * WN + r, ks * 4 + fg) * 16);
       }
+    }
+    if (early) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                  // every wave holds its fragments of stage kt: the slot may be refilled
+      asm volatile("" ::: "memory");
+      if (kt + ns < nk) issue(islot);
+      islot = islot + 1 >= ns ? 0 : islot + 1;
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -1857,6 +1899,9 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     if (const char* e = getenv("MVLT_NT_NS")) { ns = atoi(e); if (ns > nkd) ns = nkd; if (ns < 2) ns = nkd < 2 ? nkd : 2; if (ns > 6) ns = 6; }
     size_t lds2 = (size_t)ns * (BM + bn) * (bkd * 2);
     if (lds2 < stage) lds2 = stage;
+    static const int early_flag = getenv("MVLT_NT_EARLY") ? (atoi(getenv("MVLT_NT_EARLY")) ? 0x100 : 0) : MVLT_NT_EARLY_DEFAULT;
+    const int ns_lds = ns;
+    if (nkd >= 2) ns |= early_flag;                // (a single k-step has nothing to refill)
     if (a->post_y) {                            // EPI 8: attn.proj + residual + Block.norm2 (whole rows in one tile)
       MVLT_REQUIRE(epi == 2 && a->N == bn && a->a_map.mode == 0 && a->c_map.mode == 0 && a->c_map.rows_per_batch == 0 && a->post_gamma && a->post_beta &&
                    a->post_mean && a->post_rstd && a->post_ld % 8 == 0 && ((uintptr_t)a->post_y & 15) == 0 && ((uintptr_t)a->post_gamma & 15) == 0,
@@ -1901,7 +1946,7 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     if (wide) {
       const int tn192 = a->N / 192;
       dim3 grid192((unsigned)(8 * ((tiles_m + 7) / 8) * tn192), 1);
-      size_t lds3 = (size_t)ns * (BM + 192) * ROW_BYTES;
+      size_t lds3 = (size_t)ns_lds * (BM + 192) * ROW_BYTES;
       const size_t stage192 = (size_t)4 * 32 * 100 * sizeof(float);
       if (lds3 < stage192) lds3 = stage192;
       if (a->a_map.mode == 0 && epi == 1) hipLaunchKernelGGL((gemm_nt_dma_kernel<192, 0, 1, 64>), grid192, block, lds3, s, *a, ns);
