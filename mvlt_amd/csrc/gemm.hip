@@ -17,6 +17,9 @@
 #ifndef MVLT_NT_EARLY_DEFAULT
 #define MVLT_NT_EARLY_DEFAULT 0x100  // early slot release in the NT K-loop: logits GEMM 172 -> 163 us, step -0.16 ms (same-box A/B, MVLT_NT_EARLY=0 / 1)
 #endif
+#ifndef MVLT_ABL
+#define MVLT_ABL 0                   // timing ablations of the NT K-loop (wrong results): 1 no DMA, 2 no MFMA, 3 no fragment reads
+#endif
 #ifndef MVLT_TN_EARLY
 #define MVLT_TN_EARLY 0
 #endif
@@ -1565,6 +1568,7 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
       tdy = dy - 1; tdx = seg - dy * 3 - 1;
       off_bytes += (tdy * amap.w_in + tdx) * (2 * p.lda);
     }
+    if (MVLT_ABL == 1) { kpos += BK; return; }          // ablation: no DMA at all
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       bool ok = a_ok[i] && k_ok;
@@ -1624,12 +1628,12 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
 #pragma unroll
       for (int i = 0; i < TM_; ++i) {
         int r = i * 16 + fr;
-        fa[ks][i] = *(const u32x4*)(a_s + r * ROWB + swzk(wm * WM + r, ks * 4 + fg) * 16);
+        fa[ks][i] = MVLT_ABL == 3 ? u32x4{(unsigned)r, 1u, 2u, 3u} : *(const u32x4*)(a_s + r * ROWB + swzk(wm * WM + r, ks * 4 + fg) * 16);
       }
 #pragma unroll
       for (int j = 0; j < TN_; ++j) {
         int r = j * 16 + fr;
-        fb[ks][j] = *(const u32x4*)(b_s + r * ROWB + swzk(wn * WN + r, ks * 4 + fg) * 16);
+        fb[ks][j] = MVLT_ABL == 3 ? u32x4{(unsigned)r, 5u, 6u, 7u} : *(const u32x4*)(b_s + r * ROWB + swzk(wn * WN + r, ks * 4 + fg) * 16);
       }
     }
     if (early) {
@@ -1642,6 +1646,11 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       __builtin_amdgcn_sched_barrier(0);             // keeps every ds_read ahead of the MFMAs (one wait per tile)
+      if (MVLT_ABL == 2) {                              // ablation: no MFMAs (the fragments are consumed by one XOR each)
+#pragma unroll
+        for (int i = 0; i < TM_; ++i) acc[i][0][0] += __builtin_bit_cast(float, fa[ks][i][0] ^ fb[ks][i % TN_][1]);
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < TM_; ++i)
 #pragma unroll
