@@ -18,7 +18,7 @@
 #define MVLT_NT_EARLY_DEFAULT 0x100  // early slot release in the NT K-loop: logits GEMM 172 -> 163 us, step -0.16 ms (same-box A/B, MVLT_NT_EARLY=0 / 1)
 #endif
 #ifndef MVLT_ABL
-#define MVLT_ABL 0                   // timing ablations of the NT K-loop (wrong results): 1 no DMA, 2 no MFMA, 3 no fragment reads
+#define MVLT_ABL 0                   // timing ablations of the NT K-loop (wrong results): 1 no DMA, 2 no MFMA, 3 no fragment reads, 4 every DMA reads the zero page
 #endif
 #ifndef MVLT_TN_EARLY
 #define MVLT_TN_EARLY 0
@@ -1573,11 +1573,12 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
     for (int i = 0; i < A_ITERS; ++i) {
       bool ok = a_ok[i] && k_ok;
       if constexpr (AMODE == 2) ok = ok && (unsigned)(a_y[i] + tdy) < (unsigned)amap.h_in && (unsigned)(a_x[i] + tdx) < (unsigned)amap.w_in;
+      if (MVLT_ABL == 4) ok = false;                      // ablation: every DMA instruction is issued, all of them read the (L2-resident) zero page
       glds16(ok ? a_ptr[i] + off_bytes : zsrc, __builtin_amdgcn_readfirstlane(smem_lds + slot * STAGE + (i * NTHREADS + wave * 64) * 16));
     }
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i)
-      glds16((b_ok[i] && k_ok) ? b_ptr[i] + kpos * 2 : zsrc,
+      glds16((b_ok[i] && k_ok && MVLT_ABL != 4) ? b_ptr[i] + kpos * 2 : zsrc,
              __builtin_amdgcn_readfirstlane(smem_lds + slot * STAGE + BMT * ROWB + (i * NTHREADS + wave * 64) * 16));
     kpos += BK;
     if constexpr (AMODE != 0) {
