@@ -241,9 +241,12 @@ __device__ __forceinline__ u32x4 tr_frag16(const char* lds_addr) {
   unsigned long long l = __builtin_bit_cast(unsigned long long, lo), h = __builtin_bit_cast(unsigned long long, hi);
   return u32x4{(unsigned)l, (unsigned)(l >> 32), (unsigned)h, (unsigned)(h >> 32)};
 }
+#ifndef MVLT_GLDS_MOD
+#define MVLT_GLDS_MOD ""             // cache-policy bits of the LDS-DMA loads (" sc1", " nt", " sc0 sc1": measured, no gain -- DESIGN 6.0)
+#endif
 __device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_base) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MVLT_GLDS_MOD "\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(src), "s"(lds_wave_base) : "memory");
 }
 // zero source for LDS slots whose row / column / 3x3 tap does not exist: every thread issues the same number of DMAs per
