@@ -153,8 +153,12 @@ __device__ __forceinline__ float gelu_poly_dg_s(float xc, float s) {           /
   r = __builtin_fmaf(r, s, 7.967216338e-01f);
   return __builtin_fmaf(xc, r, 0.5f);
 }
+// The Phi polynomial overshoots past its fit range (Phi_poly(4) = 1 + 7.2e-5, Phi_poly(-4) = -7.2e-5): clamped at +-4 the forward returned
+// +7.2e-5 |x| for x < -4 -- wrong sign, growing with |x|.  It crosses 1 / 0 at |x| = 3.98504; clamped at 3.985 it saturates at
+// 1 - 6e-7 / 6e-7 (true Phi(3.985) = 1 - 3.4e-5: inside the fit's 1e-4 bound), so the tail is x * 6e-7 with the right sign, no extra instruction.
+#define MVLT_GELU_PHI_CLAMP 3.985f
 __device__ __forceinline__ float gelu_poly1(float x) {
-  const float xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
+  const float xc = __builtin_amdgcn_fmed3f(x, -MVLT_GELU_PHI_CLAMP, MVLT_GELU_PHI_CLAMP);
   return x * gelu_poly_phi_s(xc, xc * xc);
 }
 __device__ __forceinline__ float gelu_poly_grad1(float x) {
@@ -163,7 +167,7 @@ __device__ __forceinline__ float gelu_poly_grad1(float x) {
 }
 // GELU and GELU' together: Phi by the polynomial, the Gaussian term by one exponential (12 plain + 1 transcendental against 12 + 2)
 __device__ __forceinline__ void gelu_poly_both1(float x, float& g, float& dg) {
-  const float xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
+  const float xc = __builtin_amdgcn_fmed3f(x, -MVLT_GELU_PHI_CLAMP, MVLT_GELU_PHI_CLAMP);
   const float s = xc * xc;
   const float ph = gelu_poly_phi_s(xc, s);
   const float e = __builtin_amdgcn_exp2f(s * (-0.5f * MVLT_LOG2E));
@@ -190,7 +194,7 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
 __device__ __forceinline__ void gelu_fast_both2(f32x2 x, f32x2& g, f32x2& dg) {
 #if MVLT_GELU_POLY & 4
   {                                            // the polynomial form on the packed-f32 ops: 16 instructions per PAIR of activations
-    const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x[1], -4.0f, 4.0f)};
+    const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -MVLT_GELU_PHI_CLAMP, MVLT_GELU_PHI_CLAMP), __builtin_amdgcn_fmed3f(x[1], -MVLT_GELU_PHI_CLAMP, MVLT_GELU_PHI_CLAMP)};
     const f32x2 s = xc * xc;
     f32x2 r = s * 2.816099979e-08f + -1.891889492e-06f;
     r = r * s + 5.419039730e-05f;

@@ -596,7 +596,9 @@ extern "C" int mvlt_bert_embed_bwd(const void* dy, const long* ids, const float*
 
 extern "C" int mvlt_patchify(const float* img, void* out, int B, int Cin, int H, int W, int k, int dtype, void* stream) {
   MVLT_REQUIRE(img && out && B > 0 && Cin > 0 && k > 0 && H % k == 0 && W % k == 0, "mvlt_patchify: bad arguments (H, W must be divisible by k)");
-  if (k == 4 && Cin == 3 && W <= 2048 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+  // strip kernel: 4 image rows x 3 channels of a sample in LDS; widths whose strip exceeds the 64 KB default dynamic-LDS limit (W > 1361)
+  // and widths that are not whole 16-byte groups take the generic kernel
+  if (k == 4 && Cin == 3 && W % 4 == 0 && (size_t)12 * (W + 4) * sizeof(float) <= 65536 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)out & 15) == 0) {
     const size_t lds = (size_t)12 * (W + 4) * sizeof(float);
     dim3 sgrid((unsigned)(B * (H / 4))), sblock(NT);
     if (dtype == 0) hipLaunchKernelGGL((patchify_strip_kernel<bf16>), sgrid, sblock, lds, (hipStream_t)stream, img, (bf16*)out, H, W);

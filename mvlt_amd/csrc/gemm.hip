@@ -14,6 +14,7 @@
 #define MVLT_GELU_POLY 0     // the GELU / GELU' GEMM epilogues keep the sigmoid form: the polynomial one measured no gain here (HBM-bound launches; same-box A/B 22.60 / 22.73 against 22.63 / 22.67 ms)
 #endif
 #include "common.h"
+#include <type_traits>
 #ifndef MVLT_NT_EARLY_DEFAULT
 #define MVLT_NT_EARLY_DEFAULT 0x100  // early slot release in the NT K-loop: logits GEMM 172 -> 163 us, step -0.16 ms (same-box A/B, MVLT_NT_EARLY=0 / 1)
 #endif
@@ -272,9 +273,11 @@ __device__ __forceinline__ int fdiv24(int m, int d, float inv) {      // exact m
   int r = m - q * d;
   return q + (r >= d) - (r < 0);
 }
-template <int BN, int EPIX, int TM = 4>
+// NWN = waves along N (2: the 4-wave 2 x 2 kernels; 4: the 8-wave 256 x 256 kernel, whose wave tile is (TM * 16) x 64 = "BN 128" here)
+template <int BN, int EPIX, int TM = 4, int NWN = 2>
 __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32x4 (&acc)[TM][BN / 32], char* smem, int m0, int n0,
                                                  int wave, int lane) {
+  static_assert(NWN == 2 || EPIX != 8, "the LayerNorm epilogue pairs the two waves of a row: 2 x 2 wave grids only");
   constexpr bool SCAT = (EPIX == 6 || EPIX == 7);     // EPI 6 / 7 = EPI 1 / 2 with a patch-scatter c_map (mode 1)
   constexpr bool POST = EPIX == 8;                    // EPI 8 = EPI 2 + LayerNorm of the output row
   constexpr int EPI = EPIX == 6 ? 1 : (EPIX == 7 || EPIX == 8) ? 2 : EPIX;
@@ -284,7 +287,7 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
   constexpr int CPR = WN / 8;
   constexpr int RPI = 64 / CPR;
   constexpr int NIT = 32 / RPI;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int fr = lane & 15, fg = lane >> 4;
   // the GELU / GELU' epilogues write (and read) operand-dtype tensors only -- the host dispatch guarantees it -- so their fp32 store / load
   // paths and the second half of every prefetch slot are not compiled in (EPI 4: 119 -> fewer registers, a third workgroup per CU)
@@ -1665,6 +1668,594 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
   else nt_epilogue_lean<BN, EPI, TM_>(p, acc, smem, m0, n0, wave, lane);
 }
 
+// ------------------------------------------------------------------------------------------------ NT, bf16, 8 waves, 8-phase K-loop (256 x 256 x 64 and relatives)
+// The 128 x 128 kernel above asks the CU's vector-memory path for 32 KB per 64-deep k-step and workgroup -- 60 B per clock and CU at matrix-pipe
+// speed against the 64 B per clock the texture / L1 path is specified at (round 3: TA busy 54-68 %, TCP_PENDING_STALL ~50 % of the launch) --
+// and runs its whole workgroup in lockstep (DMA issue, barrier, fragment reads, MFMAs).  This kernel halves the operand bytes per FLOP (256 x 256
+// tile: 64 KB per k-step for 4x the MFMAs) and replaces the lockstep by the phase schedule of cdna_hip_programming.md 5 ("256^2 8-phase template"):
+//   * 8 waves as 2 (M) x 4 (N); a wave owns (2 HM) x (HN0 + HN1) accumulator tiles of 16 x 16 -- 8 x 4 for the 256 x 256 tile, 6 x 4 for
+//     192 x 256, 6 x 5 for 192 x 320; one workgroup per CU, two k-tile buffers of {A0, A1, B0, B1} half-tiles in LDS (128 KB at most).  Half h
+//     of A holds the rows {wr * 2 HM 16 + h * HM 16 + r} of both wave rows, half h of B the columns of all four wave columns: every wave reads
+//     ITS part of a half-tile, and a half-tile is free for its refill as soon as the one phase that reads it is over.
+//   * a k-tile is four phases, one accumulator quadrant (HM x HNh tiles x K 64: 16 MFMAs at 256 x 256) each: (A0, B0) -> (A0, B1) -> (A1, B1) ->
+//     (A1, B0); a phase is {fragment reads of the half-tile(s) it needs, ONE half-tile refill (2-3 LDS-DMA instructions per thread), barrier,
+//     its MFMAs at raised priority, barrier}.  The refills run two k-tiles ahead; the only vmcnt wait is in phase 4 and leaves the three
+//     youngest half-tiles in flight -- never zero inside the loop.
+//   * the two wave rows run half a phase apart (wr == 1 takes one extra barrier up front, wr == 0 one at the end): while one wave of a SIMD
+//     issues its MFMAs the other reads fragments and issues DMA, so the matrix pipe sees a new MFMA group as soon as the last one drains.
+// Hazards (who may touch which half-tile when): a refill targets a half-tile whose last reads were retired by an lgkmcnt wait at least one barrier
+// earlier in EVERY wave (B0: the counted lgkmcnt of phase 1, refilled in phase 2; A0 / B1 / A1: read in phase 1 / 2 / 3, refilled in phase
+// 3 / 4 / 1); a half-tile is read one phase or more after the barrier that follows the vmcnt wait that retired its DMA in every wave (the wait
+// of phase 4 covers k-tile t + 1 whole: the three half-tiles issued after its last one, A1(t + 1) in phase 1, are B0 / A0 / B1 of k-tile t + 2).
+// Tile shapes: the launches of this model are 1.5 .. 10 tiles per CU, so whole rounds matter as much as the loop: 49152 x 512 is 384 tiles of
+// 256 x 256 (1.5 rounds of 256 CUs) but 512 tiles of 192 x 256 (2 rounds of 3/4 the work each); 98304 x 320 is 512 tiles of 192 x 320.
+// Preconditions (host dispatch): bf16, identity a_map, M % BM == 0, N % BN == 0, K % 64 == 0, lean epilogue (EPI 1-5; the 80-column wave
+// tile of BN 320 carries EPI 1 / 2 only).
+__device__ __forceinline__ void glds16_s(const char* sbase, unsigned voff, unsigned dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
+#define MVLT_BAR()                                  \
+  do {                                              \
+    __builtin_amdgcn_sched_barrier(0);              \
+    __builtin_amdgcn_s_barrier();                   \
+    asm volatile("" ::: "memory");                  \
+    __builtin_amdgcn_sched_barrier(0);              \
+  } while (0)
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+// epilogue of the 80-column wave tile (BN 320 = 4 waves x 5 accumulator tiles): a 32-row half of the wave tile is 32 x 10 chunks of 8 columns =
+// 5 chunks per lane.  EPI 1: C = AB^T (+bias); EPI 2: C = (AB^T + bias) * row_scale + R.  Identity or batch-strided c_map, fp32 / bf16 output.
+template <int EPI, int TM>
+__device__ __forceinline__ void nt_epilogue_w80(const mvlt_gemm_nt_args& p, f32x4 (&acc)[TM][5], char* smem, int m0, int n0, int wave, int lane) {
+  static_assert(EPI == 1 || EPI == 2, "the 80-column wave tile carries the plain and the residual epilogue");
+  constexpr int WN = 80, LDW = WN + 4, NH = TM / 2, NIT = 5;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ofp32 = p.out_dtype;
+  float* stage = (float*)smem + wave * 32 * LDW;
+  const int rpb = p.c_map.rows_per_batch;
+  const float inv_rpb = rpb > 0 ? 1.0f / (float)rpb : 0.f;
+  const float inv_rps = (EPI == 2 && p.rows_per_scale > 0) ? 1.0f / (float)p.rows_per_scale : 0.f;
+  int rl[NIT], cc[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int sidx = it * 64 + lane;
+    rl[it] = sidx / 10;
+    cc[it] = (sidx - rl[it] * 10) * 8;
+  }
+  // the residual rows (EPI 2) of a 32-row half are requested one half ahead, in two rotating slots: their HBM latency hides behind the
+  // previous half's staging, arithmetic and stores (the fragment registers of the K-loop are dead here)
+  long idx[2][NIT];
+  float rs[2][NIT];
+  u32x4 raw[2][NIT][2];
+  auto request = [&](int half) {
+    const int sl = half & 1;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + wm * (TM * 16) + half * 32 + rl[it];
+      long phys = m;
+      if (rpb > 0) {
+        const int b = fdiv24(m, rpb, inv_rpb);
+        phys = (long)b * p.c_map.batch_stride + p.c_map.offset + (m - b * rpb);
+      }
+      idx[sl][it] = phys * p.ldc + n0 + wn * WN + cc[it];
+      rs[sl][it] = 1.0f;
+      if (EPI == 2) {
+        if (p.row_scale) rs[sl][it] = p.row_scale[fdiv24(m, p.rows_per_scale, inv_rps)];
+        if (ofp32) { raw[sl][it][0] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)p.R + idx[sl][it])); raw[sl][it][1] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)p.R + idx[sl][it] + 4)); }
+        else raw[sl][it][0] = ld_g<MVLT_NT_LD>((const u32x4*)((const bf16*)p.R + idx[sl][it]));
+      }
+    }
+  };
+  request(0);
+#pragma unroll
+  for (int half = 0; half < NH; ++half) {
+    const int sl = half & 1;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(ii * 16 + 4 * fg + r) * LDW + j * 16 + fr] = acc[half * 2 + ii][j][r];
+    if (half + 1 < NH) request(half + 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const f32x4 v0 = *(const f32x4*)(stage + rl[it] * LDW + cc[it]), v1 = *(const f32x4*)(stage + rl[it] * LDW + cc[it] + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      if (p.bias) {
+        const f32x4 b0 = *(const f32x4*)(p.bias + n0 + wn * WN + cc[it]), b1 = *(const f32x4*)(p.bias + n0 + wn * WN + cc[it] + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+      }
+      if (EPI == 2) {
+        float o8[8];
+        if (ofp32) {
+          const f32x4 a = __builtin_bit_cast(f32x4, raw[sl][it][0]), b = __builtin_bit_cast(f32x4, raw[sl][it][1]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o8[e] = a[e]; o8[4 + e] = b[e]; }
+        } else {
+          const bf16x8 a = __builtin_bit_cast(bf16x8, raw[sl][it][0]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = (float)a[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[sl][it] + o8[e];
+      }
+      if (ofp32) {
+        st_g<MVLT_NT_GEMM>((f32x4*)((float*)p.C + idx[sl][it]), f32x4{v[0], v[1], v[2], v[3]});
+        st_g<MVLT_NT_GEMM>((f32x4*)((float*)p.C + idx[sl][it] + 4), f32x4{v[4], v[5], v[6], v[7]});
+      } else {
+        bf16x8 a;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (bf16)v[e];
+        st_g<MVLT_NT_GEMM>((bf16x8*)((bf16*)p.C + idx[sl][it]), a);
+      }
+    }
+  }
+}
+
+template <int EPI, int HM, int HN0, int HN1>
+__global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p) {
+  constexpr int WMT = 2 * HM, WNT = HN0 + HN1;                    // accumulator tiles per wave
+  constexpr int BMT = 2 * WMT * 16, BNT = 4 * WNT * 16;           // workgroup tile
+  constexpr int AH = 2 * HM * 16, BH0 = 4 * HN0 * 16, BH1 = 4 * HN1 * 16;      // rows of the A / B0 / B1 half-tiles
+  constexpr int A_IT = (AH + 63) / 64, B_IT0 = BH0 / 64, B_IT1 = BH1 / 64;     // DMA instructions per thread (the last A one: waves 0-3 only when AH = 96)
+  constexpr bool A_PART = AH % 64 != 0;
+  static_assert(BH0 % 64 == 0 && BH1 % 64 == 0 && (!A_PART || AH % 64 == 32), "half-tile geometry");
+  constexpr int OFF_A1 = AH * 128, OFF_B0 = 2 * AH * 128, OFF_B1 = OFF_B0 + BH0 * 128, BUF = OFF_B1 + BH1 * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 buffers][A0 | A1 | B0 | B1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_m = p.M / BMT, tiles_n = p.N / BNT;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, bslot = bid >> 3;
+  const int tile_m = (bslot / tiles_n) * 8 + xcd, tile_n = bslot % tiles_n;      // the n-tiles of an m-tile are neighbours on one XCD
+  if (tile_m >= tiles_m) return;
+  const int m0 = tile_m * BMT, n0 = tile_n * BNT;
+  const unsigned smem_lds = (unsigned)(uintptr_t)smem;
+  const int nk = p.K >> 6;
+
+  // ---- loader: DMA instruction i of a half-tile covers its rows 64 i .. 64 i + 63, thread -> (row (tid >> 3) + 64 i, slot tid & 7); the slot holds
+  //      source chunk slot ^ ((row >> 1) & 7) (the read-side swizzle, an involution; rows 64 apart share the mask).  Source address = a scalar
+  //      base per (operand, half, k-tile) + a per-thread 32-bit offset per instruction.
+  const int lrow = tid >> 3;
+  const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
+  const unsigned a_rs = 2u * (unsigned)p.lda, b_rs = 2u * (unsigned)p.ldb;
+  unsigned a_voff[A_IT], b_voff0[B_IT0], b_voff1[B_IT1];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int lr = lrow + 64 * i, w_ = lr / (HM * 16), rem = lr - w_ * (HM * 16);
+    a_voff[i] = (unsigned)(w_ * (WMT * 16) + rem) * a_rs + chunk * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < B_IT0; ++i) {
+    const int lr = lrow + 64 * i, w_ = lr / (HN0 * 16), rem = lr - w_ * (HN0 * 16);
+    b_voff0[i] = (unsigned)(w_ * (WNT * 16) + rem) * b_rs + chunk * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < B_IT1; ++i) {
+    const int lr = lrow + 64 * i, w_ = lr / (HN1 * 16), rem = lr - w_ * (HN1 * 16);
+    b_voff1[i] = (unsigned)(w_ * (WNT * 16) + HN0 * 16 + rem) * b_rs + chunk * 16;
+  }
+  const char* const a_base = (const char*)p.A + (size_t)m0 * a_rs;
+  const char* const b_base = (const char*)p.B + (size_t)n0 * b_rs;
+  const unsigned dst_wave = smem_lds + wave * 1024;
+  // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1 (compile-time at every call site)
+  auto stage = [&](int which, int t, int buf) {
+    if (which < 2) {
+      const char* sb = a_base + (size_t)(which * HM * 16) * a_rs + t * 128;
+      const unsigned dst = dst_wave + buf * BUF + which * OFF_A1;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i)
+        if (!A_PART || i + 1 < A_IT || wave < 4) glds16_s(sb, a_voff[i], dst + i * 8192);
+    } else if (which == 2) {
+      const char* sb = b_base + t * 128;
+      const unsigned dst = dst_wave + buf * BUF + OFF_B0;
+#pragma unroll
+      for (int i = 0; i < B_IT0; ++i) glds16_s(sb, b_voff0[i], dst + i * 8192);
+    } else {
+      const char* sb = b_base + t * 128;
+      const unsigned dst = dst_wave + buf * BUF + OFF_B1;
+#pragma unroll
+      for (int i = 0; i < B_IT1; ++i) glds16_s(sb, b_voff1[i], dst + i * 8192);
+    }
+  };
+  // DMA instructions of THIS wave in the three youngest half-tiles (B0, A0, B1) = what the wait of phase 4 leaves in flight
+  constexpr int INFL0 = B_IT0 + A_IT + B_IT1, INFL1 = B_IT0 + (A_PART ? A_IT - 1 : A_IT) + B_IT1;
+  auto wait_tile = [&](bool more) {
+    if (!more) wait_vm<0>();
+    else if (wr == 0) wait_vm<INFL0>();
+    else wait_vm<INFL1>();
+  };
+
+  // ---- fragment geometry: lane (fr, fg) reads row fr of a 16-row tile, chunk (ks * 4 + fg) ^ ((fr >> 1) & 7)
+  const int fr = lane & 15, fg = lane >> 4;
+  const int sw = (fr >> 1) & 7;
+  const char* const fa_base = smem + (wr * HM * 16 + fr) * 128;
+  const char* const fb0_base = smem + OFF_B0 + (wc * HN0 * 16 + fr) * 128;
+  const char* const fb1_base = smem + OFF_B1 + (wc * HN1 * 16 + fr) * 128;
+  const int koff0 = ((fg ^ sw) & 7) << 4, koff1 = (((4 + fg) ^ sw) & 7) << 4;
+
+  f32x4 acc[WMT][WNT];
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 fa[2][HM], fb0[2][HN0], fb1[2][HN1];
+
+#define MVLT_LDA(BUFI, MH)                                                                                         \
+  _Pragma("unroll") for (int i = 0; i < HM; ++i) {                                                                 \
+    fa[0][i] = *(const u32x4*)(fa_base + (BUFI) * BUF + (MH) * OFF_A1 + i * 2048 + koff0);                         \
+    fa[1][i] = *(const u32x4*)(fa_base + (BUFI) * BUF + (MH) * OFF_A1 + i * 2048 + koff1);                         \
+  }
+#define MVLT_LDB0(BUFI)                                                                                            \
+  _Pragma("unroll") for (int j = 0; j < HN0; ++j) {                                                                \
+    fb0[0][j] = *(const u32x4*)(fb0_base + (BUFI) * BUF + j * 2048 + koff0);                                       \
+    fb0[1][j] = *(const u32x4*)(fb0_base + (BUFI) * BUF + j * 2048 + koff1);                                       \
+  }
+#define MVLT_LDB1(BUFI)                                                                                            \
+  _Pragma("unroll") for (int j = 0; j < HN1; ++j) {                                                                \
+    fb1[0][j] = *(const u32x4*)(fb1_base + (BUFI) * BUF + j * 2048 + koff0);                                       \
+    fb1[1][j] = *(const u32x4*)(fb1_base + (BUFI) * BUF + j * 2048 + koff1);                                       \
+  }
+#define MVLT_MMA(MH, JBASE, HN, FB)                                                                                \
+  do {                                                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+      _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < (HN); ++j)                                                           \
+          acc[(MH) * HM + i][(JBASE) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                               \
+              __builtin_bit_cast(bf16x8, fa[ks][i]), __builtin_bit_cast(bf16x8, FB[ks][j]), acc[(MH) * HM + i][(JBASE) + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+  } while (0)
+
+  // ---- prologue: k-tile 0 whole, and the first three half-tiles of k-tile 1, in the loop's own issue order (B0, A0, B1, A1)
+  stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+  if (nk > 1) { stage(2, 1, 1); stage(0, 1, 1); stage(3, 1, 1); }
+  wait_tile(nk > 1);
+  MVLT_BAR();
+  if (wr == 1) MVLT_BAR();                        // the second wave row runs half a phase behind the first
+
+  auto ktile = [&](auto bufc, int t) {
+    constexpr int B = decltype(bufc)::value;
+    // phase 1: quadrant (0, 0); refill A1 of k-tile t + 1 (other buffer: last read in phase 3 of k-tile t - 1)
+    MVLT_LDB0(B)
+    __builtin_amdgcn_sched_barrier(0);
+    MVLT_LDA(B, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nk) stage(1, t + 1, B ^ 1);
+    wait_lgkm<2 * HM>();                          // the B0 reads (issued first) are back: B0 may be refilled in phase 2
+    MVLT_BAR();
+    MVLT_MMA(0, 0, HN0, fb0);
+    MVLT_BAR();
+    // phase 2: quadrant (0, 1); refill B0 of k-tile t + 2
+    MVLT_LDB1(B)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nk) stage(2, t + 2, B);
+    MVLT_BAR();
+    MVLT_MMA(0, HN0, HN1, fb1);
+    MVLT_BAR();
+    // phase 3: quadrant (1, 1); refill A0 of k-tile t + 2
+    MVLT_LDA(B, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nk) stage(0, t + 2, B);
+    MVLT_BAR();
+    MVLT_MMA(1, HN0, HN1, fb1);
+    MVLT_BAR();
+    // phase 4: quadrant (1, 0) from registers; refill B1 of k-tile t + 2; k-tile t + 1 must have landed when this phase ends
+    if (t + 2 < nk) stage(3, t + 2, B);
+    wait_tile(t + 2 < nk);
+    MVLT_BAR();
+    MVLT_MMA(1, 0, HN0, fb0);
+    MVLT_BAR();
+  };
+  for (int t = 0; t < nk; t += 2) {
+    ktile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
+  }
+  if (wr == 0) MVLT_BAR();
+  MVLT_BAR();                                      // every wave is out of the loop: the epilogue may reuse the LDS
+#undef MVLT_LDA
+#undef MVLT_LDB0
+#undef MVLT_LDB1
+#undef MVLT_MMA
+  if constexpr (WNT == 4) nt_epilogue_lean<128, EPI, WMT, 4>(p, acc, smem, m0, n0, wave, lane);
+  else nt_epilogue_w80<EPI, WMT>(p, acc, smem, m0, n0, wave, lane);
+}
+
+template <int EPI, int HM, int HN0, int HN1> void launch_nt_p8(const mvlt_gemm_nt_args& a, hipStream_t s) {
+  constexpr int BMT = 64 * HM, BNT = 64 * (HN0 + HN1);
+  constexpr int LDS_LOOP = 2 * (2 * (2 * HM * 16) + 64 * (HN0 + HN1)) * 128;
+  constexpr int LDS_EPI = 8 * 32 * (16 * (HN0 + HN1) + 4) * 4;
+  constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
+  static bool once = (hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<EPI, HM, HN0, HN1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess);
+  (void)once;
+  const int tiles_m = a.M / BMT, tiles_n = a.N / BNT;
+  dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n)), block(512);
+  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI, HM, HN0, HN1>), grid, block, LDS, s, a);
+}
+template <int HM, int HN0, int HN1> bool dispatch_nt_p8(const mvlt_gemm_nt_args& a, int epi, hipStream_t s) {
+  switch (epi) {
+    case 1: launch_nt_p8<1, HM, HN0, HN1>(a, s); return true;
+    case 2: launch_nt_p8<2, HM, HN0, HN1>(a, s); return true;
+    default: break;
+  }
+  if constexpr (HN0 + HN1 == 4) {
+    switch (epi) {
+      case 3: launch_nt_p8<3, HM, HN0, HN1>(a, s); return true;
+      case 4: launch_nt_p8<4, HM, HN0, HN1>(a, s); return true;
+      case 5: launch_nt_p8<5, HM, HN0, HN1>(a, s); return true;
+      default: break;
+    }
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------------ TN (weight gradients), bf16, 8 waves, 8-phase loop
+// C[N1, N2] += A[M, N1]^T B[M, N2] on the schedule of gemm_nt_p8_kernel: the reduction runs over the ROWS of both operands (k-tile = 64 rows), the
+// operand tiles keep their natural [m][n] layout in LDS (LDS-DMA cannot transpose) and the MFMA fragments -- 8 consecutive m of one n per lane --
+// come from two ds_read_b64_tr_b16 each, as in gemm_tn_dma_kernel.  Half h of A holds the columns {wr * 2 HM 16 + h * HM 16 + c} of both wave rows
+// as a [64 m][2 HM 16] image, half h of B the columns of all four wave columns as [64 m][4 HNh 16]; row pitches 128 / 256 / 384 B, the 16-byte
+// chunks of a row XOR-ed (on the source side) with a hash of the row so that the eight rows a 32-lane transposed read touches (m .. m+3, m+8 ..
+// m+11) fall into eight different 32-byte bank windows: pitch 256 -> (row & 3) | bit 3 of the row; pitch 128 and 384 (both 4 windows mod 8 per
+// row) -> bit 1 | bit 3.  Tiles: 256 x 256 (2048 x 512 at stage 4) and 128 x 320 (1280 x 320 at stage 3); an output whose 320-multiple side is N1 is
+// computed as its transpose (operands swapped by the host, the MFMA operand order flipped so that a lane's 16 consecutive outputs stay contiguous
+// in memory).  The m range is split over workgroups (one per CU), partial tiles meet by fp32 atomics; bias gradients = ones-fragment MFMAs,
+// taken in turns by the workgroups that share an operand column range.
+template <int PITCH> __device__ __forceinline__ int tn_hash(int row) {
+  return PITCH == 256 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+}
+template <int HM, int HN0, int HN1, bool TRANS>
+__global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p, int kt_per, int t1, int t2, int splits) {
+  constexpr int WMT = 2 * HM, WNT = HN0 + HN1;
+  constexpr int AC = 2 * HM * 16, BC0 = 4 * HN0 * 16, BC1 = 4 * HN1 * 16;          // columns of the A / B0 / B1 half-tiles
+  constexpr int PA = AC * 2, PB0 = BC0 * 2, PB1 = BC1 * 2;                         // row pitches in bytes
+  constexpr int A_IT = 64 * PA / 8192, B_IT0 = 64 * PB0 / 8192, B_IT1 = 64 * PB1 / 8192;
+  static_assert((PA == 128 || PA == 256) && (PB0 == 256 || PB0 == 384) && PB1 == 256, "half-tile pitches with a bank hash");
+  constexpr int OFF_A1 = 64 * PA, OFF_B0 = 2 * 64 * PA, OFF_B1 = OFF_B0 + 64 * PB0, BUF = OFF_B1 + 64 * PB1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  // all output tiles of one m-split on ONE XCD (workgroup b runs on XCD b % 8): the operand rows pass that L2 once
+  const int txy = t1 * t2;
+  int bz, xy;
+  if (splits >= 8) {
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    const int zq = kq / txy;
+    xy = kq - zq * txy;
+    bz = zq * 8 + xcd;
+    if (bz >= splits) return;
+  } else {
+    bz = blockIdx.x / txy;
+    xy = blockIdx.x - bz * txy;
+  }
+  const int bx = xy % t1, by = xy / t1;
+  const int n1_0 = bx * (2 * WMT * 16), n2_0 = by * (4 * WNT * 16);
+  const int nkt = p.M >> 6;
+  const int kt0 = bz * kt_per;
+  const int nk = min(kt_per, nkt - kt0);
+  if (nk <= 0) return;
+  const unsigned smem_lds = (unsigned)(uintptr_t)smem;
+  const unsigned a_rs = 2u * (unsigned)p.lda, b_rs = 2u * (unsigned)p.ldb;
+
+  // ---- loader: chunk q = tid + 512 i of a half-tile = (row q / CPR, slot q % CPR); the slot holds source chunk slot ^ (hash(row) << 1)
+  unsigned a_voff[A_IT], b_voff0[B_IT0], b_voff1[B_IT1];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    constexpr int CPR = PA / 16;
+    const int q = tid + 512 * i, row = q / CPR, lc = ((q - row * CPR) ^ (tn_hash<PA>(row) << 1)) * 8;
+    const int w_ = lc / (HM * 16);
+    a_voff[i] = (unsigned)row * a_rs + 2u * (unsigned)(w_ * (WMT * 16) + (lc - w_ * (HM * 16)));
+  }
+#pragma unroll
+  for (int i = 0; i < B_IT0; ++i) {
+    constexpr int CPR = PB0 / 16;
+    const int q = tid + 512 * i, row = q / CPR, lc = ((q - row * CPR) ^ (tn_hash<PB0>(row) << 1)) * 8;
+    const int w_ = lc / (HN0 * 16);
+    b_voff0[i] = (unsigned)row * b_rs + 2u * (unsigned)(w_ * (WNT * 16) + (lc - w_ * (HN0 * 16)));
+  }
+#pragma unroll
+  for (int i = 0; i < B_IT1; ++i) {
+    constexpr int CPR = PB1 / 16;
+    const int q = tid + 512 * i, row = q / CPR, lc = ((q - row * CPR) ^ (tn_hash<PB1>(row) << 1)) * 8;
+    const int w_ = lc / (HN1 * 16);
+    b_voff1[i] = (unsigned)row * b_rs + 2u * (unsigned)(w_ * (WNT * 16) + HN0 * 16 + (lc - w_ * (HN1 * 16)));
+  }
+  const char* const a_base = (const char*)p.A + (size_t)(kt0 * 64) * a_rs + (size_t)n1_0 * 2;
+  const char* const b_base = (const char*)p.B + (size_t)(kt0 * 64) * b_rs + (size_t)n2_0 * 2;
+  const unsigned dst_wave = smem_lds + wave * 1024;
+  auto stage = [&](int which, int t, int buf) {
+    if (which < 2) {
+      const char* sb = a_base + (size_t)(t * 64) * a_rs + which * (HM * 16 * 2);
+      const unsigned dst = dst_wave + buf * BUF + which * OFF_A1;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) glds16_s(sb, a_voff[i], dst + i * 8192);
+    } else if (which == 2) {
+      const char* sb = b_base + (size_t)(t * 64) * b_rs;
+      const unsigned dst = dst_wave + buf * BUF + OFF_B0;
+#pragma unroll
+      for (int i = 0; i < B_IT0; ++i) glds16_s(sb, b_voff0[i], dst + i * 8192);
+    } else {
+      const char* sb = b_base + (size_t)(t * 64) * b_rs;
+      const unsigned dst = dst_wave + buf * BUF + OFF_B1;
+#pragma unroll
+      for (int i = 0; i < B_IT1; ++i) glds16_s(sb, b_voff1[i], dst + i * 8192);
+    }
+  };
+  constexpr int INFL = B_IT0 + A_IT + B_IT1;          // DMA instructions per thread in the three youngest half-tiles (B0, A0, B1)
+
+  // ---- fragment geometry (transposed reads): lane (g, L) supplies k-row 8 g + (L >> 2) and the row 4 below, 8-byte piece L & 3 of a 16-column
+  //      window; the k32 step ks adds 32 rows
+  const int g = lane >> 4, L = lane & 15;
+  const int frow = 8 * g + (L >> 2);
+  int aoff[HM], boff0[HN0], boff1[HN1];
+#pragma unroll
+  for (int i = 0; i < HM; ++i) aoff[i] = frow * PA + (((wr * HM + i) ^ tn_hash<PA>(frow)) << 5) + ((L & 3) << 3);
+#pragma unroll
+  for (int j = 0; j < HN0; ++j) boff0[j] = OFF_B0 + frow * PB0 + (((wc * HN0 + j) ^ tn_hash<PB0>(frow)) << 5) + ((L & 3) << 3);
+#pragma unroll
+  for (int j = 0; j < HN1; ++j) boff1[j] = OFF_B1 + frow * PB1 + (((wc * HN1 + j) ^ tn_hash<PB1>(frow)) << 5) + ((L & 3) << 3);
+
+  f32x4 acc[WMT][WNT];
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradients: column sums of A (colsum_a) or of B (colsum_b) by one MFMA against an all-ones fragment.  The A fragments of accumulator row tile
+  // i are read by the four waves of a wave row: wave wc takes i == wc; the B fragments of column tile j by the two wave rows: j & 1 == wr.
+  f32x4 csa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 csb[(WNT + 1) / 2];
+#pragma unroll
+  for (int j = 0; j < (WNT + 1) / 2; ++j) csb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+  const bool do_csa = p.colsum_a != nullptr, do_csb = p.colsum_b != nullptr;
+  u32x4 fa[2][HM], fb0[2][HN0], fb1[2][HN1];
+
+#define MVLT_TLDA(BUFI, MH)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < HM; ++i) {                                                                 \
+    fa[0][i] = tr_frag(smem + (BUFI) * BUF + (MH) * OFF_A1 + aoff[i], PA);                                         \
+    fa[1][i] = tr_frag(smem + (BUFI) * BUF + (MH) * OFF_A1 + aoff[i] + 32 * PA, PA);                               \
+  }
+#define MVLT_TLDB0(BUFI)                                                                                           \
+  _Pragma("unroll") for (int j = 0; j < HN0; ++j) {                                                                \
+    fb0[0][j] = tr_frag(smem + (BUFI) * BUF + boff0[j], PB0);                                                      \
+    fb0[1][j] = tr_frag(smem + (BUFI) * BUF + boff0[j] + 32 * PB0, PB0);                                           \
+  }
+#define MVLT_TLDB1(BUFI)                                                                                           \
+  _Pragma("unroll") for (int j = 0; j < HN1; ++j) {                                                                \
+    fb1[0][j] = tr_frag(smem + (BUFI) * BUF + boff1[j], PB1);                                                      \
+    fb1[1][j] = tr_frag(smem + (BUFI) * BUF + boff1[j] + 32 * PB1, PB1);                                           \
+  }
+#define MVLT_TMMA(MH, JBASE, HN, FB)                                                                               \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                 \
+    _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                                 \
+      _Pragma("unroll") for (int j = 0; j < (HN); ++j) {                                                           \
+        f32x4& c_ = acc[(MH) * HM + i][(JBASE) + j];                                                               \
+        if (TRANS) c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FB[ks][j]), __builtin_bit_cast(bf16x8, fa[ks][i]), c_, 0, 0, 0); \
+        else c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks][i]), __builtin_bit_cast(bf16x8, FB[ks][j]), c_, 0, 0, 0);       \
+      }
+#define MVLT_TCSA(MH)                                                                                              \
+  if (csa_now) {                                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+      _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                               \
+        if (i == wc) csa[MH] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks][i]), ones, csa[MH], 0, 0, 0); \
+  }
+#define MVLT_TCSB(JBASE, HN, FB)                                                                                   \
+  if (csb_now) {                                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+      _Pragma("unroll") for (int j = 0; j < (HN); ++j)                                                             \
+        if ((((JBASE) + j) & 1) == wr) csb[((JBASE) + j) >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, FB[ks][j]), csb[((JBASE) + j) >> 1], 0, 0, 0); \
+  }
+
+  stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+  if (nk > 1) { stage(2, 1, 1); stage(0, 1, 1); stage(3, 1, 1); wait_vm<INFL>(); }
+  else wait_vm<0>();
+  MVLT_BAR();
+  if (wr == 1) MVLT_BAR();
+
+  auto ktile = [&](auto bufc, int t) {
+    constexpr int B = decltype(bufc)::value;
+    const bool csa_now = do_csa && (t % t2) == by, csb_now = do_csb && (t % t1) == bx;       // the workgroups sharing A (B) columns take turns
+    MVLT_TLDB0(B)
+    __builtin_amdgcn_sched_barrier(0);
+    MVLT_TLDA(B, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nk) stage(1, t + 1, B ^ 1);
+    wait_lgkm<(4 * HM < 15 ? 4 * HM : 15)>();     // the B0 reads (two 8-byte reads per fragment, issued first) are back (the counter has 4 bits)
+    MVLT_BAR();
+    __builtin_amdgcn_s_setprio(1);
+    MVLT_TMMA(0, 0, HN0, fb0)
+    MVLT_TCSA(0)
+    MVLT_TCSB(0, HN0, fb0)
+    __builtin_amdgcn_s_setprio(0);
+    MVLT_BAR();
+    MVLT_TLDB1(B)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nk) stage(2, t + 2, B);
+    MVLT_BAR();
+    __builtin_amdgcn_s_setprio(1);
+    MVLT_TMMA(0, HN0, HN1, fb1)
+    MVLT_TCSB(HN0, HN1, fb1)
+    __builtin_amdgcn_s_setprio(0);
+    MVLT_BAR();
+    MVLT_TLDA(B, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nk) stage(0, t + 2, B);
+    MVLT_BAR();
+    __builtin_amdgcn_s_setprio(1);
+    MVLT_TMMA(1, HN0, HN1, fb1)
+    MVLT_TCSA(1)
+    __builtin_amdgcn_s_setprio(0);
+    MVLT_BAR();
+    if (t + 2 < nk) { stage(3, t + 2, B); wait_vm<INFL>(); }
+    else wait_vm<0>();
+    MVLT_BAR();
+    __builtin_amdgcn_s_setprio(1);
+    MVLT_TMMA(1, 0, HN0, fb0)
+    __builtin_amdgcn_s_setprio(0);
+    MVLT_BAR();
+  };
+  for (int t = 0; t < nk; t += 2) {
+    ktile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
+  }
+  if (wr == 0) MVLT_BAR();
+#undef MVLT_TLDA
+#undef MVLT_TLDB0
+#undef MVLT_TLDB1
+#undef MVLT_TMMA
+#undef MVLT_TCSA
+#undef MVLT_TCSB
+  const int fr = lane & 15, fg = lane >> 4;
+  if (do_csa && fr == 0 && wc < HM) {            // csa[mh][r]: column n1 = tile (mh * HM + wc), row 4 fg + r of it (identical in every lane column)
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&p.colsum_a[n1_0 + wr * (WMT * 16) + (mh * HM + wc) * 16 + 4 * fg + r], csa[mh][r]);
+  }
+  if (do_csb && fg == 0) {                        // csb[j >> 1][0]: column n2 = tile j, lane column fr
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+      if ((j & 1) == wr) atomicAdd(&p.colsum_b[n2_0 + wc * (WNT * 16) + j * 16 + fr], csb[j >> 1][0]);
+  }
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (TRANS) {                              // acc[r] = C[n2 tile j row 4 fg + r][n1 tile i column fr], stored transposed: consecutive lanes = consecutive n1
+          const int n2 = n2_0 + wc * (WNT * 16) + j * 16 + 4 * fg + r, n1 = n1_0 + wr * (WMT * 16) + i * 16 + fr;
+          atomicAdd(&p.C[(long)n2 * p.ldc + n1], acc[i][j][r]);
+        } else {
+          const int n1 = n1_0 + wr * (WMT * 16) + i * 16 + 4 * fg + r, n2 = n2_0 + wc * (WNT * 16) + j * 16 + fr;
+          atomicAdd(&p.C[(long)n1 * p.ldc + n2], acc[i][j][r]);
+        }
+      }
+}
+
+template <int HM, int HN0, int HN1, bool TRANS> void launch_tn_p8(const mvlt_gemm_tn_args& a, hipStream_t s) {
+  constexpr int BM1 = 64 * HM, BN2 = 64 * (HN0 + HN1);
+  constexpr int LDS = 2 * 64 * 2 * (2 * (2 * HM * 16) + BN2);
+  static bool once = (hipFuncSetAttribute((const void*)gemm_tn_p8_kernel<HM, HN0, HN1, TRANS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess);
+  (void)once;
+  const int t1 = a.N1 / BM1, t2 = a.N2 / BN2, nkt = a.M / 64;
+  int splits = a.splits > 0 ? a.splits : 256 / (t1 * t2);
+  if (splits < 1) splits = 1;
+  if (splits > nkt) splits = nkt;
+  const int kt_per = (nkt + splits - 1) / splits;
+  splits = (nkt + kt_per - 1) / kt_per;
+  dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * t1 * t2)), block(512);
+  hipLaunchKernelGGL((gemm_tn_p8_kernel<HM, HN0, HN1, TRANS>), grid, block, LDS, s, a, kt_per, t1, t2, splits);
+}
+
 // ------------------------------------------------------------------------------------------------ conv3x3 forward / dgrad, LDS halo
 // C[pixel][n] = sum over taps t and channels c of x[pixel + tap t][c] * B[n][t*cin + c]: the MIM decoder's conv3x3 (and its input
 // gradient, the same gather with flipped taps) as the NT GEMM with a_map mode 2.  In gemm_nt_dma_kernel every k-step fetches its own
@@ -1868,6 +2459,9 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   MVLT_REQUIRE(a->a_map.mode == 0 || a->K == a->a_map.r * a->a_map.r * a->a_map.c_seg, "mvlt_gemm_nt: gather K != r*r*c_seg");
   MVLT_REQUIRE(a->c_map.mode == 0 || a->N == a->c_map.r * a->c_map.r * a->c_map.c_seg, "mvlt_gemm_nt: scatter N != r*r*c_seg");
   MVLT_REQUIRE(a->c_map.mode != 2, "mvlt_gemm_nt: the 3x3 map is a gather only (its dgrad is a gather with flipped taps)");
+  // EPI 8 (LayerNorm of the finished row) exists in the bf16 LDS-DMA kernel only: every other launch path refuses instead of skipping it silently
+  MVLT_REQUIRE(!a->post_y || (a->dtype == 0 && a->split_k <= 1 && !getenv("MVLT_NT_LEGACY")),
+               "mvlt_gemm_nt: post_y needs the bf16 LDS-DMA path (no fp32 operands, no split_k, no MVLT_NT_LEGACY)");
   if (a->M == 0) return MVLT_OK;
   hipStream_t s = (hipStream_t)stream;
   const int tiles_m = (a->M + BM - 1) / BM;
@@ -1950,6 +2544,28 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
       bool done = a->a_map.w_in == 32 ? dispatch_conv3_nt<32>(*a, epi, s) : a->a_map.w_in == 16 ? dispatch_conv3_nt<16>(*a, epi, s) : dispatch_conv3_nt<64>(*a, epi, s);
       if (done) return mvlt_check_launch("mvlt_gemm_nt");
     }
+    // 8-wave kernels with the 8-phase K-loop (gemm_nt_p8_kernel) for the MFMA-bound shapes of the stage 3-4 MLPs: one workgroup per CU, so the
+    // tile height is chosen by whole rounds of 256 CUs (rows x rounds = time): 256 x 256, 192 x 256, or 192 x 320 for N % 320 == 0
+    static const int ntp8 = getenv("MVLT_NT_P8") ? atoi(getenv("MVLT_NT_P8")) : 7;       // bit 0: 256 x 256, bit 1: 192 x 256, bit 2: 192 x 320
+    // (the GELU / GELU' epilogues are VALU-bound at two waves per SIMD: at K = 320 the 128-wide kernel's four workgroups per CU cover them
+    //  better -- stage-3 fc1 + GELU 173 us either way, GELU' dgrad 207 against 196 us -- from K = 512 on the 8-phase loop wins, -11 % / -5 %)
+    if (ntp8 && a->a_map.mode == 0 && a->a_map.rows_per_batch == 0 && a->c_map.mode == 0 && epi >= 1 && epi <= 5 && a->K % 64 == 0 && a->K >= 128 &&
+        ((epi != 3 && epi != 4) || a->K >= 512 || (ntp8 & 8))) {
+      auto cost = [&](int bm, int bn) -> long {                         // rows x rounds; 0 = shape does not fit
+        if (a->M % bm || a->N % bn) return 0;
+        const long tiles = (long)(a->M / bm) * (a->N / bn);
+        if (tiles < 192) return 0;
+        return ((tiles + 255) / 256) * (long)bm * bn;
+      };
+      const long c256 = (ntp8 & 1) ? cost(256, 256) : 0, c192 = (ntp8 & 2) ? cost(192, 256) : 0;
+      // (192 x 320 with the fp32 residual epilogue pays from K = 640 on: 98304 x 320 x 320 + R 93 us against 73 us on the 128-wide kernel, K = 1280 138 against 155)
+      const long c320 = ((ntp8 & 4) && a->N % 256 != 0 && (epi == 1 || (epi == 2 && a->K >= 640))) ? cost(192, 320) : 0;
+      bool done = false;
+      if (c320) done = dispatch_nt_p8<3, 3, 2>(*a, epi, s);
+      else if (c256 && (!c192 || c256 <= c192)) done = dispatch_nt_p8<4, 2, 2>(*a, epi, s);
+      else if (c192) done = dispatch_nt_p8<3, 2, 2>(*a, epi, s);
+      if (done) return mvlt_check_launch("mvlt_gemm_nt");
+    }
     // N % 192 == 0 (the 192-channel convolutions): one 192-wide tile instead of 128 + a half-empty 128
     const bool wide = !narrow && a->N % 192 == 0 && a->N % 128 != 0 && (epi == 1 || epi == 5) && a->c_map.mode == 0 && a->a_map.mode != 1 &&
                       a->K >= 128 && !getenv("MVLT_NT_NO192");
@@ -2010,6 +2626,33 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
     if (a->b_map.w_in == 32) return launch_conv3_wgrad<32>(*a, s2);
     if (a->b_map.w_in == 16) return launch_conv3_wgrad<16>(*a, s2);
     return launch_conv3_wgrad<8>(*a, s2);
+  }
+  // 8-wave kernel on the 8-phase loop (gemm_tn_p8_kernel): plain rows, whole 64-row k-tiles, outputs of whole 256 x 256 or 128 x 320 tiles, at
+  // least 16 k-tiles per split.  An output whose 320-multiple side is N1 is computed as its transpose (operands swapped, bias gradient on the B side).
+  static const int tnp8 = getenv("MVLT_TN_P8") ? atoi(getenv("MVLT_TN_P8")) : 3;           // bit 0: 256 x 256, bit 1: 128 x 320
+  if (tnp8 && a->dtype == 0 && a->a_map.mode == 0 && a->b_map.mode == 0 && a->a_map.rows_per_batch == 0 && a->b_map.rows_per_batch == 0 && a->c_taps <= 1 &&
+      a->M % 64 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0) {
+    const int nkt = a->M / 64;
+    auto fits = [&](int n1, int n2, int b1, int b2) {
+      if (n1 % b1 || n2 % b2) return false;
+      const int tiles = (n1 / b1) * (n2 / b2);
+      return tiles <= 256 && tiles >= 4 && nkt / (256 / tiles) >= 16;
+    };
+    mvlt_gemm_tn_args sw = *a;                       // the same product with the operand roles swapped (C^T = B^T A)
+    sw.A = a->B; sw.B = a->A; sw.N1 = a->N2; sw.N2 = a->N1; sw.lda = a->ldb; sw.ldb = a->lda;
+    sw.colsum_a = a->colsum_b; sw.colsum_b = a->colsum_a; sw.trans_c = !a->trans_c;
+    if ((tnp8 & 1) && fits(a->N1, a->N2, 256, 256)) {
+      if (a->trans_c) launch_tn_p8<4, 2, 2, true>(*a, s); else launch_tn_p8<4, 2, 2, false>(*a, s);
+      return mvlt_check_launch("mvlt_gemm_tn");
+    }
+    if ((tnp8 & 2) && a->N2 % 256 != 0 && fits(a->N1, a->N2, 128, 320)) {
+      if (a->trans_c) launch_tn_p8<2, 3, 2, true>(*a, s); else launch_tn_p8<2, 3, 2, false>(*a, s);
+      return mvlt_check_launch("mvlt_gemm_tn");
+    }
+    if ((tnp8 & 2) && a->N1 % 256 != 0 && fits(a->N2, a->N1, 128, 320)) {
+      if (sw.trans_c) launch_tn_p8<2, 3, 2, true>(sw, s); else launch_tn_p8<2, 3, 2, false>(sw, s);
+      return mvlt_check_launch("mvlt_gemm_tn");
+    }
   }
   if (a->dtype == 0 && a->M < (1 << 24) && !getenv("MVLT_TN_LEGACY")) {
     // LDS-DMA kernel: A tile 128 or 64 wide, B tile 128 or 64 wide; ~1024 workgroups, splits a multiple of the 8 XCDs

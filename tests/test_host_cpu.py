@@ -300,6 +300,26 @@ def test_gradient_accumulation_survives_a_frozen_first_parameter():
     assert float(S.G.max()) == 6.0
 
 
+def test_zero_grad_over_a_subset_restarts_only_that_subset():
+    """with SOME parameters reset (optimizer built over a subset, or p.grad = None by hand) and the others still
+    aliasing G, torch semantics are per parameter: the reset ones start from zero, the others keep their running sum.  Round 3's
+    any-alias rule kept the old sums of the reset ones and handed them out again."""
+    m = _toy_store()
+    S = m.store
+    names = [n for n, _ in S.fn_params]
+    x = torch.ones(2, requires_grad=True)
+    _SideEffectFn.apply(x, S, 3.0, *[p for _, p in S.fn_params]).sum().backward()
+    reset = names[1::2]
+    for n in reset:
+        S.params[n].grad = None
+    _SideEffectFn.apply(x, S, 2.0, *[p for _, p in S.fn_params]).sum().backward()
+    for n in names:
+        want = 2.0 if n in reset else 5.0
+        g = S.params[n].grad
+        assert g is not None and g.data_ptr() == S.grad(n).data_ptr(), n
+        assert float(g.max()) == want and float(g.min()) == want, (n, float(g.max()), want)
+
+
 def test_deferred_data_parallel_scale_is_applied_once():
     m = _toy_store()
     S = m.store

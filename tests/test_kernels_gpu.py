@@ -83,6 +83,63 @@ def test_gemm_nt_epilogues(ops, dtype, N):
     assert maxrel(out4, ref_pre) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,N", [(6400, 2048), (6144, 2048), (7680, 1600)])      # -> 256 x 256, 192 x 256, 192 x 320 tiles (host dispatch by whole rounds)
+@pytest.mark.parametrize("K", [128, 320, 512, 64 * 7])
+def test_gemm_nt_8phase_tiles(ops, K, M, N):
+    """the 8-wave kernels with the 8-phase K-loop (gemm_nt_p8_kernel; taken from 192 tiles on): every epilogue they carry, odd and even
+    k-tile counts (the K-loop is unrolled by two k-tiles with a two-k-tile-deep refill pipeline), a result that must not depend on
+    the launch (run twice, bit-identical: a refill landing under a late reader shows as a differing tile), and agreement with the
+    fp32 reference.  (The 192 x 320 tile carries the plain and the residual epilogue; its other cases run on the 128-wide kernels.)"""
+    dt = torch.bfloat16
+    Bsz = 5 if M % 5 == 0 and (M // 5) % 8 == 0 else 6
+    A, W = rnd(M, K, dtype=dt), rnd(N, K, dtype=dt, seed=1, scale=0.2)
+    bias = rnd(N, dtype=torch.float32, seed=2)
+    pre = A.float() @ W.float().t()
+    ref_pre = pre + bias
+    # EPI 1: plain + bias, bf16 and fp32 outputs
+    for odt in (dt, torch.float32):
+        out = torch.empty(M, N, device=dev(), dtype=odt)
+        ops.gemm_nt(A, W, out, M, N, K, K, K, N, bias=bias)
+        assert maxrel(out.float(), ref_pre) < TOL[dt], (K, odt)
+        out_b = torch.empty_like(out)
+        ops.gemm_nt(A, W, out_b, M, N, K, K, K, N, bias=bias)
+        assert torch.equal(out, out_b), "launch-to-launch difference"
+    # EPI 3: GELU with the pre-activation stored
+    out, H = torch.empty(M, N, device=dev(), dtype=dt), torch.empty(M, N, device=dev(), dtype=dt)
+    ops.gemm_nt(A, W, out, M, N, K, K, K, N, bias=bias, act=1, H=H)
+    assert maxrel(H.float(), ref_pre) < TOL[dt] and maxrel(out.float(), F.gelu(ref_pre)) < TOL[dt]
+    # EPI 4: x gelu'(H)
+    Hin = rnd(M, N, dtype=dt, seed=5)
+    out2 = torch.empty_like(out)
+    ops.gemm_nt(A, W, out2, M, N, K, K, K, N, act=2, H=Hin)
+    h = Hin.float().requires_grad_(True)
+    F.gelu(h).sum().backward()
+    assert maxrel(out2.float(), pre * h.grad) < TOL[dt]
+    # EPI 2: bias, per-sample factor, fp32 residual in place
+    Rres = rnd(M, N, dtype=torch.float32, seed=7)
+    scale = torch.tensor([0.0, 1.0 / 0.9, 1.0, 1.0 / 0.9, 0.0, 1.0], device=dev())[:Bsz].contiguous()
+    out3 = Rres.clone()
+    ops.gemm_nt(A, W, out3, M, N, K, K, K, N, bias=bias, row_scale=scale, rows_per_scale=M // Bsz, R=out3)
+    assert maxrel(out3, ref_pre * scale.repeat_interleave(M // Bsz)[:, None] + Rres) < TOL[dt]
+    Rb = rnd(M, N, dtype=dt, seed=8)
+    out3b = torch.empty_like(Rb)
+    ops.gemm_nt(A, W, out3b, M, N, K, K, K, N, R=Rb)
+    assert maxrel(out3b.float(), pre + Rb.float()) < TOL[dt]
+    # EPI 5: column sum / sum of squares of the stored values
+    cs, cq = torch.zeros(N, device=dev()), torch.zeros(N, device=dev())
+    out5 = torch.empty(M, N, device=dev(), dtype=torch.float32)
+    ops.gemm_nt(A, W, out5, M, N, K, K, K, N, col_sum=cs, col_sumsq=cq)
+    assert maxrel(out5, pre) < TOL[dt] and rel(cs, out5.sum(0)) < 1e-3 and rel(cq, (out5 * out5).sum(0)) < 1e-3
+    # batch-strided output rows (a token sub-range of a (B, N_tok, C) buffer)
+    rows, stride, off = M // Bsz, M // Bsz + 40, 24
+    buf = torch.zeros(Bsz * stride, N, device=dev(), dtype=dt)
+    from mvlt_amd._lib import rowmap
+    ops.gemm_nt(A, W, buf, M, N, K, K, K, N, bias=bias, c_map=rowmap(rows, stride, off))
+    got = buf.view(Bsz, stride, N)[:, off:off + rows].reshape(M, N)
+    assert maxrel(got.float(), ref_pre) < TOL[dt]
+    assert float(buf.view(Bsz, stride, N)[:, :off].abs().max()) == 0.0 and float(buf.view(Bsz, stride, N)[:, off + rows:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("N,K,M,out_dtype", [(64, 64, 8448, torch.float32), (128, 128, 1000, torch.float32), (64, 64, 200, torch.bfloat16)])
 def test_gemm_nt_layernorm_epilogue(ops, N, K, M, out_dtype):
     """attn.proj + DropPath + residual with Block.norm2 of the finished row on the epilogue (reference libs/pvlt.py:140-142):
@@ -201,6 +258,25 @@ def test_gemm_tn(ops, dtype, M, N1, N2):
     # accumulate semantics: a second call doubles
     ops.gemm_tn(Ap, B, out, M, N1, N2, lda, N2, N2)
     assert maxrel(out, 2 * ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("M,N1,N2", [(16384, 2048, 512), (16384, 512, 2048), (25600, 1280, 320), (25600, 320, 1280), (64 * 17 * 16, 2048, 512), (64 * 19 * 25, 1280, 320)])
+def test_gemm_tn_8phase_tiles(ops, M, N1, N2):
+    """weight-gradient GEMM on the 8-wave / 8-phase kernel (gemm_tn_p8_kernel): 256 x 256 and 128 x 320 output tiles, the transposed
+    form for a 320-multiple N1, bias gradients on either operand, an odd number of k-tiles per split, accumulation into a non-zero C,
+    and two launches giving the same sums (fp32 atomics: equal up to the order of the partial sums)."""
+    dt = torch.bfloat16
+    A, B = rnd(M, N1, dtype=dt, scale=0.5), rnd(M, N2, dtype=dt, seed=1, scale=0.5)
+    ref = A.float().t() @ B.float()
+    cs_ref = A.float().sum(0)
+    base = rnd(N1, N2, dtype=torch.float32, seed=3)
+    out, cs = base.clone(), torch.zeros(N1, device=dev())
+    ops.gemm_tn(A, B, out, M, N1, N2, N1, N2, N2, colsum=cs)
+    assert maxrel(out - base, ref) < 1e-3, (M, N1, N2)
+    assert maxrel(cs, cs_ref) < 1e-3
+    out2 = torch.zeros(N1, N2, device=dev())
+    ops.gemm_tn(A, B, out2, M, N1, N2, N1, N2, N2)
+    assert maxrel(out2, ref) < 1e-3 and maxrel(out2, out - base) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

@@ -142,22 +142,27 @@ def test_eval_forward_parity(golden_dir, parity, name, dtype):
             key = k.split("/")[2]
             assert tuple(out[key].shape) == tuple(g[k].shape), (key, out[key].shape)
             if dtype == torch.bfloat16 and key == "itm_logits":
-                # B x 2 numbers: a relative error of the logits measures cancellation luck (the reference's own bf16
-                # autocast is 1.7e-2..4.6e-2 off on them); bound the class probabilities they turn into instead
+                # B x 2 numbers = 768-term dot products of the LayerNorm-ed [CLS] embedding with the two rows of itm_head.linear.  Their natural
+                # scale is S = |w| |e| / sqrt(768) (what a dot product of that length gives without cancellation; 0.99 for these fillers), the
+                # fixtures' logits are 0.03 .. 1.1: on tiny224 the two numbers cancel 30-fold, and a relative error against THEM measures the
+                # cancellation, not the arithmetic (the reference's own bf16 autocast run is 3.7e-2 .. 4.6e-2 off its fp32 self on three of
+                # the six fixtures).  Round 4 moved the head chain to fp32 from the fp32 residual stream (schedule._ClsHeadFn): the plain
+                # relative error did not move (tiny224: 1.6e-1 -> 1.8e-1), so what is left is the trunk's bf16 noise (~1e-2 on the stage-4
+                # features) seen through that cancellation.  The gate, on ALL fixtures and without reference to the reference's own floor:
+                # ||delta|| <= 2e-2 * max(||logits||, S sqrt(count)) -- 2e-2 of the scale the dot product works at -- plus the class
+                # probabilities the logits are consumed as.  The plain relative error stays on record next to the reference's floor.
+                o_, r_ = out[key].float().cpu().numpy().astype(np.float64).ravel(), np.asarray(g[k], dtype=np.float64).ravel()
                 e = head_prob_err(out[key].float().cpu().numpy(), g[k])
                 if not parity(f"full/{key}(prob)", e, TOL[dtype]):
                     bad[k + "(prob)"] = e
-                # ... and the logits themselves: 2e-2 like every other output wherever the reference's OWN bf16
-                # autocast run stays under 2e-2 on them (stored by make_golden.py as eval/bf16_floor/itm_logits: 3 of the 6 cases);
-                # where the reference's own floor is above the bar (3.7e-2 .. 4.6e-2 on the B x 2 logits of the tiny 224 / 256 cases)
-                # the probability bound above is the gate and the logits error is on record only
-                floor = float(g["eval/bf16_floor/itm_logits"]) if "eval/bf16_floor/itm_logits" in g.files else 1.0
-                el = err_metric(out[key].float().cpu().numpy(), g[k], dtype)
-                if floor <= TOL[dtype]:
-                    if not parity(f"full/{key}(logits)", el, TOL[dtype]):
-                        bad[k + "(logits)"] = el
-                else:
-                    parity(f"full-logits-info/{key} (reference bf16 floor {floor:.1e})", el, 1.0)
+                w_ = sd["itm_head.linear.weight"].double()
+                e_norm = float((sd["itm_head_embed.1.weight"].double() ** 2 + sd["itm_head_embed.1.bias"].double() ** 2).sum().sqrt())
+                S_ = float(w_.norm(dim=1).mean()) * e_norm / w_.shape[1] ** 0.5
+                el = np.linalg.norm(o_ - r_) / max(np.linalg.norm(r_), S_ * r_.size ** 0.5)
+                if not parity(f"full/{key}(logits, against max(|logits|, dot-product scale))", el, TOL[dtype]):
+                    bad[k + "(logits)"] = el
+                floor = float(g["eval/bf16_floor/itm_logits"]) if "eval/bf16_floor/itm_logits" in g.files else float("nan")
+                parity(f"full-logits-info/{key} plain relative (reference's own bf16 floor {floor:.1e})", err_metric(o_, r_, dtype), 1.0)
                 continue
             e = err_metric(out[key].float().cpu().numpy(), g[k], dtype)
             if not parity(f"full/{key}", e, tol_for(g, key, dtype)):
