@@ -2026,6 +2026,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p,
   // all output tiles of one m-split on ONE XCD (workgroup b runs on XCD b % 8): the operand rows pass that L2 once
   const int txy = t1 * t2;
   int bz, xy;
+#ifdef MVLT_TNP8_LOCAL                            // experiment: all splits of a tile on ONE XCD (b % 8 placement assumed), output atomics in that XCD's L2
+  {
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    xy = xcd + 8 * (kq / splits);
+    bz = kq % splits;
+    if (xy >= txy) return;
+  }
+#else
   if (splits >= 8) {
     const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
     const int zq = kq / txy;
@@ -2036,6 +2044,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p,
     bz = blockIdx.x / txy;
     xy = blockIdx.x - bz * txy;
   }
+#endif
   const int bx = xy % t1, by = xy / t1;
   const int n1_0 = bx * (2 * WMT * 16), n2_0 = by * (4 * WNT * 16);
   const int nkt = p.M >> 6;
@@ -2225,18 +2234,76 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p,
     for (int j = 0; j < WNT; ++j)
       if ((j & 1) == wr) atomicAdd(&p.colsum_b[n2_0 + wc * (WNT * 16) + j * 16 + fr], csb[j >> 1][0]);
   }
+#ifdef MVLT_TNP8_ROWS
+  // experiment: every atomic instruction covers 64 CONSECUTIVE floats (two whole 128-byte lines) instead of 4 rows x 16 floats: the accumulator
+  // tiles of one 16-row (non-transposed) / 16-column group go through a per-wave LDS tile and leave row by row
+  MVLT_BAR();
+  {
+    float* stg = (float*)smem + wave * (16 * 132);
+    if (!TRANS) {
+#pragma unroll
+      for (int i = 0; i < WMT; ++i) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stg[(4 * fg + r) * (WNT * 16 + 4) + j * 16 + fr] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n1b = n1_0 + wr * (WMT * 16) + i * 16, n2b = n2_0 + wc * (WNT * 16);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          if (lane < WNT * 16) atomicAdd(&p.C[(long)(n1b + rr) * p.ldc + n2b + lane], stg[rr * (WNT * 16 + 4) + lane]);
+          if (WNT * 16 > 64 && lane + 64 < WNT * 16) atomicAdd(&p.C[(long)(n1b + rr) * p.ldc + n2b + 64 + lane], stg[rr * (WNT * 16 + 4) + 64 + lane]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stg[(4 * fg + r) * (WMT * 16 + 4) + i * 16 + fr] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n2b = n2_0 + wc * (WNT * 16) + j * 16, n1b = n1_0 + wr * (WMT * 16);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          atomicAdd(&p.C[(long)(n2b + rr) * p.ldc + n1b + lane], stg[rr * (WMT * 16 + 4) + lane]);
+          if (WMT * 16 > 64) atomicAdd(&p.C[(long)(n2b + rr) * p.ldc + n1b + 64 + lane], stg[rr * (WMT * 16 + 4) + 64 + lane]);
+        }
+      }
+    }
+  }
+  return;
+#endif
+#ifdef MVLT_TNP8_ABL                              // timing ablation: no output atomics (wrong results)
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) asm volatile("" ::"v"(acc[i][j]));
+  return;
+#endif
 #pragma unroll
   for (int i = 0; i < WMT; ++i)
 #pragma unroll
     for (int j = 0; j < WNT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+#ifdef MVLT_TNP8_LOCAL
+#define MVLT_TN_ATOMIC(ptr, v) __hip_atomic_fetch_add(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#else
+#define MVLT_TN_ATOMIC(ptr, v) atomicAdd(ptr, v)
+#endif
         if (TRANS) {                              // acc[r] = C[n2 tile j row 4 fg + r][n1 tile i column fr], stored transposed: consecutive lanes = consecutive n1
           const int n2 = n2_0 + wc * (WNT * 16) + j * 16 + 4 * fg + r, n1 = n1_0 + wr * (WMT * 16) + i * 16 + fr;
-          atomicAdd(&p.C[(long)n2 * p.ldc + n1], acc[i][j][r]);
+          MVLT_TN_ATOMIC(&p.C[(long)n2 * p.ldc + n1], acc[i][j][r]);
         } else {
           const int n1 = n1_0 + wr * (WMT * 16) + i * 16 + 4 * fg + r, n2 = n2_0 + wc * (WNT * 16) + j * 16 + fr;
-          atomicAdd(&p.C[(long)n1 * p.ldc + n2], acc[i][j][r]);
+          MVLT_TN_ATOMIC(&p.C[(long)n1 * p.ldc + n2], acc[i][j][r]);
         }
       }
 }
