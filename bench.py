@@ -178,8 +178,14 @@ def time_dominant_kernel(model, B, device):
     (profiles/*_roofline_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, collected offline: counters cannot be read inside this process)."""
     (_, f1, flops1), (_, f2, bytes2), (_, f3, flops3) = roofline_cases(B, device)
     ms, ms2, ms3 = _time_launch(f1), _time_launch(f2), _time_launch(f3)
+    from mvlt_amd.build import source_hash
     tj = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_roofline_traffic.json")) if B == 256 else []
     t = json.load(open(os.path.join(ROOT, "profiles", tj[-1]))) if tj else {}
+    # the counters cannot be read inside this process: the committed pass is used only if it was collected for THESE kernel sources
+    stale = None
+    if t and t.get("_source_hash") != source_hash():
+        stale = f"profiles/{tj[-1]} was collected for kernel sources {t.get('_source_hash')}, this tree is {source_hash()}: traffic not reported"
+        t = {}
     tr = lambda k: t.get(k, {}).get("hbm_bytes")
     tf1, tf3 = flops1 / (ms * 1e-3) / 1e12, flops3 / (ms3 * 1e-3) / 1e12
     M2 = B * 4224
@@ -198,17 +204,62 @@ def time_dominant_kernel(model, B, device):
                          unit="TFLOP/s", frac=round(tf1 / PEAK_BF16_TFLOPS, 4), traffic=tr("conv192"), ms_per_launch=round(ms, 4), algorithmic_flops=flops1),
                     dict(kernel="gemm_nt_dma_kernel<64, 0, 1, 64, 128> (bf16, 128x64 tile): K=64 N=64 projection, M=B*4224", bound="hbm",
                          achieved=round(bytes2 / (ms2 * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                         frac=round(bytes2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), ms_per_launch=round(ms2, 4), algorithmic_bytes=bytes2, traffic=tr("proj64"))])
+                         frac=round(bytes2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), ms_per_launch=round(ms2, 4), algorithmic_bytes=bytes2, traffic=tr("proj64"))],
+                **({"traffic_stale": stale} if stale else {"traffic_source": f"profiles/{tj[-1]}" if tj else None}))
 
 
 def step_traffic():
-    """HBM GB per step of the committed FETCH_SIZE / WRITE_SIZE passes over whole steps (tools/step_traffic.sh -> profiles/rNN_step_traffic.txt)"""
+    """HBM GB per step of the committed FETCH_SIZE / WRITE_SIZE passes over whole steps (tools/step_traffic.sh -> profiles/rNN_step_traffic.txt);
+    (None, why) when that pass was collected for other kernel sources than this tree's"""
     import re
+    from mvlt_amd.build import source_hash
     fs = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_step_traffic.txt"))
     if not fs:
         return None, None
-    m = re.search(r"([0-9.]+) GB", open(os.path.join(ROOT, "profiles", fs[-1])).readline())
+    head = open(os.path.join(ROOT, "profiles", fs[-1])).readline()
+    m = re.search(r"([0-9.]+) GB", head)
+    h = re.search(r"source_hash=([0-9a-f]+)", head)
+    if not h or h.group(1) != source_hash():
+        return None, f"{fs[-1]} is stale (collected for kernel sources {h.group(1) if h else 'unknown'}, this tree is {source_hash()})"
     return (float(m.group(1)) if m else None), fs[-1]
+
+
+def other_configs(device):
+    """BASELINE configurations #4 and #5 at one GPU, behind the headline's timed region: short runs of the same engine entry
+    -- PVT-medium at 384 px, batch 64 (5 + 10 iterations), and the CLS-head fine-tune step of pvlt_tiny at batch 256 (20 + 20: its first
+    ~20 iterations are ~15 % slower) -- so that the driver's own record carries them."""
+    from mvlt_amd import pvlt
+    from mvlt_amd.engine import BF16Scaler
+    from mvlt_amd.optim import FusedAdamW
+    import engine_grid_masking as E
+    out = {}
+    for key, name, img, B, lt, warm, steps, gflop in (
+            ("medium384_b64", "pvlt_medium", 384, 64, dict(mlm=1, itm=1, t2i=1, cls=0), 5, 10, 197.25),
+            ("finetune", "pvlt_tiny", 256, 256, dict(mlm=0, itm=0, t2i=0, cls=1), 20, 20, 25.00)):
+        torch.manual_seed(4321)
+        model = getattr(pvlt, name)(pretrained=False, token_hidden_size=768, num_text_tokens=128, loss_type=lt, pretrained_pth=None,
+                                    drop_path_rate=0.1, drop_rate=0.0, num_classes=1000, in_chans=3).cuda(device)
+        batch = synth_batch(B, img, 128, device, 99)
+        opt = FusedAdamW(model, lr=2.5e-4 * B / 512.0, weight_decay=0.01)
+        scaler = BF16Scaler()
+        eargs = argparse.Namespace(loss_type=lt)
+
+        def epoch(n, ep):
+            with contextlib.redirect_stdout(sys.stderr):
+                return E.train_one_epoch_vl(model, None, [batch] * n, opt, device, ep, scaler, None, None, None, True, False, eargs)
+
+        epoch(warm, 0)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        st = epoch(steps, 1)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        out[key] = {"workload": f"{name} MVLT " + ("pre-train (MLM+MIM+ITM)" if lt["mlm"] else "fine-tune (CLS heads)") + f", {img}x{img} + 128 tokens, batch {B}, bf16",
+                    "pairs_s": round(B * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warm,
+                    "step_tflops_reference_equivalent": round(B * steps / dt * gflop / 1e3, 1), "epoch_avg_loss": round(st["total_loss"], 4)}
+        del model, opt, batch
+        torch.cuda.empty_cache()
+    return out
 
 
 def spawn_ranks(n):
@@ -248,6 +299,7 @@ def main():
                     help="pretrain = {mlm,itm,t2i} (BASELINE configs 2-4); finetune = {cls} only (config 5, dws_mvlt_ft_exp48)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the isolated roofline launches (whole-step counter passes: tools/step_traffic.sh)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configurations #4 / #5 behind the headline")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--spawn", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1 (RCCL path at world size 1)")
     args = ap.parse_args()
@@ -367,6 +419,8 @@ def main():
             gb, src = step_traffic()
             line["step"] = {"executed_tflops": round(per_gpu * executed / 1e12, 1), "ms": round(ms_step, 3),
                             "hbm_gb_per_step": gb, "hbm_tb_per_s": round(gb / ms_step, 2) if gb else None, "hbm_source": src}
+            if world == 1 and B == 256 and not args.no_other_configs and not args.no_roofline:
+                line["other_configs"] = other_configs(device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)

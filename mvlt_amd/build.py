@@ -23,6 +23,19 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and the C ABI header: what a profile was collected FOR.  tools/roofline_traffic.py
+    and tools/step_traffic.py stamp it into their outputs; bench.py drops a committed counter figure whose stamp is not the tree's."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc")))
+    files.append(os.path.join(HERE, "..", "include", "mvlt_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _deps_mtime():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(HERE, "..", "include", "mvlt_hip.h"))

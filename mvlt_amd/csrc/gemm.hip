@@ -1998,331 +1998,6 @@ template <int HM, int HN0, int HN1> bool dispatch_nt_p8(const mvlt_gemm_nt_args&
   return false;
 }
 
-// ------------------------------------------------------------------------------------------------ TN (weight gradients), bf16, 8 waves, 8-phase loop
-// C[N1, N2] += A[M, N1]^T B[M, N2] on the schedule of gemm_nt_p8_kernel: the reduction runs over the ROWS of both operands (k-tile = 64 rows), the
-// operand tiles keep their natural [m][n] layout in LDS (LDS-DMA cannot transpose) and the MFMA fragments -- 8 consecutive m of one n per lane --
-// come from two ds_read_b64_tr_b16 each, as in gemm_tn_dma_kernel.  Half h of A holds the columns {wr * 2 HM 16 + h * HM 16 + c} of both wave rows
-// as a [64 m][2 HM 16] image, half h of B the columns of all four wave columns as [64 m][4 HNh 16]; row pitches 128 / 256 / 384 B, the 16-byte
-// chunks of a row XOR-ed (on the source side) with a hash of the row so that the eight rows a 32-lane transposed read touches (m .. m+3, m+8 ..
-// m+11) fall into eight different 32-byte bank windows: pitch 256 -> (row & 3) | bit 3 of the row; pitch 128 and 384 (both 4 windows mod 8 per
-// row) -> bit 1 | bit 3.  Tiles: 256 x 256 (2048 x 512 at stage 4) and 128 x 320 (1280 x 320 at stage 3); an output whose 320-multiple side is N1 is
-// computed as its transpose (operands swapped by the host, the MFMA operand order flipped so that a lane's 16 consecutive outputs stay contiguous
-// in memory).  The m range is split over workgroups (one per CU), partial tiles meet by fp32 atomics; bias gradients = ones-fragment MFMAs,
-// taken in turns by the workgroups that share an operand column range.
-template <int PITCH> __device__ __forceinline__ int tn_hash(int row) {
-  return PITCH == 256 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
-}
-template <int HM, int HN0, int HN1, bool TRANS>
-__global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p, int kt_per, int t1, int t2, int splits) {
-  constexpr int WMT = 2 * HM, WNT = HN0 + HN1;
-  constexpr int AC = 2 * HM * 16, BC0 = 4 * HN0 * 16, BC1 = 4 * HN1 * 16;          // columns of the A / B0 / B1 half-tiles
-  constexpr int PA = AC * 2, PB0 = BC0 * 2, PB1 = BC1 * 2;                         // row pitches in bytes
-  constexpr int A_IT = 64 * PA / 8192, B_IT0 = 64 * PB0 / 8192, B_IT1 = 64 * PB1 / 8192;
-  static_assert((PA == 128 || PA == 256) && (PB0 == 256 || PB0 == 384) && PB1 == 256, "half-tile pitches with a bank hash");
-  constexpr int OFF_A1 = 64 * PA, OFF_B0 = 2 * 64 * PA, OFF_B1 = OFF_B0 + 64 * PB0, BUF = OFF_B1 + 64 * PB1;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  // all output tiles of one m-split on ONE XCD (workgroup b runs on XCD b % 8): the operand rows pass that L2 once
-  const int txy = t1 * t2;
-  int bz, xy;
-#ifdef MVLT_TNP8_LOCAL                            // experiment: all splits of a tile on ONE XCD (b % 8 placement assumed), output atomics in that XCD's L2
-  {
-    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
-    xy = xcd + 8 * (kq / splits);
-    bz = kq % splits;
-    if (xy >= txy) return;
-  }
-#else
-  if (splits >= 8) {
-    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
-    const int zq = kq / txy;
-    xy = kq - zq * txy;
-    bz = zq * 8 + xcd;
-    if (bz >= splits) return;
-  } else {
-    bz = blockIdx.x / txy;
-    xy = blockIdx.x - bz * txy;
-  }
-#endif
-  const int bx = xy % t1, by = xy / t1;
-  const int n1_0 = bx * (2 * WMT * 16), n2_0 = by * (4 * WNT * 16);
-  const int nkt = p.M >> 6;
-  const int kt0 = bz * kt_per;
-  const int nk = min(kt_per, nkt - kt0);
-  if (nk <= 0) return;
-  const unsigned smem_lds = (unsigned)(uintptr_t)smem;
-  const unsigned a_rs = 2u * (unsigned)p.lda, b_rs = 2u * (unsigned)p.ldb;
-
-  // ---- loader: chunk q = tid + 512 i of a half-tile = (row q / CPR, slot q % CPR); the slot holds source chunk slot ^ (hash(row) << 1)
-  unsigned a_voff[A_IT], b_voff0[B_IT0], b_voff1[B_IT1];
-#pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    constexpr int CPR = PA / 16;
-    const int q = tid + 512 * i, row = q / CPR, lc = ((q - row * CPR) ^ (tn_hash<PA>(row) << 1)) * 8;
-    const int w_ = lc / (HM * 16);
-    a_voff[i] = (unsigned)row * a_rs + 2u * (unsigned)(w_ * (WMT * 16) + (lc - w_ * (HM * 16)));
-  }
-#pragma unroll
-  for (int i = 0; i < B_IT0; ++i) {
-    constexpr int CPR = PB0 / 16;
-    const int q = tid + 512 * i, row = q / CPR, lc = ((q - row * CPR) ^ (tn_hash<PB0>(row) << 1)) * 8;
-    const int w_ = lc / (HN0 * 16);
-    b_voff0[i] = (unsigned)row * b_rs + 2u * (unsigned)(w_ * (WNT * 16) + (lc - w_ * (HN0 * 16)));
-  }
-#pragma unroll
-  for (int i = 0; i < B_IT1; ++i) {
-    constexpr int CPR = PB1 / 16;
-    const int q = tid + 512 * i, row = q / CPR, lc = ((q - row * CPR) ^ (tn_hash<PB1>(row) << 1)) * 8;
-    const int w_ = lc / (HN1 * 16);
-    b_voff1[i] = (unsigned)row * b_rs + 2u * (unsigned)(w_ * (WNT * 16) + HN0 * 16 + (lc - w_ * (HN1 * 16)));
-  }
-  const char* const a_base = (const char*)p.A + (size_t)(kt0 * 64) * a_rs + (size_t)n1_0 * 2;
-  const char* const b_base = (const char*)p.B + (size_t)(kt0 * 64) * b_rs + (size_t)n2_0 * 2;
-  const unsigned dst_wave = smem_lds + wave * 1024;
-  auto stage = [&](int which, int t, int buf) {
-    if (which < 2) {
-      const char* sb = a_base + (size_t)(t * 64) * a_rs + which * (HM * 16 * 2);
-      const unsigned dst = dst_wave + buf * BUF + which * OFF_A1;
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) glds16_s(sb, a_voff[i], dst + i * 8192);
-    } else if (which == 2) {
-      const char* sb = b_base + (size_t)(t * 64) * b_rs;
-      const unsigned dst = dst_wave + buf * BUF + OFF_B0;
-#pragma unroll
-      for (int i = 0; i < B_IT0; ++i) glds16_s(sb, b_voff0[i], dst + i * 8192);
-    } else {
-      const char* sb = b_base + (size_t)(t * 64) * b_rs;
-      const unsigned dst = dst_wave + buf * BUF + OFF_B1;
-#pragma unroll
-      for (int i = 0; i < B_IT1; ++i) glds16_s(sb, b_voff1[i], dst + i * 8192);
-    }
-  };
-  constexpr int INFL = B_IT0 + A_IT + B_IT1;          // DMA instructions per thread in the three youngest half-tiles (B0, A0, B1)
-
-  // ---- fragment geometry (transposed reads): lane (g, L) supplies k-row 8 g + (L >> 2) and the row 4 below, 8-byte piece L & 3 of a 16-column
-  //      window; the k32 step ks adds 32 rows
-  const int g = lane >> 4, L = lane & 15;
-  const int frow = 8 * g + (L >> 2);
-  int aoff[HM], boff0[HN0], boff1[HN1];
-#pragma unroll
-  for (int i = 0; i < HM; ++i) aoff[i] = frow * PA + (((wr * HM + i) ^ tn_hash<PA>(frow)) << 5) + ((L & 3) << 3);
-#pragma unroll
-  for (int j = 0; j < HN0; ++j) boff0[j] = OFF_B0 + frow * PB0 + (((wc * HN0 + j) ^ tn_hash<PB0>(frow)) << 5) + ((L & 3) << 3);
-#pragma unroll
-  for (int j = 0; j < HN1; ++j) boff1[j] = OFF_B1 + frow * PB1 + (((wc * HN1 + j) ^ tn_hash<PB1>(frow)) << 5) + ((L & 3) << 3);
-
-  f32x4 acc[WMT][WNT];
-#pragma unroll
-  for (int i = 0; i < WMT; ++i)
-#pragma unroll
-    for (int j = 0; j < WNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // bias gradients: column sums of A (colsum_a) or of B (colsum_b) by one MFMA against an all-ones fragment.  The A fragments of accumulator row tile
-  // i are read by the four waves of a wave row: wave wc takes i == wc; the B fragments of column tile j by the two wave rows: j & 1 == wr.
-  f32x4 csa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  f32x4 csb[(WNT + 1) / 2];
-#pragma unroll
-  for (int j = 0; j < (WNT + 1) / 2; ++j) csb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
-  const bool do_csa = p.colsum_a != nullptr, do_csb = p.colsum_b != nullptr;
-  u32x4 fa[2][HM], fb0[2][HN0], fb1[2][HN1];
-
-#define MVLT_TLDA(BUFI, MH)                                                                                        \
-  _Pragma("unroll") for (int i = 0; i < HM; ++i) {                                                                 \
-    fa[0][i] = tr_frag(smem + (BUFI) * BUF + (MH) * OFF_A1 + aoff[i], PA);                                         \
-    fa[1][i] = tr_frag(smem + (BUFI) * BUF + (MH) * OFF_A1 + aoff[i] + 32 * PA, PA);                               \
-  }
-#define MVLT_TLDB0(BUFI)                                                                                           \
-  _Pragma("unroll") for (int j = 0; j < HN0; ++j) {                                                                \
-    fb0[0][j] = tr_frag(smem + (BUFI) * BUF + boff0[j], PB0);                                                      \
-    fb0[1][j] = tr_frag(smem + (BUFI) * BUF + boff0[j] + 32 * PB0, PB0);                                           \
-  }
-#define MVLT_TLDB1(BUFI)                                                                                           \
-  _Pragma("unroll") for (int j = 0; j < HN1; ++j) {                                                                \
-    fb1[0][j] = tr_frag(smem + (BUFI) * BUF + boff1[j], PB1);                                                      \
-    fb1[1][j] = tr_frag(smem + (BUFI) * BUF + boff1[j] + 32 * PB1, PB1);                                           \
-  }
-#define MVLT_TMMA(MH, JBASE, HN, FB)                                                                               \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                 \
-    _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                                 \
-      _Pragma("unroll") for (int j = 0; j < (HN); ++j) {                                                           \
-        f32x4& c_ = acc[(MH) * HM + i][(JBASE) + j];                                                               \
-        if (TRANS) c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FB[ks][j]), __builtin_bit_cast(bf16x8, fa[ks][i]), c_, 0, 0, 0); \
-        else c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks][i]), __builtin_bit_cast(bf16x8, FB[ks][j]), c_, 0, 0, 0);       \
-      }
-#define MVLT_TCSA(MH)                                                                                              \
-  if (csa_now) {                                                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
-      _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                               \
-        if (i == wc) csa[MH] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks][i]), ones, csa[MH], 0, 0, 0); \
-  }
-#define MVLT_TCSB(JBASE, HN, FB)                                                                                   \
-  if (csb_now) {                                                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
-      _Pragma("unroll") for (int j = 0; j < (HN); ++j)                                                             \
-        if ((((JBASE) + j) & 1) == wr) csb[((JBASE) + j) >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, FB[ks][j]), csb[((JBASE) + j) >> 1], 0, 0, 0); \
-  }
-
-  stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
-  if (nk > 1) { stage(2, 1, 1); stage(0, 1, 1); stage(3, 1, 1); wait_vm<INFL>(); }
-  else wait_vm<0>();
-  MVLT_BAR();
-  if (wr == 1) MVLT_BAR();
-
-  auto ktile = [&](auto bufc, int t) {
-    constexpr int B = decltype(bufc)::value;
-    const bool csa_now = do_csa && (t % t2) == by, csb_now = do_csb && (t % t1) == bx;       // the workgroups sharing A (B) columns take turns
-    MVLT_TLDB0(B)
-    __builtin_amdgcn_sched_barrier(0);
-    MVLT_TLDA(B, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < nk) stage(1, t + 1, B ^ 1);
-    wait_lgkm<(4 * HM < 15 ? 4 * HM : 15)>();     // the B0 reads (two 8-byte reads per fragment, issued first) are back (the counter has 4 bits)
-    MVLT_BAR();
-    __builtin_amdgcn_s_setprio(1);
-    MVLT_TMMA(0, 0, HN0, fb0)
-    MVLT_TCSA(0)
-    MVLT_TCSB(0, HN0, fb0)
-    __builtin_amdgcn_s_setprio(0);
-    MVLT_BAR();
-    MVLT_TLDB1(B)
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 2 < nk) stage(2, t + 2, B);
-    MVLT_BAR();
-    __builtin_amdgcn_s_setprio(1);
-    MVLT_TMMA(0, HN0, HN1, fb1)
-    MVLT_TCSB(HN0, HN1, fb1)
-    __builtin_amdgcn_s_setprio(0);
-    MVLT_BAR();
-    MVLT_TLDA(B, 1)
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 2 < nk) stage(0, t + 2, B);
-    MVLT_BAR();
-    __builtin_amdgcn_s_setprio(1);
-    MVLT_TMMA(1, HN0, HN1, fb1)
-    MVLT_TCSA(1)
-    __builtin_amdgcn_s_setprio(0);
-    MVLT_BAR();
-    if (t + 2 < nk) { stage(3, t + 2, B); wait_vm<INFL>(); }
-    else wait_vm<0>();
-    MVLT_BAR();
-    __builtin_amdgcn_s_setprio(1);
-    MVLT_TMMA(1, 0, HN0, fb0)
-    __builtin_amdgcn_s_setprio(0);
-    MVLT_BAR();
-  };
-  for (int t = 0; t < nk; t += 2) {
-    ktile(std::integral_constant<int, 0>{}, t);
-    if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
-  }
-  if (wr == 0) MVLT_BAR();
-#undef MVLT_TLDA
-#undef MVLT_TLDB0
-#undef MVLT_TLDB1
-#undef MVLT_TMMA
-#undef MVLT_TCSA
-#undef MVLT_TCSB
-  const int fr = lane & 15, fg = lane >> 4;
-  if (do_csa && fr == 0 && wc < HM) {            // csa[mh][r]: column n1 = tile (mh * HM + wc), row 4 fg + r of it (identical in every lane column)
-#pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&p.colsum_a[n1_0 + wr * (WMT * 16) + (mh * HM + wc) * 16 + 4 * fg + r], csa[mh][r]);
-  }
-  if (do_csb && fg == 0) {                        // csb[j >> 1][0]: column n2 = tile j, lane column fr
-#pragma unroll
-    for (int j = 0; j < WNT; ++j)
-      if ((j & 1) == wr) atomicAdd(&p.colsum_b[n2_0 + wc * (WNT * 16) + j * 16 + fr], csb[j >> 1][0]);
-  }
-#ifdef MVLT_TNP8_ROWS
-  // experiment: every atomic instruction covers 64 CONSECUTIVE floats (two whole 128-byte lines) instead of 4 rows x 16 floats: the accumulator
-  // tiles of one 16-row (non-transposed) / 16-column group go through a per-wave LDS tile and leave row by row
-  MVLT_BAR();
-  {
-    float* stg = (float*)smem + wave * (16 * 132);
-    if (!TRANS) {
-#pragma unroll
-      for (int i = 0; i < WMT; ++i) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < WNT; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) stg[(4 * fg + r) * (WNT * 16 + 4) + j * 16 + fr] = acc[i][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int n1b = n1_0 + wr * (WMT * 16) + i * 16, n2b = n2_0 + wc * (WNT * 16);
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          if (lane < WNT * 16) atomicAdd(&p.C[(long)(n1b + rr) * p.ldc + n2b + lane], stg[rr * (WNT * 16 + 4) + lane]);
-          if (WNT * 16 > 64 && lane + 64 < WNT * 16) atomicAdd(&p.C[(long)(n1b + rr) * p.ldc + n2b + 64 + lane], stg[rr * (WNT * 16 + 4) + 64 + lane]);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < WNT; ++j) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < WMT; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) stg[(4 * fg + r) * (WMT * 16 + 4) + i * 16 + fr] = acc[i][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int n2b = n2_0 + wc * (WNT * 16) + j * 16, n1b = n1_0 + wr * (WMT * 16);
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          atomicAdd(&p.C[(long)(n2b + rr) * p.ldc + n1b + lane], stg[rr * (WMT * 16 + 4) + lane]);
-          if (WMT * 16 > 64) atomicAdd(&p.C[(long)(n2b + rr) * p.ldc + n1b + 64 + lane], stg[rr * (WMT * 16 + 4) + 64 + lane]);
-        }
-      }
-    }
-  }
-  return;
-#endif
-#ifdef MVLT_TNP8_ABL                              // timing ablation: no output atomics (wrong results)
-#pragma unroll
-  for (int i = 0; i < WMT; ++i)
-#pragma unroll
-    for (int j = 0; j < WNT; ++j) asm volatile("" ::"v"(acc[i][j]));
-  return;
-#endif
-#pragma unroll
-  for (int i = 0; i < WMT; ++i)
-#pragma unroll
-    for (int j = 0; j < WNT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#ifdef MVLT_TNP8_LOCAL
-#define MVLT_TN_ATOMIC(ptr, v) __hip_atomic_fetch_add(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#else
-#define MVLT_TN_ATOMIC(ptr, v) atomicAdd(ptr, v)
-#endif
-        if (TRANS) {                              // acc[r] = C[n2 tile j row 4 fg + r][n1 tile i column fr], stored transposed: consecutive lanes = consecutive n1
-          const int n2 = n2_0 + wc * (WNT * 16) + j * 16 + 4 * fg + r, n1 = n1_0 + wr * (WMT * 16) + i * 16 + fr;
-          MVLT_TN_ATOMIC(&p.C[(long)n2 * p.ldc + n1], acc[i][j][r]);
-        } else {
-          const int n1 = n1_0 + wr * (WMT * 16) + i * 16 + 4 * fg + r, n2 = n2_0 + wc * (WNT * 16) + j * 16 + fr;
-          MVLT_TN_ATOMIC(&p.C[(long)n1 * p.ldc + n2], acc[i][j][r]);
-        }
-      }
-}
-
-template <int HM, int HN0, int HN1, bool TRANS> void launch_tn_p8(const mvlt_gemm_tn_args& a, hipStream_t s) {
-  constexpr int BM1 = 64 * HM, BN2 = 64 * (HN0 + HN1);
-  constexpr int LDS = 2 * 64 * 2 * (2 * (2 * HM * 16) + BN2);
-  static bool once = (hipFuncSetAttribute((const void*)gemm_tn_p8_kernel<HM, HN0, HN1, TRANS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess);
-  (void)once;
-  const int t1 = a.N1 / BM1, t2 = a.N2 / BN2, nkt = a.M / 64;
-  int splits = a.splits > 0 ? a.splits : 256 / (t1 * t2);
-  if (splits < 1) splits = 1;
-  if (splits > nkt) splits = nkt;
-  const int kt_per = (nkt + splits - 1) / splits;
-  splits = (nkt + kt_per - 1) / kt_per;
-  dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * t1 * t2)), block(512);
-  hipLaunchKernelGGL((gemm_tn_p8_kernel<HM, HN0, HN1, TRANS>), grid, block, LDS, s, a, kt_per, t1, t2, splits);
-}
-
 // ------------------------------------------------------------------------------------------------ conv3x3 forward / dgrad, LDS halo
 // C[pixel][n] = sum over taps t and channels c of x[pixel + tap t][c] * B[n][t*cin + c]: the MIM decoder's conv3x3 (and its input
 // gradient, the same gather with flipped taps) as the NT GEMM with a_map mode 2.  In gemm_nt_dma_kernel every k-step fetches its own
@@ -2694,33 +2369,10 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
     if (a->b_map.w_in == 16) return launch_conv3_wgrad<16>(*a, s2);
     return launch_conv3_wgrad<8>(*a, s2);
   }
-  // 8-wave kernel on the 8-phase loop (gemm_tn_p8_kernel): plain rows, whole 64-row k-tiles, outputs of whole 256 x 256 or 128 x 320 tiles, at
-  // least 16 k-tiles per split.  An output whose 320-multiple side is N1 is computed as its transpose (operands swapped, bias gradient on the B side).
-  static const int tnp8 = getenv("MVLT_TN_P8") ? atoi(getenv("MVLT_TN_P8")) : 3;           // bit 0: 256 x 256, bit 1: 128 x 320
-  if (tnp8 && a->dtype == 0 && a->a_map.mode == 0 && a->b_map.mode == 0 && a->a_map.rows_per_batch == 0 && a->b_map.rows_per_batch == 0 && a->c_taps <= 1 &&
-      a->M % 64 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0) {
-    const int nkt = a->M / 64;
-    auto fits = [&](int n1, int n2, int b1, int b2) {
-      if (n1 % b1 || n2 % b2) return false;
-      const int tiles = (n1 / b1) * (n2 / b2);
-      return tiles <= 256 && tiles >= 4 && nkt / (256 / tiles) >= 16;
-    };
-    mvlt_gemm_tn_args sw = *a;                       // the same product with the operand roles swapped (C^T = B^T A)
-    sw.A = a->B; sw.B = a->A; sw.N1 = a->N2; sw.N2 = a->N1; sw.lda = a->ldb; sw.ldb = a->lda;
-    sw.colsum_a = a->colsum_b; sw.colsum_b = a->colsum_a; sw.trans_c = !a->trans_c;
-    if ((tnp8 & 1) && fits(a->N1, a->N2, 256, 256)) {
-      if (a->trans_c) launch_tn_p8<4, 2, 2, true>(*a, s); else launch_tn_p8<4, 2, 2, false>(*a, s);
-      return mvlt_check_launch("mvlt_gemm_tn");
-    }
-    if ((tnp8 & 2) && a->N2 % 256 != 0 && fits(a->N1, a->N2, 128, 320)) {
-      if (a->trans_c) launch_tn_p8<2, 3, 2, true>(*a, s); else launch_tn_p8<2, 3, 2, false>(*a, s);
-      return mvlt_check_launch("mvlt_gemm_tn");
-    }
-    if ((tnp8 & 2) && a->N1 % 256 != 0 && fits(a->N2, a->N1, 128, 320)) {
-      if (sw.trans_c) launch_tn_p8<2, 3, 2, true>(sw, s); else launch_tn_p8<2, 3, 2, false>(sw, s);
-      return mvlt_check_launch("mvlt_gemm_tn");
-    }
-  }
+  // (Round 4 built this kernel's 8-wave / 8-phase sibling -- 256 x 256 and 128 x 320 output tiles, one workgroup per CU, commit 6d0e8d3 -- and
+  //  removed it again: its main loop ran at 1.1-1.16 PFLOP/s, but one workgroup per CU means 16 m-splits of the 2048 x 512 outputs, and the fp32
+  //  atomics that combine the splits complete at ~0.3 floats per ns chip-wide whatever their scope or coalescing: 55 us of tail per launch,
+  //  147 us against the 122 us of the 128 x 128 tiles below with their 8 splits and a second workgroup per CU to hide the tail.  DESIGN.md 6.)
   if (a->dtype == 0 && a->M < (1 << 24) && !getenv("MVLT_TN_LEGACY")) {
     // LDS-DMA kernel: A tile 128 or 64 wide, B tile 128 or 64 wide; ~1024 workgroups, splits a multiple of the 8 XCDs
     // outputs of at most 128 x 128 take 64 x 64 tiles: every output cache line receives one atomic request per m-split, those

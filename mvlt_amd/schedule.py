@@ -390,6 +390,9 @@ class TrunkStep:
             dx = self._stage_backward(i, sv, dx.view(B, sv["N"], sv["C"]), into)
             merged = into is not None
             self.S.announce_stage(i)
+        # the learned position embeddings (root parameters: they sit in front of the stage blocks in the flat layout) got their last
+        # contribution from stage 1's backward: final now, so that only the BERT embedding block is left for the end of the pass
+        self.S.announce_prefix("pos_embed", "text_pos_embed")
         self.S.fold_copies()
         self.saved = []
 

@@ -260,25 +260,6 @@ def test_gemm_tn(ops, dtype, M, N1, N2):
     assert maxrel(out, 2 * ref) < TOL[dtype]
 
 
-@pytest.mark.parametrize("M,N1,N2", [(16384, 2048, 512), (16384, 512, 2048), (25600, 1280, 320), (25600, 320, 1280), (64 * 17 * 16, 2048, 512), (64 * 19 * 25, 1280, 320)])
-def test_gemm_tn_8phase_tiles(ops, M, N1, N2):
-    """weight-gradient GEMM on the 8-wave / 8-phase kernel (gemm_tn_p8_kernel): 256 x 256 and 128 x 320 output tiles, the transposed
-    form for a 320-multiple N1, bias gradients on either operand, an odd number of k-tiles per split, accumulation into a non-zero C,
-    and two launches giving the same sums (fp32 atomics: equal up to the order of the partial sums)."""
-    dt = torch.bfloat16
-    A, B = rnd(M, N1, dtype=dt, scale=0.5), rnd(M, N2, dtype=dt, seed=1, scale=0.5)
-    ref = A.float().t() @ B.float()
-    cs_ref = A.float().sum(0)
-    base = rnd(N1, N2, dtype=torch.float32, seed=3)
-    out, cs = base.clone(), torch.zeros(N1, device=dev())
-    ops.gemm_tn(A, B, out, M, N1, N2, N1, N2, N2, colsum=cs)
-    assert maxrel(out - base, ref) < 1e-3, (M, N1, N2)
-    assert maxrel(cs, cs_ref) < 1e-3
-    out2 = torch.zeros(N1, N2, device=dev())
-    ops.gemm_tn(A, B, out2, M, N1, N2, N1, N2, N2)
-    assert maxrel(out2, ref) < 1e-3 and maxrel(out2, out - base) < 1e-4
-
-
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_tn_patch_gather(ops, dtype):
     from mvlt_amd._lib import patchmap

@@ -13,8 +13,12 @@ Values are averaged over the 5 dispatches of each kernel.
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvlt_amd.build import source_hash  # noqa: E402
 
 CASE = {"mlp_wgrad2_kernel<64": "mlp_dw64", "mlp_wgrad_kernel<64": "mlp_dw64", "conv3_nt_kernel<32, 192": "conv192", "gemm_nt_dma_kernel<192": "conv192", "gemm_nt_dma_kernel<128": "conv192", "gemm_nt_dma_kernel<64": "proj64", "gemm_nt_kernelIDF16bLi128": "conv192",
         "gemm_nt_kernelIDF16bLi64": "proj64", "bfloat16_copy_kernel": "calib_cast"}
@@ -45,5 +49,6 @@ if __name__ == "__main__":
     n = 262144 * 192
     res["calib_cast"]["expected_read_bytes"] = 4 * n
     res["calib_cast"]["expected_write_bytes"] = 2 * n
+    res["_source_hash"] = source_hash()          # the kernel sources these counters were collected for (bench.py checks it)
     json.dump(res, open(dst, "w"), indent=1)
     print(json.dumps(res, indent=1))

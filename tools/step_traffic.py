@@ -3,8 +3,10 @@
 `bench.py --steps S --warmup 0 --no-cpu-baseline`, joined per kernel name.
     python3 tools/step_traffic.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> [steps]   -> table on stdout (steps = AdamW launches seen)
 read bytes = 2 x FETCH_SIZE KiB (gfx950 half-count correction, MI355X_MICROARCH.md), written = WRITE_SIZE KiB."""
-import csv, glob, re, sys
+import csv, glob, os, re, sys
 from collections import defaultdict
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvlt_amd.build import source_hash  # noqa: E402
 
 
 def load(d, counter):
@@ -34,7 +36,7 @@ if __name__ == "__main__":
         rows.append((rb + wb, rb, wb, us, calls[n] / steps, n))
     rows.sort(reverse=True)
     tot = sum(r[0] for r in rows)
-    print(f"total HBM bytes per step (all launches of the bench process, setup included, over the {steps} steps it ran): {tot / 1e9:.2f} GB")
+    print(f"total HBM bytes per step (all launches of the bench process, setup included, over the {steps} steps it ran): {tot / 1e9:.2f} GB   [source_hash={source_hash()}]")
     print(f"{'MB/step':>9} {'read':>8} {'written':>8} {'us/step':>9} {'TB/s':>6} {'calls':>6}  kernel")
     for t, rb, wb, us, c, n in rows[:45]:
         print(f"{t / 1e6:9.1f} {rb / 1e6:8.1f} {wb / 1e6:8.1f} {us:9.1f} {t / us / 1e6 if us else 0:6.2f} {c:6.1f}  {n}")
