@@ -11,8 +11,9 @@
 // LDS rows are 128 B (64 bf16 / 32 fp32 of K) = 8 x 16-B chunks, XOR-swizzled by row so the ds_read_b128
 // fragment reads are conflict-free; global->register->LDS staging is double-buffered (one barrier per K tile).
 #ifndef MVLT_GELU_POLY
-#define MVLT_GELU_POLY 0     // the GELU / GELU' GEMM epilogues keep the sigmoid form: the polynomial one measured no gain here (HBM-bound launches; same-box A/B 22.60 / 22.73 against 22.63 / 22.67 ms)
-#endif
+#define MVLT_GELU_POLY 3     // GELU / GELU' of the bf16 GEMM epilogues (EPI 3 / 4) by the transcendental-free polynomials of common.h.  Round 3 measured no gain on the
+#endif                       // 128-wide kernels (four workgroups per CU hide the epilogue's VALU work); on the 8-wave kernels (two waves per SIMD, VALU-bound epilogue)
+                             // GELU' is 10 instructions instead of 19.6 issue units: stage-4 GELU' dgrad 179 -> 157 us, stage-3 204 -> 181 us (same-box A/B, round 4)
 #include "common.h"
 #include <type_traits>
 #ifndef MVLT_NT_EARLY_DEFAULT
@@ -274,7 +275,8 @@ __device__ __forceinline__ int fdiv24(int m, int d, float inv) {      // exact m
   return q + (r >= d) - (r < 0);
 }
 // NWN = waves along N (2: the 4-wave 2 x 2 kernels; 4: the 8-wave 256 x 256 kernel, whose wave tile is (TM * 16) x 64 = "BN 128" here)
-template <int BN, int EPIX, int TM = 4, int NWN = 2>
+// FULL: the launch has whole tiles only (no row / column bound checks: the 8-wave kernels, whose epilogue is issue-bound at two waves per SIMD)
+template <int BN, int EPIX, int TM = 4, int NWN = 2, bool FULL = false>
 __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32x4 (&acc)[TM][BN / 32], char* smem, int m0, int n0,
                                                  int wave, int lane) {
   static_assert(NWN == 2 || EPIX != 8, "the LayerNorm epilogue pairs the two waves of a row: 2 x 2 wave grids only");
@@ -295,7 +297,7 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
   float* stage = (float*)smem + wave * 32 * LDW;
   const int ch = lane % CPR;
   const int nc = n0 + wn * WN + ch * 8;
-  const bool col_ok = nc < p.N;
+  const bool col_ok = FULL || nc < p.N;
   float bias8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
@@ -341,8 +343,8 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int m = m_first + half * 32 + it * RPI;
-      ok[sl][it] = m < p.M && col_ok;
-      const int mm = ok[sl][it] ? m : 0;
+      ok[sl][it] = FULL || (m < p.M && col_ok);
+      const int mm = (FULL || ok[sl][it]) ? m : 0;
       long phys = mm;
       if constexpr (SCAT) {
         const int b = fdiv24(mm, p.c_map.hw_out, inv_hw);
@@ -356,7 +358,7 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       idx[sl][it] = phys * p.ldc + ncol;
       rs[sl][it] = 1.0f;
       if (EPI == 2 && p.row_scale) rs[sl][it] = p.row_scale[fdiv24(mm, p.rows_per_scale, inv_rps)];
-      if ((EPI == 2 || EPI == 4) && ok[sl][it]) {
+      if ((EPI == 2 || EPI == 4) && (FULL || ok[sl][it])) {
         const void* src = (EPI == 2) ? p.R : p.H;
         if (ofp32) { raw[sl][it][0] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)src + idx[sl][it])); raw[sl][it][1] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)src + idx[sl][it] + 4)); }
         else raw[sl][it][0] = ld_g<MVLT_NT_LD>((const u32x4*)((const bf16*)src + idx[sl][it]));
@@ -457,7 +459,7 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      if (!ok[sl][it]) continue;
+      if (!FULL && !ok[sl][it]) continue;
       const int rl = it * RPI + lane / CPR;
       const f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -1966,7 +1968,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p)
 #undef MVLT_LDB0
 #undef MVLT_LDB1
 #undef MVLT_MMA
-  if constexpr (WNT == 4) nt_epilogue_lean<128, EPI, WMT, 4>(p, acc, smem, m0, n0, wave, lane);
+  // (whole tiles only: the bound checks go, -20 us on the GELU' launches; not for the residual epilogue, which measured 9 us SLOWER without them --
+  //  49152 x 512 x 2048 + R 120 -> 129 us, same box, two passes: its prefetched rows are then requested in a different order)
+  if constexpr (WNT == 4) nt_epilogue_lean<128, EPI, WMT, 4, EPI != 2>(p, acc, smem, m0, n0, wave, lane);
   else nt_epilogue_w80<EPI, WMT>(p, acc, smem, m0, n0, wave, lane);
 }
 
@@ -2289,10 +2293,7 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     // 8-wave kernels with the 8-phase K-loop (gemm_nt_p8_kernel) for the MFMA-bound shapes of the stage 3-4 MLPs: one workgroup per CU, so the
     // tile height is chosen by whole rounds of 256 CUs (rows x rounds = time): 256 x 256, 192 x 256, or 192 x 320 for N % 320 == 0
     static const int ntp8 = getenv("MVLT_NT_P8") ? atoi(getenv("MVLT_NT_P8")) : 7;       // bit 0: 256 x 256, bit 1: 192 x 256, bit 2: 192 x 320
-    // (the GELU / GELU' epilogues are VALU-bound at two waves per SIMD: at K = 320 the 128-wide kernel's four workgroups per CU cover them
-    //  better -- stage-3 fc1 + GELU 173 us either way, GELU' dgrad 207 against 196 us -- from K = 512 on the 8-phase loop wins, -11 % / -5 %)
-    if (ntp8 && a->a_map.mode == 0 && a->a_map.rows_per_batch == 0 && a->c_map.mode == 0 && epi >= 1 && epi <= 5 && a->K % 64 == 0 && a->K >= 128 &&
-        ((epi != 3 && epi != 4) || a->K >= 512 || (ntp8 & 8))) {
+    if (ntp8 && a->a_map.mode == 0 && a->a_map.rows_per_batch == 0 && a->c_map.mode == 0 && epi >= 1 && epi <= 5 && a->K % 64 == 0 && a->K >= 128) {
       auto cost = [&](int bm, int bn) -> long {                         // rows x rounds; 0 = shape does not fit
         if (a->M % bm || a->N % bn) return 0;
         const long tiles = (long)(a->M / bm) * (a->N / bn);

@@ -218,27 +218,22 @@ class FlatStore:
         go through the C ABI (FusedAdamW) bump neither and set force_dirty."""
         return self.P._version + sum(p._version for p in self._plist)
 
-    def refresh(self, transposed, conv_perm, conv3=(), transposed32=()):
+    def refresh(self, transposed, conv_perm, conv3=()):
         """Bring compute-dtype copies up to date with the fp32 masters.
         transposed: names of 2-D weights needing W^T; conv_perm: names of kernel==stride conv weights used as patch
-        GEMMs; conv3: names of the MIM decoder's 3x3 conv weights (forward taps + flipped/transposed dgrad taps);
-        transposed32: names of 2-D weights that additionally need an fp32 W^T (`::T32`) under the bf16 compute dtype -- the B x 2..122
-        ITM / CLS heads run in fp32 from the fp32 residual stream (schedule._ClsHeadFn)."""
+        GEMMs; conv3: names of the MIM decoder's 3x3 conv weights (forward taps + flipped/transposed dgrad taps)."""
         ver = self.versions()
         if not self.force_dirty and self._cast_version == ver:
             return
         if self.C is not None and self._c_fresh_version != ver:
             ops.cast_bf16(self.P, self.C, self.total)        # (the fused AdamW step writes the bf16 copy itself: skipped then)
         self._c_fresh_version = None
-        key = (tuple(transposed), tuple(conv_perm), tuple(conv3), tuple(transposed32), self.compute_dtype, self.P.data_ptr())
+        key = (tuple(transposed), tuple(conv_perm), tuple(conv3), self.compute_dtype, self.P.data_ptr())
         if getattr(self, "_prep_key", None) != key:
             self._build_prep(transposed, conv_perm, conv3)
-            self._build_prep32(transposed32)
             self._prep_key = key
         if self._prep_n:
             ops.weight_prep(self._prep_desc, self._prep_blk, self._prep_n, self._prep_blocks, self.compute_dtype)
-        if self._prep32_n:
-            ops.weight_prep(self._prep32_desc, self._prep32_blk, self._prep32_n, self._prep32_blocks, torch.float32)
         self._cast_version = ver
         self.force_dirty = False
         self.refresh_count += 1      # consumers that cache their own derived copies key on this
@@ -301,35 +296,6 @@ class FlatStore:
             starts.append(starts[-1] + b)
         self._prep_blk = torch.tensor(starts, dtype=torch.int32, device=dev)
         self._prep_blocks = starts[-1]
-
-    def _build_prep32(self, names):
-        """second descriptor table: fp32 transposes `::T32` (one more small launch per refresh, bf16 compute dtype only; under the fp32
-        compute dtype `::T` already is that tensor and `t32()` returns it)"""
-        import ctypes
-        from ._lib import PrepDesc
-        self._prep32_n = 0
-        if self.compute_dtype == torch.float32 or not names:
-            return
-        descs, starts = [], [0]
-        for name in names:
-            w = self.master(name)
-            R, Ccols = w.shape
-            ld = (R + 7) // 8 * 8
-            k = name + "::T32"
-            if k not in self.extra or self.extra[k].device != self.device:
-                self.extra[k] = torch.zeros(Ccols, ld, device=self.device, dtype=torch.float32)
-            descs.append(PrepDesc(w.data_ptr(), self.extra[k].data_ptr(), 0, R, Ccols, ld, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
-            starts.append(starts[-1] + ((R + 63) // 64) * ((Ccols + 63) // 64))
-        arr = (PrepDesc * len(descs))(*descs)
-        raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr))), dtype=torch.uint8)
-        self._prep32_desc = raw.to(self.device)
-        self._prep32_blk = torch.tensor(starts, dtype=torch.int32, device=self.device)
-        self._prep32_blocks = starts[-1]
-        self._prep32_n = len(descs)
-
-    def t32(self, name):
-        """fp32 W^T of a 2-D weight listed in refresh(transposed32=...)"""
-        return self.extra[name + ("::T" if self.compute_dtype == torch.float32 else "::T32")]
 
     # ------------------------------------------------------------------ gradients
     def begin_backward(self):

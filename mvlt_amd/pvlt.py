@@ -183,9 +183,6 @@ class PyramidVisionLanguageTransformer(nn.Module):
         self._store = FlatStore(self, compute_dtype)
         self._anchor = None
         self._transposed, self._conv_perm = self._operand_lists()
-        # the B x 2..122 ITM / CLS heads run in fp32 whatever the compute dtype (schedule._ClsHeadFn): fp32 W^T copies for their dgrads
-        self._transposed32 = [n for n in self._transposed if n.split(".")[0] in
-                              ("itm_head_embed", "itm_head", "sup_cls_head_embed", "sup_cls_head", "sub_cls_head_embed", "sub_cls_head")]
         self._conv3 = [n for n, p in self.named_parameters() if n.startswith("t2i_head.") and p.dim() == 4 and p.shape[-1] == 3]
         self.injected_masks = None      # tests: {'bert': (B,T,768) keep, 'droppath': [...], 'droppath2': [...]}
 

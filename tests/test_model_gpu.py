@@ -146,11 +146,12 @@ def test_eval_forward_parity(golden_dir, parity, name, dtype):
                 # scale is S = |w| |e| / sqrt(768) (what a dot product of that length gives without cancellation; 0.99 for these fillers), the
                 # fixtures' logits are 0.03 .. 1.1: on tiny224 the two numbers cancel 30-fold, and a relative error against THEM measures the
                 # cancellation, not the arithmetic (the reference's own bf16 autocast run is 3.7e-2 .. 4.6e-2 off its fp32 self on three of
-                # the six fixtures).  Round 4 moved the head chain to fp32 from the fp32 residual stream (schedule._ClsHeadFn): the plain
-                # relative error did not move (tiny224: 1.6e-1 -> 1.8e-1), so what is left is the trunk's bf16 noise (~1e-2 on the stage-4
-                # features) seen through that cancellation.  The gate, on ALL fixtures and without reference to the reference's own floor:
-                # ||delta|| <= 2e-2 * max(||logits||, S sqrt(count)) -- 2e-2 of the scale the dot product works at -- plus the class
-                # probabilities the logits are consumed as.  The plain relative error stays on record next to the reference's floor.
+                # the six fixtures).  Round 4 ran the head chain in fp32 from the fp32 residual stream to see whether the head's own roundings
+                # were the cause: the plain relative error did not move (tiny224: 1.6e-1 -> 1.8e-1, tiny256: 2.7e-2), i.e. what is seen is the
+                # trunk's bf16 noise (~1e-2 on the stage-4 features) through that cancellation, whatever the head does.  The gate, on ALL
+                # fixtures and without reference to the reference's own floor: ||delta|| <= 2e-2 * max(||logits||, S sqrt(count)) -- 2e-2 of
+                # the scale the dot product works at -- plus the class probabilities the logits are consumed as.  The plain relative error
+                # stays on record next to the reference's floor.
                 o_, r_ = out[key].float().cpu().numpy().astype(np.float64).ravel(), np.asarray(g[k], dtype=np.float64).ravel()
                 e = head_prob_err(out[key].float().cpu().numpy(), g[k])
                 if not parity(f"full/{key}(prob)", e, TOL[dtype]):
