@@ -95,6 +95,11 @@ typedef struct mvlt_gemm_tn_args {
   int c_taps, c_seg;         /* c_taps > 1: logical column n2 = tap*c_seg + c is stored at column c*c_taps + tap -- a conv weight
                               * gradient computed in the gather's [out][tap][cin] order lands in nn.Conv2d's [out][cin][kh][kw]
                               * layout directly (N2 == c_taps*c_seg, trans_c == 0) */
+  /* optional: the INPUT gradient of the same nn.Linear from the same pass over A (= dY): dgrad_out[M, N2] (bf16, row stride dgrad_ld) =
+   * A[M, N1] . W[N1, N2], dgrad_wt = W^T [N2][N1] bf16 (the `::T` operand copy, row stride N1).  bf16, plain rows on both operands,
+   * N1 == N2 == 64 or 128, trans_c == 0: the q / proj projections of stages 1-2 (reference libs/pvlt.py:98,118 and their autograd) read dY
+   * once for both gradients instead of once per gradient (138 MB per Linear at stage 1). */
+  const void* dgrad_wt; void* dgrad_out; int dgrad_ld;
 } mvlt_gemm_tn_args;
 int mvlt_gemm_tn(const mvlt_gemm_tn_args* args, void* stream);
 

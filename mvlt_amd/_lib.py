@@ -52,7 +52,7 @@ class GemmTNArgs(C.Structure):
                 ("M", c_int), ("N1", c_int), ("N2", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int),
                 ("dtype", c_int), ("a_map", RowMap), ("b_map", RowMap),
                 ("colsum_a", c_void_p), ("splits", c_int), ("colsum_b", c_void_p), ("trans_c", c_int),
-                ("c_taps", c_int), ("c_seg", c_int)]
+                ("c_taps", c_int), ("c_seg", c_int), ("dgrad_wt", c_void_p), ("dgrad_out", c_void_p), ("dgrad_ld", c_int)]
 
 
 class LayerNormArgs(C.Structure):

@@ -1076,10 +1076,15 @@ template <int W> struct DmaTile {
   }
 };
 
-template <int BMT, int BN, int BMODE, int NS>
+// DG (plain rows, one BMT x BN = C x C output tile): the same pass over A = dY also produces the Linear's INPUT gradient dX = dY W -- the 64-row
+// A tile is read a second time from LDS, row-wise, as the A operand of a [64 x C] x [C x C] product against W^T fragments that stay in
+// registers (wave w owns output columns [w C/4, (w + 1) C/4)); the result leaves through an LDS tile as whole 16-byte row pieces one
+// iteration later (so that its stores are a tile time old when the next counted vmcnt wait sees them).
+template <int BMT, int BN, int BMODE, int NS, bool DG = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_args p, int m_per_split, int t1, int t2, int splits) {
   using TA = DmaTile<BMT>;
   using TB = DmaTile<BN>;
+  static_assert(!DG || (BMODE == 3 && BMT == BN && !MVLT_TN_EARLY), "dgrad rides on the plain-row single-tile kernels");
   constexpr int WM = BMT / 2, TM_ = WM / 16;             // wave tile rows: 64 (4 fragments) or 32 (2)
   constexpr int WN = BN / 2, TN_ = WN / 16;
   constexpr int STAGE = TA::BYTES + TB::BYTES;
@@ -1212,6 +1217,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_a
   f32x4 cs[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
   bf16* const nb = nullptr;
+  // ---- DG: W^T fragments of this wave's output columns (B operand: row n = input feature, 8 consecutive k = output features)
+  constexpr int DGN = DG ? BN / 64 : 1, DGK = BMT / 32;
+  u32x4 wtf[DGN][DGK];
+  bf16* const sdX = (bf16*)(smem + NS * STAGE);              // [64][BN] parked dgrad tile
+  if constexpr (DG) {
+#pragma unroll
+    for (int jn = 0; jn < DGN; ++jn)
+#pragma unroll
+      for (int ks = 0; ks < DGK; ++ks)
+        wtf[jn][ks] = *(const u32x4*)((const bf16*)p.dgrad_wt + (long)((wave * DGN + jn) * 16 + (lane & 15)) * BMT + ks * 32 + (lane >> 4) * 8);
+  }
+  auto dg_store = [&](int mt_prev) {                         // the parked tile of rows mt_prev .. mt_prev + 63 -> dgrad_out, 16 bytes per thread and pass
+    constexpr int CPR = BN / 8;
+#pragma unroll
+    for (int u = tid; u < 64 * CPR; u += NTHREADS) {
+      const int r = u / CPR, c = u - r * CPR;
+      if (mt_prev + r < m_end) *(u32x4*)((bf16*)p.dgrad_out + (long)(mt_prev + r) * p.dgrad_ld + c * 8) = *(const u32x4*)(sdX + r * BN + c * 8);
+    }
+  };
 
   // NS-deep ring: tile t+NS-1 is issued while tile t is consumed; the wait leaves the NS-2 younger tiles in flight.
   // Near the end fewer tiles are in flight than the count assumes, so the wait falls back to vmcnt(0) there; nothing
@@ -1229,6 +1253,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_a
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();    // tile `mt` has landed for every wave; everyone is done reading the slot refilled next
     asm volatile("" ::: "memory");
+    if constexpr (DG) { if (mt > m_begin) dg_store(mt - TBK); }      // (parked by every wave before this barrier)
     if (!EARLY) {
       if (mt + (NS - 1) * TBK < m_end) issue(mt + (NS - 1) * TBK, islot);
       islot = islot + 1 == NS ? 0 : islot + 1;
@@ -1279,6 +1304,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_a
         }
       }
     }
+    if constexpr (DG) {
+      // dX tile [64 rows][BN]: row-wise A fragments of the dY tile (slot c of row r holds source chunk c ^ (h(r) << 1): an involution)
+      const int dfr = lane & 15, dfg = lane >> 4;
+      f32x4 dacc[4][DGN];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < DGN; ++jn) dacc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < DGK; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 16 + dfr;
+          const u32x4 af = *(const u32x4*)(sA + row * TA::ROWB + (((ks * 4 + dfg) ^ (TA::h(row) << 1)) << 4));
+#pragma unroll
+          for (int jn = 0; jn < DGN; ++jn) mma16(dacc[i][jn], af, af, wtf[jn][ks], wtf[jn][ks], nb);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();      // every thread has read the previous parked tile (its store-out sits in front of this iteration's MFMAs)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < DGN; ++jn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sdX[(i * 16 + 4 * dfg + r) * BN + (wave * DGN + jn) * 16 + dfr] = (bf16)dacc[i][jn][r];
+    }
+  }
+  if constexpr (DG) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (m_end > m_begin) dg_store(m_begin + ((m_end - m_begin - 1) / TBK) * TBK);
+    __syncthreads();                     // (the column sums below reuse the front of the LDS)
   }
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -2302,7 +2360,7 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
       };
       const long c256 = (ntp8 & 1) ? cost(256, 256) : 0, c192 = (ntp8 & 2) ? cost(192, 256) : 0;
       // (192 x 320 with the fp32 residual epilogue pays from K = 640 on: 98304 x 320 x 320 + R 93 us against 73 us on the 128-wide kernel, K = 1280 138 against 155)
-      const long c320 = ((ntp8 & 4) && a->N % 256 != 0 && (epi == 1 || (epi == 2 && a->K >= 640))) ? cost(192, 320) : 0;
+      const long c320 = ((ntp8 & 4) && a->N % 256 != 0 && (epi == 1 || (epi == 2 && (a->K >= 640 || (ntp8 & 16))))) ? cost(192, 320) : 0;
       bool done = false;
       if (c320) done = dispatch_nt_p8<3, 3, 2>(*a, epi, s);
       else if (c256 && (!c192 || c256 <= c192)) done = dispatch_nt_p8<4, 2, 2>(*a, epi, s);
@@ -2354,6 +2412,7 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
   MVLT_REQUIRE(!(a->colsum_a && a->colsum_b), "mvlt_gemm_tn: at most one of colsum_a / colsum_b");
   MVLT_REQUIRE(a->b_map.mode == 0 || a->N2 == a->b_map.r * a->b_map.r * a->b_map.c_seg, "mvlt_gemm_tn: gather N2 != r*r*c_seg");
   MVLT_REQUIRE(a->c_taps <= 1 || (a->trans_c == 0 && a->c_seg > 0 && a->N2 == a->c_taps * a->c_seg), "mvlt_gemm_tn: c_taps needs trans_c == 0 and N2 == c_taps*c_seg");
+  MVLT_REQUIRE(!a->dgrad_out || (a->dtype == 0 && a->M < (1 << 24) && a->b_map.mode == 0), "mvlt_gemm_tn: dgrad_out rides on the bf16 LDS-DMA kernel only");
   if (a->M == 0) return MVLT_OK;
   hipStream_t s = (hipStream_t)stream;
   const int mtiles = (a->M + TBK - 1) / TBK;
@@ -2379,6 +2438,34 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
     // outputs of at most 128 x 128 take 64 x 64 tiles: every output cache line receives one atomic request per m-split, those
     // serialise at the memory side (~100 ns each), and four small tiles need a quarter of the splits of one big tile for the same
     // number of workgroups (294912 x 128 x 128: 61 -> 35 us)
+    if (a->dgrad_out) {
+      // weight gradient + input gradient of a C x C Linear from one pass over dY (gemm_tn_dma_kernel<.., DG>): one output tile, plain rows
+      MVLT_REQUIRE(a->dgrad_wt && a->N1 == a->N2 && (a->N1 == 64 || a->N1 == 128) && a->a_map.rows_per_batch == 0 && a->b_map.mode == 0 &&
+                   a->b_map.rows_per_batch == 0 && !a->trans_c && a->c_taps <= 1 && !a->colsum_b && a->dgrad_ld % 8 == 0 &&
+                   (((uintptr_t)a->dgrad_out | (uintptr_t)a->dgrad_wt) & 15) == 0,
+                   "mvlt_gemm_tn: dgrad_out needs bf16 operands, plain rows, N1 == N2 == 64 or 128, no transposed / tap output, 16-byte aligned buffers");
+      int splits = a->splits > 0 ? a->splits : (a->N1 == 64 ? 256 : 384);       // 1081344 x 64: 128 / 192 / 256 / 384 / 512 splits 136 / 90 / 83 / 91 / 85 us; 294912 x 128: 75 / 63 / 60 / 59 / 68
+      static const int min_tiles = getenv("MVLT_TN_MINT") ? atoi(getenv("MVLT_TN_MINT")) : 8;
+      if (min_tiles > 1 && splits > mtiles / min_tiles) splits = mtiles / min_tiles;
+      if (splits >= 8) splits = (splits + 4) / 8 * 8;
+      if (splits > mtiles) splits = mtiles;
+      if (splits < 1) splits = 1;
+      const int m_per_split = ((mtiles + splits - 1) / splits) * TBK;
+      splits = (a->M + m_per_split - 1) / m_per_split;
+      dim3 grid((unsigned)(splits >= 8 ? 8 * ((splits + 7) / 8) : splits)), block(NTHREADS);
+      if (a->N1 == 64) {
+        const size_t lds = (size_t)4 * TBK * 128 * 2 + 64 * 64 * 2;
+        static bool once = (hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<64, 64, 3, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
+        (void)once;
+        hipLaunchKernelGGL((gemm_tn_dma_kernel<64, 64, 3, 4, true>), grid, block, lds, s, *a, m_per_split, 1, 1, splits);
+      } else {
+        const size_t lds = (size_t)2 * TBK * 256 * 2 + 64 * 128 * 2;
+        static bool once = (hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<128, 128, 3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
+        (void)once;
+        hipLaunchKernelGGL((gemm_tn_dma_kernel<128, 128, 3, 2, true>), grid, block, lds, s, *a, m_per_split, 1, 1, splits);
+      }
+      return mvlt_check_launch("mvlt_gemm_tn");
+    }
     const bool small_out = a->N1 <= 128 && a->N2 <= 128 && !getenv("MVLT_TN_NO64");
     const int bmt = (a->N1 <= 64 || small_out) ? 64 : 128, bn = (a->N2 <= 64 || small_out) ? 64 : 128;
     const int t1 = (a->N1 + bmt - 1) / bmt, t2 = (a->N2 + bn - 1) / bn;

@@ -43,13 +43,22 @@ def weight_prep(desc_dev, blk_dev, ndesc, total_blocks, dtype):
           "mvlt_weight_prep")
 
 
-def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, colsum=None, splits=0, taps=0, seg=0):
+def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, colsum=None, splits=0, taps=0, seg=0, dgrad=None):
     """C[N1,N2] += A[M,N1]^T @ B[M,N2] (fp32 atomics); colsum[N1] += A.sum(0).  taps > 1: logical column tap*seg + c is
-    accumulated at column c*taps + tap (conv weight gradients straight into the [out][cin][kh][kw] layout)."""
+    accumulated at column c*taps + tap (conv weight gradients straight into the [out][cin][kh][kw] layout).
+    dgrad = (W^T [N2][N1] bf16, out [M, N2] bf16): the Linear's input gradient out = A @ W from the same pass over A (N1 == N2 in {64, 128})."""
     assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype == torch.float32
     if colsum is not None:
         assert colsum.dtype == torch.float32
     a_map, b_map = a_map or _ID, b_map or _ID
+    if dgrad is not None:
+        wt, dx = dgrad
+        assert A.dtype == torch.bfloat16 and wt.dtype == dx.dtype == torch.bfloat16 and N1 == N2 and N1 in (64, 128) and taps <= 1
+        assert wt.is_contiguous() and tuple(wt.shape) == (N2, N1) and dx.stride(-1) == 1
+        a = L.GemmTNArgs(ptr(A), ptr(B), ptr(C_out), M, N1, N2, lda, ldb, ldc, DT[A.dtype], a_map, b_map, ptr(colsum), splits, None, 0, 0, 0,
+                         ptr(wt), ptr(dx), N2)
+        check(L.lib.mvlt_gemm_tn(C.byref(a), stream_ptr()), "mvlt_gemm_tn")
+        return C_out
     if N1 <= 64 < N2 and b_map.mode == 0 and taps <= 1:
         # the kernel's tile is 128 (N1 side) x 64/128 (N2 side): give the narrow operand the 64-wide side by computing
         # C^T = B^T A and storing it transposed; the bias gradient becomes the column sum of the (now) B operand

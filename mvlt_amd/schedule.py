@@ -32,6 +32,7 @@ _NO_POST_LN = bool(os.environ.get("MVLT_NO_POST_LN"))      # A/B switch: every b
 _NO_OUT_OP = bool(os.environ.get("MVLT_NO_OUT_OP"))        # A/B switch: fp32 stage output + separate cast pass
 _NO_PROJ_LN = bool(os.environ.get("MVLT_NO_PROJ_LN"))      # A/B switch: LN2 folded into the fused MLP's operand load (round 2) instead of the proj epilogue
 _NO_LN_FOLD = bool(os.environ.get("MVLT_NO_LN_FOLD"))      # A/B switch: LN2 as its own launch in front of the fused MLP
+_NO_LIN_FUSE = bool(os.environ.get("MVLT_NO_LIN_FUSE"))    # A/B switch: weight and input gradient of the C x C Linears of stages 1-2 as two launches
 # A/B switches: conv weight gradients accumulated straight into the [out][cin][kh][kw] layout by the wgrad epilogue (strided atomics),
 # or through a pooled [out][kh][kw][cin] buffer + one permuted ATen add per convolution, instead of the store's tap arena
 WGRAD_TAPS = bool(os.environ.get("MVLT_WGRAD_TAPS"))
@@ -507,9 +508,15 @@ class TrunkStep:
                               dx2=dy1 if fuse else None, dx2_scale=bs["s1"], dx2_rows_per_scale=N, lddx2=C)
         if not fuse:
             dy1 = self._scaled(dx, bs["s1"], N)
-        ops.gemm_tn(dy1, bs["ao"], self.g(p + "attn.proj.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.proj.bias"))
+        # stages 1-2 (C = 64 / 128, HBM-bound): the weight gradient and the input gradient of a C x C Linear come out of ONE pass over dY
+        lin_fuse = dt == torch.bfloat16 and C in (64, 128) and not _NO_LIN_FUSE
         dao = dxn2          # reuse
-        ops.gemm_nt(dy1, self.wT(p + "attn.proj.weight"), dao, M, C, C, C, C, C)
+        if lin_fuse:
+            ops.gemm_tn(dy1, bs["ao"], self.g(p + "attn.proj.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.proj.bias"),
+                        dgrad=(self.wT(p + "attn.proj.weight"), dao.view(M, C)))
+        else:
+            ops.gemm_tn(dy1, bs["ao"], self.g(p + "attn.proj.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.proj.bias"))
+            ops.gemm_nt(dy1, self.wT(p + "attn.proj.weight"), dao, M, C, C, C, C, C)
         Mk = bs["Mk"]
         dq = _empty((B, N, C), dt, dev)
         # dK/dV: one query chunk per (batch, head) from B*heads >= 512 on (mvlt_sr_attention_bwd then stores plainly, every
@@ -523,9 +530,13 @@ class TrunkStep:
             dkv = dkv32.to(dt)
             del dkv32
         # q projection
-        ops.gemm_tn(dq, bs["xn1"], self.g(p + "attn.q.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.q.bias"))
         dxn1 = dao          # reuse again: d(LN1 output), every row written by the q dgrad
-        ops.gemm_nt(dq, self.wT(p + "attn.q.weight"), dxn1, M, C, C, C, C, C)
+        if lin_fuse:
+            ops.gemm_tn(dq, bs["xn1"], self.g(p + "attn.q.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.q.bias"),
+                        dgrad=(self.wT(p + "attn.q.weight"), dxn1.view(M, C)))
+        else:
+            ops.gemm_tn(dq, bs["xn1"], self.g(p + "attn.q.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.q.bias"))
+            ops.gemm_nt(dq, self.wT(p + "attn.q.weight"), dxn1, M, C, C, C, C, C)
         gkvw, gkvb = self.g(p + "attn.kv.weight"), self.g(p + "attn.kv.bias")
         wkvT = self.wT(p + "attn.kv.weight")
         if r > 1:

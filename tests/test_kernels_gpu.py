@@ -260,6 +260,27 @@ def test_gemm_tn(ops, dtype, M, N1, N2):
     assert maxrel(out, 2 * ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("C,M", [(64, 64 * 300 + 17), (128, 64 * 150 + 40), (64, 130), (128, 4224 * 8)])
+def test_gemm_tn_with_fused_input_gradient(ops, C, M):
+    """weight gradient + bias gradient + INPUT gradient of a C x C Linear from one pass over dY (mvlt_gemm_tn dgrad_*; the q / proj
+    projections of stages 1-2): dW += dY^T X, db += colsum(dY), dX = dY W -- against fp32 references, ragged last tile included, and
+    the two-launch form (gemm_tn + gemm_nt) as a second witness for dX."""
+    dt = torch.bfloat16
+    dY, X = rnd(M, C, dtype=dt, scale=0.5), rnd(M, C, dtype=dt, seed=1, scale=0.5)
+    W = rnd(C, C, dtype=dt, seed=2, scale=C ** -0.5)                  # [out][in]
+    WT = W.t().contiguous()
+    dW, db = torch.zeros(C, C, device=dev()), torch.zeros(C, device=dev())
+    dX = torch.full((M, C), float("nan"), device=dev(), dtype=dt)
+    ops.gemm_tn(dY, X, dW, M, C, C, C, C, C, colsum=db, dgrad=(WT, dX))
+    assert maxrel(dW, dY.float().t() @ X.float()) < 1e-3
+    assert maxrel(db, dY.float().sum(0)) < 1e-3
+    assert torch.isfinite(dX.float()).all()
+    assert maxrel(dX.float(), dY.float() @ W.float()) < TOL[dt]
+    dX2 = torch.empty_like(dX)
+    ops.gemm_nt(dY, WT, dX2, M, C, C, C, C, C)
+    assert maxrel(dX.float(), dX2.float()) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_tn_patch_gather(ops, dtype):
     from mvlt_amd._lib import patchmap
