@@ -1243,8 +1243,10 @@ template <int C, int MODE> int launch(const mvlt_mlp_args& a, hipStream_t s) {
   const size_t stage = (size_t)4 * 16 * (C + 4) * 4;       // epilogue staging (4 waves x 16 rows) reuses the weight buffers
   if (lds < stage) lds = stage;
   static const bool legacy = getenv("MVLT_MLP_LEGACY") != nullptr;
-  static const bool force128 = getenv("MVLT_MLP_PIPE128") != nullptr;
-  if (!legacy && !a.h_out && a.hid >= 128 && !(C == 128 && MODE == 1 && !force128)) {      // the software-pipelined kernel (no pre-activation store: nothing in the step asks for one)
+  // the pipelined input-gradient kernel at C = 128: 390 us (236 B of scratch) against the round-2 kernel's 327 us with the sigmoid-form GELU' of mid round 3;
+  // with the polynomial GELU' it needs 44 B and runs 297 us against 339 us (round 4, same box) -- the default now, MVLT_MLP_PIPE128=0 selects the old kernel
+  static const bool pipe128 = !(getenv("MVLT_MLP_PIPE128") && atoi(getenv("MVLT_MLP_PIPE128")) == 0);
+  if (!legacy && !a.h_out && a.hid >= 128 && !(C == 128 && MODE == 1 && !pipe128)) {      // the software-pipelined kernel (no pre-activation store: nothing in the step asks for one)
     size_t l2 = (size_t)2 * (MODE == 1 ? 2 : 1) * 32 * 2 * C + (size_t)2 * C * 64 + (size_t)a.hid * 4;
     if ((MVLT_GELU_LUT >> (MODE == 1 ? 1 : 2)) & 1) l2 += GELU_LUT_BYTES;
     if (l2 < stage) l2 = stage;

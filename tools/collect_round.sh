@@ -10,6 +10,10 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_n1.jso
 cut -c1-300 gpurun_out/${tag}_bench_n1.json
 bash tools/profile_bench.sh $tag --steps 6 --warmup 3 > /dev/null 2>&1
 cp gpurun_out/kernel_stats_$tag.csv gpurun_out/${tag}_kernel_stats.csv 2>/dev/null
+python3 tools/step_launches.py gpurun_out/prof_$tag/trace_kernel_trace.csv > gpurun_out/${tag}_step_launches.txt 2>&1
+RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 MVLT_DP_FORCE_COLLECTIVES=1 python3 tools/overlap_trace.py > gpurun_out/${tag}_overlap.txt 2>/dev/null
+bash tools/l1_stalls.sh > /dev/null 2>&1; cp gpurun_out/l1_stalls.txt gpurun_out/${tag}_l1_stalls.txt 2>/dev/null
+bash tools/step_traffic.sh $tag > /dev/null 2>&1
 python3 tools/gemm_shapes.py > gpurun_out/${tag}_gemm_shapes.txt 2>&1
 bash tools/pmc_collect.sh $tag > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do

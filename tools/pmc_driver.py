@@ -42,6 +42,26 @@ def main():
     todo.append(lambda: ops.gemm_nt(a, w, o, M, N, K, K, K, N, bias=bias, act=1, H=h))
     dwg = torch.zeros(N, K, device=dev)
     todo.append(lambda: ops.gemm_tn(o, a, dwg, M, N, K, N, K, K))
+    # round 4: the other launches of the 8-wave / 8-phase NT kernels -- stage-3 GELU' dgrad (256 x 256, EPI 4), fc2 + fp32 residual and fc1 dgrad
+    # (192 x 320 tiles, K = 1280), stage-4 fc1 dgrad (192 x 256, K = 2048) -- and the fused weight + input gradient of a stage-1 C x C Linear
+    dyh = torch.randn(M, K, device=dev).to(bf)
+    w2t = (torch.randn(N, K, device=dev) * K ** -0.5).to(bf)
+    dh = torch.empty(M, N, device=dev, dtype=bf)
+    todo.append(lambda: ops.gemm_nt(dyh, w2t, dh, M, N, K, K, K, N, act=2, H=h))
+    w2 = (torch.randn(K, N, device=dev) * N ** -0.5).to(bf)
+    b2, r32, o32 = torch.randn(K, device=dev), torch.randn(M, K, device=dev), torch.empty(M, K, device=dev)
+    todo.append(lambda: ops.gemm_nt(o, w2, o32, M, K, N, N, N, K, bias=b2, R=r32))
+    dxn = torch.empty(M, K, device=dev, dtype=bf)
+    todo.append(lambda: ops.gemm_nt(dh, w2, dxn, M, K, N, N, N, K))
+    M4, C4, H4 = B * 192, 512, 2048
+    dh4, w14 = torch.randn(M4, H4, device=dev).to(bf), (torch.randn(C4, H4, device=dev) * H4 ** -0.5).to(bf)
+    dx4 = torch.empty(M4, C4, device=dev, dtype=bf)
+    todo.append(lambda: ops.gemm_nt(dh4, w14, dx4, M4, C4, H4, H4, H4, C4))
+    M1 = B * 4224
+    dq, xn = torch.randn(M1, 64, device=dev).to(bf), torch.randn(M1, 64, device=dev).to(bf)
+    wqt = (torch.randn(64, 64, device=dev) * 0.125).to(bf)
+    dwq, dbq, dxq = torch.zeros(64, 64, device=dev), torch.zeros(64, device=dev), torch.empty(M1, 64, device=dev, dtype=bf)
+    todo.append(lambda: ops.gemm_tn(dq, xn, dwq, M1, 64, 64, 64, 64, 64, colsum=dbq, dgrad=(wqt, dxq)))
     # MIM decoder: weight gradient of the 192 -> 192 conv3x3 at 32 x 32 (conv3_wgrad_kernel: LDS-resident halo)
     from mvlt_amd._lib import conv3map
     Mc, Cc2 = B * 1024, 192
