@@ -1067,6 +1067,36 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
     const int r = tid >> 3, c = tid & 7;
     if (q_prev + r < q_end) st_g<MVLT_NT_ATTN>((u32x4*)(dQg + (long)(q_prev + r) * p.ldq + c * 8), *(const u32x4*)(sdQ + r * HD + c * 8));
   }
+  // ---- flush dK / dV.  One query chunk per (batch, head) and a bf16 dKV (stages 2-4): the accumulator layout gives a lane one column and four ROWS --
+  //      stored directly that was 32 two-byte stores per key tile and lane, 12 / 20 / 35 us of the 152 / 152 / 146 us launches of stages 2 / 3 / 4 (ablation,
+  //      round 4).  Each wave parks a [16 keys][K 64 | V 64] tile in its own LDS slice (the ring is free now) and stores whole 16-byte row pieces.
+  if (nq_chunks == 1 && p.dkv_dtype == 0) {
+    constexpr int LDW = 128 + 8;
+    bf16* sX = (bf16*)smem + wave * 16 * LDW;
+    __syncthreads();                                   // every wave is done with the K^T / dS tiles this overlays
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sX[(4 * fg + r) * LDW + dt * 16 + fr] = (bf16)dKacc[t][dt][r];
+          sX[(4 * fg + r) * LDW + 64 + dt * 16 + fr] = (bf16)dVacc[t][dt][r];
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = i * 64 + lane, row = q >> 4, c = q & 15;
+        const int key = (wave * TPW + t) * 16 + row;
+        if (key < p.M)
+          *(u32x4*)((bf16*)p.dKV + ((long)b * p.M + key) * p.lddkv + (c < 8 ? p.k_off : p.v_off) + h * HD + (c & 7) * 8) = *(const u32x4*)(sX + row * LDW + c * 8);
+      }
+    }
+    return;
+  }
   // ---- flush dK / dV
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
