@@ -52,7 +52,7 @@ typedef struct mvlt_gemm_nt_args {
   const void* A; const void* B; void* C;
   int M, N, K, lda, ldb, ldc;
   int dtype;                 /* of A and B */
-  int out_dtype;             /* of C, R, H */
+  int out_dtype;             /* of C, R, H: 0 bf16, 1 fp32; 2 = fp16 C, with col_sum only (the conv output z that BatchNorm normalises) */
   mvlt_rowmap a_map, c_map;
   const float* bias;         /* [N] fp32 or NULL */
   int act;
@@ -354,13 +354,15 @@ int mvlt_add_column_sums(const float* in, long rows, int cols, int ld, float* ds
 int mvlt_col_stats(const float* z, int ldz, long M, int C, float* sum, float* sumsq, void* stream);         /* += */
 int mvlt_bn_finalize(const float* sum, const float* sumsq, int copies /* accumulators [copies][C], summed here */, long M, int C, float eps, float momentum, float* mean, float* rstd,
                      float* running_mean, float* running_var /* nullable pair: updated like nn.BatchNorm2d */, void* stream);
-int mvlt_bn_norm(const float* z, int ldz, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
+/* z, the pre-BatchNorm conv output, is fp32 (z_dtype 1) or fp16 (z_dtype 2: what mvlt_gemm_nt writes with out_dtype 2 -- no MFMA reads z, and it is
+ * written once and read three times per step, so the bf16 path keeps it at half the bytes in the type the reference's autocast gives it) */
+int mvlt_bn_norm(const void* z, int ldz, int z_dtype, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
                  float* y32, int ld32, void* y_op, int ld_op, int op_dtype /* dtype of y_op: the MFMA-operand copy */, void* stream);
 /* dy (the gradient w.r.t. the BatchNorm output) is fp32 (dy_dtype 1) or bf16 (dy_dtype 0: what the decoder's first backward stages hand
  * over -- a gradient tensor is read twice here and written once by its producer) */
-int mvlt_bn_bwd_reduce(const void* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, long M, int C,
+int mvlt_bn_bwd_reduce(const void* dy, int lddy, const void* z, int ldz, int z_dtype, const float* mean, const float* rstd, long M, int C,
                        float* s1 /* += sum dy = dbeta */, float* s2 /* += sum dy*xhat = dgamma */, int dy_dtype, void* stream);
-int mvlt_bn_bwd_apply(const void* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd, const float* gamma,
+int mvlt_bn_bwd_apply(const void* dy, int lddy, const void* z, int ldz, int z_dtype, const float* mean, const float* rstd, const float* gamma,
                       const float* s1, const float* s2, long M, int C, void* dz_op, int lddz,
                       float* g_beta, float* g_gamma /* nullable pair: += s1, += s2 (the BatchNorm parameter gradients) */,
                       int op_dtype, int dy_dtype, void* stream);

@@ -62,6 +62,20 @@ __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a0, const u32x4& 
   for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[j], fb1[j], acc, 0, 0, 0);
 }
 
+// out_dtype 2 (fp16; EPI 5 only: the pre-BatchNorm conv output z, which no MFMA reads -- 11 significand bits at half the bytes of fp32, the
+// reference's own autocast type for it, reference libs/vl_heads.py:15-21 under torch.cuda.amp): values saturate at the fp16 range instead of
+// turning into inf, and the column statistics are taken from the ROUNDED values (mean / rstd describe z as the normalisation reads it)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void round_f16_8(float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)(_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+}
+template <bool NTF> __device__ __forceinline__ void store_f16_8(void* base, long ix, const float (&v)[8]) {
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+  st_g<NTF>((f16x8*)((_Float16*)base + ix), o);
+}
 template <typename T> __device__ __forceinline__ void store_out(void* base, long idx, float v, int out_fp32) {
   if (out_fp32) ((float*)base)[idx] = v; else ((bf16*)base)[idx] = (bf16)v;
 }
@@ -467,7 +481,10 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       for (int e = 0; e < 8; ++e) v[e] += bias8[e];
       const long ix = idx[sl][it];
       auto store8 = [&](void* base, const float* o) {
-        if (ofp32) {
+        if (EPI == 5 && ofp32 == 2) {
+          const float o8h[8] = {o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
+          store_f16_8<MVLT_NT_GEMM>(base, ix, o8h);
+        } else if (ofp32) {
           st_g<MVLT_NT_GEMM>((f32x4*)((float*)base + ix), f32x4{o[0], o[1], o[2], o[3]});
           st_g<MVLT_NT_GEMM>((f32x4*)((float*)base + ix + 4), f32x4{o[4], o[5], o[6], o[7]});
         } else {
@@ -509,6 +526,7 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
         for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[sl][it] + o8[e];
       }
       if (EPI == 5) {
+        if (ofp32 == 2) round_f16_8(v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { cs8[e] += v[e]; cq8[e] += v[e] * v[e]; }
       }
@@ -595,11 +613,14 @@ __device__ __forceinline__ void nt_epilogue_192(const mvlt_gemm_nt_args& p, f32x
           for (int e = 0; e < 8; ++e) v[e] += p.bias[nc + e];
         }
         if (EPI == 5) {
+          if (ofp32 == 2) round_f16_8(v);
 #pragma unroll
           for (int e = 0; e < 8; ++e) { cs[g][e] += v[e]; cq[g][e] += v[e] * v[e]; }
         }
         const long ix = phys * p.ldc + nc;
-        if (ofp32) {
+        if (EPI == 5 && ofp32 == 2) {
+          store_f16_8<MVLT_NT_GEMM>(p.C, ix, v);
+        } else if (ofp32) {
           st_g<MVLT_NT_GEMM>((f32x4*)((float*)p.C + ix), f32x4{v[0], v[1], v[2], v[3]});
           st_g<MVLT_NT_GEMM>((f32x4*)((float*)p.C + ix + 4), f32x4{v[4], v[5], v[6], v[7]});
         } else {
@@ -2258,6 +2279,10 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
                                    a->a_map.mode == 0 && a->c_map.mode == 0 && a->split_k <= 64),
                "mvlt_gemm_nt: split_k needs bf16 operands, fp32 C (zeroed by the caller) and a plain epilogue");
   MVLT_REQUIRE(a->col_copies >= 0, "mvlt_gemm_nt: col_copies < 0");
+  MVLT_REQUIRE(a->out_dtype >= 0 && a->out_dtype <= 2, "mvlt_gemm_nt: out_dtype is 0 (bf16), 1 (fp32) or 2 (fp16, with col_sum only)");
+  MVLT_REQUIRE(a->out_dtype != 2 || (a->dtype == 0 && a->col_sum && a->act == 0 && !a->R && !a->row_scale && a->split_k <= 1 && a->c_map.mode == 0 && a->N % 8 == 0 &&
+                                     a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 && a->M < (1 << 24) && !getenv("MVLT_NT_GENERIC_EPI") && !getenv("MVLT_NT_LEGACY")),
+               "mvlt_gemm_nt: fp16 output exists in the column-statistics epilogue of the bf16 LDS-DMA kernels only (plain c_map, N % 8 == 0, 16-byte aligned C)");
   if (int e = check_rowmap(a->a_map, "mvlt_gemm_nt a_map")) return e;
   if (int e = check_rowmap(a->c_map, "mvlt_gemm_nt c_map")) return e;
   MVLT_REQUIRE(a->a_map.mode == 0 || a->K == a->a_map.r * a->a_map.r * a->a_map.c_seg, "mvlt_gemm_nt: gather K != r*r*c_seg");

@@ -18,9 +18,44 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const f32x4&
 // gradients over in bf16: they are read twice by the BatchNorm backward and once by the producer)
 template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
 template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *(const f32x4*)p; }
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <> __device__ __forceinline__ f32x4 load4<_Float16>(const _Float16* p) {     // the fp16 pre-BatchNorm conv output (mvlt_gemm_nt out_dtype 2)
+  const f16x4 v = *(const f16x4*)p;
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
 template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
   const bf16x4 v = *(const bf16x4*)p;
   return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+// eight consecutive values (one 16-byte access of a two-byte type): the fp16-z forms of the BatchNorm kernels below move 16 bytes per lane and tensor
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v)[8]) {
+  const bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+}
+template <> __device__ __forceinline__ void load8<_Float16>(const _Float16* p, float (&v)[8]) {
+  const f16x8 a = *(const f16x8*)p;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+}
+template <typename TO> __device__ __forceinline__ void store8(TO* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+  st_g<MVLT_NT_MIM>((f32x4*)p, f32x4{v[0], v[1], v[2], v[3]});
+  st_g<MVLT_NT_MIM>((f32x4*)(p + 4), f32x4{v[4], v[5], v[6], v[7]});
+}
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+  st_g<MVLT_NT_MIM>((bf16x8*)p, o);
 }
 
 // ---- per-column sum / sum of squares (BatchNorm batch statistics) and the two backward reductions
@@ -63,8 +98,8 @@ __global__ __launch_bounds__(NT) void col_reduce_kernel(const float* z, int ldz,
 
 // The same two reductions with 16-byte loads: C/4 lanes span a row, NT/(C/4) rows per pass, four passes in flight per thread
 // (the 4-byte form above keeps too few bytes in flight to reach HBM speed at C = 64).  C % 4 == 0, ld % 4 == 0, 16-byte aligned.
-template <int MODE, int NT, typename TDY = float>
-__global__ __launch_bounds__(NT) void col_reduce4_kernel(const float* z, int ldz, const TDY* dy, int lddy, const float* mean, const float* rstd,
+template <int MODE, int NT, typename TDY = float, typename TZ = float>
+__global__ __launch_bounds__(NT) void col_reduce4_kernel(const TZ* z, int ldz, const TDY* dy, int lddy, const float* mean, const float* rstd,
                                                          long M, int C, float* s1, float* s2, int rows_per_wg) {
   extern __shared__ float sm[];             // [2][C]
   for (int i = threadIdx.x; i < 2 * C; i += NT) sm[i] = 0.f;
@@ -82,7 +117,7 @@ __global__ __launch_bounds__(NT) void col_reduce4_kernel(const float* z, int ldz
       f32x4 zv[U], dv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        zv[u] = *(const f32x4*)(z + (r + (long)u * rpp) * ldz + tc);
+        zv[u] = load4<TZ>(z + (r + (long)u * rpp) * ldz + tc);
         if (MODE == 1) dv[u] = load4<TDY>(dy + (r + (long)u * rpp) * lddy + tc);
       }
 #pragma unroll
@@ -94,7 +129,7 @@ __global__ __launch_bounds__(NT) void col_reduce4_kernel(const float* z, int ldz
         }
     }
     for (; r < r1; r += rpp) {
-      f32x4 zv = *(const f32x4*)(z + r * ldz + tc), dv = zv;
+      f32x4 zv = load4<TZ>(z + r * ldz + tc), dv = zv;
       if (MODE == 1) dv = load4<TDY>(dy + r * lddy + tc);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -102,8 +137,18 @@ __global__ __launch_bounds__(NT) void col_reduce4_kernel(const float* z, int ldz
         else { a1[e] += dv[e]; a2[e] += dv[e] * (zv[e] - mu[e]) * rs[e]; }
       }
     }
+    if (64 % cq == 0) {                       // (see col_reduce8_kernel)
+      for (int o = cq; o < 64; o <<= 1)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { atomicAdd(&sm[tc + e], a1[e]); atomicAdd(&sm[C + tc + e], a2[e]); }
+        for (int e = 0; e < 4; ++e) { a1[e] += __shfl_xor(a1[e], o); a2[e] += __shfl_xor(a2[e], o); }
+      if ((threadIdx.x & 63) < cq) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { atomicAdd(&sm[tc + e], a1[e]); atomicAdd(&sm[C + tc + e], a2[e]); }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { atomicAdd(&sm[tc + e], a1[e]); atomicAdd(&sm[C + tc + e], a2[e]); }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < C; i += NT) { atomicAdd(&s1[i], sm[i]); atomicAdd(&s2[i], sm[C + i]); }
@@ -128,13 +173,13 @@ __global__ void bn_finalize_kernel(const float* sum, const float* sumsq, int cop
 }
 
 // y = (z - mean) * rstd * gamma + beta   -> fp32 (optional) and / or bf16 (optional), each with its own row stride
-template <typename TO>
-__global__ __launch_bounds__(NT) void bn_norm_kernel(const float* z, int ldz, const float* mean, const float* rstd, const float* gamma, const float* beta,
+template <typename TO, typename TZ = float>
+__global__ __launch_bounds__(NT) void bn_norm_kernel(const TZ* z, int ldz, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                                      long M, int C, float* y32, int ld32, TO* y16, int ld16) {
   const int cq = C / 4;
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
     long r = i / cq; int c = (int)(i - r * cq) * 4;
-    f32x4 v = *(const f32x4*)(z + r * ldz + c);
+    f32x4 v = load4<TZ>(z + r * ldz + c);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean[c + e]) * rstd[c + e] * gamma[c + e] + beta[c + e];
@@ -144,8 +189,8 @@ __global__ __launch_bounds__(NT) void bn_norm_kernel(const float* z, int ldz, co
 }
 
 // dz = gamma * rstd * (dy - s1/M - xhat * s2/M)   (bf16: it is the A operand of the conv dgrad / wgrad GEMMs)
-template <typename TO, typename TDY = float>
-__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const TDY* dy, int lddy, const float* z, int ldz, const float* mean, const float* rstd,
+template <typename TO, typename TDY = float, typename TZ = float>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const TDY* dy, int lddy, const TZ* z, int ldz, const float* mean, const float* rstd,
                                                           const float* gamma, const float* s1, const float* s2, long M, int C, TO* dz, int lddz,
                                                           float* g_beta, float* g_gamma) {
   const int cq = C / 4;
@@ -154,7 +199,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const TDY* dy, int ldd
     for (int c = threadIdx.x; c < C; c += NT) { g_beta[c] += s1[c]; g_gamma[c] += s2[c]; }
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
     long r = i / cq; int c = (int)(i - r * cq) * 4;
-    f32x4 d = load4<TDY>(dy + r * lddy + c), zv = *(const f32x4*)(z + r * ldz + c);
+    f32x4 d = load4<TDY>(dy + r * lddy + c), zv = load4<TZ>(z + r * ldz + c);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -162,6 +207,101 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const TDY* dy, int ldd
       o[e] = gamma[c + e] * rstd[c + e] * (d[e] - s1[c + e] * invM - xh * s2[c + e] * invM);
     }
     store4<TO>(dz + r * lddz + c, o);
+  }
+}
+
+// ---- the fp16-z forms (bf16 path; C % 8 == 0, strides multiples of 8, 16-byte aligned rows): eight channels per lane
+// mode 1 reduction: s1 += sum dy, s2 += sum dy * xhat.  C % 64 == 0: a wave covers 8 rows x one 64-column group (lane = 8 * row + chunk), the waves of a
+// workgroup are dealt to the C / 64 groups in turn, so the per-column partial sums fold inside the wave (xor 8 / 16 / 32) and only eight lanes per wave touch
+// the LDS accumulators (the 4-wide kernel's LDS atomics were 32 .. 64-way contended: at the few rows per thread of these launches, most of its time)
+template <int NT, typename TDY>
+__global__ __launch_bounds__(NT) void col_reduce8_kernel(const _Float16* z, int ldz, const TDY* dy, int lddy, const float* mean, const float* rstd,
+                                                         long M, int C, float* s1, float* s2, int rows_per_wg) {
+  extern __shared__ float sm[];             // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += NT) sm[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int G = C >> 6, g = wave % G, wr = wave / G;
+  const int rpp = (NT / 64 / G) * 8;                    // rows per pass
+  const int tc = g * 64 + (lane & 7) * 8, tr = wr * 8 + (lane >> 3);
+  float a1[8], a2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+  if (tr < rpp) {
+    float mu[8], rs[8];
+    load8<float>(mean + tc, mu);
+    load8<float>(rstd + tc, rs);
+    const long r0 = (long)blockIdx.x * rows_per_wg;
+    const long r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
+    long r = r0 + tr;
+    constexpr int U = 4;
+    for (; r + (long)(U - 1) * rpp < r1; r += (long)U * rpp) {
+      float zv[U][8], dv[U][8];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        load8<_Float16>(z + (r + (long)u * rpp) * ldz + tc, zv[u]);
+        load8<TDY>(dy + (r + (long)u * rpp) * lddy + tc, dv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a1[e] += dv[u][e]; a2[e] += dv[u][e] * (zv[u][e] - mu[e]) * rs[e]; }
+    }
+    for (; r < r1; r += rpp) {
+      float zv[8], dv[8];
+      load8<_Float16>(z + r * ldz + tc, zv);
+      load8<TDY>(dy + r * lddy + tc, dv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a1[e] += dv[e]; a2[e] += dv[e] * (zv[e] - mu[e]) * rs[e]; }
+    }
+  }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a1[e] += __shfl_xor(a1[e], o); a2[e] += __shfl_xor(a2[e], o); }
+  if (lane < 8 && tr < rpp) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(&sm[tc + e], a1[e]); atomicAdd(&sm[C + tc + e], a2[e]); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += NT) { atomicAdd(&s1[i], sm[i]); atomicAdd(&s2[i], sm[C + i]); }
+}
+
+__global__ __launch_bounds__(NT) void bn_norm8_kernel(const _Float16* z, int ldz, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                                      long M, int C, float* y32, int ld32, bf16* y16, int ld16) {
+  const int cq = C / 8;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
+    long r = i / cq; int c = (int)(i - r * cq) * 8;
+    float v[8], mu[8], rs[8], ga[8], be[8], o[8];
+    load8<_Float16>(z + r * ldz + c, v);
+    load8<float>(mean + c, mu); load8<float>(rstd + c, rs); load8<float>(gamma + c, ga); load8<float>(beta + c, be);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (v[e] - mu[e]) * rs[e] * ga[e] + be[e];
+    if (y32) store8<float>(y32 + r * ld32 + c, o);
+    if (y16) store8<bf16>(y16 + r * ld16 + c, o);
+  }
+}
+
+template <typename TDY>
+__global__ __launch_bounds__(NT) void bn_bwd_apply8_kernel(const TDY* dy, int lddy, const _Float16* z, int ldz, const float* mean, const float* rstd,
+                                                           const float* gamma, const float* s1, const float* s2, long M, int C, bf16* dz, int lddz,
+                                                           float* g_beta, float* g_gamma) {
+  const int cq = C / 8;
+  const float invM = 1.0f / (float)M;
+  if (g_beta && blockIdx.x == 0)             // BatchNorm parameter gradients: d beta += s1, d gamma += s2 (one writer)
+    for (int c = threadIdx.x; c < C; c += NT) { g_beta[c] += s1[c]; g_gamma[c] += s2[c]; }
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
+    long r = i / cq; int c = (int)(i - r * cq) * 8;
+    float d[8], zv[8], mu[8], rs[8], ga[8], t1[8], t2[8], o[8];
+    load8<TDY>(dy + r * lddy + c, d);
+    load8<_Float16>(z + r * ldz + c, zv);
+    load8<float>(mean + c, mu); load8<float>(rstd + c, rs); load8<float>(gamma + c, ga); load8<float>(s1 + c, t1); load8<float>(s2 + c, t2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (zv[e] - mu[e]) * rs[e];
+      o[e] = ga[e] * rs[e] * (d[e] - t1[e] * invM - xh * t2[e] * invM);
+    }
+    store8<bf16>(dz + r * lddz + c, o);
   }
 }
 
@@ -664,55 +804,93 @@ extern "C" int mvlt_bn_finalize(const float* sum, const float* sumsq, int copies
   return mvlt_check_launch("mvlt_bn_finalize");
 }
 
-extern "C" int mvlt_bn_norm(const float* z, int ldz, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
+extern "C" int mvlt_bn_norm(const void* z_, int ldz, int z_dtype, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
                             float* y32, int ld32, void* y16, int ld16, int op_dtype, void* stream) {
-  MVLT_REQUIRE(z && mean && rstd && gamma && beta && (y32 || y16) && C % 4 == 0 && ldz % 4 == 0, "mvlt_bn_norm: bad arguments (C, ld multiples of 4)");
+  MVLT_REQUIRE(z_ && mean && rstd && gamma && beta && (y32 || y16) && C % 4 == 0 && ldz % 4 == 0, "mvlt_bn_norm: bad arguments (C, ld multiples of 4)");
   MVLT_REQUIRE((!y32 || ld32 % 4 == 0) && (!y16 || ld16 % 4 == 0), "mvlt_bn_norm: output strides must be multiples of 4");
+  MVLT_REQUIRE(z_dtype == 1 || (z_dtype == 2 && op_dtype == 0), "mvlt_bn_norm: z is fp32 (z_dtype 1), or fp16 (2) on the bf16 path");
   if (M <= 0) return MVLT_OK;
-  if (op_dtype == 0) hipLaunchKernelGGL((bn_norm_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
+  const float* z = (const float*)z_;
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  if (z_dtype == 2 && C % 8 == 0 && ldz % 8 == 0 && (!y32 || (ld32 % 4 == 0 && al16(y32))) && (!y16 || (ld16 % 8 == 0 && al16(y16))) && al16(z_) && al16(mean) && al16(rstd) &&
+      al16(gamma) && al16(beta))
+    hipLaunchKernelGGL(bn_norm8_kernel, dim3(grid_for(M * (C / 8))), dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
+  else if (z_dtype == 2) hipLaunchKernelGGL((bn_norm_kernel<bf16, _Float16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
+  else if (op_dtype == 0) hipLaunchKernelGGL((bn_norm_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
   else hipLaunchKernelGGL((bn_norm_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (float*)y16, ld16);
   return mvlt_check_launch("mvlt_bn_norm");
 }
 
-extern "C" int mvlt_bn_bwd_reduce(const void* dy_, int lddy, const float* z, int ldz, const float* mean, const float* rstd, long M, int C,
+extern "C" int mvlt_bn_bwd_reduce(const void* dy_, int lddy, const void* z_, int ldz, int z_dtype, const float* mean, const float* rstd, long M, int C,
                                   float* s1, float* s2, int dy_dtype, void* stream) {
-  MVLT_REQUIRE(dy_ && z && mean && rstd && s1 && s2 && C > 0 && C <= 256 && (dy_dtype == 0 || dy_dtype == 1), "mvlt_bn_bwd_reduce: bad arguments (C <= 256)");
+  MVLT_REQUIRE(dy_ && z_ && mean && rstd && s1 && s2 && C > 0 && C <= 256 && (dy_dtype == 0 || dy_dtype == 1) && (z_dtype == 1 || z_dtype == 2),
+               "mvlt_bn_bwd_reduce: bad arguments (C <= 256)");
   if (M <= 0) return MVLT_OK;
   const float* dy = (const float*)dy_;
+  const float* z = (const float*)z_;
   const bool dy_vec = dy_dtype == 1 ? vec4_ok(dy, lddy, C) : (C % 4 == 0 && C <= 256 && lddy % 4 == 0 && ((uintptr_t)dy_ & 7) == 0);
-  MVLT_REQUIRE(dy_dtype == 1 || (dy_vec && vec4_ok(z, ldz, C)), "mvlt_bn_bwd_reduce: bf16 dy needs C, ld multiples of 4 and aligned rows");
-  if (vec4_ok(z, ldz, C) && dy_vec && (((uintptr_t)mean | (uintptr_t)rstd) & 15) == 0) {
+  const bool z_vec = z_dtype == 1 ? vec4_ok(z, ldz, C) : (C % 4 == 0 && ldz % 4 == 0 && ((uintptr_t)z_ & 7) == 0);
+  MVLT_REQUIRE(dy_dtype == 1 || (dy_vec && z_vec), "mvlt_bn_bwd_reduce: bf16 dy needs C, ld multiples of 4 and aligned rows");
+  if (z_vec && dy_vec && (((uintptr_t)mean | (uintptr_t)rstd) & 15) == 0) {
     // measured at M = 262144: C = 64 34.7 -> 30.6 us with 512 threads, C = 192 98.8 -> 80.0 us with 1024 (5.0 TB/s)
     const int nt = C <= 64 ? 512 : 1024;
     int rows_per_wg = reduce_rows_per_wg(M, C, nt, RWGS);
     int grid = (int)((M + rows_per_wg - 1) / rows_per_wg);
     const size_t lds = 2 * C * sizeof(float);
-    if (dy_dtype == 0) {
-      if (nt == 512) hipLaunchKernelGGL((col_reduce4_kernel<1, 512, bf16>), dim3(grid), dim3(512), lds, (hipStream_t)stream, z, ldz, (const bf16*)dy_, lddy, mean, rstd, M, C, s1, s2, rows_per_wg);
-      else hipLaunchKernelGGL((col_reduce4_kernel<1, 1024, bf16>), dim3(grid), dim3(1024), lds, (hipStream_t)stream, z, ldz, (const bf16*)dy_, lddy, mean, rstd, M, C, s1, s2, rows_per_wg);
+    const bf16* dyh = (const bf16*)dy_;
+    const _Float16* zh = (const _Float16*)z_;
+#define MVLT_RED_LAUNCH(NT_, TDY_, TZ_, DY_, Z_) \
+    hipLaunchKernelGGL((col_reduce4_kernel<1, NT_, TDY_, TZ_>), dim3(grid), dim3(NT_), lds, (hipStream_t)stream, Z_, ldz, DY_, lddy, mean, rstd, M, C, s1, s2, rows_per_wg)
+    const bool wide = z_dtype == 2 && C % 64 == 0 && ldz % 8 == 0 && ((uintptr_t)z_ & 15) == 0 && ((uintptr_t)dy_ & 15) == 0 && lddy % (dy_dtype == 0 ? 8 : 4) == 0;
+    if (wide) {
+      const int nt8 = C == 64 ? 512 : C == 192 ? 768 : 1024;           // whole waves per 64-column group
+      const int rpp8 = (nt8 / 64 / (C / 64)) * 8;
+      long rows8 = (M + RWGS - 1) / RWGS;
+      rows8 = (rows8 + 4 * rpp8 - 1) / (4 * rpp8) * (4 * rpp8);
+      const int grid8 = (int)((M + rows8 - 1) / rows8);
+#define MVLT_RED8(NT_, TDY_, DY_) hipLaunchKernelGGL((col_reduce8_kernel<NT_, TDY_>), dim3(grid8), dim3(NT_), lds, (hipStream_t)stream, zh, ldz, DY_, lddy, mean, rstd, M, C, s1, s2, (int)rows8)
+      if (dy_dtype == 0) { if (nt8 == 512) MVLT_RED8(512, bf16, dyh); else if (nt8 == 768) MVLT_RED8(768, bf16, dyh); else MVLT_RED8(1024, bf16, dyh); }
+      else { if (nt8 == 512) MVLT_RED8(512, float, dy); else if (nt8 == 768) MVLT_RED8(768, float, dy); else MVLT_RED8(1024, float, dy); }
+#undef MVLT_RED8
+    } else if (z_dtype == 2) {
+      if (dy_dtype == 0) { if (nt == 512) MVLT_RED_LAUNCH(512, bf16, _Float16, dyh, zh); else MVLT_RED_LAUNCH(1024, bf16, _Float16, dyh, zh); }
+      else { if (nt == 512) MVLT_RED_LAUNCH(512, float, _Float16, dy, zh); else MVLT_RED_LAUNCH(1024, float, _Float16, dy, zh); }
+    } else if (dy_dtype == 0) {
+      if (nt == 512) MVLT_RED_LAUNCH(512, bf16, float, dyh, z); else MVLT_RED_LAUNCH(1024, bf16, float, dyh, z);
     } else {
-      if (nt == 512) hipLaunchKernelGGL((col_reduce4_kernel<1, 512>), dim3(grid), dim3(512), lds, (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, M, C, s1, s2, rows_per_wg);
-      else hipLaunchKernelGGL((col_reduce4_kernel<1, 1024>), dim3(grid), dim3(1024), lds, (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, M, C, s1, s2, rows_per_wg);
+      if (nt == 512) MVLT_RED_LAUNCH(512, float, float, dy, z); else MVLT_RED_LAUNCH(1024, float, float, dy, z);
     }
+#undef MVLT_RED_LAUNCH
     return mvlt_check_launch("mvlt_bn_bwd_reduce");
   }
-  MVLT_REQUIRE(dy_dtype == 1, "mvlt_bn_bwd_reduce: bf16 dy needs the vectorised path (16-byte aligned mean / rstd)");
+  MVLT_REQUIRE(dy_dtype == 1 && z_dtype == 1, "mvlt_bn_bwd_reduce: bf16 dy / fp16 z need the vectorised path (16-byte aligned mean / rstd)");
   int grid = (int)((M + 63) / 64); if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(grid), dim3(NT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, (int)M, C, s1, s2);
   return mvlt_check_launch("mvlt_bn_bwd_reduce");
 }
 
-extern "C" int mvlt_bn_bwd_apply(const void* dy_, int lddy, const float* z, int ldz, const float* mean, const float* rstd, const float* gamma,
+extern "C" int mvlt_bn_bwd_apply(const void* dy_, int lddy, const void* z_, int ldz, int z_dtype, const float* mean, const float* rstd, const float* gamma,
                                  const float* s1, const float* s2, long M, int C, void* dz_bf16, int lddz, float* g_beta, float* g_gamma,
                                  int op_dtype, int dy_dtype, void* stream) {
-  MVLT_REQUIRE(dy_ && z && mean && rstd && gamma && s1 && s2 && dz_bf16 && C % 4 == 0 && lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0 && (dy_dtype == 0 || dy_dtype == 1),
+  MVLT_REQUIRE(dy_ && z_ && mean && rstd && gamma && s1 && s2 && dz_bf16 && C % 4 == 0 && lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0 && (dy_dtype == 0 || dy_dtype == 1),
                "mvlt_bn_bwd_apply: bad arguments");
   MVLT_REQUIRE((g_beta == nullptr) == (g_gamma == nullptr), "mvlt_bn_bwd_apply: g_beta and g_gamma go together");
+  MVLT_REQUIRE(z_dtype == 1 || (z_dtype == 2 && op_dtype == 0), "mvlt_bn_bwd_apply: z is fp32 (z_dtype 1), or fp16 (2) on the bf16 path");
   if (M <= 0) return MVLT_OK;
   const dim3 grid(grid_for(M * (C / 4)));
   const float* dy = (const float*)dy_;
   const bf16* dyh = (const bf16*)dy_;
-  if (op_dtype == 0 && dy_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  const float* z = (const float*)z_;
+  const _Float16* zh = (const _Float16*)z_;
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  const bool wide = z_dtype == 2 && C % 8 == 0 && ldz % 8 == 0 && lddz % 8 == 0 && lddy % (dy_dtype == 0 ? 8 : 4) == 0 && al16(dy_) && al16(z_) && al16(dz_bf16) && al16(mean) &&
+                    al16(rstd) && al16(gamma) && al16(s1) && al16(s2);
+  const dim3 grid8(grid_for(M * (C / 8)));
+  if (wide && dy_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply8_kernel<bf16>), grid8, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, zh, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else if (wide) hipLaunchKernelGGL((bn_bwd_apply8_kernel<float>), grid8, dim3(NT), 0, (hipStream_t)stream, dy, lddy, zh, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else if (z_dtype == 2 && dy_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, bf16, _Float16>), grid, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, zh, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else if (z_dtype == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, float, _Float16>), grid, dim3(NT), 0, (hipStream_t)stream, dy, lddy, zh, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else if (op_dtype == 0 && dy_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
   else if (op_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
   else if (dy_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (float*)dz_bf16, lddz, g_beta, g_gamma);
   else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), grid, dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (float*)dz_bf16, lddz, g_beta, g_gamma);

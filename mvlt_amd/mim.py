@@ -23,6 +23,7 @@ CONVS = ("reduction1", "reduction2", "reduction3", "conv_upsample1", "conv_upsam
 
 
 _FP32_DY = bool(os.environ.get("MVLT_MIM_FP32_DY"))      # A/B switch: every gradient map of the decoder's backward in fp32
+_FP32_Z = bool(os.environ.get("MVLT_MIM_FP32_Z"))        # A/B switch: the pre-BatchNorm conv outputs stay fp32 on the bf16 path (rounds 1-3)
 _NO_BN_FOLD = bool(os.environ.get("MVLT_MIM_NO_BN_FOLD"))   # A/B switch: eval mode keeps the separate BatchNorm pass over an fp32 z
 
 
@@ -60,7 +61,10 @@ class MimStep:
             r = dict(name=name, p=p, fold=self._folded(name, p, bn, cin, cout), xin=xin, ld_in=ld_in, amap=amap, cin=cin, cout=cout, M=M)
             self.rec[name] = r
             return r
-        z = _e((M, cout), dev)
+        # z, the conv output BatchNorm normalises: written once, read three times (normalise, the two backward passes) and never an MFMA operand.  On
+        # the bf16 path it is kept in fp16 -- the type the reference's autocast gives it -- with the batch statistics taken from the rounded values
+        z16 = self.training and self.dt == torch.bfloat16 and not _FP32_Z and not _SEPARATE_STATS
+        z = _e((M, cout), dev, torch.float16 if z16 else torch.float32)
         st = _z((2, STAT_COPIES, cout), dev) if self.training else (None, None)   # batch statistics ride on the conv's epilogue
         if _SEPARATE_STATS and self.training:
             ops.gemm_nt(xin, S.extra[p + ".0.weight::K"], z, M, cout, 9 * cin, ld_in, 9 * cin, cout, a_map=amap)

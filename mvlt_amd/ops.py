@@ -15,7 +15,7 @@ def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias
             row_scale=None, rows_per_scale=0, R=None, col_sum=None, col_sumsq=None, col_copies=0, split_k=0, post_ln=None):
     """C[M,N] = epi(A[M,K] @ B[N,K]^T); see mvlt_gemm_nt in include/mvlt_hip.h.  post_ln = (gamma, beta, eps, y, mean, rstd): LayerNorm of the
     finished output rows rides on the epilogue (N == 64 / 128, bf16 operands, R given)."""
-    assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype in DT
+    assert A.dtype == B.dtype and A.dtype in DT and (C_out.dtype in DT or (C_out.dtype == torch.float16 and col_sum is not None))
     if bias is not None:
         assert bias.dtype == torch.float32
     if row_scale is not None:
@@ -26,7 +26,7 @@ def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias
         assert H.dtype == C_out.dtype
     if col_sum is not None:
         assert col_sum.dtype == torch.float32 and col_sumsq is not None and col_sumsq.dtype == torch.float32
-    a = L.GemmNTArgs(ptr(A), ptr(B), ptr(C_out), M, N, K, lda, ldb, ldc, DT[A.dtype], DT[C_out.dtype],
+    a = L.GemmNTArgs(ptr(A), ptr(B), ptr(C_out), M, N, K, lda, ldb, ldc, DT[A.dtype], 2 if C_out.dtype == torch.float16 else DT[C_out.dtype],
                      a_map or _ID, c_map or _ID, ptr(bias), act, ptr(H), ptr(row_scale), rows_per_scale, ptr(R),
                      ptr(col_sum), ptr(col_sumsq), col_copies, split_k)
     if post_ln is not None:
@@ -261,9 +261,10 @@ def transpose_cast(w, out, R, Ccols, ld_out):
 # ------------------------------------------------------------------ MIM decoder helpers (csrc/mim.hip)
 L.lib.mvlt_col_stats.argtypes = [_vp, _i, _l, _i, _vp, _vp, _vp]
 L.lib.mvlt_bn_finalize.argtypes = [_vp, _vp, _i, _l, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]
-L.lib.mvlt_bn_norm.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _i, _i, _vp]
-L.lib.mvlt_bn_bwd_reduce.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _vp]
-L.lib.mvlt_bn_bwd_apply.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _vp, _i, _i, _vp]
+L.lib.mvlt_bn_norm.argtypes = [_vp, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _i, _i, _vp]
+L.lib.mvlt_bn_bwd_reduce.argtypes = [_vp, _i, _vp, _i, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _vp]
+L.lib.mvlt_bn_bwd_apply.argtypes = [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _vp, _i, _i, _vp]
+ZDT = {torch.float32: 1, torch.float16: 2}       # the pre-BatchNorm conv output z: fp32, or fp16 on the bf16 path (mvlt_gemm_nt out_dtype 2)
 L.lib.mvlt_ew_mul.argtypes = [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _l, _i, _i, _vp, _i, _i, _vp]
 L.lib.mvlt_upsample_fwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]
 L.lib.mvlt_upsample_bwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]
@@ -280,18 +281,18 @@ def bn_finalize(s, ss, M, Cdim, eps, momentum, mean, rstd, running_mean=None, ru
 
 
 def bn_norm(z, ldz, mean, rstd, gamma, beta, M, Cdim, y32=None, ld32=0, y16=None, ld16=0):
-    check(L.lib.mvlt_bn_norm(_p(z), ldz, _p(mean), _p(rstd), _p(gamma), _p(beta), M, Cdim, _p(y32), ld32, _p(y16), ld16,
+    check(L.lib.mvlt_bn_norm(_p(z), ldz, ZDT[z.dtype], _p(mean), _p(rstd), _p(gamma), _p(beta), M, Cdim, _p(y32), ld32, _p(y16), ld16,
                              DT[y16.dtype] if y16 is not None else 0, stream_ptr()), "mvlt_bn_norm")
 
 
 def bn_bwd_reduce(dy, lddy, z, ldz, mean, rstd, M, Cdim, s1, s2):
-    assert dy.dtype in DT and z.dtype == torch.float32
-    check(L.lib.mvlt_bn_bwd_reduce(_p(dy), lddy, _p(z), ldz, _p(mean), _p(rstd), M, Cdim, _p(s1), _p(s2), DT[dy.dtype], stream_ptr()), "mvlt_bn_bwd_reduce")
+    assert dy.dtype in DT and z.dtype in ZDT
+    check(L.lib.mvlt_bn_bwd_reduce(_p(dy), lddy, _p(z), ldz, ZDT[z.dtype], _p(mean), _p(rstd), M, Cdim, _p(s1), _p(s2), DT[dy.dtype], stream_ptr()), "mvlt_bn_bwd_reduce")
 
 
 def bn_bwd_apply(dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, Cdim, dz16, lddz, g_beta=None, g_gamma=None):
-    assert dy.dtype in DT and z.dtype == torch.float32
-    check(L.lib.mvlt_bn_bwd_apply(_p(dy), lddy, _p(z), ldz, _p(mean), _p(rstd), _p(gamma), _p(s1), _p(s2), M, Cdim, _p(dz16), lddz,
+    assert dy.dtype in DT and z.dtype in ZDT
+    check(L.lib.mvlt_bn_bwd_apply(_p(dy), lddy, _p(z), ldz, ZDT[z.dtype], _p(mean), _p(rstd), _p(gamma), _p(s1), _p(s2), M, Cdim, _p(dz16), lddz,
                                   _p(g_beta), _p(g_gamma), DT[dz16.dtype], DT[dy.dtype], stream_ptr()), "mvlt_bn_bwd_apply")
 
 

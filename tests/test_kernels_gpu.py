@@ -190,6 +190,13 @@ def test_gemm_nt_column_statistics(ops, dtype, M, N, K):
     assert maxrel(cs4.sum(0), out.sum(0)) < 1e-4 and maxrel(cq4.sum(0), (out * out).sum(0)) < 1e-4
     if M > 128 * 4:
         assert (cs4.abs().sum(1) > 0).all()
+    if dtype == torch.bfloat16 and N % 8 == 0:
+        # fp16 output (out_dtype 2: the pre-BatchNorm conv output on the bf16 path): the fp32 result rounded to fp16, statistics of the ROUNDED values
+        o16 = torch.empty(M, N, device=dev(), dtype=torch.float16)
+        c16, q16 = torch.zeros(N, device=dev()), torch.zeros(N, device=dev())
+        ops.gemm_nt(A, W, o16, M, N, K, K, K, N, col_sum=c16, col_sumsq=q16)
+        assert torch.equal(o16, out.to(torch.float16))
+        assert maxrel(c16, o16.float().sum(0)) < 1e-4 and maxrel(q16, (o16.float() ** 2).sum(0)) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -869,6 +876,23 @@ def test_batchnorm_fwd_bwd(ops, M, C, lddy, off):
         ops.bn_bwd_apply(dyr.contiguous(), C, z, C, mean, rstd, gamma, r32[0], r32[1], M, C, d32, C)
         ops.bn_bwd_apply(dyh, lddy, z, C, mean, rstd, gamma, r32[0], r32[1], M, C, d16, C)
         assert torch.equal(d16, d32)
+        # fp16 z (the bf16 path's conv output): the same kernels reading half the bytes == the fp32 kernels fed the fp16-rounded z
+        zh = z.to(torch.float16)
+        zr32 = zh.float()
+        yb, yh = torch.empty(M, C, device=dev(), dtype=torch.bfloat16), torch.empty(M, C, device=dev(), dtype=torch.bfloat16)
+        y32b, y32h = torch.empty(M, C, device=dev()), torch.empty(M, C, device=dev())
+        ops.bn_norm(zr32, C, mean, rstd, gamma, beta, M, C, y32=y32b, ld32=C, y16=yb, ld16=C)
+        ops.bn_norm(zh, C, mean, rstd, gamma, beta, M, C, y32=y32h, ld32=C, y16=yh, ld16=C)
+        assert torch.equal(yb, yh) and torch.equal(y32b, y32h)
+        for dyv, ldv in ((dyh, lddy), (dy, lddy)):
+            ra, rb = torch.zeros(2, C, device=dev()), torch.zeros(2, C, device=dev())
+            ops.bn_bwd_reduce(dyv, ldv, zr32, C, mean, rstd, M, C, ra[0], ra[1])
+            ops.bn_bwd_reduce(dyv, ldv, zh, C, mean, rstd, M, C, rb[0], rb[1])
+            assert maxrel(rb, ra) < 1e-5
+            da, db = torch.empty(M, C, device=dev(), dtype=torch.bfloat16), torch.empty(M, C, device=dev(), dtype=torch.bfloat16)
+            ops.bn_bwd_apply(dyv, ldv, zr32, C, mean, rstd, gamma, ra[0], ra[1], M, C, da, C)
+            ops.bn_bwd_apply(dyv, ldv, zh, C, mean, rstd, gamma, ra[0], ra[1], M, C, db, C)
+            assert torch.equal(da, db)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -1098,6 +1122,11 @@ def test_conv3x3_nt_lds_halo(ops, side, Cin, Cout, Bsz, tokens_extra, variant):
         assert maxrel(out, ref) < TOL[bf]
         assert maxrel(st[0].sum(0), out.sum(0)) < 1e-4
         assert maxrel(st[1].sum(0), (out * out).sum(0)) < 1e-4
+        o16 = torch.empty(M, Cout, device=dev(), dtype=torch.float16)          # the same launch writing fp16 (what the decoder's bf16 path stores)
+        s16 = torch.zeros(2, 4, Cout, device=dev())
+        ops.gemm_nt(X, Wk, o16, M, Cout, 9 * Cin, Cin, 9 * Cin, Cout, a_map=amap, col_sum=s16[0], col_sumsq=s16[1], col_copies=4)
+        assert torch.equal(o16, out.to(torch.float16))
+        assert maxrel(s16[0].sum(0), o16.float().sum(0)) < 1e-4 and maxrel(s16[1].sum(0), (o16.float() ** 2).sum(0)) < 1e-4
     elif variant == "acc":
         base = rnd(M, Cout, dtype=torch.float32, seed=5)
         out = base.clone()
