@@ -142,7 +142,8 @@ typedef struct mvlt_layernorm_bwd_args {
   void* dx2; const float* dx2_scale; int dx2_rows_per_scale; int lddx2;
   /* dg_copies > 1: dgamma / dbeta are the first of dg_copies interleaved accumulators dg_copy_stride floats apart and workgroup
    * b adds into copy b % dg_copies (mvlt_fold_copies sums them): every workgroup of a launch adds 2*C floats to the same few
-   * cache lines, and those requests serialise at the memory side at ~100 ns each (16-27 us per call with one copy). */
+   * cache lines, and those requests serialise at the memory side at ~100 ns each (16-27 us per call with one copy).  With dg_copies >= 64
+   * the launch uses at most dg_copies workgroups, one copy each, and adds without atomics. */
   int dg_copies; long dg_copy_stride;
 } mvlt_layernorm_bwd_args;
 int mvlt_layernorm_bwd(const mvlt_layernorm_bwd_args* args, void* stream);

@@ -245,24 +245,39 @@ __global__ __launch_bounds__(NT) void ln_fwd_fixed_kernel(mvlt_layernorm_args p)
   }
 }
 
+// The launch is one 1024-thread workgroup per CU (launch_bwd): four waves per SIMD, 128 registers each.  Left to itself hipcc aims the two-chunk
+// variants at EIGHT waves per SIMD (64 registers) and spills 36 bytes per lane inside the row loop (rocprofv3 Scratch_Size, round 4: 98304 x 320 ran
+// at 3.6-4.0 TB/s); the occupancy the launch can actually reach is stated instead.
+#ifndef MVLT_LN_BWD_WAVES
+#define MVLT_LN_BWD_WAVES(NT_) __attribute__((amdgpu_waves_per_eu((NT_) / 256, (NT_) / 256)))
+#endif
 // ITS = chunks per lane (1 when the lane group covers the row: C <= 8 G; the second slot of the arrays would only hold
 // registers: 126 -> ~90 VGPRs, 4 -> 5 waves per SIMD on an HBM-bound kernel)
 template <typename T, typename TX, typename TDX, int G, int ITS, int NT>
-__global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
-  constexpr int GROUPS = NT / G;
-  extern __shared__ __attribute__((aligned(16))) float s_part[];               // [2][C] block partials of dgamma / dbeta
+__global__ __launch_bounds__(NT) MVLT_LN_BWD_WAVES(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
+  constexpr int GROUPS = NT / G, NW = NT / 64;
+  // LDS: [NW][2][C] per-wave partial sums of dgamma / dbeta in [e][chunk] order, then (two chunks per lane) gamma [C].  The partials used to be LDS
+  // atomics into one [2][C] block: sixteen waves adding to the same words cost 12 / 20 / 29 us per launch at C = 320 / 512 / 768 (round 4 ablation),
+  // more than the rows themselves on the short launches.
+  extern __shared__ __attribute__((aligned(16))) float s_part[];
   const int gl = threadIdx.x % G, grp = threadIdx.x / G;
   const int nchunk = p.C / VN;
   const RowMap dym = rm0(p.dy_map), xm = rm0(p.x_map), dxm = rm0(p.dx_map);
   const float inv_c = 1.0f / (float)p.C;
-  for (int i = threadIdx.x; i < 2 * p.C; i += NT) s_part[i] = 0.f;
-  __syncthreads();
-  float dg[ITS][VN], db[ITS][VN], gam[ITS][VN];
+  float* const s_gam = s_part + (size_t)NW * 2 * p.C;
+  float dg[ITS][VN], db[ITS][VN], gam[ITS == 1 ? 1 : 1][VN];
 #pragma unroll
-  for (int it = 0; it < ITS; ++it) {
-    int c = gl + it * G;
+  for (int it = 0; it < ITS; ++it)
 #pragma unroll
-    for (int e = 0; e < VN; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; gam[it][e] = c < nchunk ? p.gamma[c * VN + e] : 0.f; }
+    for (int e = 0; e < VN; ++e) { dg[it][e] = 0.f; db[it][e] = 0.f; }
+  if constexpr (ITS == 1) {
+#pragma unroll
+    for (int e = 0; e < VN; ++e) gam[0][e] = gl < nchunk ? p.gamma[gl * VN + e] : 0.f;
+  } else {
+    // two chunks per lane: gamma is re-read from LDS per row instead of living in 16 registers (with them the kernel needed more than the 128
+    // registers of a 1024-thread workgroup and spilled inside the row loop)
+    for (int i = threadIdx.x; i < p.C; i += NT) s_gam[i] = p.gamma[i];
+    __syncthreads();
   }
 
   for (int row = blockIdx.x * GROUPS + grp; row < p.rows; row += gridDim.x * GROUPS) {
@@ -277,13 +292,21 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
     for (int it = 0; it < ITS; ++it) {
       int c = gl + it * G;
       if (c < nchunk) {
-        float dyv[VN], xv[VN];
+        float dyv[VN], xv[VN], gm[VN];
         Vec<T>::load_s(dyr + c * VN, dyv);
         Vec<TX>::load_s(xr + c * VN, xv);
+        if constexpr (ITS == 1) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) gm[e] = gam[0][e];
+        } else {
+          const f32x4 g0 = *(const f32x4*)(s_gam + c * VN), g1 = *(const f32x4*)(s_gam + c * VN + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { gm[e] = g0[e]; gm[4 + e] = g1[e]; }
+        }
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
           float h = (xv[e] - mean) * rstd;
-          float gg = dyv[e] * gam[it][e];
+          float gg = dyv[e] * gm[e];
           xh[it][e] = h; g[it][e] = gg;
           s1 += gg; s2 += gg * h;
           dg[it][e] += dyv[e] * h;
@@ -316,14 +339,15 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
     }
   }
   if (p.dgamma) {
-    // the 64 / G row groups of a wave hold partial sums of the same columns: combine them in registers first, so that only
-    // G lanes per wave go to the LDS atomics (at G = 8 that is 8x fewer, and no two lanes of an instruction share an address)
+    // the 64 / G row groups of a wave hold partial sums of the same columns: combine them in registers first; lanes 0 .. G-1 then hold the wave's
+    // sums of every column and park them in the wave's own LDS slice ([e][chunk]: the lanes of a store hit consecutive words)
 #pragma unroll
     for (int off = G; off < 64; off <<= 1)
 #pragma unroll
       for (int it = 0; it < ITS; ++it)
 #pragma unroll
         for (int e = 0; e < VN; ++e) { dg[it][e] += __shfl_xor(dg[it][e], off); db[it][e] += __shfl_xor(db[it][e], off); }
+    float* const mine = s_part + (size_t)(threadIdx.x >> 6) * 2 * p.C;
     if ((threadIdx.x & 63) < G) {
 #pragma unroll
       for (int it = 0; it < ITS; ++it) {
@@ -331,17 +355,25 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(mvlt_layernorm_bwd_args p) {
         if (c < nchunk) {
 #pragma unroll
           for (int e = 0; e < VN; ++e) {
-            atomicAdd(&s_part[c * VN + e], dg[it][e]);
-            atomicAdd(&s_part[p.C + c * VN + e], db[it][e]);
+            mine[e * nchunk + c] = dg[it][e];
+            mine[p.C + e * nchunk + c] = db[it][e];
           }
         }
       }
     }
     __syncthreads();
     const long cp = p.dg_copies > 1 ? (long)(blockIdx.x % p.dg_copies) * p.dg_copy_stride : 0;
-    for (int i = threadIdx.x; i < p.C; i += NT) {
-      atomicAdd(&p.dgamma[cp + i], s_part[i]);
-      atomicAdd(&p.dbeta[cp + i], s_part[p.C + i]);
+    const bool own = p.dg_copies >= (int)gridDim.x;
+    // a copy per workgroup (own): no other workgroup of this launch touches these floats and launches are stream-ordered, so the sums are added
+    // without atomics; mvlt_fold_copies sums the copies afterwards
+    for (int i = threadIdx.x; i < 2 * p.C; i += NT) {
+      const int col = i < p.C ? i : i - p.C;
+      const int si = (i < p.C ? 0 : p.C) + (col % VN) * nchunk + col / VN;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += s_part[(size_t)w * 2 * p.C + si];
+      float* dst = (i < p.C ? p.dgamma : p.dbeta) + cp + col;
+      if (own) *dst += t; else atomicAdd(dst, t);
     }
   }
 }
@@ -352,6 +384,27 @@ __global__ __launch_bounds__(NT) void fold_copies_kernel(float* arena, int copie
   float t = 0.f;
   for (int k = 0; k < copies; ++k) { t += arena[(long)k * stride + j]; arena[(long)k * stride + j] = 0.f; }
   dst[dst_index[j]] += t;
+}
+
+// the same for many copies (one per workgroup of the LayerNorm backward launches): a workgroup owns 64 slots, its 16 waves take every 16th copy
+__global__ __launch_bounds__(1024) void fold_copies_wide_kernel(float* arena, int copies, long stride, const int* dst_index, int j0, int j1, float* dst) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
+  const int j = j0 + blockIdx.x * 64 + lane;
+  float t = 0.f;
+  if (j < j1) {
+    for (int k = kq; k < copies; k += 16) {
+      const float v = arena[(long)k * stride + j];
+      if (v != 0.f) { t += v; arena[(long)k * stride + j] = 0.f; }       // (most copies of a short launch were never written: read-only then)
+    }
+  }
+  part[kq][lane] = t;
+  __syncthreads();
+  if (kq == 0 && j < j1) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += part[k][lane];
+    dst[dst_index[j]] += t;
+  }
 }
 
 // out[r, c] = sum_b in[b*batch_stride_rows + r][c]   (gradient of a broadcast "+ pos_embed"); fp32 out
@@ -450,12 +503,18 @@ template <typename T, typename TX, typename TDX> int launch_bwd(const mvlt_layer
   int groups = nt / g;
   int grid = (a.rows + groups - 1) / groups;
   if (grid > bcap) grid = bcap;
-  size_t lds = 2 * a.C * sizeof(float);
+  if (a.dgamma && a.dg_copies >= 64 && grid > a.dg_copies) grid = a.dg_copies;     // a copy per workgroup: plain adds (see the kernel's tail)
   const bool one = g * VN >= a.C;               // one chunk per lane covers the row
+  size_t lds = ((size_t)(nt / 64) * 2 + (one ? 0 : 1)) * a.C * sizeof(float);      // per-wave dgamma / dbeta slices (+ gamma): 101 KB at C = 768
 #define MVLT_LN_BWD_N(G_, NT_)                                                                                       \
   do {                                                                                                               \
-    if (one) hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, G_, 1, NT_>), dim3(grid), dim3(NT_), lds, s, a);          \
-    else hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, G_, MAXIT, NT_>), dim3(grid), dim3(NT_), lds, s, a);          \
+    if (one) {                                                                                                       \
+      if (lds > 65536) hipFuncSetAttribute((const void*)ln_bwd_kernel<T, TX, TDX, G_, 1, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, G_, 1, NT_>), dim3(grid), dim3(NT_), lds, s, a);                  \
+    } else {                                                                                                         \
+      if (lds > 65536) hipFuncSetAttribute((const void*)ln_bwd_kernel<T, TX, TDX, G_, MAXIT, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, G_, MAXIT, NT_>), dim3(grid), dim3(NT_), lds, s, a);              \
+    }                                                                                                                \
   } while (0)
 #define MVLT_LN_BWD(G_)                                                                                              \
   do {                                                                                                               \
@@ -490,7 +549,8 @@ extern "C" int mvlt_layernorm_fwd(const mvlt_layernorm_args* a, void* stream) {
 extern "C" int mvlt_fold_copies(float* arena, int copies, long stride, const int* dst_index, int j0, int j1, float* dst, void* stream) {
   MVLT_REQUIRE(arena && dst_index && dst && copies >= 1 && j0 >= 0 && j1 >= j0 && stride >= j1, "mvlt_fold_copies: bad arguments");
   if (j1 == j0) return MVLT_OK;
-  hipLaunchKernelGGL(fold_copies_kernel, dim3((j1 - j0 + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, arena, copies, stride, dst_index, j0, j1, dst);
+  if (copies >= 32) hipLaunchKernelGGL(fold_copies_wide_kernel, dim3((j1 - j0 + 63) / 64), dim3(1024), 0, (hipStream_t)stream, arena, copies, stride, dst_index, j0, j1, dst);
+  else hipLaunchKernelGGL(fold_copies_kernel, dim3((j1 - j0 + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, arena, copies, stride, dst_index, j0, j1, dst);
   return mvlt_check_launch("mvlt_fold_copies");
 }
 

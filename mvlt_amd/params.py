@@ -11,6 +11,7 @@ Memory layout (sized for 288 GB HBM: everything stays resident)
       copy W^T (dgrad operand) and conv weights a [out][kh][kw][cin] re-ordering (patch-GEMM operand)
 """
 import math
+import os
 import weakref
 from collections import OrderedDict
 
@@ -382,11 +383,12 @@ class FlatStore:
 
     # ---- interleaved accumulators for the LayerNorm parameter gradients ------------------------------------------------
     # Every workgroup of a LayerNorm backward adds its 2*C partial sums to the same few cache lines; those atomics serialise at
-    # the memory side (~100 ns each, 16-27 us per launch).  The launches therefore add into LN_COPIES copies (workgroup b ->
-    # copy b % LN_COPIES) inside a small arena, and one `mvlt_fold_copies` launch per backward stage sums the copies into G
-    # (and zeroes them again).  Arena slots are handed out in first-use order, so a stage's slots are one contiguous range; a
-    # copy has room for every 1-D parameter of the model, whatever its depth.
-    LN_COPIES = 8
+    # the memory side (16-27 us per launch with one accumulator; still 12 / 20 / 29 us at C = 320 / 512 / 768 with 8 interleaved copies, round 4).
+    # The launches therefore add into LN_COPIES copies inside an arena -- ONE PER WORKGROUP (the launch has at most 256), so the adds need no
+    # atomics at all -- and one `mvlt_fold_copies` launch per backward stage sums the copies into G (and zeroes the ones that were written).
+    # Arena slots are handed out in first-use order, so a stage's slots are one contiguous range; a copy has room for every 1-D parameter of the
+    # model, whatever its depth (pvlt_tiny: 256 x 56 k floats = 57 MB).
+    LN_COPIES = int(os.environ.get("MVLT_LN_COPIES", "256"))
 
     @property
     def ln_stride(self):

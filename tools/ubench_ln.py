@@ -11,7 +11,7 @@ def timeit(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for rows, C in [(1081344, 64), (294912, 128), (98304, 320), (49152, 512)]:
+for rows, C in [(1081344, 64), (294912, 128), (98304, 320), (49152, 512), (1048576, 64), (262144, 128), (65536, 320), (32768, 320), (32768, 768), (16384, 512), (16384, 64)]:
     x = torch.randn(rows, C, device=dev); y = torch.empty(rows, C, device=dev, dtype=bf)
     g = torch.ones(C, device=dev); b = torch.zeros(C, device=dev); mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
     t = timeit(lambda: ops.layernorm_fwd(x, y, g, b, rows, C, C, C, 1e-6, mean=mean, rstd=rstd))
