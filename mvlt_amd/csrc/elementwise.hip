@@ -56,10 +56,8 @@ __global__ __launch_bounds__(NT) void bert_embed_bwd_kernel(const T* dy, const l
                                                             float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
                                                             int rows, int Tlen) {
   constexpr int PER = HID / 64;
-  __shared__ float s_g[HID], s_b[HID], s_t[HID];
-  for (int i = threadIdx.x; i < HID; i += NT) { s_g[i] = 0.f; s_b[i] = 0.f; s_t[i] = 0.f; }
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
+  __shared__ float s_w[NT / 64][HID];       // one slice per wave (LDS atomics from sixteen waves onto the same words were most of this kernel's tail)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ag[PER], ab[PER], at[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) { ag[i] = 0.f; ab[i] = 0.f; at[i] = 0.f; }
@@ -96,15 +94,21 @@ __global__ __launch_bounds__(NT) void bert_embed_bwd_kernel(const T* dy, const l
       at[i] += dx;
     }
   }
+  // the three per-column sums of the workgroup, one after the other through the per-wave slices
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    int c = lane + 64 * i;
-    atomicAdd(&s_g[c], ag[i]); atomicAdd(&s_b[c], ab[i]); atomicAdd(&s_t[c], at[i]);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < HID; i += NT) {
-    atomicAdd(&dgamma[i], s_g[i]); atomicAdd(&dbeta[i], s_b[i]); atomicAdd(&dtype0[i], s_t[i]);
-    atomicAdd(&dpos[(long)t * HID + i], s_t[i]);
+  for (int q = 0; q < 3; ++q) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s_w[wave][lane + 64 * i] = q == 0 ? ag[i] : q == 1 ? ab[i] : at[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < HID; i += NT) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) v += s_w[w][i];
+      if (q == 0) atomicAdd(&dgamma[i], v);
+      else if (q == 1) atomicAdd(&dbeta[i], v);
+      else { atomicAdd(&dtype0[i], v); atomicAdd(&dpos[(long)t * HID + i], v); }
+    }
+    __syncthreads();
   }
 }
 
