@@ -283,10 +283,10 @@ int mvlt_transpose_cast(const float* in, void* out, int R, int C, int ld_out, in
  * operands) or a 3-D strided gather-cast (dst[i0*ds0 + i1*ds1 + i2*ds2] = src[src_off + i0*ss0 + i1*ss1 + i2*ss2]: the
  * [out][kh][kw][cin] / flipped-tap re-orderings of the conv weights of reference libs/pvlt.py:104,168 and
  * libs/vl_heads.py:107-165).  blk_start[ndesc + 1] = prefix sums of the workgroups each descriptor needs
- * (kind 0: ceil(R/64)*ceil(C/64), kind 1: ceil(d0*d1*d2 / 256)). */
+ * (kind 0 / 2: ceil(R/64)*ceil(C/64), kind 1: ceil(d0*d1*d2 / 256)). */
 typedef struct mvlt_prep_desc {
   const float* src; void* dst;
-  int kind;                 /* 0 = transpose, 1 = gather */
+  int kind;                 /* 0 = transpose, 1 = gather, 2 = transpose of a bf16 source (src points at bf16; C % 8 == 0, ld_out % 8 == 0, bf16 dst) */
   int R, C, ld_out;         /* kind 0 */
   int d0, d1, d2;           /* kind 1: loop extents (i2 fastest) */
   int src_off, ss0, ss1, ss2;

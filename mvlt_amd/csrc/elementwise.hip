@@ -467,6 +467,34 @@ __global__ __launch_bounds__(NT) void weight_prep_kernel(const mvlt_prep_desc* d
       int c = c0 + ty + 4 * jj, r = r0 + tx;
       if (c < d.C && r < d.R) out[(long)c * d.ld_out + r] = (T)tile[tx][ty + 4 * jj];
     }
+  } else if (d.kind == 2) {
+    // transpose of a bf16 source (the compute-dtype copy of the parameters the fused optimizer step writes): 16-byte loads and stores, half the
+    // bytes read; C % 8 == 0, ld_out % 8 == 0.  Rows of the tile are 64 + 8 bf16 apart in LDS (144 B: the column reads of eight rows spread over banks).
+    if constexpr (sizeof(T) == 2) {
+      constexpr int LDT = TS + 8;
+      bf16* t16 = (bf16*)&tile[0][0];                            // 64 x 72 bf16 = 9 KB of the 16.6 KB tile
+      const bf16* src = (const bf16*)d.src;
+      const int tiles_c = (d.C + TS - 1) / TS;
+      const int c0 = (lb % tiles_c) * TS, r0 = (lb / tiles_c) * TS;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int q = threadIdx.x + k * NT, rr = q >> 3, cc = (q & 7) * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + rr < d.R && c0 + cc < d.C) v = *(const u32x4*)(src + (long)(r0 + rr) * d.C + c0 + cc);
+        *(u32x4*)(t16 + rr * LDT + cc) = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int q = threadIdx.x + k * NT, cc = q >> 3, rr = (q & 7) * 8;
+        if (c0 + cc < d.C && r0 + rr < d.ld_out) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = t16[(rr + e) * LDT + cc];          // rows >= R were loaded as zeros: the padding columns of W^T stay 0
+          *(bf16x8*)((bf16*)d.dst + (long)(c0 + cc) * d.ld_out + r0 + rr) = o;
+        }
+      }
+    }
   } else {
     const long i = (long)lb * NT + threadIdx.x;
     const long n = (long)d.d0 * d.d1 * d.d2;

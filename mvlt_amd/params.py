@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import ops
 
+_PREP_FP32_SRC = bool(os.environ.get("MVLT_PREP_FP32_SRC"))     # A/B switch: transposed weight copies read the fp32 masters (rounds 1-3)
 ALIGN = 8
 
 
@@ -257,7 +258,12 @@ class FlatStore:
             k = name + "::T"
             if k not in self.extra or self.extra[k].dtype != dt or self.extra[k].device != dev:
                 self.extra[k] = torch.zeros(Ccols, ld, device=dev, dtype=dt)
-            descs.append(PrepDesc(src_ptr(name), self.extra[k].data_ptr(), 0, R, Ccols, ld, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+            if self.C is not None and dt == torch.bfloat16 and Ccols % 8 == 0 and not _PREP_FP32_SRC:
+                # W^T from the bf16 copy of the parameters (fresh whenever this launch runs: refresh() casts first, or the fused optimizer step wrote
+                # it): identical values -- bf16(W)^T -- at half the bytes read, in 16-byte accesses
+                descs.append(PrepDesc(self.comp(name).data_ptr(), self.extra[k].data_ptr(), 2, R, Ccols, ld, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+            else:
+                descs.append(PrepDesc(src_ptr(name), self.extra[k].data_ptr(), 0, R, Ccols, ld, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
             blocks.append(((R + 63) // 64) * ((Ccols + 63) // 64))
 
         def gather(name, suffix, shape, dims, src_off, ss, ds):
