@@ -316,7 +316,10 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
   if (p.bias && col_ok) {
-    if (((uintptr_t)p.bias & 15) == 0) {
+    if (!FULL && nc + 8 > p.N) {                       // the last, partial chunk of a row whose length is not a multiple of 8 (EPI 1 only: host dispatch)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (nc + e < p.N) bias8[e] = p.bias[nc + e];
+    } else if (((uintptr_t)p.bias & 15) == 0) {
       f32x4 b0 = *(const f32x4*)(p.bias + nc), b1 = *(const f32x4*)(p.bias + nc + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
@@ -529,6 +532,14 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
         if (ofp32 == 2) round_f16_8(v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { cs8[e] += v[e]; cq8[e] += v[e] * v[e]; }
+      }
+      if constexpr (EPI == 1 && !FULL && !SCAT) {
+        if (nc + 8 > p.N) {                            // partial last chunk: its valid columns one by one, nothing past column N - 1 is touched
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (nc + e < p.N) { if (ofp32) ((float*)p.C)[ix + e] = v[e]; else ((bf16*)p.C)[ix + e] = (bf16)v[e]; }
+          continue;
+        }
       }
       store8(p.C, v);
     }
@@ -1882,8 +1893,10 @@ __device__ __forceinline__ void nt_epilogue_w80(const mvlt_gemm_nt_args& p, f32x
   }
 }
 
-template <int EPI, int HM, int HN0, int HN1>
+template <int EPI, int HM, int HN0, int HN1, bool RAG = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p) {
+  // RAG: M and / or N are not whole tiles (the MLM logits: ~1500 selected rows x 30522 words).  The loader then points the rows past the end at
+  // the last valid row -- their products are never stored: the epilogue runs with its bound checks -- which costs nothing inside the K-loop.
   constexpr int WMT = 2 * HM, WNT = HN0 + HN1;                    // accumulator tiles per wave
   constexpr int BMT = 2 * WMT * 16, BNT = 4 * WNT * 16;           // workgroup tile
   constexpr int AH = 2 * HM * 16, BH0 = 4 * HN0 * 16, BH1 = 4 * HN1 * 16;      // rows of the A / B0 / B1 half-tiles
@@ -1894,7 +1907,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p)
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 buffers][A0 | A1 | B0 | B1]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int tiles_m = p.M / BMT, tiles_n = p.N / BNT;
+  const int tiles_m = RAG ? (p.M + BMT - 1) / BMT : p.M / BMT, tiles_n = RAG ? (p.N + BNT - 1) / BNT : p.N / BNT;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, bslot = bid >> 3;
   const int tile_m = (bslot / tiles_n) * 8 + xcd, tile_n = bslot % tiles_n;      // the n-tiles of an m-tile are neighbours on one XCD
@@ -1909,21 +1922,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p)
   const int lrow = tid >> 3;
   const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
   const unsigned a_rs = 2u * (unsigned)p.lda, b_rs = 2u * (unsigned)p.ldb;
-  unsigned a_voff[A_IT], b_voff0[B_IT0], b_voff1[B_IT1];
+  unsigned a_voff[A_IT], a_voff1[RAG ? A_IT : 1], b_voff0[B_IT0], b_voff1[B_IT1];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int lr = lrow + 64 * i, w_ = lr / (HM * 16), rem = lr - w_ * (HM * 16);
-    a_voff[i] = (unsigned)(w_ * (WMT * 16) + rem) * a_rs + chunk * 16;
+    const int trow = w_ * (WMT * 16) + rem;                     // row inside the tile, half 0; half 1 is HM * 16 rows further
+    a_voff[i] = (unsigned)(RAG ? min(trow, p.M - 1 - m0) : trow) * a_rs + chunk * 16;
+    if (RAG) a_voff1[i] = (unsigned)min(trow + HM * 16, p.M - 1 - m0) * a_rs + chunk * 16;
   }
 #pragma unroll
   for (int i = 0; i < B_IT0; ++i) {
     const int lr = lrow + 64 * i, w_ = lr / (HN0 * 16), rem = lr - w_ * (HN0 * 16);
-    b_voff0[i] = (unsigned)(w_ * (WNT * 16) + rem) * b_rs + chunk * 16;
+    const int trow = w_ * (WNT * 16) + rem;
+    b_voff0[i] = (unsigned)(RAG ? min(trow, p.N - 1 - n0) : trow) * b_rs + chunk * 16;
   }
 #pragma unroll
   for (int i = 0; i < B_IT1; ++i) {
     const int lr = lrow + 64 * i, w_ = lr / (HN1 * 16), rem = lr - w_ * (HN1 * 16);
-    b_voff1[i] = (unsigned)(w_ * (WNT * 16) + HN0 * 16 + rem) * b_rs + chunk * 16;
+    const int trow = w_ * (WNT * 16) + HN0 * 16 + rem;
+    b_voff1[i] = (unsigned)(RAG ? min(trow, p.N - 1 - n0) : trow) * b_rs + chunk * 16;
   }
   const char* const a_base = (const char*)p.A + (size_t)m0 * a_rs;
   const char* const b_base = (const char*)p.B + (size_t)n0 * b_rs;
@@ -1931,11 +1948,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p)
   // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1 (compile-time at every call site)
   auto stage = [&](int which, int t, int buf) {
     if (which < 2) {
-      const char* sb = a_base + (size_t)(which * HM * 16) * a_rs + t * 128;
+      const char* sb = a_base + (RAG ? (size_t)0 : (size_t)(which * HM * 16) * a_rs) + t * 128;
       const unsigned dst = dst_wave + buf * BUF + which * OFF_A1;
 #pragma unroll
       for (int i = 0; i < A_IT; ++i)
-        if (!A_PART || i + 1 < A_IT || wave < 4) glds16_s(sb, a_voff[i], dst + i * 8192);
+        if (!A_PART || i + 1 < A_IT || wave < 4) glds16_s(sb, (RAG && which == 1) ? a_voff1[i] : a_voff[i], dst + i * 8192);
     } else if (which == 2) {
       const char* sb = b_base + t * 128;
       const unsigned dst = dst_wave + buf * BUF + OFF_B0;
@@ -2049,20 +2066,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p)
 #undef MVLT_MMA
   // (whole tiles only: the bound checks go, -20 us on the GELU' launches; not for the residual epilogue, which measured 9 us SLOWER without them --
   //  49152 x 512 x 2048 + R 120 -> 129 us, same box, two passes: its prefetched rows are then requested in a different order)
-  if constexpr (WNT == 4) nt_epilogue_lean<128, EPI, WMT, 4, EPI != 2>(p, acc, smem, m0, n0, wave, lane);
+  if constexpr (WNT == 4) nt_epilogue_lean<128, EPI, WMT, 4, EPI != 2 && !RAG>(p, acc, smem, m0, n0, wave, lane);
   else nt_epilogue_w80<EPI, WMT>(p, acc, smem, m0, n0, wave, lane);
 }
 
-template <int EPI, int HM, int HN0, int HN1> void launch_nt_p8(const mvlt_gemm_nt_args& a, hipStream_t s) {
+template <int EPI, int HM, int HN0, int HN1, bool RAG = false> void launch_nt_p8(const mvlt_gemm_nt_args& a, hipStream_t s) {
   constexpr int BMT = 64 * HM, BNT = 64 * (HN0 + HN1);
   constexpr int LDS_LOOP = 2 * (2 * (2 * HM * 16) + 64 * (HN0 + HN1)) * 128;
   constexpr int LDS_EPI = 8 * 32 * (16 * (HN0 + HN1) + 4) * 4;
   constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
-  static bool once = (hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<EPI, HM, HN0, HN1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess);
+  static bool once = (hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<EPI, HM, HN0, HN1, RAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess);
   (void)once;
-  const int tiles_m = a.M / BMT, tiles_n = a.N / BNT;
+  const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = (a.N + BNT - 1) / BNT;
   dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n)), block(512);
-  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI, HM, HN0, HN1>), grid, block, LDS, s, a);
+  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI, HM, HN0, HN1, RAG>), grid, block, LDS, s, a);
 }
 template <int HM, int HN0, int HN1> bool dispatch_nt_p8(const mvlt_gemm_nt_args& a, int epi, hipStream_t s) {
   switch (epi) {
@@ -2307,7 +2324,9 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     const int nk = ((a->K + 63) / 64 + (a->split_k > 1 ? a->split_k : 1) - 1) / (a->split_k > 1 ? a->split_k : 1);
     // compile-time epilogue variant (see nt_epilogue_lean); 0 = generic
     int epi = 0;
-    const bool lean_ok = (a->c_map.mode == 0 || (a->c_map.mode == 1 && a->c_map.c_seg % 8 == 0)) && a->split_k <= 1 && a->N % 8 == 0 && a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 &&
+    // (N % 8 != 0 -- the 30522-word MLM logits -- takes the plain lean epilogue too: its last chunk of a row is stored column by column)
+    const bool plain_epi = a->act == 0 && !a->R && !a->row_scale && !a->col_sum && !a->H && a->c_map.mode == 0;
+    const bool lean_ok = (a->c_map.mode == 0 || (a->c_map.mode == 1 && a->c_map.c_seg % 8 == 0)) && a->split_k <= 1 && (a->N % 8 == 0 || plain_epi) && a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 &&
                          (!a->R || ((uintptr_t)a->R & 15) == 0) && (!a->H || ((uintptr_t)a->H & 15) == 0) && a->M < (1 << 24) &&
                          !getenv("MVLT_NT_GENERIC_EPI");
     if (lean_ok && a->c_map.mode == 1) {
@@ -2375,7 +2394,7 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     }
     // 8-wave kernels with the 8-phase K-loop (gemm_nt_p8_kernel) for the MFMA-bound shapes of the stage 3-4 MLPs: one workgroup per CU, so the
     // tile height is chosen by whole rounds of 256 CUs (rows x rounds = time): 256 x 256, 192 x 256, or 192 x 320 for N % 320 == 0
-    static const int ntp8 = getenv("MVLT_NT_P8") ? atoi(getenv("MVLT_NT_P8")) : 7;       // bit 0: 256 x 256, bit 1: 192 x 256, bit 2: 192 x 320
+    static const int ntp8 = getenv("MVLT_NT_P8") ? atoi(getenv("MVLT_NT_P8")) : 15;      // bit 0: 256 x 256, bit 1: 192 x 256, bit 2: 192 x 320, bit 3: ragged 256 x 256 (EPI 1)
     if (ntp8 && a->a_map.mode == 0 && a->a_map.rows_per_batch == 0 && a->c_map.mode == 0 && epi >= 1 && epi <= 5 && a->K % 64 == 0 && a->K >= 128) {
       auto cost = [&](int bm, int bn) -> long {                         // rows x rounds; 0 = shape does not fit
         if (a->M % bm || a->N % bn) return 0;
@@ -2387,6 +2406,12 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
       // (192 x 320 with the fp32 residual epilogue pays from K = 640 on: 98304 x 320 x 320 + R 93 us against 73 us on the 128-wide kernel, K = 1280 138 against 155)
       const long c320 = ((ntp8 & 4) && a->N % 256 != 0 && (epi == 1 || (epi == 2 && (a->K >= 640 || (ntp8 & 16))))) ? cost(192, 320) : 0;
       bool done = false;
+      // ragged M / N (the MLM logits, ~1500 x 30522 x 768, fp32 out): 256 x 256 tiles with the loader clamped at the last row and the checked epilogue
+      if (!c320 && !c256 && !c192 && epi == 1 && (ntp8 & 8) && (a->M % 256 || a->N % 256)) {
+        const long tiles = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+        if (tiles >= 384) { launch_nt_p8<1, 4, 2, 2, true>(*a, s); done = true; }
+      }
+      if (done) return mvlt_check_launch("mvlt_gemm_nt");
       if (c320) done = dispatch_nt_p8<3, 3, 2>(*a, epi, s);
       else if (c256 && (!c192 || c256 <= c192)) done = dispatch_nt_p8<4, 2, 2>(*a, epi, s);
       else if (c192) done = dispatch_nt_p8<3, 2, 2>(*a, epi, s);

@@ -83,6 +83,25 @@ def test_gemm_nt_epilogues(ops, dtype, N):
     assert maxrel(out4, ref_pre) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,N,K,ldc", [(1490, 30522, 768, 30528), (257, 98309, 128, 98312), (1024, 24580, 192, 24584), (1490, 3002, 768, 3008)])
+@pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
+def test_gemm_nt_ragged_rows_and_columns(ops, M, N, K, ldc, odt):
+    """the MLM logits shape: neither M nor N whole tiles, N not even a multiple of 8 (row stride padded to one).  From 384 tiles on this is the ragged
+    form of the 8-phase kernel (loader clamped at the last row, checked epilogue); the last chunk of a row is stored column by column, so the
+    padding columns of the buffer keep what they held.  The last case stays on the 128-wide kernel (same epilogue)."""
+    dt = torch.bfloat16
+    A, W = rnd(M, K, dtype=dt), rnd(N, K, dtype=dt, seed=1, scale=0.2)
+    bias = rnd(N, dtype=torch.float32, seed=2)
+    ref = A.float() @ W.float().t() + bias
+    buf = torch.full((M + 1, ldc), 7.0, device=dev(), dtype=odt)          # one guard row behind the last
+    ops.gemm_nt(A, W, buf, M, N, K, K, K, ldc, bias=bias)
+    assert maxrel(buf[:M, :N].float(), ref) < TOL[dt]
+    assert (buf[:M, N:] == 7.0).all() and (buf[M] == 7.0).all(), "wrote outside the M x N block"
+    again = torch.full_like(buf, 7.0)
+    ops.gemm_nt(A, W, again, M, N, K, K, K, ldc, bias=bias)
+    assert torch.equal(buf, again), "launch-to-launch difference"
+
+
 @pytest.mark.parametrize("M,N", [(6400, 2048), (6144, 2048), (7680, 1600)])      # -> 256 x 256, 192 x 256, 192 x 320 tiles (host dispatch by whole rounds)
 @pytest.mark.parametrize("K", [128, 320, 512, 64 * 7])
 def test_gemm_nt_8phase_tiles(ops, K, M, N):
