@@ -77,6 +77,9 @@ typedef struct mvlt_gemm_nt_args {
   void* post_y; int post_ld;
   const float* post_gamma; const float* post_beta; float post_eps;
   float* post_mean; float* post_rstd;
+  /* 1: R is fp32 while C (out_dtype 0) is bf16 -- the last block of a stage adds the fp32 residual stream and hands the next stage / the heads
+   * the MFMA-operand copy directly (no fp32 stage output + cast pass); 0: R has C's dtype */
+  int r_fp32;
 } mvlt_gemm_nt_args;
 int mvlt_gemm_nt(const mvlt_gemm_nt_args* args, void* stream);
 

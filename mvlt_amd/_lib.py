@@ -38,7 +38,7 @@ class GemmNTArgs(C.Structure):
                 ("row_scale", c_void_p), ("rows_per_scale", c_int), ("R", c_void_p),
                 ("col_sum", c_void_p), ("col_sumsq", c_void_p), ("col_copies", c_int), ("split_k", c_int),
                 ("post_y", c_void_p), ("post_ld", c_int), ("post_gamma", c_void_p), ("post_beta", c_void_p), ("post_eps", C.c_float),
-                ("post_mean", c_void_p), ("post_rstd", c_void_p)]
+                ("post_mean", c_void_p), ("post_rstd", c_void_p), ("r_fp32", c_int)]
 
 
 class PrepDesc(C.Structure):

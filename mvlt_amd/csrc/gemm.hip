@@ -308,6 +308,7 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
   // the GELU / GELU' epilogues write (and read) operand-dtype tensors only -- the host dispatch guarantees it -- so their fp32 store / load
   // paths and the second half of every prefetch slot are not compiled in (EPI 4: 119 -> fewer registers, a third workgroup per CU)
   const int ofp32 = (EPI == 3 || EPI == 4) ? 0 : p.out_dtype;
+  const int rfp32 = (EPI == 2 && !POST) ? (ofp32 | p.r_fp32) : ofp32;      // EPI 2: the residual may be fp32 beside a bf16 C (mvlt_gemm_nt_args.r_fp32)
   float* stage = (float*)smem + wave * 32 * LDW;
   const int ch = lane % CPR;
   const int nc = n0 + wn * WN + ch * 8;
@@ -377,7 +378,7 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       if (EPI == 2 && p.row_scale) rs[sl][it] = p.row_scale[fdiv24(mm, p.rows_per_scale, inv_rps)];
       if ((EPI == 2 || EPI == 4) && (FULL || ok[sl][it])) {
         const void* src = (EPI == 2) ? p.R : p.H;
-        if (ofp32) { raw[sl][it][0] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)src + idx[sl][it])); raw[sl][it][1] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)src + idx[sl][it] + 4)); }
+        if (rfp32) { raw[sl][it][0] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)src + idx[sl][it])); raw[sl][it][1] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)src + idx[sl][it] + 4)); }
         else raw[sl][it][0] = ld_g<MVLT_NT_LD>((const u32x4*)((const bf16*)src + idx[sl][it]));
       }
     }
@@ -499,7 +500,7 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       };
       float o8[8];
       if (EPI == 2 || EPI == 4) {
-        if (ofp32) {
+        if (rfp32) {
           const f32x4 a = __builtin_bit_cast(f32x4, raw[sl][it][0]), b = __builtin_bit_cast(f32x4, raw[sl][it][1]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { o8[e] = a[e]; o8[4 + e] = b[e]; }
@@ -1807,6 +1808,7 @@ __device__ __forceinline__ void nt_epilogue_w80(const mvlt_gemm_nt_args& p, f32x
   const int wm = wave >> 2, wn = wave & 3;
   const int fr = lane & 15, fg = lane >> 4;
   const int ofp32 = p.out_dtype;
+  const int rfp32 = ofp32 | p.r_fp32;                  // the residual may be fp32 beside a bf16 C (mvlt_gemm_nt_args.r_fp32)
   float* stage = (float*)smem + wave * 32 * LDW;
   const int rpb = p.c_map.rows_per_batch;
   const float inv_rpb = rpb > 0 ? 1.0f / (float)rpb : 0.f;
@@ -1837,7 +1839,7 @@ __device__ __forceinline__ void nt_epilogue_w80(const mvlt_gemm_nt_args& p, f32x
       rs[sl][it] = 1.0f;
       if (EPI == 2) {
         if (p.row_scale) rs[sl][it] = p.row_scale[fdiv24(m, p.rows_per_scale, inv_rps)];
-        if (ofp32) { raw[sl][it][0] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)p.R + idx[sl][it])); raw[sl][it][1] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)p.R + idx[sl][it] + 4)); }
+        if (rfp32) { raw[sl][it][0] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)p.R + idx[sl][it])); raw[sl][it][1] = ld_g<MVLT_NT_LD>((const u32x4*)((const float*)p.R + idx[sl][it] + 4)); }
         else raw[sl][it][0] = ld_g<MVLT_NT_LD>((const u32x4*)((const bf16*)p.R + idx[sl][it]));
       }
     }
@@ -1868,7 +1870,7 @@ __device__ __forceinline__ void nt_epilogue_w80(const mvlt_gemm_nt_args& p, f32x
       }
       if (EPI == 2) {
         float o8[8];
-        if (ofp32) {
+        if (rfp32) {
           const f32x4 a = __builtin_bit_cast(f32x4, raw[sl][it][0]), b = __builtin_bit_cast(f32x4, raw[sl][it][1]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { o8[e] = a[e]; o8[4 + e] = b[e]; }
@@ -2296,6 +2298,10 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
                                    a->a_map.mode == 0 && a->c_map.mode == 0 && a->split_k <= 64),
                "mvlt_gemm_nt: split_k needs bf16 operands, fp32 C (zeroed by the caller) and a plain epilogue");
   MVLT_REQUIRE(a->col_copies >= 0, "mvlt_gemm_nt: col_copies < 0");
+  MVLT_REQUIRE(!a->r_fp32 || (a->R && a->R != a->C && a->dtype == 0 && a->out_dtype == 0 && a->act == 0 && !a->col_sum && !a->post_y && a->split_k <= 1 && a->c_map.mode == 0 &&
+                              a->N % 8 == 0 && a->ldc % 8 == 0 && (((uintptr_t)a->C | (uintptr_t)a->R) & 15) == 0 && a->M < (1 << 24) && !getenv("MVLT_NT_GENERIC_EPI") &&
+                              !getenv("MVLT_NT_LEGACY")),
+               "mvlt_gemm_nt: r_fp32 (fp32 residual beside a bf16 C) exists in the residual epilogue of the bf16 LDS-DMA kernels only (plain c_map, N % 8 == 0, 16-byte aligned C / R)");
   MVLT_REQUIRE(a->out_dtype >= 0 && a->out_dtype <= 2, "mvlt_gemm_nt: out_dtype is 0 (bf16), 1 (fp32) or 2 (fp16, with col_sum only)");
   MVLT_REQUIRE(a->out_dtype != 2 || (a->dtype == 0 && a->col_sum && a->act == 0 && !a->R && !a->row_scale && a->split_k <= 1 && a->c_map.mode == 0 && a->N % 8 == 0 &&
                                      a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 && a->M < (1 << 24) && !getenv("MVLT_NT_GENERIC_EPI") && !getenv("MVLT_NT_LEGACY")),

@@ -21,7 +21,7 @@ def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias
     if row_scale is not None:
         assert row_scale.dtype == torch.float32
     if R is not None:
-        assert R.dtype == C_out.dtype
+        assert R.dtype == C_out.dtype or (R.dtype == torch.float32 and C_out.dtype == torch.bfloat16)       # (the second: mvlt_gemm_nt_args.r_fp32)
     if H is not None:
         assert H.dtype == C_out.dtype
     if col_sum is not None:
@@ -29,6 +29,8 @@ def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias
     a = L.GemmNTArgs(ptr(A), ptr(B), ptr(C_out), M, N, K, lda, ldb, ldc, DT[A.dtype], 2 if C_out.dtype == torch.float16 else DT[C_out.dtype],
                      a_map or _ID, c_map or _ID, ptr(bias), act, ptr(H), ptr(row_scale), rows_per_scale, ptr(R),
                      ptr(col_sum), ptr(col_sumsq), col_copies, split_k)
+    if R is not None and R.dtype != C_out.dtype:
+        a.r_fp32 = 1
     if post_ln is not None:
         g, b, eps, y, mean, rstd = post_ln
         assert g.dtype == b.dtype == mean.dtype == rstd.dtype == torch.float32 and y.dtype == torch.bfloat16 and y.is_contiguous()

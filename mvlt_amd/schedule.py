@@ -328,7 +328,9 @@ class TrunkStep:
         # the last block of a stage has no fp32 consumer (its output feeds the next stage's patch embedding and the heads, which read
         # the MFMA-operand copy): the fused MLP then writes that copy itself and no fp32 stream -- no separate cast pass
         last_op = fused and j == m.depths[i] - 1 and self.dt != self.rt and not _NO_OUT_OP
-        xo = _empty((B, N, C), dt if last_op else self.rt, dev)
+        # stages 3-4: the same through fc2's residual epilogue (bf16 C beside the fp32 residual, mvlt_gemm_nt_args.r_fp32)
+        last_gemm = (not fused) and j == m.depths[i] - 1 and dt == torch.bfloat16 and self.rt == torch.float32 and not _NO_OUT_OP
+        xo = _empty((B, N, C), dt if (last_op or last_gemm) else self.rt, dev)
         if fused:
             # stages 1-2: LN2 -> fc1 -> GELU -> fc2 -> DropPath -> +residual in ONE kernel.  The (tokens x hidden) activation stays on
             # chip and is recomputed by the fused backward kernels; LN2 is folded into the operand load (the kernel reads the fp32

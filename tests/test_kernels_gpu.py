@@ -81,6 +81,13 @@ def test_gemm_nt_epilogues(ops, dtype, N):
     out4 = torch.empty(M, N, device=dev(), dtype=torch.float32)
     ops.gemm_nt(A, W, out4, M, N, K, K, K, N, bias=bias)
     assert maxrel(out4, ref_pre) < TOL[dtype]
+    if dtype == torch.bfloat16 and N % 8 == 0:
+        # fp32 residual beside a bf16 C (mvlt_gemm_nt_args.r_fp32) == the all-fp32 epilogue's result rounded once
+        R32 = rnd(M, N, dtype=torch.float32, seed=9)
+        o32, o16 = torch.empty(M, N, device=dev(), dtype=torch.float32), torch.empty(M, N, device=dev(), dtype=dtype)
+        ops.gemm_nt(A, W, o32, M, N, K, K, K, N, bias=bias, row_scale=scale, rows_per_scale=M // Bsz, R=R32)
+        ops.gemm_nt(A, W, o16, M, N, K, K, K, N, bias=bias, row_scale=scale, rows_per_scale=M // Bsz, R=R32)
+        assert torch.equal(o16, o32.to(dtype))
 
 
 @pytest.mark.parametrize("M,N,K,ldc", [(1490, 30522, 768, 30528), (257, 98309, 128, 98312), (1024, 24580, 192, 24584), (1490, 3002, 768, 3008)])
@@ -144,6 +151,10 @@ def test_gemm_nt_8phase_tiles(ops, K, M, N):
     out3b = torch.empty_like(Rb)
     ops.gemm_nt(A, W, out3b, M, N, K, K, K, N, R=Rb)
     assert maxrel(out3b.float(), pre + Rb.float()) < TOL[dt]
+    # fp32 residual beside a bf16 C (r_fp32: the last block of stages 3-4 hands over the operand copy directly) == the fp32 result rounded once
+    out3c = torch.empty(M, N, device=dev(), dtype=dt)
+    ops.gemm_nt(A, W, out3c, M, N, K, K, K, N, bias=bias, row_scale=scale, rows_per_scale=M // Bsz, R=Rres)
+    assert torch.equal(out3c, out3.to(dt))
     # EPI 5: column sum / sum of squares of the stored values
     cs, cq = torch.zeros(N, device=dev()), torch.zeros(N, device=dev())
     out5 = torch.empty(M, N, device=dev(), dtype=torch.float32)
