@@ -11,5 +11,6 @@ run() {
 run "default build" "MVLT_DUMMY=1"
 run "MVLT_NO_PROJ_LN=1" "MVLT_NO_PROJ_LN=1"
 run "MVLT_NT_P8=0 MVLT_NO_LIN_FUSE=1 MVLT_MLP_PIPE128=0 (round-3 kernel selection)" "MVLT_NT_P8=0 MVLT_NO_LIN_FUSE=1 MVLT_MLP_PIPE128=0"
+run "MVLT_MIM_FP32_Z=1 MVLT_NO_OUT_OP=1 (fp32 pre-BatchNorm conv outputs, fp32 stage outputs + cast pass)" "MVLT_MIM_FP32_Z=1 MVLT_NO_OUT_OP=1"
 [ -f ab/libmvlt_sigm.so ] && run "sigmoid-form GELU build (ab/libmvlt_sigm.so)" "MVLT_HIP_LIB=ab/libmvlt_sigm.so"
 [ -f ab/libmvlt_sigm.so ] && run "sigmoid-form GELU build + MVLT_NO_PROJ_LN=1" "MVLT_HIP_LIB=ab/libmvlt_sigm.so MVLT_NO_PROJ_LN=1"
