@@ -393,9 +393,16 @@ __global__ __launch_bounds__(1024) void fold_copies_wide_kernel(float* arena, in
   const int j = j0 + blockIdx.x * 64 + lane;
   float t = 0.f;
   if (j < j1) {
-    for (int k = kq; k < copies; k += 16) {
-      const float v = arena[(long)k * stride + j];
-      if (v != 0.f) { t += v; arena[(long)k * stride + j] = 0.f; }       // (most copies of a short launch were never written: read-only then)
+    // sixteen copies per thread and pass, all requested before the first is used (a load / test / store chain per copy was sixteen round trips)
+    for (int k0 = kq; k0 < copies; k0 += 256) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const int k = k0 + 16 * i; v[i] = k < copies ? arena[(long)k * stride + j] : 0.f; }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        t += v[i];
+        if (v[i] != 0.f) arena[(long)(k0 + 16 * i) * stride + j] = 0.f;    // (most copies of a short launch were never written: read-only then)
+      }
     }
   }
   part[kq][lane] = t;
