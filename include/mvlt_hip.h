@@ -361,7 +361,8 @@ int mvlt_bn_finalize(const float* sum, const float* sumsq, int copies /* accumul
 /* z, the pre-BatchNorm conv output, is fp32 (z_dtype 1) or fp16 (z_dtype 2: what mvlt_gemm_nt writes with out_dtype 2 -- no MFMA reads z, and it is
  * written once and read three times per step, so the bf16 path keeps it at half the bytes in the type the reference's autocast gives it) */
 int mvlt_bn_norm(const void* z, int ldz, int z_dtype, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
-                 float* y32, int ld32, void* y_op, int ld_op, int op_dtype /* dtype of y_op: the MFMA-operand copy */, void* stream);
+                 void* y32, int ld32, int y32_dtype /* 1 fp32; 2 fp16 (with an fp16 z: the factors of the decoder's three-way feature product, which only
+                 elementwise kernels read) */, void* y_op, int ld_op, int op_dtype /* dtype of y_op: the MFMA-operand copy */, void* stream);
 /* dy (the gradient w.r.t. the BatchNorm output) is fp32 (dy_dtype 1) or bf16 (dy_dtype 0: what the decoder's first backward stages hand
  * over -- a gradient tensor is read twice here and written once by its producer) */
 int mvlt_bn_bwd_reduce(const void* dy, int lddy, const void* z, int ldz, int z_dtype, const float* mean, const float* rstd, long M, int C,
@@ -371,11 +372,11 @@ int mvlt_bn_bwd_apply(const void* dy, int lddy, const void* z, int ldz, int z_dt
                       float* g_beta, float* g_gamma /* nullable pair: += s1, += s2 (the BatchNorm parameter gradients) */,
                       int op_dtype, int dy_dtype, void* stream);
 /* out (+)= a*b(*c) elementwise over [M, C] fp32 with row strides; optional operand-dtype copy of the result */
-int mvlt_ew_mul(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c, int ldc, long M, int C,
-                int accumulate, void* out_op, int ld_op, int op_dtype, void* stream);
+int mvlt_ew_mul(float* out, int ldo, const void* a, int lda, const void* b, int ldb, const void* c, int ldc, int in_dtype /* of a, b, c: 1 fp32, 2 fp16 */,
+                long M, int C, int accumulate, void* out_op, int ld_op, int op_dtype, void* stream);
 /* gradients of y = a*b*c (all [M, C] fp32, row stride ld; dy row stride lddy): da = dy*b*c, db = dy*a*c, dc = dy*a*b
  * (the three-way feature product of reference libs/vl_heads.py:152) */
-int mvlt_ew_mul3_bwd(const void* dy /* fp32 or bf16 (dy_dtype) */, int lddy, const float* a, const float* b, const float* c, int ld,
+int mvlt_ew_mul3_bwd(const void* dy /* fp32 or bf16 (dy_dtype) */, int lddy, const void* a, const void* b, const void* c, int ld, int in_dtype /* 1 fp32, 2 fp16 */,
                      void* da, void* db, void* dc /* dy's dtype */, long M, int C, int dy_dtype, void* stream);
 /* bilinear resize by an integer factor, align_corners=True.  x fp32 [B,H,W,C] (row stride ldx) -> [B,sH,sW,C] (bf16/fp32,
  * row stride ldo) or NCHW fp32 [B,C,sH,sW]; bwd is the exact adjoint in gather form (no atomics); its dx is fp32 (dx_dtype 1) or,

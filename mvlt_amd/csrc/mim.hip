@@ -51,6 +51,12 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
   st_g<MVLT_NT_MIM>((f32x4*)p, f32x4{v[0], v[1], v[2], v[3]});
   st_g<MVLT_NT_MIM>((f32x4*)(p + 4), f32x4{v[4], v[5], v[6], v[7]});
 }
+template <> __device__ __forceinline__ void store8<_Float16>(_Float16* p, const float (&v)[8]) {
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+  st_g<MVLT_NT_MIM>((f16x8*)p, o);
+}
 template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[8]) {
   bf16x8 o;
 #pragma unroll
@@ -267,8 +273,9 @@ __global__ __launch_bounds__(NT) void col_reduce8_kernel(const _Float16* z, int 
   for (int i = threadIdx.x; i < C; i += NT) { atomicAdd(&s1[i], sm[i]); atomicAdd(&s2[i], sm[C + i]); }
 }
 
+template <typename TY>
 __global__ __launch_bounds__(NT) void bn_norm8_kernel(const _Float16* z, int ldz, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                                      long M, int C, float* y32, int ld32, bf16* y16, int ld16) {
+                                                      long M, int C, TY* y32, int ld32, bf16* y16, int ld16) {
   const int cq = C / 8;
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
     long r = i / cq; int c = (int)(i - r * cq) * 8;
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(NT) void bn_norm8_kernel(const _Float16* z, int ldz
     load8<float>(mean + c, mu); load8<float>(rstd + c, rs); load8<float>(gamma + c, ga); load8<float>(beta + c, be);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (v[e] - mu[e]) * rs[e] * ga[e] + be[e];
-    if (y32) store8<float>(y32 + r * ld32 + c, o);
+    if (y32) store8<TY>(y32 + r * ld32 + c, o);
     if (y16) store8<bf16>(y16 + r * ld16 + c, o);
   }
 }
@@ -306,18 +313,18 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply8_kernel(const TDY* dy, int ld
 }
 
 // out (+)= a * b (* c)   fp32, optional bf16 copy of the final value
-template <typename TO>
-__global__ __launch_bounds__(NT) void ew_mul_kernel(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c3, int ldc,
+template <typename TO, typename TI = float>
+__global__ __launch_bounds__(NT) void ew_mul_kernel(float* out, int ldo, const TI* a, int lda, const TI* b, int ldb, const TI* c3, int ldc,
                                                     long M, int C, int accumulate, TO* o16, int ld16) {
   const int cq = C / 4;
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
     long r = i / cq; int c = (int)(i - r * cq) * 4;
-    f32x4 v = *(const f32x4*)(a + r * lda + c);
-    f32x4 w = *(const f32x4*)(b + r * ldb + c);
+    f32x4 v = load4<TI>(a + r * lda + c);
+    f32x4 w = load4<TI>(b + r * ldb + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= w[e];
     if (c3) {
-      f32x4 u = *(const f32x4*)(c3 + r * ldc + c);
+      f32x4 u = load4<TI>(c3 + r * ldc + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= u[e];
     }
@@ -333,14 +340,14 @@ __global__ __launch_bounds__(NT) void ew_mul_kernel(float* out, int ldo, const f
 
 // gradients of the three-way product y = a * b * c (reference libs/vl_heads.py:152: conv_upsample2(..) * conv_upsample3(..) * low):
 // da = dy b c, db = dy a c, dc = dy a b in one pass (three ew_mul launches read dy and two of the factors each)
-template <typename TDY, typename TO>
-__global__ __launch_bounds__(NT) void ew_mul3_bwd_kernel(const TDY* dy, int lddy, const float* a, const float* b, const float* c, int ld,
+template <typename TDY, typename TO, typename TI = float>
+__global__ __launch_bounds__(NT) void ew_mul3_bwd_kernel(const TDY* dy, int lddy, const TI* a, const TI* b, const TI* c, int ld,
                                                          TO* da, TO* db, TO* dc, long M, int C) {
   const int cq = C / 4;
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
     long r = i / cq; int col = (int)(i - r * cq) * 4;
     const f32x4 g = load4<TDY>(dy + r * lddy + col);
-    const f32x4 va = *(const f32x4*)(a + r * ld + col), vb = *(const f32x4*)(b + r * ld + col), vc = *(const f32x4*)(c + r * ld + col);
+    const f32x4 va = load4<TI>(a + r * ld + col), vb = load4<TI>(b + r * ld + col), vc = load4<TI>(c + r * ld + col);
     f32x4 oa, ob, oc;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { oa[e] = g[e] * vb[e] * vc[e]; ob[e] = g[e] * va[e] * vc[e]; oc[e] = g[e] * va[e] * vb[e]; }
@@ -805,7 +812,9 @@ extern "C" int mvlt_bn_finalize(const float* sum, const float* sumsq, int copies
 }
 
 extern "C" int mvlt_bn_norm(const void* z_, int ldz, int z_dtype, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
-                            float* y32, int ld32, void* y16, int ld16, int op_dtype, void* stream) {
+                            void* y32_, int ld32, int y32_dtype, void* y16, int ld16, int op_dtype, void* stream) {
+  float* y32 = (float*)y32_;
+  MVLT_REQUIRE(!y32_ || y32_dtype == 1 || y32_dtype == 2, "mvlt_bn_norm: y32_dtype is 1 (fp32) or 2 (fp16)");
   MVLT_REQUIRE(z_ && mean && rstd && gamma && beta && (y32 || y16) && C % 4 == 0 && ldz % 4 == 0, "mvlt_bn_norm: bad arguments (C, ld multiples of 4)");
   MVLT_REQUIRE((!y32 || ld32 % 4 == 0) && (!y16 || ld16 % 4 == 0), "mvlt_bn_norm: output strides must be multiples of 4");
   MVLT_REQUIRE(z_dtype == 1 || (z_dtype == 2 && op_dtype == 0), "mvlt_bn_norm: z is fp32 (z_dtype 1), or fp16 (2) on the bf16 path");
@@ -814,7 +823,13 @@ extern "C" int mvlt_bn_norm(const void* z_, int ldz, int z_dtype, const float* m
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   if (z_dtype == 2 && C % 8 == 0 && ldz % 8 == 0 && (!y32 || (ld32 % 4 == 0 && al16(y32))) && (!y16 || (ld16 % 8 == 0 && al16(y16))) && al16(z_) && al16(mean) && al16(rstd) &&
       al16(gamma) && al16(beta))
-    hipLaunchKernelGGL(bn_norm8_kernel, dim3(grid_for(M * (C / 8))), dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
+  {
+    if (y32_ && y32_dtype == 2) {
+      MVLT_REQUIRE(ld32 % 8 == 0, "mvlt_bn_norm: an fp16 y needs a row stride that is a multiple of 8");
+      hipLaunchKernelGGL((bn_norm8_kernel<_Float16>), dim3(grid_for(M * (C / 8))), dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, mean, rstd, gamma, beta, M, C, (_Float16*)y32_, ld32, (bf16*)y16, ld16);
+    } else hipLaunchKernelGGL((bn_norm8_kernel<float>), dim3(grid_for(M * (C / 8))), dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
+  }
+  else if (y32_ && y32_dtype == 2) { mvlt_set_error("mvlt_bn_norm: an fp16 y exists with an fp16 z on the 8-wide path only (C, strides multiples of 8, 16-byte aligned)"); return MVLT_ERR_UNSUPPORTED; }
   else if (z_dtype == 2) hipLaunchKernelGGL((bn_norm_kernel<bf16, _Float16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
   else if (op_dtype == 0) hipLaunchKernelGGL((bn_norm_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
   else hipLaunchKernelGGL((bn_norm_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (float*)y16, ld16);
@@ -897,23 +912,29 @@ extern "C" int mvlt_bn_bwd_apply(const void* dy_, int lddy, const void* z_, int 
   return mvlt_check_launch("mvlt_bn_bwd_apply");
 }
 
-extern "C" int mvlt_ew_mul(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c, int ldc, long M, int C,
+extern "C" int mvlt_ew_mul(float* out, int ldo, const void* a_, int lda, const void* b_, int ldb, const void* c_, int ldc, int in_dtype, long M, int C,
                            int accumulate, void* out_bf16, int ld16, int op_dtype, void* stream) {
+  const float* a = (const float*)a_; const float* b = (const float*)b_; const float* c = (const float*)c_;
+  MVLT_REQUIRE(in_dtype == 1 || (in_dtype == 2 && op_dtype == 0), "mvlt_ew_mul: the factors are fp32 (in_dtype 1), or fp16 (2) on the bf16 path");
   MVLT_REQUIRE((out || out_bf16) && a && b && C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (!c || ldc % 4 == 0) && (!out || ldo % 4 == 0) &&
                (!out_bf16 || ld16 % 4 == 0), "mvlt_ew_mul: bad arguments");
   MVLT_REQUIRE(!accumulate || out, "mvlt_ew_mul: accumulate needs the fp32 output");
   if (M <= 0) return MVLT_OK;
-  if (op_dtype == 0) hipLaunchKernelGGL((ew_mul_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, c, ldc, M, C, accumulate, (bf16*)out_bf16, ld16);
+  if (in_dtype == 2) hipLaunchKernelGGL((ew_mul_kernel<bf16, _Float16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, (const _Float16*)a_, lda, (const _Float16*)b_, ldb, (const _Float16*)c_, ldc, M, C, accumulate, (bf16*)out_bf16, ld16);
+  else if (op_dtype == 0) hipLaunchKernelGGL((ew_mul_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, c, ldc, M, C, accumulate, (bf16*)out_bf16, ld16);
   else hipLaunchKernelGGL((ew_mul_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, c, ldc, M, C, accumulate, (float*)out_bf16, ld16);
   return mvlt_check_launch("mvlt_ew_mul");
 }
 
-extern "C" int mvlt_ew_mul3_bwd(const void* dy, int lddy, const float* a, const float* b, const float* c, int ld, void* da, void* db, void* dc,
+extern "C" int mvlt_ew_mul3_bwd(const void* dy, int lddy, const void* a_, const void* b_, const void* c_, int ld, int in_dtype, void* da, void* db, void* dc,
                                 long M, int C, int dy_dtype, void* stream) {
+  const float* a = (const float*)a_; const float* b = (const float*)b_; const float* c = (const float*)c_;
+  MVLT_REQUIRE(in_dtype == 1 || (in_dtype == 2 && dy_dtype == 0), "mvlt_ew_mul3_bwd: the factors are fp32 (in_dtype 1), or fp16 (2) beside a bf16 dy");
   /* da / db / dc take dy's dtype */
   MVLT_REQUIRE(dy && a && b && c && da && db && dc && C % 4 == 0 && lddy % 4 == 0 && ld % 4 == 0 && ld >= C && (dy_dtype == 0 || dy_dtype == 1), "mvlt_ew_mul3_bwd: bad arguments");
   if (M <= 0) return MVLT_OK;
-  if (dy_dtype == 0) hipLaunchKernelGGL((ew_mul3_bwd_kernel<bf16, bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, lddy, a, b, c, ld, (bf16*)da, (bf16*)db, (bf16*)dc, M, C);
+  if (in_dtype == 2) hipLaunchKernelGGL((ew_mul3_bwd_kernel<bf16, bf16, _Float16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, lddy, (const _Float16*)a_, (const _Float16*)b_, (const _Float16*)c_, ld, (bf16*)da, (bf16*)db, (bf16*)dc, M, C);
+  else if (dy_dtype == 0) hipLaunchKernelGGL((ew_mul3_bwd_kernel<bf16, bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, lddy, a, b, c, ld, (bf16*)da, (bf16*)db, (bf16*)dc, M, C);
   else hipLaunchKernelGGL((ew_mul3_bwd_kernel<float, float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const float*)dy, lddy, a, b, c, ld, (float*)da, (float*)db, (float*)dc, M, C);
   return mvlt_check_launch("mvlt_ew_mul3_bwd");
 }

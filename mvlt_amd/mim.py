@@ -126,7 +126,10 @@ class MimStep:
         ch = 64
         f = self.rec
         # reductions of the three pyramid levels to 64 channels
-        r = self.conv_bn("reduction1", x2, C2, x2.shape[1], s1, C2, ch, M1); low = _e((M1, ch), dev); self.norm(r, low, ch)
+        # the three factors of the full-resolution feature product (low, cu2o, cu3o: written once, read by the product and by its backward, never an
+        # MFMA operand) are fp16 beside the fp16 z on the bf16 training path: 0.3 GB less traffic per step
+        f16 = torch.float16 if (self.training and dt == torch.bfloat16 and not _FP32_Z and not _SEPARATE_STATS and not _FP32_DY) else torch.float32
+        r = self.conv_bn("reduction1", x2, C2, x2.shape[1], s1, C2, ch, M1); low = _e((M1, ch), dev, f16); self.norm(r, low, ch)
         r = self.conv_bn("reduction2", x3, C3, x3.shape[1], s2, C3, ch, M2); mid = _e((M2, ch), dev); self.norm(r, mid, ch)
         r = self.conv_bn("reduction3", x4, C4, x4.shape[1], s3, C4, ch, M3); high = _e((M3, ch), dev); self.norm(r, high, ch)
         uph = self.up2(high, ch, s3, ch)                                   # (B,16,16,64) operand dtype
@@ -140,9 +143,9 @@ class MimStep:
         # b = cu2(up(mid)) * cu3(up(a)) * low -> fp32 + operand copy into cat3[:, :64]
         cat3 = _e((M1, 3 * ch), dev, dt)
         upm = self.up2(mid, ch, s2, ch)
-        r = self.conv_bn("conv_upsample2", upm, ch, s1 * s1, s1, ch, ch, M1); cu2o = _e((M1, ch), dev); self.norm(r, cu2o, ch)
+        r = self.conv_bn("conv_upsample2", upm, ch, s1 * s1, s1, ch, ch, M1); cu2o = _e((M1, ch), dev, f16); self.norm(r, cu2o, ch)
         upa = self.up2(a, ch, s2, ch)
-        r = self.conv_bn("conv_upsample3", upa, ch, s1 * s1, s1, ch, ch, M1); cu3o = _e((M1, ch), dev); self.norm(r, cu3o, ch)
+        r = self.conv_bn("conv_upsample3", upa, ch, s1 * s1, s1, ch, ch, M1); cu3o = _e((M1, ch), dev, f16); self.norm(r, cu3o, ch)
         ops.ew_mul(None, 0, cu2o, ch, cu3o, ch, low, ch, M=M1, Cdim=ch, out16=cat3, ld16=3 * ch)
         upc = self.up2(c, 2 * ch, s2, 2 * ch)
         r = self.conv_bn("conv_upsample5", upc, 2 * ch, s1 * s1, s1, 2 * ch, 2 * ch, M1); self.norm(r, y16=cat3[:, ch:], ld16=3 * ch)

@@ -263,11 +263,11 @@ def transpose_cast(w, out, R, Ccols, ld_out):
 # ------------------------------------------------------------------ MIM decoder helpers (csrc/mim.hip)
 L.lib.mvlt_col_stats.argtypes = [_vp, _i, _l, _i, _vp, _vp, _vp]
 L.lib.mvlt_bn_finalize.argtypes = [_vp, _vp, _i, _l, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]
-L.lib.mvlt_bn_norm.argtypes = [_vp, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _i, _i, _vp]
+L.lib.mvlt_bn_norm.argtypes = [_vp, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _i, _vp, _i, _i, _vp]
 L.lib.mvlt_bn_bwd_reduce.argtypes = [_vp, _i, _vp, _i, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _vp]
 L.lib.mvlt_bn_bwd_apply.argtypes = [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _vp, _vp, _i, _i, _vp]
 ZDT = {torch.float32: 1, torch.float16: 2}       # the pre-BatchNorm conv output z: fp32, or fp16 on the bf16 path (mvlt_gemm_nt out_dtype 2)
-L.lib.mvlt_ew_mul.argtypes = [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _l, _i, _i, _vp, _i, _i, _vp]
+L.lib.mvlt_ew_mul.argtypes = [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _l, _i, _i, _vp, _i, _i, _vp]
 L.lib.mvlt_upsample_fwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]
 L.lib.mvlt_upsample_bwd.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]
 
@@ -283,7 +283,7 @@ def bn_finalize(s, ss, M, Cdim, eps, momentum, mean, rstd, running_mean=None, ru
 
 
 def bn_norm(z, ldz, mean, rstd, gamma, beta, M, Cdim, y32=None, ld32=0, y16=None, ld16=0):
-    check(L.lib.mvlt_bn_norm(_p(z), ldz, ZDT[z.dtype], _p(mean), _p(rstd), _p(gamma), _p(beta), M, Cdim, _p(y32), ld32, _p(y16), ld16,
+    check(L.lib.mvlt_bn_norm(_p(z), ldz, ZDT[z.dtype], _p(mean), _p(rstd), _p(gamma), _p(beta), M, Cdim, _p(y32), ld32, ZDT[y32.dtype] if y32 is not None else 1, _p(y16), ld16,
                              DT[y16.dtype] if y16 is not None else 0, stream_ptr()), "mvlt_bn_norm")
 
 
@@ -298,16 +298,17 @@ def bn_bwd_apply(dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, Cdim, dz16, ldd
                                   _p(g_beta), _p(g_gamma), DT[dz16.dtype], DT[dy.dtype], stream_ptr()), "mvlt_bn_bwd_apply")
 
 
-L.lib.mvlt_ew_mul3_bwd.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _l, _i, _i, _vp]
+L.lib.mvlt_ew_mul3_bwd.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _l, _i, _i, _vp]
 
 
 def ew_mul3_bwd(dy, lddy, a, b, c, ld, da, db, dc, M, Cdim):
-    assert dy.dtype in DT and da.dtype == db.dtype == dc.dtype == dy.dtype
-    check(L.lib.mvlt_ew_mul3_bwd(_p(dy), lddy, _p(a), _p(b), _p(c), ld, _p(da), _p(db), _p(dc), M, Cdim, DT[dy.dtype], stream_ptr()), "mvlt_ew_mul3_bwd")
+    assert dy.dtype in DT and da.dtype == db.dtype == dc.dtype == dy.dtype and a.dtype == b.dtype == c.dtype and a.dtype in ZDT
+    check(L.lib.mvlt_ew_mul3_bwd(_p(dy), lddy, _p(a), _p(b), _p(c), ld, ZDT[a.dtype], _p(da), _p(db), _p(dc), M, Cdim, DT[dy.dtype], stream_ptr()), "mvlt_ew_mul3_bwd")
 
 
 def ew_mul(out, ldo, a, lda, b, ldb, c=None, ldc=0, *, M, Cdim, accumulate=False, out16=None, ld16=0):
-    check(L.lib.mvlt_ew_mul(_p(out), ldo, _p(a), lda, _p(b), ldb, _p(c), ldc, M, Cdim, 1 if accumulate else 0, _p(out16), ld16,
+    assert a.dtype == b.dtype and (c is None or c.dtype == a.dtype) and a.dtype in ZDT
+    check(L.lib.mvlt_ew_mul(_p(out), ldo, _p(a), lda, _p(b), ldb, _p(c), ldc, ZDT[a.dtype], M, Cdim, 1 if accumulate else 0, _p(out16), ld16,
                             DT[out16.dtype] if out16 is not None else 0, stream_ptr()), "mvlt_ew_mul")
 
 

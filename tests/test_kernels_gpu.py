@@ -914,6 +914,10 @@ def test_batchnorm_fwd_bwd(ops, M, C, lddy, off):
         ops.bn_norm(zr32, C, mean, rstd, gamma, beta, M, C, y32=y32b, ld32=C, y16=yb, ld16=C)
         ops.bn_norm(zh, C, mean, rstd, gamma, beta, M, C, y32=y32h, ld32=C, y16=yh, ld16=C)
         assert torch.equal(yb, yh) and torch.equal(y32b, y32h)
+        if C % 8 == 0:
+            yf16 = torch.empty(M, C, device=dev(), dtype=torch.float16)            # fp16 "wide" output (the factors of the decoder's feature product)
+            ops.bn_norm(zh, C, mean, rstd, gamma, beta, M, C, y32=yf16, ld32=C)
+            assert torch.equal(yf16, y32h.to(torch.float16))
         for dyv, ldv in ((dyh, lddy), (dy, lddy)):
             ra, rb = torch.zeros(2, C, device=dev()), torch.zeros(2, C, device=dev())
             ops.bn_bwd_reduce(dyv, ldv, zr32, C, mean, rstd, M, C, ra[0], ra[1])
@@ -964,6 +968,17 @@ def test_ew_mul3_bwd(ops):
     ops.ew_mul3_bwd(dyh, 3 * Cd, a, b, c, Cd, dah, dbh, dch, M, Cd)
     dy = dyh[:, :Cd].float()
     assert torch.equal(dah, (dy * b * c).to(torch.bfloat16)) and torch.equal(dbh, (dy * a * c).to(torch.bfloat16)) and torch.equal(dch, (dy * a * b).to(torch.bfloat16))
+    # fp16 factors (what the bf16 training path keeps of low / cu2o / cu3o): the same kernels fed the fp16-rounded factors; forward product too
+    ah, bh, ch = a.to(torch.float16), b.to(torch.float16), c.to(torch.float16)
+    d2 = [torch.empty(M, Cd, device=dev(), dtype=torch.bfloat16) for _ in range(3)]
+    d3 = [torch.empty(M, Cd, device=dev(), dtype=torch.bfloat16) for _ in range(3)]
+    ops.ew_mul3_bwd(dyh, 3 * Cd, ah, bh, ch, Cd, *d2, M, Cd)
+    ops.ew_mul3_bwd(dyh, 3 * Cd, ah.float(), bh.float(), ch.float(), Cd, *d3, M, Cd)
+    assert all(torch.equal(x, y) for x, y in zip(d2, d3))
+    p16, p32 = torch.empty(M, 3 * Cd, device=dev(), dtype=torch.bfloat16), torch.empty(M, 3 * Cd, device=dev(), dtype=torch.bfloat16)
+    ops.ew_mul(None, 0, ah, Cd, bh, Cd, ch, Cd, M=M, Cdim=Cd, out16=p16, ld16=3 * Cd)
+    ops.ew_mul(None, 0, ah.float(), Cd, bh.float(), Cd, ch.float(), Cd, M=M, Cdim=Cd, out16=p32, ld16=3 * Cd)
+    assert torch.equal(p16[:, :Cd], p32[:, :Cd])
 
 
 # ------------------------------------------------------------------ round 2 additions
