@@ -145,7 +145,7 @@ def roofline_cases(B, device):
     w2 = (torch.randn(64, 64, device=device) * 0.125).to(bf)
     b2 = torch.randn(64, device=device)
     o2 = torch.empty(M2, 64, device=device, dtype=bf)
-    # the single largest launch of the step (profiles/r03_kernel_stats.csv): the fused-MLP weight gradients of a stage-1 block,
+    # the roofline launch since round 3 (then the single largest of the step; profiles/r04_gemm_shapes.txt): the fused-MLP weight gradients of a stage-1 block,
     # dW1 / db1 / dW2 / db2 from x and dy with the hidden activation recomputed on chip (M = B*4224 tokens, C = 64, hidden 512), with the
     # per-sample DropPath factors of the step (one sample in ten dropped)
     hid = 512
@@ -165,9 +165,9 @@ def roofline_cases(B, device):
 
 
 def time_dominant_kernel(model, B, device):
-    """`roofline` = the launch with the largest share of the step (profiles/r03_kernel_stats.csv: the fused-MLP weight gradients of the two
-    stage-1 blocks, ~0.35 ms each since their activation comes from a table; the other three fused-MLP backward launches of stages 1-2 are
-    within 5 % of it), timed alone with HIP events on torch's current stream = the stream the C ABI launches on.
+    """`roofline` = the launch VERDICT r3 named (profiles/r04_gemm_shapes.txt: the fused-MLP weight gradients of the two stage-1 blocks,
+    ~0.35 ms each since their activation comes from a table; the three other fused-MLP backward launches of stages 1-2 take 0.33-0.40 ms each, two per
+    step each -- together the 1.43 + 1.47 ms of `mlp_wgrad2_kernel` / `mlp_pipe_kernel<.., 1>` in profiles/r04_step_launches.txt), timed alone with HIP events on torch's current stream = the stream the C ABI launches on.
     Its ALGORITHMIC work is the two weight-gradient products dW1 = dh^T x and dW2 = dy^T g: 2 x 2*M*C*hid FLOP (M = B*4224, C = 64, hid = 512)
     over 2 x M*C bf16 operand bytes; the kernel EXECUTES twice that (h = x W1^T and dg = dy W2 are recomputed on chip so that nothing of
     size M x hid touches HBM) plus 9.5 VALU instructions and one 8-byte LDS gather per hidden element and token for GELU / GELU' (17 VALU
@@ -191,8 +191,8 @@ def time_dominant_kernel(model, B, device):
     M2 = B * 4224
     return dict(kernel="mlp_wgrad2_kernel<64, 4> (bf16): fused-MLP weight gradients of a stage-1 block, M = B*4224 tokens, C = 64, hidden 512 "
                        "(dW1, db1, dW2, db2; h / dg / GELU / GELU' recomputed on chip; DropPath factors per sample, dropped samples skipped)",
-                share_of_step="largest kernel of the step by total time: 2 x ~0.35 ms of a ~22 ms step; the three other fused-MLP backward launches "
-                              "of stages 1-2 take 0.34-0.36 ms each, two per step each (profiles/r03_kernel_stats.csv)",
+                share_of_step="2 x ~0.35 ms of a ~21 ms step; the three other fused-MLP backward launches of stages 1-2 take 0.33-0.40 ms each, two per step "
+                              "each (profiles/r04_gemm_shapes.txt)",
                 bound="mfma", achieved=round(tf3, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf3 / PEAK_BF16_TFLOPS, 4),
                 traffic=tr("mlp_dw64"), ms_per_launch=round(ms3, 4), algorithmic_flops=flops3, executed_flops=2 * flops3,
                 algorithmic_bytes=2.0 * 2 * M2 * 64,
