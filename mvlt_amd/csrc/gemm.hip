@@ -2415,8 +2415,10 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
       // ragged M / N (the MLM logits, ~1500 x 30522 x 768, fp32 out): 256 x 256 tiles with the loader clamped at the last row and the checked epilogue
       if (!c320 && !c256 && !c192 && epi == 1 && (ntp8 & 8) && (a->M % 256 || a->N % 256)) {
         const long tiles = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
-        // ... when the padded tiles are at least 90 % real work (294912 x 128: half of every 256-wide tile would be padding, 36 -> 56 us)
-        if (tiles >= 384 && (double)a->M * a->N >= 0.9 * (double)tiles * 65536.0) { launch_nt_p8<1, 4, 2, 2, true>(*a, s); done = true; }
+        // ... when the whole rounds of padded tiles are at least 85 % real work: 294912 x 128 would pad half of every 256-wide tile (36 -> 56 us), and
+        // 1558 selected rows make 7 x 120 tiles = 4 rounds where 1490 rows make 3 (the 128-wide kernel then wins)
+        const long rounds = (tiles + 255) / 256;
+        if (tiles >= 384 && (double)a->M * a->N >= 0.85 * (double)rounds * 256.0 * 65536.0) { launch_nt_p8<1, 4, 2, 2, true>(*a, s); done = true; }
       }
       if (done) return mvlt_check_launch("mvlt_gemm_nt");
       if (c320) done = dispatch_nt_p8<3, 3, 2>(*a, epi, s);

@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Regenerates the measured tables of DESIGN.md section 3 (3.1: one step by kernel family, 3.2: the MFMA-carrying launches) from the committed
+profiles of a round, so that the document cannot drift from the files it cites:
+    python tools/design_tables.py r04            # rewrites the text between the <!-- BEGIN:3.x --> / <!-- END:3.x --> markers of DESIGN.md"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+P = lambda name: os.path.join(ROOT, "profiles", f"{tag}_{name}")
+
+# ---------------------------------------------------------------- 3.1
+head = open(P("step_launches.txt")).readline()
+m = re.search(r"(\d+) launches, ([\d.]+) ms .*kernels busy ([\d.]+) ms \(([\d.]+) %\); ATen kernels (\d+), __amd_rocclr_copyBuffer (\d+)", head)
+n_launch, span_ms, busy_ms, busy_pct, n_aten, n_copy = int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4)), int(m.group(5)), int(m.group(6))
+fam = {}
+for line in open(P("step_launches.txt")).read().split("\n")[2:]:
+    mm = re.match(r"\s*(\d+)\s+([\d.]+)\s+(.*)$", line)
+    if not mm:
+        continue
+    n, us, name = int(mm.group(1)), float(mm.group(2)), mm.group(3)
+    if "ln_bwd" in name or "ln_fwd" in name:
+        k = "ln"
+    elif any(x in name for x in ("bn_", "col_reduce", "upsample", "ew_mul")):
+        k = "mim"
+    elif "at::" in name or "rocclr" in name:
+        k = "aten"
+    else:
+        k = next((x for x in ("gemm_tn_dma", "gemm_nt_p8", "gemm_nt_dma", "mlp_pipe", "mlp_wgrad2", "attn_bwd", "attn_fwd2", "conv3_nt", "conv3_wgrad", "adamw",
+                              "bert_embed_bwd", "bert_embed_fwd", "weight_prep", "ce_fwd", "ce_bwd", "fold_copies") if name.startswith(x)), "other")
+    a = fam.setdefault(k, [0, 0.0])
+    a[0] += n
+    a[1] += us
+total = sum(v[1] for v in fam.values())
+row = lambda k: (fam.get(k, [0, 0.0])[0], fam.get(k, [0, 0.0])[1], 100.0 * fam.get(k, [0, 0.0])[1] / total)
+R = {}
+for k in fam:
+    R[k] = row(k)
+rest_keys = [k for k in fam if k in ("adamw", "bert_embed_bwd", "bert_embed_fwd", "weight_prep", "ce_fwd", "ce_bwd", "fold_copies", "other", "aten")]
+rest_n, rest_us = sum(fam[k][0] for k in rest_keys), sum(fam[k][1] for k in rest_keys)
+g = lambda k: f"{R[k][0]} | {R[k][1]:.0f} | {R[k][2]:.1f} %"
+us = lambda k: fam.get(k, [0, 0.0])[1]
+t31 = f"""### 3.1 One steady-state step: {n_launch} launches, kernels busy {busy_ms:.2f} ms (`profiles/{tag}_step_launches.txt`)
+
+(The span from the step's first kernel to the optimizer's end is {span_ms:.2f} ms under `rocprofv3 --kernel-trace` -- {busy_pct:.1f} % busy: the traced host thread needs longer to
+enqueue a step than the GPU needs to run it, `docs/experiments_r4.md` 9.  Unprofiled the bench step equals the sum of the kernel durations.)
+
+| kernel family | launches | us / step | share | bound by (evidence) |
+|---|---|---|---|---|
+| `gemm_tn_dma_kernel` (weight gradients; 8 launches carry the input gradient too) | {g('gemm_tn_dma')} | MFMA-bound shapes 0.24-0.38 of peak (3.2), the K <= 128 shapes HBM (4.5-5.6 TB/s); split reductions cost outputs x splits / 0.3 ns (`experiments_r4.md` 2) |
+| `gemm_nt_dma_kernel` (128-wide NT GEMMs: K <= 128 projections, gathers, small heads) | {g('gemm_nt_dma')} | HBM for K = 64 / 128 (`proj64` sibling: 0.60-0.70 of 8 TB/s); TA / L1 path for the rest (`r03_l1_stalls.txt`) |
+| `gemm_nt_p8_kernel` (8-wave / 8-phase NT GEMMs, stage 3-4, MLM logits) | {g('gemm_nt_p8')} | K-loop ~1.45 PFLOP/s while a round is full; launches 0.23-0.57 of peak: whole-round quantisation + an epilogue nothing overlaps; the activation-storing launches within 1.4 x of their HBM floor (3.2, 3.3) |
+| `mlp_pipe_kernel` (fused MLP forward / input gradient, stages 1-2) | {g('mlp_pipe')} | VALU (GELU: 10 instructions per hidden element) + MFMA, partly overlapped: MFMA-busy 0.28-0.35, VALU-active 0.26-0.35 (`{tag}_mfma_counters.csv`) |
+| `mlp_wgrad2_kernel` (fused MLP weight gradients) | {g('mlp_wgrad2')} | VALU + MFMA add up (`roofline`: 0.166 algorithmic / 0.33 executed); LDS table gather 0.43 conflicts (inherent, `experiments_r4.md` 4) |
+| LayerNorm forward / backward (standalone launches) | {g('ln')} | HBM + Infinity Cache: 4.5-7.8 TB/s algorithmic (streaming passes over the fp32 residual stream); round 3 / first half of round 4: 2238 us (`experiments_r4.md` 7) |
+| `conv3_nt_kernel` (MIM conv3x3 forward / dgrad) | {g('conv3_nt')} | MFMA / LDS-DMA: 1.0-1.24 PFLOP/s (0.41-0.50), MFMA-busy 0.48 |
+| MIM decoder non-GEMM (BatchNorm, upsample, products, fused loss) | {g('mim')} | HBM streaming, fp16 z and product factors (first half of round 4: 1482 us, `experiments_r4.md` 8) |
+| `attn_bwd_dma_kernel` | {g('attn_bwd')} | dependent chain per 32-query tile at two waves per SIMD: MFMA-busy 0.23, waits 0.37 + 0.26; stage 1 = 2.4 x its HBM floor |
+| `conv3_wgrad_kernel` | {g('conv3_wgrad')} | 1.02 PFLOP/s (0.41), MFMA-busy 0.41 |
+| `attn_fwd2_kernel` | {g('attn_fwd2')} | Q / O streaming at stage 1 (77-80 us vs ~55 us floor), K / V staging at stages 3-4 |
+| AdamW {us('adamw'):.0f}, BERT-embedding bwd / fwd {us('bert_embed_bwd'):.0f} / {us('bert_embed_fwd'):.0f}, weight prep {us('weight_prep'):.0f}, cross entropy {us('ce_fwd') + us('ce_bwd'):.0f}, gradient-copy folds {us('fold_copies'):.0f}, ATen leftovers ({R.get('aten', (0, 0, 0))[0]} launches) {us('aten'):.0f}, other helpers | {rest_n} | {rest_us:.0f} | {100 * rest_us / total:.1f} % | HBM (AdamW: 1.2 GB at 5.7-6.4 TB/s; the embedding backward: 25 M fp32 atomics at 0.3 per ns) |
+"""
+
+# ---------------------------------------------------------------- 3.2
+shapes = {}
+for line in open(P("gemm_shapes.txt")):
+    mm = re.match(r"\s*([\d.]+) ms\s+x\s+(\d+)\s+([\d.]+) us\s+(?:([\d.]+) TF/s\s+)?(.*)$", line)
+    if mm:
+        shapes[" ".join(mm.group(5).split())] = (int(mm.group(2)), float(mm.group(3)), float(mm.group(4)) if mm.group(4) else None)
+tot_line = [l for l in open(P("gemm_shapes.txt")) if l.startswith("total")][0].strip()
+
+
+def S(key):
+    for k, v in shapes.items():
+        if k.startswith(key):
+            return v
+    raise KeyError(key)
+
+
+def r(key, flops=None):
+    n, us_, tf = S(key)
+    if tf is None and flops:
+        tf = flops / us_ / 1e6
+    return us_, tf
+
+
+def line(label, kern, key, floor, r3, flops=None):
+    us_, tf = r(key, flops)
+    return f"| {label} | {kern} | {us_:.1f} | {tf:.0f} | {tf / 2500:.2f} | {floor} | {r3} |"
+
+
+def line2(label, kern, key_a, key_b, floor, r3):
+    (ua, ta), (ub, tb) = r(key_a), r(key_b)
+    return f"| {label} | {kern} | {ua:.1f} / {ub:.1f} | {ta:.0f} / {tb:.0f} | {ta / 2500:.2f} / {tb / 2500:.2f} | {floor} | {r3} |"
+
+
+rows = [
+    line("stage-3 fc1 + GELU 98304 x 1280 x 320 (H and G stored)", "p8 256 x 256", "gemm_nt 98304 1280 320 A:- C:- b act1", 91, 137.5),
+    line2("stage-3 fc2 + fp32 residual 98304 x 320 x 1280 (first block: fp32 out / last block: bf16 out, `r_fp32`)", "p8 192 x 320", "gemm_nt 98304 320 1280 A:- C:- b act0 R float32",
+          "gemm_nt 98304 320 1280 A:- C:- b act0 R bfloat16", "80 / 70", 155.1),
+    line("stage-3 GELU' dgrad 98304 x 1280 x 320", "p8 256 x 256", "gemm_nt 98304 1280 320 A:- C:- act2", 90, 176.0),
+    line("stage-3 fc1 dgrad 98304 x 320 x 1280", "p8 192 x 320", "gemm_nt 98304 320 1280 A:- C:- act0 bfloat16", 50, 106.2),
+]
+a, b = r("gemm_tn 98304 1280 320"), r("gemm_tn 98304 320 1280")
+rows.append(f"| stage-3 dW2 / dW1 (TN, 98304 rows) | tn 128 x 128 | {a[0]:.1f} / {b[0]:.1f} | {a[1]:.0f} / {b[1]:.0f} | {a[1] / 2500:.2f} / {b[1] / 2500:.2f} | 50 | 134.0 / 121.0 |")
+rows += [
+    line("stage-4 fc1 + GELU 49152 x 2048 x 512", "p8 256 x 256", "gemm_nt 49152 2048 512 A:- C:- b act1", 72, 150.3),
+    line2("stage-4 fc2 + fp32 residual 49152 x 512 x 2048 (fp32 out / bf16 out)", "p8 192 x 256", "gemm_nt 49152 512 2048 A:- C:- b act0 R float32",
+          "gemm_nt 49152 512 2048 A:- C:- b act0 R bfloat16", "64 / 56", 139.6),
+    line("stage-4 GELU' dgrad 49152 x 2048 x 512", "p8 256 x 256", "gemm_nt 49152 2048 512 A:- C:- act2", 72, 168.7),
+    line("stage-4 fc1 dgrad 49152 x 512 x 2048", "p8 192 x 256", "gemm_nt 49152 512 2048 A:- C:- act0 bfloat16", 40, 91.8),
+]
+a, b = r("gemm_tn 49152 2048 512"), r("gemm_tn 49152 512 2048")
+rows.append(f"| stage-4 dW2 / dW1 (TN, 49152 rows) | tn 128 x 128 | {a[0]:.1f} / {b[0]:.1f} | {a[1]:.0f} / {b[1]:.0f} | {a[1] / 2500:.2f} / {b[1] / 2500:.2f} | 40 | 131.0 / 112.0 |")
+twelve = sum(r(k)[0] for k in ("gemm_nt 98304 1280 320 A:- C:- b act1", "gemm_nt 98304 320 1280 A:- C:- b act0 R float32", "gemm_nt 98304 1280 320 A:- C:- act2",
+                               "gemm_nt 98304 320 1280 A:- C:- act0 bfloat16", "gemm_tn 98304 1280 320", "gemm_tn 98304 320 1280",
+                               "gemm_nt 49152 2048 512 A:- C:- b act1", "gemm_nt 49152 512 2048 A:- C:- b act0 R float32", "gemm_nt 49152 2048 512 A:- C:- act2",
+                               "gemm_nt 49152 512 2048 A:- C:- act0 bfloat16", "gemm_tn 49152 2048 512", "gemm_tn 49152 512 2048"))
+rows.append(f"| **the twelve MLP launches of a stage-3 + a stage-4 block** | | **{twelve:.0f}** | | | | **1623** (VERDICT r3 target 1200) |")
+cf, cd, cw = r("gemm_nt 262144 192 1728 A:m2r3 C:- act0 float16"), r("gemm_nt 262144 192 1728 A:m2r3 C:- act0 bfloat16"), r("gemm_tn 262144 192 1728")
+rows.append(f"| MIM conv3x3 192 -> 192 @ 32 x 32 forward (fp16 z + BN statistics) / dgrad (bf16) | conv3_nt | {cf[0]:.1f} / {cd[0]:.1f} | {cf[1]:.0f} / {cd[1]:.0f} | {cf[1] / 2500:.2f} / {cd[1] / 2500:.2f} | 40 | 178.1 / 145.9 |")
+rows.append(f"| its weight gradient | conv3_wgrad | {cw[0]:.1f} | {cw[1]:.0f} | {cw[1] / 2500:.2f} | 32 | 180.3 |")
+rows.append(line("MLM logits 1490 x 30522 x 768 (fp32 out)", "p8 256 x 256, ragged", "gemm_nt 1490 30522 768", 37, 157.6))
+GF1, GF2 = 2.0 * 1081344 * 64 * 512, 2.0 * 294912 * 128 * 1024       # one GEMM unit of the fused MLP
+f1, x1, w1 = S("mlp_fwd 1081344 64 512")[1], S("mlp_bwd_dx 1081344 64 512")[1], S("mlp_bwd_dw 1081344 64 512")[1]
+f2, x2, w2 = S("mlp_fwd 294912 128 1024")[1], S("mlp_bwd_dx 294912 128 1024")[1], S("mlp_bwd_dw 294912 128 1024")[1]
+tfs = lambda units, gf, us_: units * gf / us_ / 1e6
+rows.append(f"| fused MLP stage 1 (M = 1081344, C = 64, hidden 512): forward / input gradient (+ `norm2` backward) / weight gradients | mlp_pipe / mlp_wgrad2 | {f1:.1f} / {x1:.1f} / {w1:.1f} | "
+            f"{tfs(2, GF1, f1):.0f} / {tfs(3, GF1, x1):.0f} / {tfs(4, GF1, w1):.0f} executed | {tfs(2, GF1, f1) / 2500:.2f} / {tfs(3, GF1, x1) / 2500:.2f} / {tfs(4, GF1, w1) / 2500:.2f} executed | 50-100 | 291 / 409 / 355 |")
+rows.append(f"| fused MLP stage 2 (M = 294912, C = 128, hidden 1024) | same | {f2:.1f} / {x2:.1f} / {w2:.1f} | {tfs(2, GF2, f2):.0f} / {tfs(3, GF2, x2):.0f} / {tfs(4, GF2, w2):.0f} executed | "
+            f"{tfs(2, GF2, f2) / 2500:.2f} / {tfs(3, GF2, x2) / 2500:.2f} / {tfs(4, GF2, w2) / 2500:.2f} executed | 30-60 | 235 / 353 / 357 |")
+ab = [S(f"sr_attention_bwd 256 {h} {n} 192")[1] for h, n in ((1, 4224), (2, 1152), (5, 384), (8, 192))]
+af = [S(f"sr_attention_fwd 256 {h} {n} 192")[1] for h, n in ((1, 4224), (2, 1152), (5, 384), (8, 192))]
+fl = [256 * h * n * 192 * 64 * 2.0 for h, n in ((1, 4224), (2, 1152), (5, 384), (8, 192))]
+rows.append("| SR attention backward, stages 1 / 2 / 3 / 4 | attn_bwd_dma | " + " / ".join(f"{x:.1f}" for x in ab) + " | " + " / ".join(f"{5 * f / x / 1e6:.0f}" for f, x in zip(fl, ab)) + " | " +
+            " / ".join(f"{5 * f / x / 1e6 / 2500:.2f}" for f, x in zip(fl, ab)) + " | 100 / 27 / 27 / 27 | 240.7 / 129.1 / 140.7 / 140.9 |")
+rows.append("| SR attention forward, stages 1-4 | attn_fwd2 | " + " / ".join(f"{x:.1f}" for x in af) + " | " + " / ".join(f"{2 * f / x / 1e6:.0f}" for f, x in zip(fl, af)) + " | " +
+            " / ".join(f"{2 * f / x / 1e6 / 2500:.2f}" for f, x in zip(fl, af)) + " | 55 / 15 / 15 / 15 | 82.3 / 52.0 / 47.3 / 50.7 |")
+d1, d2 = S("gemm_tn 1081344 64 64")[1], S("gemm_tn 294912 128 128")[1]
+b1, b2 = (1081344 * 64 * 2 * 3 + 0.0) / d1 / 1e6, (294912 * 128 * 2 * 3 + 0.0) / d2 / 1e6
+rows.append(f"| q / proj weight + input gradient in one pass, stage 1 (1081344 x 64 x 64) / stage 2 (294912 x 128 x 128) | tn 64 x 64 / 128 x 128 + DG | {d1:.1f} / {d2:.1f} | HBM: {b1:.1f} / {b2:.1f} TB/s | "
+            f"{b1 / 8:.2f} / {b2 / 8:.2f} of 8 TB/s | 66 / 36 | 102.5 / 68.8 (two launches) |")
+bench = json.loads(open(P("bench_n1.json")).read().strip().split("\n")[-1])
+bo = bench["flops"]["blocks_only"]
+t32 = f"""### 3.2 The MFMA-carrying launches (`profiles/{tag}_gemm_shapes.txt`: every distinct launch of the step re-timed alone with the step's arguments; {tot_line})
+
+fraction = 2 M N K / time / 2.5 PFLOP/s; "HBM floor" = algorithmic bytes / 6.3 TB/s.
+
+| launch (M x N x K, epilogue) | kernel / tile | us | TFLOP/s | fraction | HBM floor us | round 3 us |
+|---|---|---|---|---|---|---|
+""" + "\n".join(rows) + f"""
+
+Blocks-only MFMA fraction (north_star's figure, `flops.blocks_only` of the bench line): **{bo['mfma_frac']:.3f}** ({bo['ms_per_step']:.2f} ms for 6.15 TFLOP; round 3: 0.165; target 0.40
+-- the ceiling argument of round 3 stands: in stages 1-2, half of the block FLOPs, the VALU floor of the activation alone is 1.6-2.7 x the MFMA time of the GEMMs
+around it, `docs/experiments_r1-r3.md` B "Instruction issue rates").
+"""
+
+p = os.path.join(ROOT, "DESIGN.md")
+s = open(p).read()
+for name, text in (("3.1", t31), ("3.2", t32)):
+    b, e = f"<!-- BEGIN:{name} -->", f"<!-- END:{name} -->"
+    i, j = s.index(b) + len(b), s.index(e)
+    s = s[:i] + "\n" + text + s[j:]
+open(p, "w").write(s)
+print(f"DESIGN.md 3.1 / 3.2 rewritten from profiles/{tag}_*: {n_launch} launches, busy {busy_ms:.2f} ms, twelve MLP launches {twelve:.0f} us, blocks-only {bo['mfma_frac']:.3f}")
