@@ -157,9 +157,37 @@ Blocks-only MFMA fraction (north_star's figure, `flops.blocks_only` of the bench
 around it, `docs/experiments_r1-r3.md` B "Instruction issue rates").
 """
 
+# ---------------------------------------------------------------- 6: the line of the final build
+rf, fl_, st, cb, oc = bench["roofline"], bench["flops"], bench["step"], bench["cpu_baseline"], bench.get("other_configs", {})
+sib = rf["siblings"]
+tj = json.load(open(P("roofline_traffic.json")))
+ks = [l for l in open(P("kernel_stats.csv")) if "mlp_wgrad2_kernel<64" in l][0].rsplit('",', 1)[1].split(",")
+ks_calls, ks_avg_us = int(ks[0]), float(ks[2]) / 1e3
+mw, cal = tj["mlp_dw64"], tj["calib_cast"]
+pairs = lambda x: f"{x:,.0f}".replace(",", " ")
+t6 = f"""**The line of the final build** (`profiles/{tag}_bench_n1.json`, command `python bench.py`, sources `{tj['_source_hash']}`): **{pairs(bench['value'])} pairs/s, {bench['ms_per_step']:.2f} ms/step**
+(round 3's driver line: 11 428 / 22.40; the first half of this round: 11 903 / 21.51).  The boxes of the pool differ by +-2.5 %: the final tree (and its last few predecessors, which differ by < 0.05 ms) measured 20.19, 20.56, 20.66, 20.68,
+21.09, 21.15 and 21.33 ms on seven boxes of the last afternoon; every A/B below is same-box.  Same-box A/Bs of this round add up to -1.6 ms (-7 %): 8-phase NT GEMMs -0.15, polynomial GELU' + whole-tile
+epilogues + K = 320 launches on them -0.12, weight + input gradient in one pass -0.15, pipelined C = 128 input gradient -0.04 (first half); LayerNorm backward without LDS
+atomics -0.38, fp16 pre-BatchNorm conv outputs and product factors -0.25, attention-backward dK / dV flush -0.06, bf16 stage outputs from the fc2 epilogue, MLM logits on the 8-phase
+kernel, `weight_prep` from the bf16 copy, embedding backward together -0.15 (second half, `docs/experiments_r4.md` 7-9).  Loss trajectory unchanged (epoch average 10.67, same synthetic batch).
+
+| field | value | how to recompute it |
+|---|---|---|
+| `value`, `ms_per_step` | {pairs(bench['value'])} pairs/s, {bench['ms_per_step']:.3f} ms | 256 pairs x 20 steps / wall time between `torch.cuda.synchronize()`s around `train_one_epoch_vl`; kernel sum of one step: {busy_ms:.2f} ms (`{tag}_step_launches.txt`) |
+| `flops.blocks_only` | {bo['ms_per_step']:.2f} ms, {bo['tflops']:.1f} TFLOP/s, **{bo['mfma_frac']:.3f}** | HIP events around the Block kernels of every stage, fwd + bwd, two extra iterations; 3 x 8.003 GFLOP x 256 / {bo['ms_per_step']:.2f} ms / 2.5 PFLOP/s |
+| `flops.mfma_frac_executed` | {fl_['mfma_frac_executed']:.3f} | {fl_['executed_gflop_per_pair']:.2f} GFLOP/pair executed (MLM head on the selected rows of 32768 only; + 2.32 fc1 recomputed) x {pairs(bench['value'])} / 2.5 PFLOP/s |
+| `roofline` (kernel `mlp_wgrad2_kernel<64, 4>`, the launch VERDICT r3 named) | achieved {rf['achieved']:.1f} TFLOP/s, **frac {rf['frac']:.3f}**, {rf['ms_per_launch']:.3f} ms | algorithmic FLOPs 2 x 2 M C hid = 4 x 1081344 x 64 x 512 = 141.73 GFLOP / {rf['ms_per_launch']:.3f} ms (HIP events, 20 launches, torch's current stream = the launch stream); `{tag}_kernel_stats.csv`: {ks_avg_us:.1f} us average over {ks_calls} calls (in-step + this timing) -> {141.73392 / ks_avg_us * 1e3:.1f} TFLOP/s = {141.73392 / ks_avg_us * 1e3 / 2500:.3f}; executed FLOPs are twice the algorithmic ones (h and dg recomputed on chip) |
+| `roofline.traffic` | {rf['traffic'] / 1e6:.1f} MB per launch | `{tag}_roofline_traffic.json`: 2 x FETCH_SIZE ({mw['fetch_size_kib']:,.0f} KiB) + WRITE_SIZE ({mw['write_size_kib']:,.0f} KiB), separate `--pmc` passes over `tools/roofline_launch.py`, {mw['dispatches']} dispatches; calibration in the same run: torch's fp32 -> bf16 cast of a 262144 x 192 tensor reads {cal['read_bytes'] / 1e6:.2f} MB (expected {cal['expected_read_bytes'] / 1e6:.2f}) and writes {cal['write_bytes'] / 1e6:.2f} ({cal['expected_write_bytes'] / 1e6:.2f}); algorithmic bytes 276.8 MB -> {rf['traffic'] / 276.824064e6:.2f} x (the partial-sum flushes) |
+| `roofline.siblings` | conv3x3 192 -> 192: {sib[0]['achieved']:.0f} TFLOP/s = **{sib[0]['frac']:.2f}**, {sib[0]['traffic'] / 1e6:.1f} MB; K = 64 projection: {sib[1]['achieved'] / 1e3:.2f} TB/s = **{sib[1]['frac']:.2f}** of 8 TB/s, {sib[1]['traffic'] / 1e6:.0f} MB | 173.9 GFLOP / {sib[0]['ms_per_launch']:.4f} ms; 276.8 MB / {sib[1]['ms_per_launch']:.4f} ms |
+| `step.hbm_gb_per_step` | {st['hbm_gb_per_step']:.2f} GB, {st['hbm_tb_per_s']:.2f} TB/s | `{tag}_step_traffic.txt`: FETCH_SIZE x 2 + WRITE_SIZE over 6 whole steps of the bench process, per kernel (round 3: 66.65; first half of round 4: 66.05) |
+| `cpu_baseline` | {cb['value']:.1f} pairs/s train step, {cb.get('forward_loss_value', 0):.1f} forward + loss, {cb['cores']} cores, `kind: {cb['kind']}` | the oracle at config #1 shapes (4 pairs, fp32), ~20 s sample on the box's host cores; a reported baseline, not a target |
+| `other_configs` | medium384_b64 **{pairs(oc['medium384_b64']['pairs_s'])} pairs/s** ({oc['medium384_b64']['ms_per_step']:.1f} ms), finetune **{pairs(oc['finetune']['pairs_s'])} pairs/s** ({oc['finetune']['ms_per_step']:.1f} ms) | BASELINE configurations #4 / #5 at one GPU, 5 + 10 / 20 + 20 iterations of the same engine entry behind the headline (round 3, builder-run: 1 570 / 13 600) |
+"""
+
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
-for name, text in (("3.1", t31), ("3.2", t32)):
+for name, text in (("3.1", t31), ("3.2", t32), ("6", t6)):
     b, e = f"<!-- BEGIN:{name} -->", f"<!-- END:{name} -->"
     i, j = s.index(b) + len(b), s.index(e)
     s = s[:i] + "\n" + text + s[j:]
