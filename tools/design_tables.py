@@ -34,6 +34,7 @@ for line in open(P("step_launches.txt")).read().split("\n")[2:]:
     a[0] += n
     a[1] += us
 total = sum(v[1] for v in fam.values())
+_rf = json.loads(open(P("bench_n1.json")).read().strip().split("\n")[-1])["roofline"]["frac"]
 row = lambda k: (fam.get(k, [0, 0.0])[0], fam.get(k, [0, 0.0])[1], 100.0 * fam.get(k, [0, 0.0])[1] / total)
 R = {}
 for k in fam:
@@ -53,7 +54,7 @@ enqueue a step than the GPU needs to run it, `docs/experiments_r4.md` 9.  Unprof
 | `gemm_nt_dma_kernel` (128-wide NT GEMMs: K <= 128 projections, gathers, small heads) | {g('gemm_nt_dma')} | HBM for K = 64 / 128 (`proj64` sibling: 0.60-0.70 of 8 TB/s); TA / L1 path for the rest (`r03_l1_stalls.txt`) |
 | `gemm_nt_p8_kernel` (8-wave / 8-phase NT GEMMs, stage 3-4, MLM logits) | {g('gemm_nt_p8')} | K-loop ~1.45 PFLOP/s while a round is full; launches 0.23-0.57 of peak: whole-round quantisation + an epilogue nothing overlaps; the activation-storing launches within 1.4 x of their HBM floor (3.2, 3.3) |
 | `mlp_pipe_kernel` (fused MLP forward / input gradient, stages 1-2) | {g('mlp_pipe')} | VALU (GELU: 10 instructions per hidden element) + MFMA, partly overlapped: MFMA-busy 0.28-0.35, VALU-active 0.26-0.35 (`{tag}_mfma_counters.csv`) |
-| `mlp_wgrad2_kernel` (fused MLP weight gradients) | {g('mlp_wgrad2')} | VALU + MFMA add up (`roofline`: 0.166 algorithmic / 0.33 executed); LDS table gather 0.43 conflicts (inherent, `experiments_r4.md` 4) |
+| `mlp_wgrad2_kernel` (fused MLP weight gradients) | {g('mlp_wgrad2')} | VALU + MFMA add up (`roofline`: {_rf:.3f} algorithmic / {2 * _rf:.2f} executed); LDS table gather 0.43 conflicts (inherent, `experiments_r4.md` 4) |
 | LayerNorm forward / backward (standalone launches) | {g('ln')} | HBM + Infinity Cache: 4.5-7.8 TB/s algorithmic (streaming passes over the fp32 residual stream); round 3 / first half of round 4: 2238 us (`experiments_r4.md` 7) |
 | `conv3_nt_kernel` (MIM conv3x3 forward / dgrad) | {g('conv3_nt')} | MFMA / LDS-DMA: 1.0-1.24 PFLOP/s (0.41-0.50), MFMA-busy 0.48 |
 | MIM decoder non-GEMM (BatchNorm, upsample, products, fused loss) | {g('mim')} | HBM streaming, fp16 z and product factors (first half of round 4: 1482 us, `experiments_r4.md` 8) |
