@@ -505,6 +505,18 @@ def test_integration_md_binding_snippet_matches_the_header():
     assert C.sizeof(ns["GemmNTArgs"]) == L.lib.mvlt_sizeof(b"mvlt_gemm_nt_args")
 
 
+def test_design_tables_match_the_committed_profiles():
+    """DESIGN.md sections 3.1 / 3.2 / 6 are generated from the committed profiles of a round (tools/design_tables.py rNN): the committed document
+    must be what those files say.  (Whether the counter files still belong to the kernel sources of the tree is bench.py's business: it reports
+    `traffic: null` + `traffic_stale` when the stamped source hash differs.)"""
+    import re
+    import subprocess
+    import sys
+    tag = re.search(r"`profiles/(r\d+)_step_launches\.txt`", open(os.path.join(ROOT, "DESIGN.md")).read()).group(1)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_tables.py"), tag, "--check"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_cosine_schedule_per_epoch_values():
     """mvlt_amd.sched: the reference's per-epoch cosine schedule (main_vl.py:69-87,310,439; timm CosineLRScheduler restated)"""
     import math

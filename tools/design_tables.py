@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """Regenerates the measured tables of DESIGN.md section 3 (3.1: one step by kernel family, 3.2: the MFMA-carrying launches) from the committed
 profiles of a round, so that the document cannot drift from the files it cites:
-    python tools/design_tables.py r04            # rewrites the text between the <!-- BEGIN:3.x --> / <!-- END:3.x --> markers of DESIGN.md"""
+    python tools/design_tables.py r04            # rewrites the text between the <!-- BEGIN:3.x --> / <!-- END:3.x --> markers of DESIGN.md
+    python tools/design_tables.py r04 --check    # exit 1 if the document and the profiles disagree"""
 import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+tag = args[0] if args else "r04"
+CHECK = "--check" in sys.argv          # exit 1 if DESIGN.md differs from what the profiles say (tests/test_host_cpu.py)
 P = lambda name: os.path.join(ROOT, "profiles", f"{tag}_{name}")
 
 # ---------------------------------------------------------------- 3.1
@@ -192,5 +195,11 @@ for name, text in (("3.1", t31), ("3.2", t32), ("6", t6)):
     b, e = f"<!-- BEGIN:{name} -->", f"<!-- END:{name} -->"
     i, j = s.index(b) + len(b), s.index(e)
     s = s[:i] + "\n" + text + s[j:]
+if CHECK:
+    if s != open(p).read():
+        print("DESIGN.md sections 3.1 / 3.2 / 6 differ from profiles/%s_*: run python tools/design_tables.py %s" % (tag, tag))
+        sys.exit(1)
+    print("DESIGN.md sections 3.1 / 3.2 / 6 match profiles/%s_*" % tag)
+    sys.exit(0)
 open(p, "w").write(s)
 print(f"DESIGN.md 3.1 / 3.2 rewritten from profiles/{tag}_*: {n_launch} launches, busy {busy_ms:.2f} ms, twelve MLP launches {twelve:.0f} us, blocks-only {bo['mfma_frac']:.3f}")
