@@ -363,6 +363,11 @@ int mvlt_bn_finalize(const float* sum, const float* sumsq, int copies /* accumul
 int mvlt_bn_norm(const void* z, int ldz, int z_dtype, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
                  void* y32, int ld32, int y32_dtype /* 1 fp32; 2 fp16 (with an fp16 z: the factors of the decoder's three-way feature product, which only
                  elementwise kernels read) */, void* y_op, int ld_op, int op_dtype /* dtype of y_op: the MFMA-operand copy */, void* stream);
+/* mvlt_bn_finalize + mvlt_bn_norm in one launch for an fp16 z (the bf16 training path): every workgroup derives the statistics from the conv epilogue's sums,
+ * workgroup 0 stores mean / rstd for the backward pass and updates the running statistics (bit-identical to the two separate calls) */
+int mvlt_bn_finalize_norm(const void* z /* fp16 */, int ldz, const float* sum, const float* sumsq, int copies, float eps, float momentum, float* mean, float* rstd,
+                          float* running_mean, float* running_var /* nullable pair */, const float* gamma, const float* beta, long M, int C,
+                          void* y32, int ld32, int y32_dtype, void* y_op /* bf16 */, int ld_op, void* stream);
 /* dy (the gradient w.r.t. the BatchNorm output) is fp32 (dy_dtype 1) or bf16 (dy_dtype 0: what the decoder's first backward stages hand
  * over -- a gradient tensor is read twice here and written once by its producer) */
 int mvlt_bn_bwd_reduce(const void* dy, int lddy, const void* z, int ldz, int z_dtype, const float* mean, const float* rstd, long M, int C,

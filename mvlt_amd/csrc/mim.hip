@@ -289,6 +289,44 @@ __global__ __launch_bounds__(NT) void bn_norm8_kernel(const _Float16* z, int ldz
   }
 }
 
+// the same with bn_finalize_kernel's work in its prologue (eleven 64..192-thread launches of ~6.5 us each per step otherwise): every workgroup derives mean / rstd of
+// the C <= 256 channels from the conv epilogue's sums into LDS -- same operation order as bn_finalize_kernel, so the statistics are bit-identical -- and workgroup 0
+// stores them for the backward pass and updates the running statistics
+template <typename TY>
+__global__ __launch_bounds__(NT) void bn_fin_norm8_kernel(const _Float16* z, int ldz, const float* sum, const float* sumsq, int copies, long Mstat, float eps, float momentum,
+                                                          float* mean, float* rstd, float* running_mean, float* running_var, const float* gamma, const float* beta,
+                                                          long M, int C, TY* y32, int ld32, bf16* y16, int ld16) {
+  __shared__ __attribute__((aligned(16))) float s_mu[256], s_rs[256];
+  for (int c = threadIdx.x; c < C; c += NT) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < copies; ++k) { s1 += sum[(long)k * C + c]; s2 += sumsq[(long)k * C + c]; }
+    const float m = s1 / (int)Mstat;
+    const float var = fmaxf(s2 / (int)Mstat - m * m, 0.f);
+    const float r = rsqrtf(var + eps);
+    s_mu[c] = m; s_rs[c] = r;
+    if (blockIdx.x == 0) {
+      mean[c] = m; rstd[c] = r;
+      if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        const float unb = Mstat > 1 ? var * ((float)(int)Mstat / (float)((int)Mstat - 1)) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+      }
+    }
+  }
+  __syncthreads();
+  const int cq = C / 8;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < M * cq; i += (long)gridDim.x * NT) {
+    long r = i / cq; int c = (int)(i - r * cq) * 8;
+    float v[8], ga[8], be[8], o[8];
+    load8<_Float16>(z + r * ldz + c, v);
+    load8<float>(gamma + c, ga); load8<float>(beta + c, be);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (v[e] - s_mu[c + e]) * s_rs[c + e] * ga[e] + be[e];
+    if (y32) store8<TY>(y32 + r * ld32 + c, o);
+    if (y16) store8<bf16>(y16 + r * ld16 + c, o);
+  }
+}
+
 template <typename TDY>
 __global__ __launch_bounds__(NT) void bn_bwd_apply8_kernel(const TDY* dy, int lddy, const _Float16* z, int ldz, const float* mean, const float* rstd,
                                                            const float* gamma, const float* s1, const float* s2, long M, int C, bf16* dz, int lddz,
@@ -834,6 +872,25 @@ extern "C" int mvlt_bn_norm(const void* z_, int ldz, int z_dtype, const float* m
   else if (op_dtype == 0) hipLaunchKernelGGL((bn_norm_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
   else hipLaunchKernelGGL((bn_norm_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (float*)y16, ld16);
   return mvlt_check_launch("mvlt_bn_norm");
+}
+
+extern "C" int mvlt_bn_finalize_norm(const void* z_, int ldz, const float* sum, const float* sumsq, int copies, float eps, float momentum, float* mean, float* rstd,
+                                     float* running_mean, float* running_var, const float* gamma, const float* beta, long M, int C,
+                                     void* y32_, int ld32, int y32_dtype, void* y16, int ld16, void* stream) {
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  MVLT_REQUIRE(z_ && sum && sumsq && mean && rstd && gamma && beta && (y32_ || y16) && M > 0 && M < (1L << 31) && copies >= 1, "mvlt_bn_finalize_norm: bad arguments");
+  MVLT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mvlt_bn_finalize_norm: running_mean and running_var go together");
+  MVLT_REQUIRE(C % 8 == 0 && C <= 256 && ldz % 8 == 0 && al16(z_) && al16(gamma) && al16(beta) && (!y32_ || (al16(y32_) && ld32 % (y32_dtype == 2 ? 8 : 4) == 0 && (y32_dtype == 1 || y32_dtype == 2))) &&
+               (!y16 || (al16(y16) && ld16 % 8 == 0)),
+               "mvlt_bn_finalize_norm: fp16 z, C a multiple of 8 and <= 256, row strides multiples of 8, 16-byte aligned tensors (the bf16 training path of the MIM decoder)");
+  const dim3 grid(grid_for(M * (C / 8)));
+  if (y32_ && y32_dtype == 2)
+    hipLaunchKernelGGL((bn_fin_norm8_kernel<_Float16>), grid, dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, sum, sumsq, copies, M, eps, momentum, mean, rstd, running_mean, running_var,
+                       gamma, beta, M, C, (_Float16*)y32_, ld32, (bf16*)y16, ld16);
+  else
+    hipLaunchKernelGGL((bn_fin_norm8_kernel<float>), grid, dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, sum, sumsq, copies, M, eps, momentum, mean, rstd, running_mean, running_var,
+                       gamma, beta, M, C, (float*)y32_, ld32, (bf16*)y16, ld16);
+  return mvlt_check_launch("mvlt_bn_finalize_norm");
 }
 
 extern "C" int mvlt_bn_bwd_reduce(const void* dy_, int lddy, const void* z_, int ldz, int z_dtype, const float* mean, const float* rstd, long M, int C,

@@ -24,6 +24,7 @@ CONVS = ("reduction1", "reduction2", "reduction3", "conv_upsample1", "conv_upsam
 
 _FP32_DY = bool(os.environ.get("MVLT_MIM_FP32_DY"))      # A/B switch: every gradient map of the decoder's backward in fp32
 _FP32_Z = bool(os.environ.get("MVLT_MIM_FP32_Z"))        # A/B switch: the pre-BatchNorm conv outputs stay fp32 on the bf16 path (rounds 1-3)
+_NO_FIN_FUSE = bool(os.environ.get("MVLT_MIM_NO_FIN_FUSE"))   # A/B switch: BatchNorm statistics finalised by their own launch
 _NO_BN_FOLD = bool(os.environ.get("MVLT_MIM_NO_BN_FOLD"))   # A/B switch: eval mode keeps the separate BatchNorm pass over an fp32 z
 
 
@@ -72,15 +73,20 @@ class MimStep:
         else:
             ops.gemm_nt(xin, S.extra[p + ".0.weight::K"], z, M, cout, 9 * cin, ld_in, 9 * cin, cout, a_map=amap, col_sum=st[0], col_sumsq=st[1],
                         col_copies=STAT_COPIES)
+        fin = None
         if self.training:
             mean, rstd = _e((cout,), dev), _e((cout,), dev)
-            ops.bn_finalize(st[0], st[1], M, cout, BN_EPS, BN_MOM, mean, rstd, bn.running_mean, bn.running_var, copies=STAT_COPIES)
+            if z16 and cout % 8 == 0 and cout <= 256 and not _NO_FIN_FUSE:
+                # the statistics are finalised in the prologue of the normalisation launch (`norm`): eleven tiny launches fewer per step
+                fin = (st[0], st[1], bn.running_mean, bn.running_var)
+            else:
+                ops.bn_finalize(st[0], st[1], M, cout, BN_EPS, BN_MOM, mean, rstd, bn.running_mean, bn.running_var, copies=STAT_COPIES)
             self.nbt.append(bn.num_batches_tracked)        # all eleven counters are bumped by one launch at the end of forward
         else:
             mean = bn.running_mean
             rstd = torch.rsqrt(bn.running_var + BN_EPS)
         r = dict(name=name, p=p, z=z, mean=mean, rstd=rstd, xin=xin, ld_in=ld_in, amap=amap, cin=cin, cout=cout, M=M, side=side,
-                 tokens_in=tokens_in)
+                 tokens_in=tokens_in, fin=fin)
         self.rec[name] = r
         return r
 
@@ -106,6 +112,12 @@ class MimStep:
             for y, ld in ((y32, ld32), (y16, ld16)):
                 if y is not None:
                     ops.gemm_nt(r["xin"], wk, y, r["M"], r["cout"], 9 * r["cin"], r["ld_in"], 9 * r["cin"], ld, a_map=r["amap"], bias=shift)
+            return
+        if r.get("fin") is not None:
+            s1, s2, rm, rv = r["fin"]
+            r["fin"] = None                                # (a second `norm` of the same record must not update the running statistics again)
+            ops.bn_finalize_norm(r["z"], r["cout"], s1, s2, STAT_COPIES, BN_EPS, BN_MOM, r["mean"], r["rstd"], rm, rv, S.master(r["p"] + ".1.weight"),
+                                 S.master(r["p"] + ".1.bias"), r["M"], r["cout"], y32, ld32, y16, ld16)
             return
         ops.bn_norm(r["z"], r["cout"], r["mean"], r["rstd"], S.master(r["p"] + ".1.weight"), S.master(r["p"] + ".1.bias"), r["M"], r["cout"],
                     y32, ld32, y16, ld16)

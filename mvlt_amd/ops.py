@@ -287,6 +287,15 @@ def bn_norm(z, ldz, mean, rstd, gamma, beta, M, Cdim, y32=None, ld32=0, y16=None
                              DT[y16.dtype] if y16 is not None else 0, stream_ptr()), "mvlt_bn_norm")
 
 
+L.lib.mvlt_bn_finalize_norm.argtypes = [_vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _i, _vp, _i, _vp]
+
+
+def bn_finalize_norm(z, ldz, s, ss, copies, eps, momentum, mean, rstd, running_mean, running_var, gamma, beta, M, Cdim, y32=None, ld32=0, y16=None, ld16=0):
+    assert z.dtype == torch.float16 and (y16 is None or y16.dtype == torch.bfloat16)
+    check(L.lib.mvlt_bn_finalize_norm(_p(z), ldz, _p(s), _p(ss), copies, eps, momentum, _p(mean), _p(rstd), _p(running_mean), _p(running_var), _p(gamma), _p(beta), M, Cdim,
+                                      _p(y32), ld32, ZDT[y32.dtype] if y32 is not None else 1, _p(y16), ld16, stream_ptr()), "mvlt_bn_finalize_norm")
+
+
 def bn_bwd_reduce(dy, lddy, z, ldz, mean, rstd, M, Cdim, s1, s2):
     assert dy.dtype in DT and z.dtype in ZDT
     check(L.lib.mvlt_bn_bwd_reduce(_p(dy), lddy, _p(z), ldz, ZDT[z.dtype], _p(mean), _p(rstd), M, Cdim, _p(s1), _p(s2), DT[dy.dtype], stream_ptr()), "mvlt_bn_bwd_reduce")

@@ -929,6 +929,33 @@ def test_batchnorm_fwd_bwd(ops, M, C, lddy, off):
             assert torch.equal(da, db)
 
 
+@pytest.mark.parametrize("M,C,copies", [(4096, 64, 16), (3000, 192, 4), (777, 128, 1)])
+def test_batchnorm_finalize_inside_the_normalise_launch(ops, M, C, copies):
+    """mvlt_bn_finalize_norm == mvlt_bn_finalize followed by mvlt_bn_norm, bit for bit: statistics, running statistics, both outputs (fp16 z; reference
+    libs/vl_heads.py:113-125)."""
+    z = (rnd(M, C, dtype=torch.float32, scale=2.0) + 0.5).to(torch.float16)
+    gamma, beta = rnd(C, dtype=torch.float32, seed=1) + 1.0, rnd(C, dtype=torch.float32, seed=2)
+    zf = z.float()
+    parts = torch.zeros(2, copies, C, device=dev())
+    for k in range(copies):                                   # the conv epilogue's interleaved accumulators: row tile t adds into copy t % copies
+        rows = zf[k::copies]
+        parts[0, k], parts[1, k] = rows.sum(0), (rows * rows).sum(0)
+    outs = []
+    for fused in (False, True):
+        mean, rstd = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+        rm, rv = torch.full((C,), 0.25, device=dev()), torch.full((C,), 1.5, device=dev())
+        y32, y16 = torch.empty(M, C, device=dev(), dtype=torch.float16), torch.empty(M, 2 * C, device=dev(), dtype=torch.bfloat16)
+        if fused:
+            ops.bn_finalize_norm(z, C, parts[0], parts[1], copies, 1e-5, 0.1, mean, rstd, rm, rv, gamma, beta, M, C, y32=y32, ld32=C, y16=y16[:, C:], ld16=2 * C)
+        else:
+            ops.bn_finalize(parts[0], parts[1], M, C, 1e-5, 0.1, mean, rstd, rm, rv, copies=copies)
+            ops.bn_norm(z, C, mean, rstd, gamma, beta, M, C, y32=y32, ld32=C, y16=y16[:, C:], ld16=2 * C)
+        outs.append((mean, rstd, rm, rv, y32, y16[:, C:].clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert maxrel(outs[1][0], zf.mean(0)) < 1e-4 and maxrel(outs[1][1], (zf.var(0, unbiased=False) + 1e-5).rsqrt()) < 1e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_row_scale(ops, dtype):
     B, N, C = 5, 37, 64
