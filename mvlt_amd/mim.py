@@ -284,7 +284,7 @@ class _MimFn(torch.autograd.Function):
         step.S.queue_finalize()
         g2, g3, g4 = step.backward(dout, ctx.sink)
         ctx.step = ctx.sink = None
-        step.S.fold_copies()                          # the conv weight gradients leave the tap arena for G
+        step.S.fold_copies(early=True)                # the conv weight gradients leave the tap arena for G (with a data-parallel wrapper: now)
         step.S.announce_prefix("t2i_head.")          # the decoder's gradients are final: reduce them under the trunk backward
         return g2, g3, g4, None, None, None, None, None
 

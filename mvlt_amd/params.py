@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import ops
 
+_EARLY_FOLDS = bool(os.environ.get("MVLT_EARLY_FOLDS"))        # A/B switch: gradient-copy folds after every backward stage also without a data-parallel wrapper
 _PREP_FP32_SRC = bool(os.environ.get("MVLT_PREP_FP32_SRC"))     # A/B switch: transposed weight copies read the fp32 masters (rounds 1-3)
 ALIGN = 8
 
@@ -424,9 +425,14 @@ class FlatStore:
         self._ln_hi = slot + n if self._ln_hi is None else max(self._ln_hi, slot + n)
         return self._ln_arena[0, slot:slot + n]
 
-    def fold_copies(self):
-        """sum the accumulator copies (LayerNorm parameters) and the tap-ordered conv weight gradients touched since the last fold into G"""
+    def fold_copies(self, early=False):
+        """sum the accumulator copies (LayerNorm parameters) and the tap-ordered conv weight gradients touched since the last fold into G.
+        early=True marks the folds whose only purpose is to finish a range before it is handed to the data-parallel wrapper (after the MIM decoder, after
+        each trunk stage): without a wrapper they wait for the fold at the end of the trunk's backward -- two launches per step instead of nine
+        (every small launch between two large ones costs several times its own duration in drained pipelines)."""
         from . import ops
+        if early and self.on_range_ready is None and not _EARLY_FOLDS:
+            return
         if getattr(self, "_tap_lo", None) is not None:
             ops.fold_copies(self._tap_arena, 1, self._tap_arena.numel(), self._tap_index, self._tap_lo, self._tap_hi, self.G)
             self._tap_lo = self._tap_hi = None
@@ -465,7 +471,7 @@ class FlatStore:
     def announce_stage(self, i):
         """backward of stage i finished: its parameter gradients are final -> let the data-parallel wrapper start
         reducing them while the earlier stages are still running."""
-        self.fold_copies()
+        self.fold_copies(early=True)
         if self.on_range_ready is not None:
             lo, hi = self.stage_range(i)
             self._ranges_done.append((lo, hi))
