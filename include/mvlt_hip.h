@@ -156,7 +156,8 @@ int mvlt_fold_copies(float* arena, int copies, long stride, const int* dst_index
 
 /* out[r,c] (fp32) = sum_b in[(b*batch_stride_rows + r) * ld + c]: gradient of the broadcast "+ pos_embed /
  * text_pos_embed" of reference libs/pvlt.py:346 (reduction over the batch). */
-int mvlt_batch_sum(const void* in, float* out, int B, int R, int C, long batch_stride_rows, int ld, int dtype, void* stream);
+int mvlt_batch_sum(const void* in, float* out, int B, int R, int C, long batch_stride_rows, int ld, int dtype,
+                   float* acc2 /* nullable: rows r >= split are ADDED to acc2[(r - split), :] instead of stored to out (text_pos_embed's gradient) */, int split, void* stream);
 
 /* Spatial-reduction attention core: O = softmax(Q K^T * scale) V per (batch, head), head_dim = 64,
  * M <= 320 keys (whole K/V of a head stays in LDS; single-pass softmax).  No mask (reference
@@ -278,6 +279,9 @@ int mvlt_cast_bf16(const float* src, void* dst, long n, void* stream);
 /* out[row,:] = x[row,:] * scale[row / rows_per_scale] over contiguous [M, C]: the per-sample DropPath factor applied to a
  * block's incoming gradient before its branch GEMMs (timm drop_path backward, reference libs/pvlt.py:133-134). */
 int mvlt_row_scale(const void* x, const float* scale, int rows_per_scale, long M, int C, void* out, int dtype, void* stream);
+/* backward of the small classification heads (reference libs/vl_heads.py:73-104): dl[B, n_pad] (operand dtype, columns >= n zero) = dlogits[B, n] (fp32),
+ * db1[n] += column sums of dlogits, db2[n] += the same (nullable: the heads have two bias parameters, `linear.bias` and `linear_bias`); n_pad <= 256 */
+int mvlt_head_grad_prep(const float* dlogits, int B, int n, int n_pad, void* dl, float* db1, float* db2, int dtype, void* stream);
 /* out[c*ld_out + r] = in[r*C + c] (fp32 master weight -> transposed compute-dtype operand for the dgrad GEMMs) */
 int mvlt_transpose_cast(const float* in, void* out, int R, int C, int ld_out, int dtype, void* stream);
 

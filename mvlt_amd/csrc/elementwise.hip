@@ -410,6 +410,31 @@ __global__ __launch_bounds__(NT) void row_scale_kernel(const T* x, const float* 
   }
 }
 
+// ---- small classification heads (ITM: B x 2, CLS: B x 48 / B x 122; reference libs/vl_heads.py:73-104), backward: the padded operand-dtype copy of dlogits
+// that the weight- and input-gradient GEMMs read, and db += column sums of dlogits into the head's TWO bias parameters (`linear.bias` and `linear_bias`), in one
+// launch of one workgroup (six ATen launches before: zeros, cast, slice copy, sum, two adds -- each a drained pipeline between two large kernels)
+template <typename T>
+__global__ __launch_bounds__(NT) void head_grad_prep_kernel(const float* dlogits, int B, int n, int n_pad, T* dl, float* db1, float* db2) {
+  __shared__ float part[NT];
+  const int c = threadIdx.x % n_pad, r0 = threadIdx.x / n_pad, rstep = NT / n_pad;
+  float acc = 0.f;
+  if (r0 < rstep) {
+    for (int r = r0; r < B; r += rstep) {
+      const float v = c < n ? dlogits[(long)r * n + c] : 0.f;
+      dl[(long)r * n_pad + c] = from_f32<T>(v);
+      acc += v;
+    }
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < n) {
+    float t = 0.f;
+    for (int k = 0; k < rstep; ++k) t += part[k * n_pad + threadIdx.x];
+    db1[threadIdx.x] += t;
+    if (db2) db2[threadIdx.x] += t;
+  }
+}
+
 // out[c][r] = (T) in[r][c]   (fp32 master weight [R,C] -> transposed compute copy for the dgrad GEMMs)
 template <typename T>
 __global__ __launch_bounds__(NT) void transpose_cast_kernel(const float* in, T* out, int R, int Ccols, int ld_out) {
@@ -752,6 +777,13 @@ extern "C" int mvlt_row_scale(const void* x, const float* scale, int rows_per_sc
   if (dtype == 0) hipLaunchKernelGGL((row_scale_kernel<bf16>), dim3(grid_for(n / 8, 8192)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, scale, per, n, (bf16*)out);
   else hipLaunchKernelGGL((row_scale_kernel<float>), dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, (const float*)x, scale, per, n, (float*)out);
   return mvlt_check_launch("mvlt_row_scale");
+}
+
+extern "C" int mvlt_head_grad_prep(const float* dlogits, int B, int n, int n_pad, void* dl, float* db1, float* db2, int dtype, void* stream) {
+  MVLT_REQUIRE(dlogits && dl && db1 && B > 0 && n > 0 && n_pad >= n && n_pad <= 256 && (dtype == 0 || dtype == 1), "mvlt_head_grad_prep: bad arguments (n_pad <= 256)");
+  if (dtype == 0) hipLaunchKernelGGL((head_grad_prep_kernel<bf16>), dim3(1), dim3(NT), 0, (hipStream_t)stream, dlogits, B, n, n_pad, (bf16*)dl, db1, db2);
+  else hipLaunchKernelGGL((head_grad_prep_kernel<float>), dim3(1), dim3(NT), 0, (hipStream_t)stream, dlogits, B, n, n_pad, (float*)dl, db1, db2);
+  return mvlt_check_launch("mvlt_head_grad_prep");
 }
 
 extern "C" int mvlt_weight_prep(const mvlt_prep_desc* descs, const int* blk_start, int ndesc, int total_blocks, int dtype, void* stream) {

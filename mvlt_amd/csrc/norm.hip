@@ -419,7 +419,7 @@ __global__ __launch_bounds__(1024) void fold_copies_wide_kernel(float* arena, in
 // gave every item to ONE thread looping over the whole batch: 132 workgroups at stage 1, latency-bound at 2.6x the
 // HBM time); partial sums meet in LDS.
 template <typename T>
-__global__ __launch_bounds__(NT) void batch_sum_kernel(const T* in, float* out, int B, int R, int C, long batch_stride, int ld) {
+__global__ __launch_bounds__(NT) void batch_sum_kernel(const T* in, float* out, int B, int R, int C, long batch_stride, int ld, float* acc2, int split) {
   __shared__ float part[16][16][VN + 1];
   const int nchunk = C / VN;
   const long total = (long)R * nchunk;
@@ -447,7 +447,8 @@ __global__ __launch_bounds__(NT) void batch_sum_kernel(const T* in, float* out, 
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) t += part[k][item][e];
-      out[(long)r * C + c * VN + e] = t;
+      if (acc2 && r >= split) acc2[(long)(r - split) * C + c * VN + e] += t;      // rows from `split` on are ADDED to a second destination (text_pos_embed's gradient)
+      else out[(long)r * C + c * VN + e] = t;
     }
   }
 }
@@ -586,13 +587,13 @@ extern "C" int mvlt_layernorm_bwd(const mvlt_layernorm_bwd_args* a, void* stream
   }
 }
 
-extern "C" int mvlt_batch_sum(const void* in, float* out, int B, int R, int C, long batch_stride_rows, int ld, int dtype, void* stream) {
-  MVLT_REQUIRE(in && out && B > 0 && R >= 0 && C > 0, "mvlt_batch_sum: bad arguments");
+extern "C" int mvlt_batch_sum(const void* in, float* out, int B, int R, int C, long batch_stride_rows, int ld, int dtype, float* acc2, int split, void* stream) {
+  MVLT_REQUIRE(in && out && B > 0 && R >= 0 && C > 0 && (!acc2 || (split >= 0 && split <= R)), "mvlt_batch_sum: bad arguments");
   MVLT_REQUIRE(C % 8 == 0 && ld % 8 == 0, "mvlt_batch_sum: C/ld must be multiples of 8");
   if (R == 0) return MVLT_OK;
   long total = (long)R * (C / 8);
   int grid = (int)((total + 15) / 16);
-  if (dtype == 0) hipLaunchKernelGGL((batch_sum_kernel<bf16>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const bf16*)in, out, B, R, C, batch_stride_rows, ld);
-  else hipLaunchKernelGGL((batch_sum_kernel<float>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const float*)in, out, B, R, C, batch_stride_rows, ld);
+  if (dtype == 0) hipLaunchKernelGGL((batch_sum_kernel<bf16>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const bf16*)in, out, B, R, C, batch_stride_rows, ld, acc2, split);
+  else hipLaunchKernelGGL((batch_sum_kernel<float>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const float*)in, out, B, R, C, batch_stride_rows, ld, acc2, split);
   return mvlt_check_launch("mvlt_batch_sum");
 }

@@ -111,12 +111,13 @@ def fold_copies(arena, copies, stride, dst_index, j0, j1, dst):
     check(L.lib.mvlt_fold_copies(ptr(arena), copies, stride, ptr(dst_index), j0, j1, ptr(dst), stream_ptr()), "mvlt_fold_copies")
 
 
-L.lib.mvlt_batch_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]
+L.lib.mvlt_batch_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
 
 
-def batch_sum(x, out, B, R, Cdim, batch_stride_rows, ld):
-    assert out.dtype == torch.float32
-    check(L.lib.mvlt_batch_sum(ptr(x), ptr(out), B, R, Cdim, batch_stride_rows, ld, DT[x.dtype], stream_ptr()), "mvlt_batch_sum")
+def batch_sum(x, out, B, R, Cdim, batch_stride_rows, ld, acc2=None, split=0):
+    """out[r] = sum over the batch of x[b, r]; with acc2, rows r >= split are added to acc2[r - split] instead"""
+    assert out.dtype == torch.float32 and (acc2 is None or (acc2.dtype == torch.float32 and acc2.is_contiguous()))
+    check(L.lib.mvlt_batch_sum(ptr(x), ptr(out), B, R, Cdim, batch_stride_rows, ld, DT[x.dtype], ptr(acc2), split, stream_ptr()), "mvlt_batch_sum")
     return out
 
 
@@ -174,6 +175,16 @@ def bert_embed_bwd(dy, ids, word, pos, type0, gamma, keep, drop_p, mean, rstd, d
     check(L.lib.mvlt_bert_embed_bwd(_p(dy), _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(keep), drop_p,
                                     _p(mean), _p(rstd), _p(dword), _p(dpos), _p(dtype0), _p(dgamma), _p(dbeta),
                                     rows, T, word.shape[1], DT[dy.dtype], stream_ptr()), "mvlt_bert_embed_bwd")
+
+
+L.lib.mvlt_head_grad_prep.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]
+
+
+def head_grad_prep(dlogits, dl, db1, db2=None):
+    """dl[B, n_pad] = dlogits[B, n] (zero padded, dl's dtype); db1 (and db2) += dlogits.sum(0)"""
+    assert dlogits.dtype == torch.float32 and dlogits.is_contiguous() and dl.is_contiguous() and dl.dtype in DT and db1.dtype == torch.float32
+    B, n = dlogits.shape
+    check(L.lib.mvlt_head_grad_prep(_p(dlogits), B, n, dl.shape[1], _p(dl), _p(db1), _p(db2), DT[dl.dtype], stream_ptr()), "mvlt_head_grad_prep")
 
 
 def patchify(img, out, B, Cin, H, W, k):

@@ -408,8 +408,7 @@ class TrunkStep:
         f32 = torch.float32
         # pos-embed / text-pos-embed gradients: sum over the batch of d(x0)
         dpos_all = _empty((N, C), f32, dev)
-        ops.batch_sum(dx, dpos_all, B, N, C, N, C)
-        self.g(f"text_pos_embed{i+1}")[0].add_(dpos_all[HW:])
+        ops.batch_sum(dx, dpos_all, B, N, C, N, C, acc2=self.g(f"text_pos_embed{i+1}")[0], split=HW)        # text rows straight into G
         self._pos_backward(i, dpos_all[:HW])
         # patch-embed LN backward -> d(pe_pre)
         d_pe = _empty((B * HW, C), dt, dev)
@@ -680,11 +679,16 @@ class _ClsHeadFn(torch.autograd.Function):
         Hd = model.hidden
         n_out = dlogits.shape[-1]
         n_pad = (n_out + 7) // 8 * 8
-        dl = torch.zeros(B, n_pad, device=dev, dtype=dt)
-        dl[:, :n_out] = dlogits.reshape(B, n_out).to(dt)
-        db = dlogits.reshape(B, n_out).float().sum(0)
-        S.grad(name + "_head.linear.bias").add_(db)
-        S.grad(name + "_head.linear_bias").add_(db)
+        dl = _empty((B, n_pad), dt, dev)
+        if n_pad <= 256:
+            # padded operand copy + both bias gradients in one launch (six ATen launches before)
+            ops.head_grad_prep(dlogits.reshape(B, n_out).float().contiguous(), dl, S.grad(name + "_head.linear.bias"), S.grad(name + "_head.linear_bias"))
+        else:
+            dl.zero_()
+            dl[:, :n_out] = dlogits.reshape(B, n_out).to(dt)
+            db = dlogits.reshape(B, n_out).float().sum(0)
+            S.grad(name + "_head.linear.bias").add_(db)
+            S.grad(name + "_head.linear_bias").add_(db)
         ops.gemm_tn(dl, e, S.grad(name + "_head.linear.weight"), B, n_out, Hd, n_pad, Hd, Hd)
         de = _empty((B, Hd), dt, dev)
         wT = S.extra[name + "_head.linear.weight::T"]          # [768, n_pad]

@@ -416,6 +416,26 @@ def test_layernorm_into_concat_with_pos(ops, dtype):
     s = torch.empty(HW + T, Cdim, device=dev())
     ops.batch_sum(out, s, Bsz, HW + T, Cdim, HW + T, Cdim)
     assert maxrel(s, out.float().sum(0)) < 1e-5
+    # the rows from `split` on ADDED to a second destination (the trunk's text_pos_embed gradient), the others stored as before
+    full = rnd(Bsz, HW + T, Cdim, dtype=dtype, seed=11)
+    s2 = torch.full((HW + T, Cdim), 7.0, device=dev())
+    acc = torch.full((T, Cdim), 0.5, device=dev())
+    ops.batch_sum(full, s2, Bsz, HW + T, Cdim, HW + T, Cdim, acc2=acc, split=HW)
+    want = full.float().sum(0)
+    assert maxrel(s2[:HW], want[:HW]) < 1e-5 and (s2[HW:] == 7.0).all() and maxrel(acc, want[HW:] + 0.5) < 1e-5
+
+
+def test_head_grad_prep(ops):
+    """backward prologue of the small classification heads: padded operand copy of dlogits + column sums added to both bias gradients"""
+    for B, n in ((256, 2), (64, 48), (37, 122)):
+        n_pad = (n + 7) // 8 * 8
+        dlog = rnd(B, n, dtype=torch.float32, seed=n)
+        for dt in (torch.bfloat16, torch.float32):
+            dl = torch.full((B, n_pad), 9.0, device=dev(), dtype=dt)
+            b1, b2 = torch.full((n,), 1.0, device=dev()), torch.full((n,), 2.0, device=dev())
+            ops.head_grad_prep(dlog, dl, b1, b2)
+            assert torch.equal(dl[:, :n], dlog.to(dt)) and (dl[:, n:] == 0).all()
+            assert maxrel(b1 - 1.0, dlog.sum(0)) < 1e-5 and maxrel(b2 - 2.0, dlog.sum(0)) < 1e-5
 
 
 # ------------------------------------------------------------------ attention
