@@ -219,6 +219,9 @@ int mvlt_masked_select(const long* labels, int n, long ignore_index, int* idx, i
  * source map. */
 int mvlt_resize_bilinear_tokens(const float* in, int ld_in, float* out, int ld_out, int Hin, int Win, int Hout, int Wout, int C, int adjoint,
                                 void* stream);
+/* up to four of them in one launch (host arrays of `count` entries each): the position embeddings of the four stages, and their adjoints */
+int mvlt_resize_bilinear_tokens_multi(const float* const* in, const int* ld_in, float* const* out, const int* ld_out, const int* Hin, const int* Win,
+                                      const int* Hout, const int* Wout, const int* C, int count, int adjoint, void* stream);
 
 /* out = dy * gelu'(h), exact-erf GELU, elementwise over n values (autograd of reference libs/vl_heads.py:13-14,31-32) */
 int mvlt_gelu_bwd(const void* dy, const void* h, void* out, long n, int dtype, void* stream);

@@ -118,7 +118,7 @@ EXPORTS = ["mvlt_last_error", "mvlt_abi_version", "mvlt_sizeof", "mvlt_gemm_nt",
            "mvlt_scatter_rows", "mvlt_cross_entropy_fwd", "mvlt_cross_entropy_bwd", "mvlt_adamw_step", "mvlt_smooth_l1_fwd", "mvlt_smooth_l1_bwd", "mvlt_cast_bf16",
            "mvlt_transpose_cast", "mvlt_row_scale", "mvlt_head_grad_prep", "mvlt_weight_prep", "mvlt_col_stats", "mvlt_bn_finalize", "mvlt_bn_finalize_norm", "mvlt_bn_norm", "mvlt_bn_bwd_reduce", "mvlt_bn_bwd_apply", "mvlt_ew_mul3_bwd",
            "mvlt_ew_mul", "mvlt_upsample_fwd", "mvlt_upsample_bwd", "mvlt_mlp_fwd", "mvlt_mlp_bwd_dx", "mvlt_mlp_bwd_dw",
-           "mvlt_grid_mask_flags", "mvlt_grid_mask_apply", "mvlt_token_mask", "mvlt_resize_bilinear_tokens", "mvlt_gelu_bwd",
+           "mvlt_grid_mask_flags", "mvlt_grid_mask_apply", "mvlt_token_mask", "mvlt_resize_bilinear_tokens", "mvlt_resize_bilinear_tokens_multi", "mvlt_gelu_bwd",
            "mvlt_keep_mask", "mvlt_droppath_scales", "mvlt_loss_compose", "mvlt_add_column_sums",
            "mvlt_upsample_l1_fwd", "mvlt_upsample_l1_bwd"]
 

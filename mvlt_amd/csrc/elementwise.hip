@@ -578,6 +578,39 @@ __global__ __launch_bounds__(NT) void resize_tokens_kernel(const float* in, int 
   }
 }
 
+// up to four resizes in one launch (blockIdx.y = which): the four stages' position embeddings at the start of a forward pass, their four adjoints at the end of
+// the backward pass (eight 5-us launches per step otherwise, each a drained pipeline between two large kernels)
+struct ResizeMulti { const float* in[4]; float* out[4]; int ld_in[4], ld_out[4], Hin[4], Win[4], Hout[4], Wout[4], C[4]; };
+template <bool ADJ>
+__global__ __launch_bounds__(NT) void resize_tokens_multi_kernel(ResizeMulti a) {
+  const int k = blockIdx.y;
+  const float* in = a.in[k];
+  float* out = a.out[k];
+  const int ld_in = a.ld_in[k], ld_out = a.ld_out[k], Hin = a.Hin[k], Win = a.Win[k], Hout = a.Hout[k], Wout = a.Wout[k], C = a.C[k];
+  const float sh = (float)Hin / (float)Hout, sw = (float)Win / (float)Wout;
+  const long n = (long)Hout * Wout * C;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const int c = (int)(i % C);
+    const int px = (int)(i / C);
+    const int y = px / Wout, x = px - y * Wout;
+    const float fy = fmaxf(sh * ((float)y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sw * ((float)x + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    if constexpr (!ADJ) {
+      out[(long)px * ld_out + c] = w00 * in[(long)(y0 * Win + x0) * ld_in + c] + w01 * in[(long)(y0 * Win + x1) * ld_in + c] +
+                                   w10 * in[(long)(y1 * Win + x0) * ld_in + c] + w11 * in[(long)(y1 * Win + x1) * ld_in + c];
+    } else {
+      const float g = in[(long)px * ld_in + c];
+      atomicAdd(&out[(long)(y0 * Win + x0) * ld_out + c], w00 * g);
+      atomicAdd(&out[(long)(y0 * Win + x1) * ld_out + c], w01 * g);
+      atomicAdd(&out[(long)(y1 * Win + x0) * ld_out + c], w10 * g);
+      atomicAdd(&out[(long)(y1 * Win + x1) * ld_out + c], w11 * g);
+    }
+  }
+}
+
 // out = dy * gelu'(h) (exact-erf GELU; BertHeadTransform backward, reference libs/vl_heads.py:13-14,31-32)
 template <typename T>
 __global__ __launch_bounds__(NT) void gelu_bwd_kernel(const T* dy, const T* h, T* out, long n) {
@@ -677,6 +710,25 @@ extern "C" int mvlt_resize_bilinear_tokens(const float* in, int ld_in, float* ou
   if (adjoint) hipLaunchKernelGGL((resize_tokens_kernel<true>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, in, ld_in, out, ld_out, Hin, Win, Hout, Wout, C, sh, sw);
   else hipLaunchKernelGGL((resize_tokens_kernel<false>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, in, ld_in, out, ld_out, Hin, Win, Hout, Wout, C, sh, sw);
   return mvlt_check_launch("mvlt_resize_bilinear_tokens");
+}
+
+extern "C" int mvlt_resize_bilinear_tokens_multi(const float* const* in, const int* ld_in, float* const* out, const int* ld_out, const int* Hin, const int* Win,
+                                                 const int* Hout, const int* Wout, const int* C, int count, int adjoint, void* stream) {
+  MVLT_REQUIRE(in && out && ld_in && ld_out && Hin && Win && Hout && Wout && C && count >= 1 && count <= 4, "mvlt_resize_bilinear_tokens_multi: 1..4 resizes per call");
+  ResizeMulti a{};
+  long nmax = 0;
+  for (int k = 0; k < count; ++k) {
+    MVLT_REQUIRE(in[k] && out[k] && Hin[k] > 0 && Win[k] > 0 && Hout[k] > 0 && Wout[k] > 0 && C[k] > 0 && ld_in[k] >= C[k] && ld_out[k] >= C[k],
+                 "mvlt_resize_bilinear_tokens_multi: bad arguments");
+    a.in[k] = in[k]; a.out[k] = out[k]; a.ld_in[k] = ld_in[k]; a.ld_out[k] = ld_out[k];
+    a.Hin[k] = Hin[k]; a.Win[k] = Win[k]; a.Hout[k] = Hout[k]; a.Wout[k] = Wout[k]; a.C[k] = C[k];
+    const long n = (long)Hout[k] * Wout[k] * C[k];
+    if (n > nmax) nmax = n;
+  }
+  const dim3 grid(grid_for(nmax), (unsigned)count);
+  if (adjoint) hipLaunchKernelGGL((resize_tokens_multi_kernel<true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((resize_tokens_multi_kernel<false>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+  return mvlt_check_launch("mvlt_resize_bilinear_tokens_multi");
 }
 
 extern "C" int mvlt_gelu_bwd(const void* dy, const void* h, void* out, long n, int dtype, void* stream) {

@@ -505,6 +505,22 @@ def loss_compose(losses, weights, out, total):
     return out
 
 
+L.lib.mvlt_resize_bilinear_tokens_multi.argtypes = [_vp] * 9 + [_i, _i, _vp]
+
+
+def resize_bilinear_tokens_multi(jobs, adjoint=False):
+    """jobs: up to four (src, dst, hin, win, hout, wout, Cdim) like resize_bilinear_tokens, one launch"""
+    n = len(jobs)
+    assert 1 <= n <= 4
+    for src, dst, *_ in jobs:
+        assert src.dtype == torch.float32 and dst.dtype == torch.float32 and src.stride(-1) == 1 and dst.stride(-1) == 1
+    P, I = C.c_void_p * n, C.c_int * n
+    arr = lambda f: I(*[f(j) for j in jobs])
+    check(L.lib.mvlt_resize_bilinear_tokens_multi(P(*[j[0].data_ptr() for j in jobs]), arr(lambda j: j[0].stride(0)), P(*[j[1].data_ptr() for j in jobs]),
+                                                  arr(lambda j: j[1].stride(0)), arr(lambda j: j[2]), arr(lambda j: j[3]), arr(lambda j: j[4]), arr(lambda j: j[5]),
+                                                  arr(lambda j: j[6]), n, 1 if adjoint else 0, stream_ptr()), "mvlt_resize_bilinear_tokens_multi")
+
+
 def resize_bilinear_tokens(src, dst, hin, win, hout, wout, Cdim, adjoint=False):
     """src [hin*win, C] -> dst [hout*wout, C] (fp32, rows Cdim floats apart); adjoint: src is d(dst-shaped), accumulated into dst = d(source map)"""
     _need_cuda(src, dst)

@@ -32,6 +32,7 @@ _NO_POST_LN = bool(os.environ.get("MVLT_NO_POST_LN"))      # A/B switch: every b
 _NO_OUT_OP = bool(os.environ.get("MVLT_NO_OUT_OP"))        # A/B switch: fp32 stage output + separate cast pass
 _NO_PROJ_LN = bool(os.environ.get("MVLT_NO_PROJ_LN"))      # A/B switch: LN2 folded into the fused MLP's operand load (round 2) instead of the proj epilogue
 _NO_LN_FOLD = bool(os.environ.get("MVLT_NO_LN_FOLD"))      # A/B switch: LN2 as its own launch in front of the fused MLP
+_NO_POS_BATCH = bool(os.environ.get("MVLT_NO_POS_BATCH"))  # A/B switch: one resize launch per stage and direction for the position embeddings
 _NO_LIN_FUSE = bool(os.environ.get("MVLT_NO_LIN_FUSE"))    # A/B switch: weight and input gradient of the C x C Linears of stages 1-2 as two launches
 # A/B switches: conv weight gradients accumulated straight into the [out][cin][kh][kw] layout by the wgrad epilogue (strided atomics),
 # or through a pooled [out][kh][kw][cin] buffer + one permuted ATen add per convolution, instead of the store's tap arena
@@ -139,9 +140,30 @@ class TrunkStep:
         pe = (param[:, 1:] if i == 3 else param)[0]                 # (grid*grid, C) rows of the flat buffer; stage 4 skips the cls slot
         if HW == m.grids[0] ** 2:          # reference libs/pvlt.py:292 compares with stage-1's constructor grid
             return pe
+        pre = getattr(self, "_pos_pre", None)
+        if pre is not None and i in pre:
+            return pre[i]                      # resized by the one launch at the start of the forward pass (`_pos_prefetch`)
         out = _empty((HW, C), torch.float32, self.dev)
         ops.resize_bilinear_tokens(pe, out, m.grids[i], m.grids[i], side, side, C)
         return out
+
+    def _pos_prefetch(self):
+        """the resized position embeddings of all four stages in ONE launch (they depend on parameters only)"""
+        m = self.m
+        jobs, self._pos_pre = [], {}
+        for i in range(4):
+            side, C = self.side[i], m.dims[i]
+            if side * side == m.grids[0] ** 2:
+                continue
+            param = self.f32(f"pos_embed{i+1}")
+            pe = (param[:, 1:] if i == 3 else param)[0]
+            out = _empty((side * side, C), torch.float32, self.dev)
+            jobs.append((pe, out, m.grids[i], m.grids[i], side, side, C))
+            self._pos_pre[i] = out
+        if jobs and not _NO_POS_BATCH:
+            ops.resize_bilinear_tokens_multi(jobs)
+        else:
+            self._pos_pre = None
 
     def _droppath_scales(self, blk_index):
         m = self.m
@@ -166,6 +188,7 @@ class TrunkStep:
     def forward(self):
         m, S, B, T, dt, dev = self.m, self.S, self.B, self.T, self.dt, self.dev
         te = "text_embeddings."
+        self._pos_prefetch()
         # BERT embeddings (+LN eps 1e-12, +dropout in train mode)
         rows = B * T
         self.emb = _empty((rows, m.hidden), dt, dev)
@@ -371,6 +394,7 @@ class TrunkStep:
     def backward(self, dxs):
         """dxs: gradients w.r.t. the four stage outputs (None allowed).  Fills the flat gradient buffer."""
         m, B, T, dt, dev, S = self.m, self.B, self.T, self.dt, self.dev, self.S
+        self._pos_adj = []
         # gradient tensors the head nodes of this pass created themselves (the heads' shared buffer, the MIM decoder's outputs) may be
         # written in place; anything else autograd hands us is copied first
         own = [d is not None and d.dtype == dt and d.is_contiguous() and S.owns(d) for d in dxs]
@@ -393,6 +417,9 @@ class TrunkStep:
             self.S.announce_stage(i)
         # the learned position embeddings (root parameters: they sit in front of the stage blocks in the flat layout) got their last
         # contribution from stage 1's backward: final now, so that only the BERT embedding block is left for the end of the pass
+        if self._pos_adj:
+            ops.resize_bilinear_tokens_multi(self._pos_adj, adjoint=True)
+            self._pos_adj = []
         self.S.announce_prefix("pos_embed", "text_pos_embed")
         self.S.fold_copies()
         self.saved = []
@@ -445,7 +472,11 @@ class TrunkStep:
         if HW == m.grids[0] ** 2:
             gv.add_(dpos)
             return
-        ops.resize_bilinear_tokens(dpos, gv, m.grids[i], m.grids[i], side, side, dpos.shape[1], adjoint=True)   # accumulates into G
+        if _NO_POS_BATCH:
+            ops.resize_bilinear_tokens(dpos, gv, m.grids[i], m.grids[i], side, side, dpos.shape[1], adjoint=True)   # accumulates into G
+        else:
+            # the adjoints of all stages leave in one launch at the end of the trunk's backward (`backward`): dpos stays alive in the list until then
+            self._pos_adj.append((dpos, gv, m.grids[i], m.grids[i], side, side, dpos.shape[1]))
 
     def _bert_backward(self, d_emb):
         m, B, T = self.m, self.B, self.T
