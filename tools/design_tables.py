@@ -170,11 +170,11 @@ ks_calls, ks_avg_us = int(ks[0]), float(ks[2]) / 1e3
 mw, cal = tj["mlp_dw64"], tj["calib_cast"]
 pairs = lambda x: f"{x:,.0f}".replace(",", " ")
 t6 = f"""**The line of the final build** (`profiles/{tag}_bench_n1.json`, command `python bench.py`, sources `{tj['_source_hash']}`): **{pairs(bench['value'])} pairs/s, {bench['ms_per_step']:.2f} ms/step**
-(round 3's driver line: 11 428 / 22.40; the first half of this round: 11 903 / 21.51).  The boxes of the pool differ by +-2.5 %: the final tree (and its last few predecessors, which differ by < 0.05 ms) measured 20.19, 20.56, 20.66, 20.68,
-21.09, 21.15 and 21.33 ms on seven boxes of the last afternoon; every A/B below is same-box.  Same-box A/Bs of this round add up to -1.6 ms (-7 %): 8-phase NT GEMMs -0.15, polynomial GELU' + whole-tile
+(round 3's driver line: 11 428 / 22.40; the first half of this round: 11 903 / 21.51).  The boxes of the pool differ by +-2.5 %: the final tree (and its last few predecessors, which differ by < 0.05 ms) measured 20.2 .. 21.3 ms on nine boxes of the last afternoon (20.19, 20.31, 20.56, 20.66, 20.68, 20.86, 21.09, 21.15, 21.33); every A/B below is same-box.  Same-box A/Bs of this round add up to -1.75 ms (-8 %): 8-phase NT GEMMs -0.15, polynomial GELU' + whole-tile
 epilogues + K = 320 launches on them -0.12, weight + input gradient in one pass -0.15, pipelined C = 128 input gradient -0.04 (first half); LayerNorm backward without LDS
 atomics -0.38, fp16 pre-BatchNorm conv outputs and product factors -0.25, attention-backward dK / dV flush -0.06, bf16 stage outputs from the fc2 epilogue, MLM logits on the 8-phase
-kernel, `weight_prep` from the bf16 copy, embedding backward together -0.15 (second half, `docs/experiments_r4.md` 7-9).  Loss trajectory unchanged (epoch average 10.67, same synthetic batch).
+kernel, `weight_prep` from the bf16 copy, embedding backward together -0.15, BatchNorm statistics finalised inside the normalisation launch -0.145 (second half,
+`docs/experiments_r4.md` 7-10).  Loss trajectory unchanged (epoch average 10.67, same synthetic batch).
 
 | field | value | how to recompute it |
 |---|---|---|
