@@ -17,7 +17,7 @@ from ._lib import conv3map, rowmap
 
 BN_EPS, BN_MOM = 1e-5, 0.1
 _SEPARATE_STATS = bool(__import__('os').environ.get('MVLT_MIM_SEPARATE_STATS'))   # A/B switch: statistics by a second pass over z
-STAT_COPIES = 16           # interleaved batch-statistic accumulators of the conv epilogue (see mvlt_gemm_nt_args.col_copies)
+STAT_COPIES = int(os.environ.get("MVLT_MIM_STAT_COPIES", "16"))           # interleaved batch-statistic accumulators of the conv epilogue (see mvlt_gemm_nt_args.col_copies)
 CONVS = ("reduction1", "reduction2", "reduction3", "conv_upsample1", "conv_upsample2", "conv_upsample3", "conv_upsample4",
          "conv_upsample5", "conv_concat2", "conv_concat3", "conv4")
 
