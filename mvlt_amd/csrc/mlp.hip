@@ -662,6 +662,11 @@ __global__ __launch_bounds__(NT, (C == 64 && MODE == 1) ? MVLT_PIPE_WAVES_64_1 :
           gelu_lut_one2<MODE>(lut0, h0, h1, a0, a1);
           g0 = (MODE == 0 ? h0 : dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half]) * a0;
           g1 = (MODE == 0 ? h1 : dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half + 1]) * a1;
+        } else if ((MVLT_GELU_H16 >> ((C == 128 ? 2 : 0) + (MODE == 1 ? 0 : 1))) & 1) {      // packed-f16 polynomial (common.h); bits: C = 64 dx, fwd, C = 128 dx, fwd
+          float a0, a1;
+          if (MODE == 0) gelu_h16_phi2(h0, h1, a0, a1); else gelu_h16_dg2(h0, h1, a0, a1);
+          g0 = (MODE == 0 ? h0 : dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half]) * a0;
+          g1 = (MODE == 0 ? h1 : dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half + 1]) * a1;
         } else if (MODE == 0) { g0 = gelu_fast1(h0); g1 = gelu_fast1(h1); }
         else {
           g0 = dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half] * gelu_fast_grad1(h0);
