@@ -19,6 +19,11 @@ extern "C" {
 #define MVLT_DT_BF16 0
 #define MVLT_DT_FP32 1
 
+/* Version of this header: bumped whenever an exported signature or an argument struct changes.  mvlt_abi_version() returns the number the library was
+ * built with; a binding compares it with the number it was written against (mvlt_amd/_lib.py ABI_VERSION) before any other call.
+ *   2 (round 5): positional signatures of mvlt_batch_sum / mvlt_bn_norm / mvlt_bn_bwd_reduce / mvlt_bn_bwd_apply / mvlt_ew_mul / mvlt_ew_mul3_bwd as of
+ *                round 4's second half (the number had stayed 1 through those changes: ADVICE r4) */
+#define MVLT_ABI_VERSION 2
 const char* mvlt_last_error(void);
 int mvlt_abi_version(void);
 /* sizeof(struct <name>) for binding self-checks; -1 if unknown */

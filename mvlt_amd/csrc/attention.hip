@@ -828,8 +828,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_kernel(mvlt
 // Row fragments (A operands of S / dP) are 16-byte reads of those tiles, the transposed fragments (B operands of dV / dK,
 // k = queries) are ds_read_b64_tr_b16 of the same tiles; D = rowsum(dO * O) is computed by every wave for itself from
 // LDS (no workgroup barrier), dQ leaves through an LDS tile as 16-byte row stores one iteration later.
-template <int NW, int TPW>
+template <int NW, int TPW, int VAR = 0>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(mvlt_attn_bwd_args p, int nq_chunks, int q_per_wg) {
+  // VAR (round-5 experiments, compile-time MVLT_ATTN_BWD_VAR, never in the product build; docs/experiments_r5.md 2): 1 = the key-split half of a split backward, timing only -- dK / dV alone, D taken from memory (no O tile, no
+  // per-wave rowsum), no dS park, no dQ product, one barrier per tile; 2 = the transposed dO / Q fragments read once per tile instead of once per key tile
   typedef bf16 T;
   constexpr int NTH = NW * 64;
   constexpr int MP = NW * TPW * 16;           // padded keys (multiple of 32)
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
     const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + slot * STAGE + wave * 1024);
     glds16(ok ? (const void*)(Qg + (long)q * p.ldq + l_chunk * 8) : (const void*)zsrc, dst);
     glds16(ok ? (const void*)(dOg + (long)q * p.ldo + l_chunk * 8) : (const void*)zsrc, dst + TILE);
-    glds16(ok ? (const void*)(Og + (long)q * p.ldo + l_chunk * 8) : (const void*)zsrc, dst + 2 * TILE);
+    if (VAR != 1) glds16(ok ? (const void*)(Og + (long)q * p.ldo + l_chunk * 8) : (const void*)zsrc, dst + 2 * TILE);
   };
   issue(q_begin, 0);
   float lse_cur = (lane < 32 && q_begin + lane < q_end) ? Lg[q_begin + lane] : 0.f;
@@ -939,7 +941,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
     // before the loop back-edge, and the deferred dQ store below then read two or four stale rows about once in 100 launches
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                   // (A) tile q0 landed; previous tile's dS / dQ tiles are complete
-    if (q_prev >= 0 && tid < 256) {                    // deferred dQ store of the previous tile: 16 B per thread
+    if (VAR != 1 && q_prev >= 0 && tid < 256) {        // deferred dQ store of the previous tile: 16 B per thread
       const int r = tid >> 3, c = tid & 7;
       if (q_prev + r < q_end) st_g<MVLT_NT_ATTN>((u32x4*)(dQg + (long)(q_prev + r) * p.ldq + c * 8), *(const u32x4*)(sdQ + r * HD + c * 8));
     }
@@ -953,7 +955,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
     const char* tO = tQ + 2 * TILE;
 
     // ---- per-wave D = rowsum(dO * O) and lse into this wave's scratch
-    {
+    if (VAR == 1) {
+      if (lane < 32) { myD[lane] = lse_now; myL[lane] = lse_now * l2e; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
       float dsum = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -985,6 +992,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
         dof[qs][s].v = *(const bf16x8*)(tdO + qs * 16 * 128 + roff[s]);
       }
 
+    Frag<T> hdot[VAR == 2 ? 4 : 1], hqt[VAR == 2 ? 4 : 1];
+    if (VAR == 2) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        hdot[dt].v = __builtin_bit_cast(bf16x8, tr_frag16(tdO + toffs[dt]));
+        hqt[dt].v = __builtin_bit_cast(bf16x8, tr_frag16(tQ + toffs[dt]));
+      }
+    }
     // ---- per owned key tile: S, dP -> P, dS ; dV += P^T dO ; dK += dS^T Q ; park dS in LDS
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -1006,19 +1021,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
           float dsv = pv * (pacc[r] - dv[qs][r]) * p.scale;
           pfrag.v[qs * 4 + r] = (T)pv;
           dsfrag.v[qs * 4 + r] = (T)dsv;
-          sdS[ql * KS + key] = (T)dsv;
+          if (VAR != 1) sdS[ql * KS + key] = (T)dsv;
         }
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         // B operands (n = d): k-slot (fg, j) <-> q = 16 (j>>2) + 4 fg + (j&3): two transposed 8-byte reads, 16 rows apart
         Frag<T> dotf, qtf;
-        dotf.v = __builtin_bit_cast(bf16x8, tr_frag16(tdO + toffs[dt]));
-        qtf.v = __builtin_bit_cast(bf16x8, tr_frag16(tQ + toffs[dt]));
+        if (VAR == 2) { dotf = hdot[dt]; qtf = hqt[dt]; }
+        else {
+          dotf.v = __builtin_bit_cast(bf16x8, tr_frag16(tdO + toffs[dt]));
+          qtf.v = __builtin_bit_cast(bf16x8, tr_frag16(tQ + toffs[dt]));
+        }
         mma16(dVacc[t][dt], pfrag, dotf);              // dV[key = tile*16 + 4 fg + r][d = 16 dt + fr]
         mma16(dKacc[t][dt], dsfrag, qtf);
       }
     }
+    if (VAR == 1) { q_prev = q0; continue; }
     __syncthreads();                                   // (C) every wave's dS columns are parked
 
     // ---- dQ[32 x 64] = dS[32 x MP] K[MP x 64]: 8 output tiles (16 x 16) dealt round-robin to the waves -> sdQ
@@ -1063,7 +1082,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
     q_prev = q0;
   }
   __syncthreads();
-  if (q_prev >= 0 && tid < 256) {
+  if (VAR != 1 && q_prev >= 0 && tid < 256) {
     const int r = tid >> 3, c = tid & 7;
     if (q_prev + r < q_end) st_g<MVLT_NT_ATTN>((u32x4*)(dQg + (long)(q_prev + r) * p.ldq + c * 8), *(const u32x4*)(sdQ + r * HD + c * 8));
   }
@@ -1120,269 +1139,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
       }
 }
 
-// ------------------------------------------------------------------------------------------------ backward, round 3 (bf16, M <= 192 keys)
-// attn_bwd_dma_kernel with ONE workgroup barrier per 32-query tile instead of two and without the O tile in LDS:
-//  * the dS tile and the dQ tile are double-buffered, so the dQ = dS K product of tile i-1 (which needs every wave's dS columns) runs in
-//    iteration i behind the barrier that opens it -- next to tile i's score MFMAs, not behind a barrier of its own -- and the dQ rows
-//    of tile i-2 leave in the same iteration;
-//  * D = rowsum(dO * O) of tile i+1 is computed one tile AHEAD by 8 lanes per row straight from global memory (whole 128-byte lines; the
-//    rows are in L2: the DMA of the same tile is issued beside it) into a double-buffered [32] vector: the four waves used to compute all
-//    32 sums each from an LDS copy of the O tile (~150 VALU instructions and 8 LDS reads per wave and tile), and that copy was a third of
-//    the DMA ring -- without it two workgroups still fit a CU with the second dS / dQ buffers (76.3 KB each).
-template <int TPW>
-__global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(mvlt_attn_bwd_args p, int nq_chunks, int q_per_wg) {
-  typedef bf16 T;
-  constexpr int NW = 4, NTH = 256;
-  constexpr int MP = NW * TPW * 16;           // padded keys (multiple of 32)
-  constexpr int KS = MP + 8;                  // row stride of sKt and sdS (elements; 16 B of padding)
-  constexpr int TILE = 32 * 128;              // bytes of one [32 q][64 d] tile
-  constexpr int STAGE = 2 * TILE;             // Q | dO
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* sKt = (T*)smem;                          // [64 d][KS]   K^T
-  T* sdS = sKt + HD * KS;                     // [2][32 q][KS]
-  char* ring = (char*)(sdS + 2 * 32 * KS);    // [2][Q | dO]
-  T* sdQ = (T*)(ring + 2 * STAGE);            // [2][32 q][64 d]
-  float* sD = (float*)(sdQ + 2 * 32 * HD);    // [2][32]   rowsum(dO * O)
-  float* sL = sD + 2 * 32;                    // [2][32]   lse * log2(e)
-  const unsigned ring_lds = (unsigned)(uintptr_t)ring;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = lane & 15, fg = lane >> 4;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, jb = bid >> 3;
-  const int gidx = xcd + 8 * (jb / nq_chunks);
-  const int chunk_id = jb % nq_chunks;
-  if (gidx >= p.B * p.H) return;
-  const int b = gidx / p.H, h = gidx % p.H;
-
-  const T* Qg = (const T*)p.Q + (long)b * p.N * p.ldq + h * HD;
-  const T* Og = (const T*)p.O + (long)b * p.N * p.ldo + h * HD;
-  const T* dOg = (const T*)p.dO + (long)b * p.N * p.ldo + h * HD;
-  const T* Kg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.k_off + h * HD;
-  const T* Vg = (const T*)p.KV + (long)b * p.M * p.ldkv + p.v_off + h * HD;
-  T* dQg = (T*)p.dQ + (long)b * p.N * p.ldq + h * HD;
-  float* dKg = (float*)p.dKV + (long)b * p.M * p.lddkv + p.k_off + h * HD;
-  float* dVg = (float*)p.dKV + (long)b * p.M * p.lddkv + p.v_off + h * HD;
-  const float* Lg = p.lse + ((long)b * p.H + h) * p.N;
-  const int q_begin = chunk_id * q_per_wg;
-  const int q_end = min(p.N, q_begin + q_per_wg);
-  const float l2e = 1.44269504088896340736f;
-
-  // ---- DMA geometry: thread (row = tid >> 3, slot = tid & 7) fills one 16-B slot per tensor
-  const int l_row = (tid >> 3) & 31;
-  const int l_chunk = (tid & 7) ^ (((l_row >> 1) & 3) << 1);
-  const char* zsrc = (const char*)g_zero_page + ((tid * 16 + (bid & 15) * 4096) & 65535);
-  auto issue = [&](int q0, int slot) {
-    const int q = q0 + l_row;
-    const bool ok = q < q_end;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + slot * STAGE + wave * 1024);
-    glds16(ok ? (const void*)(Qg + (long)q * p.ldq + l_chunk * 8) : (const void*)zsrc, dst);
-    glds16(ok ? (const void*)(dOg + (long)q * p.ldo + l_chunk * 8) : (const void*)zsrc, dst + TILE);
-  };
-  // D and lse of one tile: thread (row = tid >> 3, chunk = tid & 7) reads 16 B of dO and of O, eight lanes finish a row.  Split in two: the
-  // loads go out at the top of an iteration, in FRONT of the tile's DMAs; their first use sits at the bottom -- hipcc's s_waitcnt for them
-  // (vmcnt counts in order, and the compiler does not know about the inline-asm DMAs behind them) then falls where everything has landed anyway
-  u32x4 st_a, st_o;
-  float st_l;
-  auto row_load = [&](int q0) {
-    const int q = q0 + l_row;
-    st_a = u32x4{0u, 0u, 0u, 0u}; st_o = st_a; st_l = 0.f;
-    if (q < q_end) {
-      st_a = *(const u32x4*)(dOg + (long)q * p.ldo + (tid & 7) * 8);
-      st_o = *(const u32x4*)(Og + (long)q * p.ldo + (tid & 7) * 8);
-      st_l = Lg[q];
-    }
-  };
-  auto row_finish = [&](int buf) {
-    const bf16x8 a = __builtin_bit_cast(bf16x8, st_a), o = __builtin_bit_cast(bf16x8, st_o);
-    float dsum = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dsum += (float)a[e] * (float)o[e];
-    dsum += __shfl_xor(dsum, 1);
-    dsum += __shfl_xor(dsum, 2);
-    dsum += __shfl_xor(dsum, 4);
-    if ((tid & 7) == 0) {
-      sD[buf * 32 + l_row] = dsum;
-      sL[buf * 32 + l_row] = st_l * l2e;
-    }
-  };
-  row_load(q_begin);
-  issue(q_begin, 0);
-  row_finish(0);
-
-  // K^T into LDS (all keys), zero beyond M
-  for (int u = tid; u < MP * 8; u += NTH) {
-    int r = u >> 3, c = u & 7;
-    u32x4 kv = {0u, 0u, 0u, 0u};
-    if (r < p.M) kv = *(const u32x4*)(Kg + (long)r * p.ldkv + c * 8);
-    T ke[8];
-    *(u32x4*)ke = kv;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sKt[(c * 8 + e) * KS + r] = ke[e];
-  }
-  // this wave's K / V fragments (B operands: n = key = fr, k = d)
-  Frag<T> kreg[TPW][2], vreg[TPW][2];
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    int key = (wave * TPW + t) * 16 + fr;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (key < p.M) {
-        kreg[t][s] = load_frag8<T>(Kg + (long)key * p.ldkv + 32 * s + 8 * fg);
-        vreg[t][s] = load_frag8<T>(Vg + (long)key * p.ldkv + 32 * s + 8 * fg);
-      } else {
-        kreg[t][s] = zero_frag<T>();
-        vreg[t][s] = zero_frag<T>();
-      }
-    }
-  }
-  f32x4 dKacc[TPW][4], dVacc[TPW][4];
-#pragma unroll
-  for (int t = 0; t < TPW; ++t)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dKacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dVacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-  const float sl2 = p.scale * l2e;
-
-  // ---- fragment geometry inside a tile (byte offsets)
-  const int hs_r = (fr >> 1) & 3;                                           // rows 16 qs + fr
-  int roff[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) roff[s] = fr * 128 + (((s * 4 + fg) ^ (hs_r << 1)) << 4);
-  const int trow = 4 * fg + (fr >> 2);                                      // transposed reads: rows trow, trow + 16
-  const int hs_t = (trow >> 1) & 3;
-  int toffs[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) toffs[dt] = trow * 128 + ((dt ^ hs_t) << 5) + ((fr & 3) << 3);
-
-  auto store_dq = [&](int q0, int buf) {        // rows of a finished dQ tile: 16 B per thread, whole lines
-    const int r = tid >> 3, c = tid & 7;
-    if (q0 + r < q_end) *(u32x4*)(dQg + (long)(q0 + r) * p.ldq + c * 8) = *(const u32x4*)(sdQ + buf * 32 * HD + r * HD + c * 8);
-  };
-  auto dq_gemm = [&](int buf) {                 // dQ[32 x 64] = dS[32 x MP] K[MP x 64]: wave w owns output tiles (qs = 0, dt = w), (qs = 1, dt = w)
-    const int dt = wave;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const T* pa0 = sdS + buf * 32 * KS + fr * KS + 8 * fg;
-    const T* pa1 = pa0 + 16 * KS;
-    const T* pb = sKt + (dt * 16 + fr) * KS + 8 * fg;
-    Frag<T> a0 = load_frag8<T>(pa0), a1 = load_frag8<T>(pa1), bb = load_frag8<T>(pb);
-#pragma unroll
-    for (int ks = 0; ks < MP / 32; ++ks) {
-      Frag<T> n0 = a0, n1 = a1, nb = bb;
-      if (ks + 1 < MP / 32) {
-        n0 = load_frag8<T>(pa0 + 32 * (ks + 1)); n1 = load_frag8<T>(pa1 + 32 * (ks + 1)); nb = load_frag8<T>(pb + 32 * (ks + 1));
-      }
-      mma16(acc0, a0, bb);
-      mma16(acc1, a1, bb);
-      a0 = n0; a1 = n1; bb = nb;
-    }
-    T* dq = sdQ + buf * 32 * HD;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dq[(4 * fg + r) * HD + dt * 16 + fr] = (T)acc0[r];
-      dq[(16 + 4 * fg + r) * HD + dt * 16 + fr] = (T)acc1[r];
-    }
-  };
-
-  int it = 0;
-  for (int q0 = q_begin; q0 < q_end; q0 += 32, ++it) {
-    const int cur = it & 1;
-    // every hand-written wait names lgkmcnt(0): the barrier must not be passed with this wave's LDS writes (dS columns, dQ pieces, D) in flight
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();                                   // tile `it` and its D / lse landed; dS(it-1) and dQ(it-2) are complete
-    if (it >= 2) store_dq(q0 - 64, cur);
-    const bool more = q0 + 32 < q_end;
-    if (more) {
-      row_load(q0 + 32);
-      issue(q0 + 32, cur ^ 1);
-    }
-    if (it >= 1) dq_gemm(cur ^ 1);                     // dQ of the previous tile: its dS columns are all parked
-    const char* tQ = ring + cur * STAGE;
-    const char* tdO = tQ + TILE;
-    T* dS = sdS + cur * 32 * KS;
-
-    // A-operand fragments of Q (rows = queries) stay in registers over the key tiles; those of dO are re-read per key tile (16 registers
-    // that the row-statistics prefetch needs: a spilled prefetch waits for its own loads at the top of every iteration)
-    Frag<T> qf[2][2];
-#pragma unroll
-    for (int qs = 0; qs < 2; ++qs)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) qf[qs][s].v = *(const bf16x8*)(tQ + qs * 16 * 128 + roff[s]);
-
-    // ---- per owned key tile: S, dP -> P, dS ; dV += P^T dO ; dK += dS^T Q ; park dS in LDS
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int key = (wave * TPW + t) * 16 + fr;
-      const bool key_ok = key < p.M;
-      Frag<T> pfrag, dsfrag;
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs) {
-        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          Frag<T> dof;
-          dof.v = *(const bf16x8*)(tdO + qs * 16 * 128 + roff[s]);
-          mma16(sacc, qf[qs][s], kreg[t][s]);          // S[q = 16 qs + 4 fg + r][key]
-          mma16(pacc, dof, vreg[t][s]);                // dP
-        }
-        // D and lse*log2e of this lane's query rows (16 qs + 4 fg + r): re-read per key tile (two LDS reads) instead of 16 live registers
-        const f32x4 dvq = *(const f32x4*)(sD + cur * 32 + qs * 16 + 4 * fg), lvq = *(const f32x4*)(sL + cur * 32 + qs * 16 + 4 * fg);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ql = qs * 16 + 4 * fg + r;
-          float pv = key_ok ? __builtin_amdgcn_exp2f(sacc[r] * sl2 - lvq[r]) : 0.f;
-          float dsv = pv * (pacc[r] - dvq[r]) * p.scale;
-          pfrag.v[qs * 4 + r] = (T)pv;
-          dsfrag.v[qs * 4 + r] = (T)dsv;
-          dS[ql * KS + key] = (T)dsv;
-        }
-      }
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        // B operands (n = d): k-slot (fg, j) <-> q = 16 (j>>2) + 4 fg + (j&3): two transposed 8-byte reads, 16 rows apart
-        Frag<T> dotf, qtf;
-        dotf.v = __builtin_bit_cast(bf16x8, tr_frag16(tdO + toffs[dt]));
-        qtf.v = __builtin_bit_cast(bf16x8, tr_frag16(tQ + toffs[dt]));
-        mma16(dVacc[t][dt], pfrag, dotf);              // dV[key = tile*16 + 4 fg + r][d = 16 dt + fr]
-        mma16(dKacc[t][dt], dsfrag, qtf);
-      }
-    }
-    if (more) row_finish(cur ^ 1);
-  }
-  // ---- drain: dQ of the last tile, stores of the last two
-  const int nt = it;
-  if (nt >= 1) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (nt >= 2) store_dq(q_begin + (nt - 2) * 32, nt & 1);
-    dq_gemm((nt - 1) & 1);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    store_dq(q_begin + (nt - 1) * 32, (nt - 1) & 1);
-  }
-  // ---- flush dK / dV
-#pragma unroll
-  for (int t = 0; t < TPW; ++t)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int key = (wave * TPW + t) * 16 + 4 * fg + r;
-        if (key < p.M) {
-          if (nq_chunks == 1 && p.dkv_dtype == 0) {       // bf16 dKV: the operand of the kv-projection gradients, no cast pass
-            ((bf16*)p.dKV)[((long)b * p.M + key) * p.lddkv + p.k_off + h * HD + dt * 16 + fr] = (bf16)dKacc[t][dt][r];
-            ((bf16*)p.dKV)[((long)b * p.M + key) * p.lddkv + p.v_off + h * HD + dt * 16 + fr] = (bf16)dVacc[t][dt][r];
-          } else if (nq_chunks == 1) {
-            dKg[(long)key * p.lddkv + dt * 16 + fr] = dKacc[t][dt][r];
-            dVg[(long)key * p.lddkv + dt * 16 + fr] = dVacc[t][dt][r];
-          } else {
-            atomicAdd(&dKg[(long)key * p.lddkv + dt * 16 + fr], dKacc[t][dt][r]);
-            atomicAdd(&dVg[(long)key * p.lddkv + dt * 16 + fr], dVacc[t][dt][r]);
-          }
-        }
-      }
-}
-
 template <typename T, int NW, int TPW> int launch_bwd_n(const mvlt_attn_bwd_args& a, hipStream_t s) {
   constexpr int MP = NW * TPW * 16;
   constexpr int PAD = 16 / sizeof(T);
@@ -1398,30 +1154,26 @@ template <typename T, int NW, int TPW> int launch_bwd_n(const mvlt_attn_bwd_args
   int q_per_wg = ((a.N + nq - 1) / nq + 31) / 32 * 32;
   nq = (a.N + q_per_wg - 1) / q_per_wg;
   const int grid = 8 * ((groups + 7) / 8) * nq;
-  if constexpr (sizeof(T) == 2 && NW == 4) {
-    // round-3 experiment, OFF by default: one barrier per query tile, D one tile ahead, no O tile in LDS.  Correct (same tests) and within
-    // +-3 % of the two-barrier kernel on all four stage shapes (309 / 149 / 156 / 148 us against 315 / 156 / 151 / 149): the backward is bound by
-    // the dependent chains inside a key tile (MFMA -> exp -> LDS park -> transposed reads -> MFMA) at two waves per SIMD, not by its barriers
-    static const bool v2 = getenv("MVLT_ATTN_BWD_V2") != nullptr && getenv("MVLT_ATTN_BWD_LEGACY") == nullptr;
-    if (v2) {
-      const size_t lds3 = (size_t)(HD * (MP + 8) + 2 * 32 * (MP + 8)) * 2 + 2 * 2 * 4096 + 2 * 4096 + 4 * 32 * sizeof(float);
-      hipFuncSetAttribute((const void*)attn_bwd2_kernel<TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-      hipLaunchKernelGGL((attn_bwd2_kernel<TPW>), dim3(grid), dim3(256), lds3, s, a, nq, q_per_wg);
-      return mvlt_check_launch("mvlt_sr_attention_bwd");
-    }
-  }
   if constexpr (sizeof(T) == 2) {
-    if (!getenv("MVLT_ATTN_BWD_LEGACY")) {
+    {
       const size_t lds2 = (size_t)(HD * (MP + 8) + 32 * (MP + 8)) * 2 + 2 * 3 * 4096 + 4096 + 2 * NW * 32 * sizeof(float);
       MVLT_REQUIRE(lds2 <= 160 * 1024, "mvlt_sr_attention_bwd: LDS %zu B > 160 KB", lds2);
+#ifdef MVLT_ATTN_BWD_VAR                       // A/B builds only (tools/build_alt.sh NAME attention.hip -DMVLT_ATTN_BWD_VAR=1): VAR 1 produces no dQ and wrong dK / dV
+      {
+        hipFuncSetAttribute((const void*)attn_bwd_dma_kernel<NW, TPW, MVLT_ATTN_BWD_VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipLaunchKernelGGL((attn_bwd_dma_kernel<NW, TPW, MVLT_ATTN_BWD_VAR>), dim3(grid), dim3(NW * 64), lds2, s, a, nq, q_per_wg);
+        return mvlt_check_launch("mvlt_sr_attention_bwd");
+      }
+#endif
       hipFuncSetAttribute((const void*)attn_bwd_dma_kernel<NW, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL((attn_bwd_dma_kernel<NW, TPW>), dim3(grid), dim3(NW * 64), lds2, s, a, nq, q_per_wg);
       return mvlt_check_launch("mvlt_sr_attention_bwd");
     }
+  } else {                                             // fp32 parity path
+    hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NW, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_bwd_kernel<T, NW, TPW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
+    return mvlt_check_launch("mvlt_sr_attention_bwd");
   }
-  hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NW, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_bwd_kernel<T, NW, TPW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
-  return mvlt_check_launch("mvlt_sr_attention_bwd");
 }
 
 template <typename T> int launch_bwd(const mvlt_attn_bwd_args& a, hipStream_t s) {
@@ -1447,14 +1199,13 @@ extern "C" int mvlt_sr_attention_fwd(const mvlt_attn_args* a, void* stream) {
                "mvlt_sr_attention_fwd: strides/offsets must be multiples of %d elements", pc);
   // round-3 kernel up to 192 keys (every 256-px configuration); beyond (272 keys at 384 px) its two score blocks no longer fit the
   // register budget of two waves per SIMD next to the O accumulators (144 + 32 of 256), and the round-2 kernel is the faster one
-  static const bool legacy = getenv("MVLT_ATTN_FWD_LEGACY") != nullptr;
-  if (a->dtype == 0 && !legacy && a->M <= 192) return launch_fwd2(*a, (hipStream_t)stream);
+  if (a->dtype == 0 && a->M <= 192) return launch_fwd2(*a, (hipStream_t)stream);
   return a->dtype == 0 ? launch_fwd<bf16>(*a, (hipStream_t)stream) : launch_fwd<float>(*a, (hipStream_t)stream);
 }
 
 extern "C" int mvlt_sr_attention_bwd(const mvlt_attn_bwd_args* a, void* stream) {
   MVLT_REQUIRE(a && a->Q && a->KV && a->O && a->dO && a->lse && a->dQ && a->dKV, "mvlt_sr_attention_bwd: null pointer");
-  MVLT_REQUIRE(a->dkv_dtype == 1 || (a->dkv_dtype == 0 && a->dtype == 0 && (long)a->B * a->H >= 512 && !getenv("MVLT_ATTN_BWD_LEGACY")),
+  MVLT_REQUIRE(a->dkv_dtype == 1 || (a->dkv_dtype == 0 && a->dtype == 0 && (long)a->B * a->H >= 512),
                "mvlt_sr_attention_bwd: bf16 dKV needs bf16 operands and B*H >= 512 (one query chunk per (batch, head), plain stores)");
   MVLT_REQUIRE(a->B > 0 && a->H > 0 && a->N > 0 && a->M > 0, "mvlt_sr_attention_bwd: bad shape");
   MVLT_REQUIRE(a->dtype == 0 || a->dtype == 1, "mvlt_sr_attention_bwd: bad dtype");

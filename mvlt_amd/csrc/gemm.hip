@@ -2299,12 +2299,11 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
                "mvlt_gemm_nt: split_k needs bf16 operands, fp32 C (zeroed by the caller) and a plain epilogue");
   MVLT_REQUIRE(a->col_copies >= 0, "mvlt_gemm_nt: col_copies < 0");
   MVLT_REQUIRE(!a->r_fp32 || (a->R && a->R != a->C && a->dtype == 0 && a->out_dtype == 0 && a->act == 0 && !a->col_sum && !a->post_y && a->split_k <= 1 && a->c_map.mode == 0 &&
-                              a->N % 8 == 0 && a->ldc % 8 == 0 && (((uintptr_t)a->C | (uintptr_t)a->R) & 15) == 0 && a->M < (1 << 24) && !getenv("MVLT_NT_GENERIC_EPI") &&
-                              !getenv("MVLT_NT_LEGACY")),
+                              a->N % 8 == 0 && a->ldc % 8 == 0 && (((uintptr_t)a->C | (uintptr_t)a->R) & 15) == 0 && a->M < (1 << 24) && !getenv("MVLT_NT_GENERIC_EPI")),
                "mvlt_gemm_nt: r_fp32 (fp32 residual beside a bf16 C) exists in the residual epilogue of the bf16 LDS-DMA kernels only (plain c_map, N % 8 == 0, 16-byte aligned C / R)");
   MVLT_REQUIRE(a->out_dtype >= 0 && a->out_dtype <= 2, "mvlt_gemm_nt: out_dtype is 0 (bf16), 1 (fp32) or 2 (fp16, with col_sum only)");
   MVLT_REQUIRE(a->out_dtype != 2 || (a->dtype == 0 && a->col_sum && a->act == 0 && !a->R && !a->row_scale && a->split_k <= 1 && a->c_map.mode == 0 && a->N % 8 == 0 &&
-                                     a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 && a->M < (1 << 24) && !getenv("MVLT_NT_GENERIC_EPI") && !getenv("MVLT_NT_LEGACY")),
+                                     a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 && a->M < (1 << 24) && !getenv("MVLT_NT_GENERIC_EPI")),
                "mvlt_gemm_nt: fp16 output exists in the column-statistics epilogue of the bf16 LDS-DMA kernels only (plain c_map, N % 8 == 0, 16-byte aligned C)");
   if (int e = check_rowmap(a->a_map, "mvlt_gemm_nt a_map")) return e;
   if (int e = check_rowmap(a->c_map, "mvlt_gemm_nt c_map")) return e;
@@ -2312,8 +2311,8 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   MVLT_REQUIRE(a->c_map.mode == 0 || a->N == a->c_map.r * a->c_map.r * a->c_map.c_seg, "mvlt_gemm_nt: scatter N != r*r*c_seg");
   MVLT_REQUIRE(a->c_map.mode != 2, "mvlt_gemm_nt: the 3x3 map is a gather only (its dgrad is a gather with flipped taps)");
   // EPI 8 (LayerNorm of the finished row) exists in the bf16 LDS-DMA kernel only: every other launch path refuses instead of skipping it silently
-  MVLT_REQUIRE(!a->post_y || (a->dtype == 0 && a->split_k <= 1 && !getenv("MVLT_NT_LEGACY")),
-               "mvlt_gemm_nt: post_y needs the bf16 LDS-DMA path (no fp32 operands, no split_k, no MVLT_NT_LEGACY)");
+  MVLT_REQUIRE(!a->post_y || (a->dtype == 0 && a->split_k <= 1),
+               "mvlt_gemm_nt: post_y needs the bf16 LDS-DMA path (no fp32 operands, no split_k)");
   if (a->M == 0) return MVLT_OK;
   hipStream_t s = (hipStream_t)stream;
   const int tiles_m = (a->M + BM - 1) / BM;
@@ -2326,7 +2325,7 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   const size_t stage = (size_t)4 * 32 * (bn / 2 + 4) * sizeof(float);      // epilogue staging (4 waves x 32 rows)
   if (lds < stage) lds = stage;
   dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n), (unsigned)(a->split_k > 1 ? a->split_k : 1)), block(NTHREADS);
-  if (a->dtype == 0 && (a->split_k > 1 || !getenv("MVLT_NT_LEGACY"))) {
+  if (a->dtype == 0) {
     const int nk = ((a->K + 63) / 64 + (a->split_k > 1 ? a->split_k : 1) - 1) / (a->split_k > 1 ? a->split_k : 1);
     // compile-time epilogue variant (see nt_epilogue_lean); 0 = generic
     int epi = 0;
@@ -2445,9 +2444,6 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
     else MVLT_NT_LAUNCH(128, 64);
 #undef MVLT_NT_LAUNCH_E
 #undef MVLT_NT_LAUNCH
-  } else if (a->dtype == 0) {
-    if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 64>), grid, block, lds, s, *a, nbuf);
-    else hipLaunchKernelGGL((gemm_nt_kernel<bf16, 128>), grid, block, lds, s, *a, nbuf);
   } else {
     if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<float, 64>), grid, block, lds, s, *a, nbuf);
     else hipLaunchKernelGGL((gemm_nt_kernel<float, 128>), grid, block, lds, s, *a, nbuf);
@@ -2471,7 +2467,8 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
   MVLT_REQUIRE(!(a->colsum_a && a->colsum_b), "mvlt_gemm_tn: at most one of colsum_a / colsum_b");
   MVLT_REQUIRE(a->b_map.mode == 0 || a->N2 == a->b_map.r * a->b_map.r * a->b_map.c_seg, "mvlt_gemm_tn: gather N2 != r*r*c_seg");
   MVLT_REQUIRE(a->c_taps <= 1 || (a->trans_c == 0 && a->c_seg > 0 && a->N2 == a->c_taps * a->c_seg), "mvlt_gemm_tn: c_taps needs trans_c == 0 and N2 == c_taps*c_seg");
-  MVLT_REQUIRE(!a->dgrad_out || (a->dtype == 0 && a->M < (1 << 24) && a->b_map.mode == 0), "mvlt_gemm_tn: dgrad_out rides on the bf16 LDS-DMA kernel only");
+  MVLT_REQUIRE(!a->dgrad_out || (a->dtype == 0 && a->M < (1 << 24) && a->b_map.mode == 0 && a->a_map.mode == 0),
+               "mvlt_gemm_tn: dgrad_out rides on the bf16 LDS-DMA kernel only (bf16 operands, M < 2^24, plain row maps): every other path would leave it unwritten");
   if (a->M == 0) return MVLT_OK;
   hipStream_t s = (hipStream_t)stream;
   const int mtiles = (a->M + TBK - 1) / TBK;
@@ -2492,7 +2489,7 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
   //  removed it again: its main loop ran at 1.1-1.16 PFLOP/s, but one workgroup per CU means 16 m-splits of the 2048 x 512 outputs, and the fp32
   //  atomics that combine the splits complete at ~0.3 floats per ns chip-wide whatever their scope or coalescing: 55 us of tail per launch,
   //  147 us against the 122 us of the 128 x 128 tiles below with their 8 splits and a second workgroup per CU to hide the tail.  DESIGN.md 6.)
-  if (a->dtype == 0 && a->M < (1 << 24) && !getenv("MVLT_TN_LEGACY")) {
+  if (a->dtype == 0 && a->M < (1 << 24)) {
     // LDS-DMA kernel: A tile 128 or 64 wide, B tile 128 or 64 wide; ~1024 workgroups, splits a multiple of the 8 XCDs
     // outputs of at most 128 x 128 take 64 x 64 tiles: every output cache line receives one atomic request per m-split, those
     // serialise at the memory side (~100 ns each), and four small tiles need a quarter of the splits of one big tile for the same

@@ -1228,8 +1228,7 @@ template <int C> int launch_wgrad(const mvlt_mlp_args& a, hipStream_t s) {
   if (splits < 1) splits = 1;
   const int m_per_split = ((mtiles + splits - 1) / splits) * 64;
   splits = (a.M + m_per_split - 1) / m_per_split;
-  static const bool legacy = getenv("MVLT_MLP_LEGACY") != nullptr || getenv("MVLT_MLP_WGRAD_LEGACY") != nullptr;
-  if (!legacy && (!a.row_scale || a.rows_per_scale % 64 == 0)) {      // tile-uniform DropPath factor: the round-3 kernel
+  if (!a.row_scale || a.rows_per_scale % 64 == 0) {      // tile-uniform DropPath factor: the round-3 kernel (other sample lengths -- 96-px inputs, T = 20 -- take the round-2 one below)
     constexpr int NW = C == 64 ? 4 : 8;
     const size_t lds_t = lds + ((MVLT_GELU_LUT & 1) ? GELU_LUT_BYTES : 0);
     hipFuncSetAttribute((const void*)mlp_wgrad2_kernel<C, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
@@ -1247,11 +1246,9 @@ template <int C, int MODE> int launch(const mvlt_mlp_args& a, hipStream_t s) {
   if (MODE == 1 && ((MVLT_GELU_LUT >> 1) & 1)) lds += GELU_LUT_BYTES;
   const size_t stage = (size_t)4 * 16 * (C + 4) * 4;       // epilogue staging (4 waves x 16 rows) reuses the weight buffers
   if (lds < stage) lds = stage;
-  static const bool legacy = getenv("MVLT_MLP_LEGACY") != nullptr;
-  // the pipelined input-gradient kernel at C = 128: 390 us (236 B of scratch) against the round-2 kernel's 327 us with the sigmoid-form GELU' of mid round 3;
-  // with the polynomial GELU' it needs 44 B and runs 297 us against 339 us (round 4, same box) -- the default now, MVLT_MLP_PIPE128=0 selects the old kernel
-  static const bool pipe128 = !(getenv("MVLT_MLP_PIPE128") && atoi(getenv("MVLT_MLP_PIPE128")) == 0);
-  if (!legacy && !a.h_out && a.hid >= 128 && !(C == 128 && MODE == 1 && !pipe128)) {      // the software-pipelined kernel (no pre-activation store: nothing in the step asks for one)
+  // the software-pipelined kernel (no pre-activation store: nothing in the step asks for one); at C = 128 the input gradient fits since the polynomial GELU'
+  // (44 B of scratch, 297 us against the round-2 kernel's 339 us).  The round-2 kernel below keeps the launches with a pre-activation output or hid == 64.
+  if (!a.h_out && a.hid >= 128) {
     size_t l2 = (size_t)2 * (MODE == 1 ? 2 : 1) * 32 * 2 * C + (size_t)2 * C * 64 + (size_t)a.hid * 4;
     if ((MVLT_GELU_LUT >> (MODE == 1 ? 1 : 2)) & 1) l2 += GELU_LUT_BYTES;
     if (l2 < stage) l2 = stage;

@@ -503,10 +503,12 @@ template <typename T, typename TX, typename TDX> int launch_bwd(const mvlt_layer
   const mvlt_layernorm_bwd_args& a = a_in;
   int g = pick_group(a.C);
   MVLT_REQUIRE(g * MAXIT * VN >= a.C, "mvlt_layernorm_bwd: C=%d too large", a.C);
+  MVLT_REQUIRE((size_t)(1024 / 64 * 2 + 1) * a.C * sizeof(float) <= 160 * 1024, "mvlt_layernorm_bwd: C=%d needs more than 160 KB of LDS for the per-wave slices", a.C);
   // every workgroup ends with 2*C atomics on the same few cache lines: the rows are spread over few, large workgroups (1024
   // threads, one per CU).  (Storing the partial rows plainly and adding them in a second launch was measured: same time.)  Same time as 1024 x 256 threads
   // on most shapes, 123 -> 96 us at 98304 x 320 (fp32 x, dx +=); more workgroups of either size are slower (1536 x 256: +10 %)
-  static const int nt = getenv("MVLT_LN_BWD_NT") ? atoi(getenv("MVLT_LN_BWD_NT")) : 1024;
+  // only the two instantiated workgroup sizes: the per-wave LDS slices below are sized from this value (512 used to size 8 slices for a 16-wave launch)
+  static const int nt = (getenv("MVLT_LN_BWD_NT") && atoi(getenv("MVLT_LN_BWD_NT")) == 256) ? 256 : 1024;
   static const int bcap = getenv("MVLT_LN_BWD_GRID") ? atoi(getenv("MVLT_LN_BWD_GRID")) : 256;
   int groups = nt / g;
   int grid = (a.rows + groups - 1) / groups;
@@ -514,15 +516,17 @@ template <typename T, typename TX, typename TDX> int launch_bwd(const mvlt_layer
   if (a.dgamma && a.dg_copies >= 64 && grid > a.dg_copies) grid = a.dg_copies;     // a copy per workgroup: plain adds (see the kernel's tail)
   const bool one = g * VN >= a.C;               // one chunk per lane covers the row
   size_t lds = ((size_t)(nt / 64) * 2 + (one ? 0 : 1)) * a.C * sizeof(float);      // per-wave dgamma / dbeta slices (+ gamma): 101 KB at C = 768
+  // the dynamic-LDS ceiling is raised ONCE per instantiation (160 KB: whatever C a later call brings) and its result checked
+#define MVLT_LN_BWD_K(KERN_, NT_)                                                                                    \
+  do {                                                                                                               \
+    static const hipError_t attr = hipFuncSetAttribute((const void*)KERN_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    MVLT_REQUIRE(lds <= 65536 || attr == hipSuccess, "mvlt_layernorm_bwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr)); \
+    hipLaunchKernelGGL(KERN_, dim3(grid), dim3(NT_), lds, s, a);                                                     \
+  } while (0)
 #define MVLT_LN_BWD_N(G_, NT_)                                                                                       \
   do {                                                                                                               \
-    if (one) {                                                                                                       \
-      if (lds > 65536) hipFuncSetAttribute((const void*)ln_bwd_kernel<T, TX, TDX, G_, 1, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, G_, 1, NT_>), dim3(grid), dim3(NT_), lds, s, a);                  \
-    } else {                                                                                                         \
-      if (lds > 65536) hipFuncSetAttribute((const void*)ln_bwd_kernel<T, TX, TDX, G_, MAXIT, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((ln_bwd_kernel<T, TX, TDX, G_, MAXIT, NT_>), dim3(grid), dim3(NT_), lds, s, a);              \
-    }                                                                                                                \
+    if (one) MVLT_LN_BWD_K((ln_bwd_kernel<T, TX, TDX, G_, 1, NT_>), NT_);                                            \
+    else MVLT_LN_BWD_K((ln_bwd_kernel<T, TX, TDX, G_, MAXIT, NT_>), NT_);                                            \
   } while (0)
 #define MVLT_LN_BWD(G_)                                                                                              \
   do {                                                                                                               \
@@ -537,6 +541,7 @@ template <typename T, typename TX, typename TDX> int launch_bwd(const mvlt_layer
   }
 #undef MVLT_LN_BWD
 #undef MVLT_LN_BWD_N
+#undef MVLT_LN_BWD_K
   return mvlt_check_launch("mvlt_layernorm_bwd");
 }
 

@@ -22,7 +22,9 @@ int mvlt_check_launch(const char* what) {
 }
 
 extern "C" const char* mvlt_last_error(void) { return g_err; }
-extern "C" int mvlt_abi_version(void) { return 1; }
+// Bumped whenever an exported signature or argument struct changes (include/mvlt_hip.h MVLT_ABI_VERSION; mvlt_amd/_lib.py refuses a library whose
+// number differs from the binding's: a stale build loaded through MVLT_HIP_LIB would otherwise be called with shifted positional arguments).
+extern "C" int mvlt_abi_version(void) { return MVLT_ABI_VERSION; }
 
 // sizeof() of every argument struct, so a foreign-language binding can verify its mirror of include/mvlt_hip.h
 extern "C" int mvlt_sizeof(const char* name) {

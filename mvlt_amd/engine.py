@@ -20,6 +20,7 @@ import math
 import torch
 import torch.nn.functional as F
 
+from ._lib import MVLTError
 from .metrics import MetricLogger, SmoothedValue
 from .params import pool_zeros
 
@@ -59,13 +60,14 @@ class _CrossEntropyFn(torch.autograd.Function):
     log_softmax / nll_loss pairs."""
 
     @staticmethod
-    def forward(ctx, logits, labels):
+    def forward(ctx, logits, labels, ignore_index):
         from . import ops
         rows, V = logits.shape
         lse = torch.empty(rows, device=logits.device, dtype=torch.float32)
         acc = pool_zeros((2,), torch.float32, logits.device)          # [loss sum, row count]
-        ops.cross_entropy_fwd(logits, labels, lse, acc[0:1], acc[1:2], rows, V, V, ignore_index=-100)
+        ops.cross_entropy_fwd(logits, labels, lse, acc[0:1], acc[1:2], rows, V, V, ignore_index=ignore_index)
         ctx.save_for_backward(logits, labels, lse, acc)
+        ctx.ignore_index = ignore_index
         return acc[0] / acc[1]
 
     @staticmethod
@@ -74,22 +76,29 @@ class _CrossEntropyFn(torch.autograd.Function):
         logits, labels, lse, acc = ctx.saved_tensors
         rows, V = logits.shape
         dl = torch.empty_like(logits)
-        ops.cross_entropy_bwd(logits, labels, lse, gout.reshape(1).float().contiguous(), acc[1:2], dl, rows, V, V, V, ignore_index=-100)
-        return dl, None
+        ops.cross_entropy_bwd(logits, labels, lse, gout.reshape(1).float().contiguous(), acc[1:2], dl, rows, V, V, V, ignore_index=ctx.ignore_index)
+        return dl, None, None
 
 
-def cross_entropy(logits, labels):
-    """F.cross_entropy(logits, labels) for 2-D logits; HIP on the GPU (fp32 logits), ATen elsewhere (CPU oracle runs)"""
-    if logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and labels.dtype == torch.int64:
-        return _CrossEntropyFn.apply(logits.contiguous(), labels.contiguous())
-    return F.cross_entropy(logits, labels)
+def cross_entropy(logits, labels, ignore_index=-100):
+    """F.cross_entropy(logits, labels, ignore_index=...) for 2-D logits.  Device tensors ALWAYS take the HIP row kernels (cast to fp32 / int64 first if the
+    caller hands something else; anything that is not a 2-D matrix raises): there is no ATen fallback on the GPU.  CPU tensors -- which the model cannot
+    produce; they reach this function only when tests/test_host_cpu.py checks the loss composition against the oracle -- take F.cross_entropy."""
+    if not logits.is_cuda:
+        return F.cross_entropy(logits, labels, ignore_index=ignore_index)
+    if logits.dim() != 2 or labels.dim() != 1 or labels.shape[0] != logits.shape[0]:
+        raise MVLTError(f"cross_entropy: need (rows, classes) logits and (rows,) labels, got {tuple(logits.shape)} / {tuple(labels.shape)}")
+    return _CrossEntropyFn.apply(logits.float().contiguous(), labels.long().contiguous(), ignore_index)
 
 
 def smooth_l1(pred, target):
-    """the T2I loss of reference engine_grid_masking.py:99; HIP on the GPU, ATen elsewhere (CPU oracle runs, odd shapes)"""
-    if pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.shape == target.shape and pred.numel() % 4 == 0:
-        return _SmoothL1Fn.apply(pred, target)
-    return F.smooth_l1_loss(pred, target)
+    """the T2I loss of reference engine_grid_masking.py:99.  Device tensors always take the two HIP passes (16-byte accesses: the element count must be a
+    multiple of 4, which 3 x S x S images with even S are; otherwise it raises); CPU tensors (host-logic test only) take F.smooth_l1_loss."""
+    if not pred.is_cuda:
+        return F.smooth_l1_loss(pred, target)
+    if pred.shape != target.shape or pred.numel() % 4 != 0:
+        raise MVLTError(f"smooth_l1: shapes {tuple(pred.shape)} / {tuple(target.shape)} must match and hold a multiple of 4 elements")
+    return _SmoothL1Fn.apply(pred.float(), target.float())
 
 
 class _ComposeFn(torch.autograd.Function):
@@ -156,7 +165,7 @@ def compute_losses(outputs, images, mlm_labels, itm_labels, sup_cls_labels, sub_
         parts["loss_mlm"] = MLM_LOSS_WEIGHT * outputs["mlm_loss"]
         total = total + parts["loss_mlm"]
     elif outputs["mlm_logits"] is not None:
-        parts["loss_mlm"] = MLM_LOSS_WEIGHT * F.cross_entropy(outputs["mlm_logits"].reshape(-1, 30522).float(), mlm_labels.view(-1), ignore_index=-1)
+        parts["loss_mlm"] = MLM_LOSS_WEIGHT * cross_entropy(outputs["mlm_logits"].reshape(-1, 30522).float(), mlm_labels.view(-1), ignore_index=-1)
         total = total + parts["loss_mlm"]
     if outputs["itm_logits"] is not None:
         parts["loss_itm"] = ITM_LOSS_WEIGHT * cross_entropy(outputs["itm_logits"].view(-1, 2).float(), itm_labels.view(-1))

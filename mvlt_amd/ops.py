@@ -57,8 +57,13 @@ def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, co
         wt, dx = dgrad
         assert A.dtype == torch.bfloat16 and wt.dtype == dx.dtype == torch.bfloat16 and N1 == N2 and N1 in (64, 128) and taps <= 1
         assert wt.is_contiguous() and tuple(wt.shape) == (N2, N1) and dx.stride(-1) == 1
+        # dx may be a row-strided view (a column slice of a wider buffer): its own row pitch goes to the kernel (N2 was passed);
+        # the fused kernel walks plain rows on both operands
+        dgrad_ld = dx.stride(-2) if dx.dim() >= 2 else N2
+        assert dgrad_ld % 8 == 0 and dgrad_ld >= N2, dgrad_ld
+        assert a_map.mode == 0 and a_map.rows_per_batch == 0 and b_map.mode == 0 and b_map.rows_per_batch == 0, "gemm_tn(dgrad=...): plain row maps only"
         a = L.GemmTNArgs(ptr(A), ptr(B), ptr(C_out), M, N1, N2, lda, ldb, ldc, DT[A.dtype], a_map, b_map, ptr(colsum), splits, None, 0, 0, 0,
-                         ptr(wt), ptr(dx), N2)
+                         ptr(wt), ptr(dx), dgrad_ld)
         check(L.lib.mvlt_gemm_tn(C.byref(a), stream_ptr()), "mvlt_gemm_tn")
         return C_out
     if N1 <= 64 < N2 and b_map.mode == 0 and taps <= 1:

@@ -33,6 +33,7 @@ _NO_OUT_OP = bool(os.environ.get("MVLT_NO_OUT_OP"))        # A/B switch: fp32 st
 _NO_PROJ_LN = bool(os.environ.get("MVLT_NO_PROJ_LN"))      # A/B switch: LN2 folded into the fused MLP's operand load (round 2) instead of the proj epilogue
 _NO_LN_FOLD = bool(os.environ.get("MVLT_NO_LN_FOLD"))      # A/B switch: LN2 as its own launch in front of the fused MLP
 _NO_POS_BATCH = bool(os.environ.get("MVLT_NO_POS_BATCH"))  # A/B switch: one resize launch per stage and direction for the position embeddings
+_NT_GENERIC_EPI = bool(os.environ.get("MVLT_NT_GENERIC_EPI"))   # the library's switch (generic GEMM epilogue): the r_fp32 stage output does not exist there
 _NO_LIN_FUSE = bool(os.environ.get("MVLT_NO_LIN_FUSE"))    # A/B switch: weight and input gradient of the C x C Linears of stages 1-2 as two launches
 # A/B switches: conv weight gradients accumulated straight into the [out][cin][kh][kw] layout by the wgrad epilogue (strided atomics),
 # or through a pooled [out][kh][kw][cin] buffer + one permuted ATen add per convolution, instead of the store's tap arena
@@ -352,7 +353,9 @@ class TrunkStep:
         # the MFMA-operand copy): the fused MLP then writes that copy itself and no fp32 stream -- no separate cast pass
         last_op = fused and j == m.depths[i] - 1 and self.dt != self.rt and not _NO_OUT_OP
         # stages 3-4: the same through fc2's residual epilogue (bf16 C beside the fp32 residual, mvlt_gemm_nt_args.r_fp32)
-        last_gemm = (not fused) and j == m.depths[i] - 1 and dt == torch.bfloat16 and self.rt == torch.float32 and not _NO_OUT_OP
+        # (r_fp32 exists in the lean residual epilogue only: rows indexed in 24 bits, 16-byte row pieces -- otherwise the fp32 output + cast pass below)
+        last_gemm = ((not fused) and j == m.depths[i] - 1 and dt == torch.bfloat16 and self.rt == torch.float32 and not _NO_OUT_OP and
+                     M < (1 << 24) and C % 8 == 0 and not _NT_GENERIC_EPI)
         xo = _empty((B, N, C), dt if (last_op or last_gemm) else self.rt, dev)
         if fused:
             # stages 1-2: LN2 -> fc1 -> GELU -> fc2 -> DropPath -> +residual in ONE kernel.  The (tokens x hidden) activation stays on

@@ -22,7 +22,8 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L.lib, name), f"{name} declared in mvlt_hip.h but not exported by libmvlt_hip.so"
     assert set(L.EXPORTS) <= declared
-    assert L.lib.mvlt_abi_version() == 1
+    # the library, the header and the binding agree on the ABI version (signature-only changes used to go unnoticed)
+    assert L.lib.mvlt_abi_version() == L.ABI_VERSION == int(re.search(r"#define MVLT_ABI_VERSION (\d+)", hdr).group(1))
     assert L.lib.mvlt_sizeof(b"no_such_struct") == -1
 
 

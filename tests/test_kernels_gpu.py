@@ -297,6 +297,28 @@ def test_gemm_tn(ops, dtype, M, N1, N2):
     assert maxrel(out, 2 * ref) < TOL[dtype]
 
 
+def test_gemm_tn_fused_input_gradient_is_never_skipped_silently(ops):
+    """every launch path of mvlt_gemm_tn that cannot produce dgrad_out must refuse -- a silently unwritten input gradient is a wrong
+    gradient.  fp32 operands (the generic kernel) with dgrad_out raise; a row-strided dX view (a column slice of a wider buffer) keeps its
+    neighbours intact because its own row pitch reaches the kernel."""
+    import ctypes as C_
+    from mvlt_amd import _lib as L
+    C, M = 64, 640
+    dY, X = rnd(M, C, dtype=torch.float32), rnd(M, C, dtype=torch.float32, seed=1)
+    WT = rnd(C, C, dtype=torch.bfloat16, seed=2)
+    dW = torch.zeros(C, C, device=dev())
+    dX = torch.zeros(M, C, device=dev(), dtype=torch.bfloat16)
+    a = L.GemmTNArgs(L.ptr(dY), L.ptr(X), L.ptr(dW), M, C, C, C, C, C, 1, L.rowmap(), L.rowmap(), None, 0, None, 0, 0, 0, L.ptr(WT), L.ptr(dX), C)
+    assert L.lib.mvlt_gemm_tn(C_.byref(a), L.stream_ptr()) != 0 and b"dgrad_out" in L.lib.mvlt_last_error()
+    dt = torch.bfloat16
+    dYb, Xb = dY.to(dt), X.to(dt)
+    wide = torch.full((M, 2 * C), 7.0, device=dev(), dtype=dt)
+    ops.gemm_tn(dYb, Xb, dW, M, C, C, C, C, C, dgrad=(WT, wide[:, :C]))
+    torch.cuda.synchronize()
+    assert (wide[:, C:] == 7.0).all()                                     # the other half of every row is untouched
+    assert maxrel(wide[:, :C].float(), dYb.float() @ WT.float().t()) < TOL[dt]
+
+
 @pytest.mark.parametrize("C,M", [(64, 64 * 300 + 17), (128, 64 * 150 + 40), (64, 130), (128, 4224 * 8)])
 def test_gemm_tn_with_fused_input_gradient(ops, C, M):
     """weight gradient + bias gradient + INPUT gradient of a C x C Linear from one pass over dY (mvlt_gemm_tn dgrad_*; the q / proj
