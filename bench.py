@@ -127,7 +127,8 @@ def _time_launch(fn, reps=20):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    from mvlt_amd._lib import last_kernel
+    return e0.elapsed_time(e1) / reps, last_kernel()     # the instantiation the library launched for this call (C ABI: mvlt_last_kernel)
 
 
 def roofline_cases(B, device):
@@ -158,26 +159,44 @@ def roofline_cases(B, device):
                           torch.zeros(64, device=device))
     rs = torch.full((B,), 1.0 / 0.9, device=device)
     rs[::10] = 0.0
+    # the top instantiation of the step's kernel trace (gemm_tn_dma_kernel<128, 128, 3, 2>) on its largest shape: the stage-3 fc2 weight gradient
+    # dW2[320, 1280] += dY[M3, 320]^T G[M3, 1280], M3 = B * 384 tokens (+ the bias gradient as a column sum of dY)
+    M3 = B * 384
+    dy3 = torch.randn(M3, 320, device=device).to(bf)
+    g3 = torch.randn(M3, 1280, device=device).to(bf)
+    dw3, db3 = torch.zeros(320, 1280, device=device), torch.zeros(320, device=device)
     return [("conv192", lambda: ops.gemm_nt(x, w, out, M, C, 9 * C, C, 9 * C, C, a_map=amap), 2.0 * M * C * 9 * C),
             ("proj64", lambda: ops.gemm_nt(x2, w2, o2, M2, 64, 64, 64, 64, 64, bias=b2), 2.0 * (2 * M2 * 64 + 64 * 64)),
             ("mlp_dw64", lambda: ops.mlp_bwd_dw(xm, dym, w1, w2t, b1, dw1, db1, dw2, db2, M2, 64, hid, row_scale=rs, rows_per_scale=4224),
-             2.0 * 2 * M2 * 64 * hid)]
+             2.0 * 2 * M2 * 64 * hid),
+            ("tn_s3dw2", lambda: ops.gemm_tn(dy3, g3, dw3, M3, 320, 1280, 320, 1280, 1280, colsum=db3), 2.0 * M3 * 320 * 1280)]
 
 
-def time_dominant_kernel(model, B, device):
-    """`roofline` = the launch VERDICT r3 named (profiles/r04_gemm_shapes.txt: the fused-MLP weight gradients of the two stage-1 blocks,
-    ~0.35 ms each since their activation comes from a table; the three other fused-MLP backward launches of stages 1-2 take 0.33-0.40 ms each, two per
-    step each -- together the 1.43 + 1.47 ms of `mlp_wgrad2_kernel` / `mlp_pipe_kernel<.., 1>` in profiles/r04_step_launches.txt), timed alone with HIP events on torch's current stream = the stream the C ABI launches on.
-    Its ALGORITHMIC work is the two weight-gradient products dW1 = dh^T x and dW2 = dy^T g: 2 x 2*M*C*hid FLOP (M = B*4224, C = 64, hid = 512)
-    over 2 x M*C bf16 operand bytes; the kernel EXECUTES twice that (h = x W1^T and dg = dy W2 are recomputed on chip so that nothing of
-    size M x hid touches HBM) plus 9.5 VALU instructions and one 8-byte LDS gather per hidden element and token for GELU / GELU' (17 VALU
-    until the end of round 3); VALU and MFMA time ADD in this kernel (issue rates measured by tools/probes/valu_rates.hip).  `bound` is "mfma" in the contract's
-    vocabulary: the fraction says how far the launch is from doing its algorithmic FLOPs at matrix-pipe speed.
-    `siblings`: round 2's roofline launch (the MIM decoder's 192->192 conv3x3 as a gathered GEMM, MFMA-bound) and the HBM-bound K = 64
-    projection of the same GEMM family.  `traffic` = HBM bytes per launch from the committed PMC passes
-    (profiles/*_roofline_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, collected offline: counters cannot be read inside this process)."""
-    (_, f1, flops1), (_, f2, bytes2), (_, f3, flops3) = roofline_cases(B, device)
-    ms, ms2, ms3 = _time_launch(f1), _time_launch(f2), _time_launch(f3)
+# what is KNOWN about a kernel instantiation (counters of earlier rounds): attached to a roofline entry only when the library reports that very
+# instantiation for the timed call -- after a dispatch change the entry says so instead of repeating prose about a kernel that no longer runs
+LIMITERS = {
+    "mlp_wgrad2_kernel<64, 4>": "VALU + MFMA time add up: 9.5 VALU instructions + one LDS gather per (token, hidden unit) for GELU and GELU' (table over the "
+                                "bf16 pre-activation) next to 4 x 64 MACs on the matrix pipe, at two waves per SIMD (216 registers)",
+    "conv3_nt_kernel<32, 192, 1>": "LDS-DMA issue + MFMA: 128 x 192 tile, 3x3-gather A from an LDS halo (MFMA-busy 0.48)",
+    "gemm_nt_dma_kernel<64, 0, 1, 64, 128>": "HBM: K = 64, 128 x 64 tile, every operand byte read once",
+    "gemm_tn_dma_kernel<128, 128, 3, 2, false>": "neither HBM- nor MFMA-bound (2.8 TB/s, MFMA-busy 0.34): 8 m-splits x 128 x 128 fp32 atomics per output tile behind "
+                                                 "a 2-stage LDS-DMA ring, two workgroups per CU",
+}
+
+
+def time_dominant_kernel(model, B, device, ms_step):
+    """`roofline` = the launch VERDICT r3 named: the fused-MLP weight gradients of a stage-1 block (two per step), timed alone with HIP events on
+    torch's current stream = the stream the C ABI launches on.  Its ALGORITHMIC work is the two weight-gradient products dW1 = dh^T x and
+    dW2 = dy^T g: 2 x 2*M*C*hid FLOP (M = B*4224, C = 64, hid = 512) over 2 x M*C bf16 operand bytes; the kernel EXECUTES twice that (h = x W1^T and
+    dg = dy W2 are recomputed on chip so that nothing of size M x hid touches HBM).  `bound` is "mfma" in the contract's vocabulary: the fraction says
+    how far the launch is from doing its algorithmic FLOPs at matrix-pipe speed.  `siblings`: round 2's roofline launch (the MIM decoder's 192->192
+    conv3x3, MFMA-bound), the HBM-bound K = 64 projection, and the top instantiation of the step's kernel trace (the 128 x 128 weight-gradient GEMM
+    on the stage-3 fc2 shape).  Every `kernel` string is what the LIBRARY reports it launched for the timed call (mvlt_last_kernel), `share_of_step` is
+    computed from the measured launch and step times, `limiter` is attached only if it was written for that instantiation.
+    `traffic` = HBM bytes per launch from the committed PMC passes (profiles/*_roofline_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, collected
+    offline: counters cannot be read inside this process)."""
+    cases = {name: (fn, work) for name, fn, work in roofline_cases(B, device)}
+    timed = {name: _time_launch(fn) for name, (fn, _) in cases.items()}
     from mvlt_amd.build import source_hash
     tj = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_roofline_traffic.json")) if B == 256 else []
     t = json.load(open(os.path.join(ROOT, "profiles", tj[-1]))) if tj else {}
@@ -187,25 +206,38 @@ def time_dominant_kernel(model, B, device):
         stale = f"profiles/{tj[-1]} was collected for kernel sources {t.get('_source_hash')}, this tree is {source_hash()}: traffic not reported"
         t = {}
     tr = lambda k: t.get(k, {}).get("hbm_bytes")
-    tf1, tf3 = flops1 / (ms * 1e-3) / 1e12, flops3 / (ms3 * 1e-3) / 1e12
-    M2 = B * 4224
-    return dict(kernel="mlp_wgrad2_kernel<64, 4> (bf16): fused-MLP weight gradients of a stage-1 block, M = B*4224 tokens, C = 64, hidden 512 "
-                       "(dW1, db1, dW2, db2; h / dg / GELU / GELU' recomputed on chip; DropPath factors per sample, dropped samples skipped)",
-                share_of_step="2 x ~0.35 ms of a ~21 ms step; the three other fused-MLP backward launches of stages 1-2 take 0.33-0.40 ms each, two per step "
-                              "each (profiles/r04_gemm_shapes.txt)",
-                bound="mfma", achieved=round(tf3, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf3 / PEAK_BF16_TFLOPS, 4),
-                traffic=tr("mlp_dw64"), ms_per_launch=round(ms3, 4), algorithmic_flops=flops3, executed_flops=2 * flops3,
-                algorithmic_bytes=2.0 * 2 * M2 * 64,
-                limiter="VALU + MFMA time add up: 9.5 VALU instructions + one LDS gather per (token, hidden unit) for GELU and GELU' (table over the "
-                        "bf16 pre-activation) next to 4 x 64 MACs on the matrix pipe, at two waves per SIMD (216 registers)",
-                siblings=[
-                    dict(kernel="conv3_nt_kernel<32, 192, 1> (bf16, 128x192 tile, 3x3-gather A from an LDS halo): MIM conv3x3 192->192 @32x32 as GEMM "
-                                "(M=B*1024, N=192, K=1728) -- round 2's roofline launch", bound="mfma", achieved=round(tf1, 1), peak=PEAK_BF16_TFLOPS,
-                         unit="TFLOP/s", frac=round(tf1 / PEAK_BF16_TFLOPS, 4), traffic=tr("conv192"), ms_per_launch=round(ms, 4), algorithmic_flops=flops1),
-                    dict(kernel="gemm_nt_dma_kernel<64, 0, 1, 64, 128> (bf16, 128x64 tile): K=64 N=64 projection, M=B*4224", bound="hbm",
-                         achieved=round(bytes2 / (ms2 * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                         frac=round(bytes2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), ms_per_launch=round(ms2, 4), algorithmic_bytes=bytes2, traffic=tr("proj64"))],
-                **({"traffic_stale": stale} if stale else {"traffic_source": f"profiles/{tj[-1]}" if tj else None}))
+    M2, M3 = B * 4224, B * 384
+
+    def entry(name, what, per_step, bound, alg_bytes=None, executed=None):
+        ms, kern = timed[name]
+        work = cases[name][1]
+        e = dict(kernel=f"{kern} (bf16): {what}", kernel_reported_by="mvlt_last_kernel() after the timed launches",
+                 share_of_step=f"{per_step} launch(es) per step x {ms:.4f} ms = {100 * per_step * ms / ms_step:.1f} % of the {ms_step:.2f} ms step",
+                 bound=bound, ms_per_launch=round(ms, 4), traffic=tr(name))
+        if bound == "mfma":
+            tf = work / (ms * 1e-3) / 1e12
+            e.update(achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_BF16_TFLOPS, 4), algorithmic_flops=work)
+            if executed:
+                e["executed_flops"] = executed
+            if alg_bytes:
+                e["algorithmic_bytes"] = alg_bytes
+        else:
+            gbs = work / (ms * 1e-3) / 1e9
+            e.update(achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), algorithmic_bytes=work)
+        e["limiter"] = LIMITERS.get(kern, f"not characterised: no counter analysis on record for {kern} (the dispatch chose another kernel than in earlier rounds)")
+        return e
+
+    top = entry("mlp_dw64", "fused-MLP weight gradients of a stage-1 block, M = B*4224 tokens, C = 64, hidden 512 (dW1, db1, dW2, db2; h / dg / GELU / GELU' "
+                "recomputed on chip; DropPath factors per sample, dropped samples skipped)", 2, "mfma", alg_bytes=2.0 * 2 * M2 * 64,
+                executed=2 * cases["mlp_dw64"][1])
+    top["siblings"] = [
+        entry("conv192", "MIM conv3x3 192->192 @32x32 as a gathered GEMM (M = B*1024, N = 192, K = 1728) -- round 2's roofline launch; 4 such forward / input-gradient "
+              "launches per step", 4, "mfma"),
+        entry("proj64", "K = 64, N = 64 projection with bias, M = B*4224 (the stage-1 q / proj forward)", 4, "hbm"),
+        entry("tn_s3dw2", f"weight gradient dW2[320, 1280] += dY^T G over M = B*384 = {M3} rows + bias gradient: the stage-3 fc2 shape, largest launch of the "
+              "trace's top instantiation (stage-3 dW1 / dW2: 4 launches per step)", 4, "mfma", alg_bytes=2.0 * (M3 * 320 + M3 * 1280) + 4.0 * 320 * 1280)]
+    top.update({"traffic_stale": stale} if stale else {"traffic_source": f"profiles/{tj[-1]}" if tj else None})
+    return top
 
 
 def step_traffic():
@@ -226,8 +258,8 @@ def step_traffic():
 
 def other_configs(device):
     """BASELINE configurations #4 and #5 at one GPU, behind the headline's timed region: short runs of the same engine entry
-    -- PVT-medium at 384 px, batch 64 (5 + 10 iterations), and the CLS-head fine-tune step of pvlt_tiny at batch 256 (20 + 20: its first
-    ~20 iterations are ~15 % slower) -- so that the driver's own record carries them."""
+    -- PVT-medium at 384 px, batch 64 (5 + 10 iterations), and the CLS-head fine-tune step of pvlt_tiny at batch 256 (5 + 20; round 4 warmed it up for 20
+    iterations on the belief of a 15 % ramp: timed per iteration it is flat from the fifth on, profiles/r05_ft_ramp.txt) -- so that the driver's own record carries them."""
     from mvlt_amd import pvlt
     from mvlt_amd.engine import BF16Scaler
     from mvlt_amd.optim import FusedAdamW
@@ -235,7 +267,7 @@ def other_configs(device):
     out = {}
     for key, name, img, B, lt, warm, steps, gflop in (
             ("medium384_b64", "pvlt_medium", 384, 64, dict(mlm=1, itm=1, t2i=1, cls=0), 5, 10, 197.25),
-            ("finetune", "pvlt_tiny", 256, 256, dict(mlm=0, itm=0, t2i=0, cls=1), 20, 20, 25.00)):
+            ("finetune", "pvlt_tiny", 256, 256, dict(mlm=0, itm=0, t2i=0, cls=1), 5, 20, 25.00)):
         torch.manual_seed(4321)
         model = getattr(pvlt, name)(pretrained=False, token_hidden_size=768, num_text_tokens=128, loss_type=lt, pretrained_pth=None,
                                     drop_path_rate=0.1, drop_rate=0.0, num_classes=1000, in_chans=3).cuda(device)
@@ -256,7 +288,8 @@ def other_configs(device):
         dt = time.time() - t0
         out[key] = {"workload": f"{name} MVLT " + ("pre-train (MLM+MIM+ITM)" if lt["mlm"] else "fine-tune (CLS heads)") + f", {img}x{img} + 128 tokens, batch {B}, bf16",
                     "pairs_s": round(B * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warm,
-                    "step_tflops_reference_equivalent": round(B * steps / dt * gflop / 1e3, 1), "epoch_avg_loss": round(st["total_loss"], 4)}
+                    "step_tflops_reference_equivalent": round(B * steps / dt * gflop / 1e3, 1),
+                    "mfma_frac_reference_equivalent": round(B * steps / dt * gflop / 1e3 / PEAK_BF16_TFLOPS, 4), "epoch_avg_loss": round(st["total_loss"], 4)}
         del model, opt, batch
         torch.cuda.empty_cache()
     return out
@@ -415,7 +448,7 @@ def main():
                                 "target": 0.40},
             }
             if not args.no_roofline:
-                line["roofline"] = time_dominant_kernel(core, B, device)
+                line["roofline"] = time_dominant_kernel(core, B, device, ms_step)
             gb, src = step_traffic()
             line["step"] = {"executed_tflops": round(per_gpu * executed / 1e12, 1), "ms": round(ms_step, 3),
                             "hbm_gb_per_step": gb, "hbm_tb_per_s": round(gb / ms_step, 2) if gb else None, "hbm_source": src}

@@ -26,6 +26,9 @@ extern "C" {
 #define MVLT_ABI_VERSION 2
 const char* mvlt_last_error(void);
 int mvlt_abi_version(void);
+/* the kernel instantiation the library launched last on the calling thread, as the HIP runtime names it, demangled (e.g. "void (anonymous
+ * namespace)::mlp_wgrad2_kernel<64, 4>(mvlt_mlp_args, int, int, int)"); "" before the first launch.  For measurement records (bench.py names its roofline launches with it). */
+const char* mvlt_last_kernel(void);
 /* sizeof(struct <name>) for binding self-checks; -1 if unknown */
 int mvlt_sizeof(const char* name);
 

@@ -104,6 +104,7 @@ class MlpArgs(C.Structure):
 
 
 lib.mvlt_last_error.restype = C.c_char_p
+lib.mvlt_last_kernel.restype = C.c_char_p
 lib.mvlt_sizeof.argtypes = [C.c_char_p]
 ABI_VERSION = 2          # include/mvlt_hip.h MVLT_ABI_VERSION this binding was written against
 if lib.mvlt_abi_version() != ABI_VERSION:
@@ -115,7 +116,7 @@ for _name, _cls in (("mvlt_rowmap", RowMap), ("mvlt_prep_desc", PrepDesc), ("mvl
     if _n != C.sizeof(_cls):
         raise ImportError(f"ABI mismatch for {_name}: library says {_n} bytes, binding has {C.sizeof(_cls)}")
 
-EXPORTS = ["mvlt_last_error", "mvlt_abi_version", "mvlt_sizeof", "mvlt_gemm_nt", "mvlt_gemm_tn",
+EXPORTS = ["mvlt_last_error", "mvlt_last_kernel", "mvlt_abi_version", "mvlt_sizeof", "mvlt_gemm_nt", "mvlt_gemm_tn",
            "mvlt_layernorm_fwd", "mvlt_layernorm_bwd", "mvlt_fold_copies", "mvlt_batch_sum", "mvlt_sr_attention_fwd", "mvlt_sr_attention_bwd",
            "mvlt_bert_embed_fwd", "mvlt_bert_embed_bwd", "mvlt_patchify", "mvlt_masked_select", "mvlt_gather_rows",
            "mvlt_scatter_rows", "mvlt_cross_entropy_fwd", "mvlt_cross_entropy_bwd", "mvlt_adamw_step", "mvlt_smooth_l1_fwd", "mvlt_smooth_l1_bwd", "mvlt_cast_bf16",
@@ -126,6 +127,22 @@ EXPORTS = ["mvlt_last_error", "mvlt_abi_version", "mvlt_sizeof", "mvlt_gemm_nt",
            "mvlt_upsample_l1_fwd", "mvlt_upsample_l1_bwd"]
 
 DT = {torch.bfloat16: 0, torch.float32: 1}
+
+
+def last_kernel():
+    """name of the kernel instantiation launched last on this thread, e.g. "mlp_wgrad2_kernel<64, 4>" (the runtime's name for the launched
+    function, demangled; return type, namespace and parameter list stripped)"""
+    s = lib.mvlt_last_kernel().decode()
+    s = s.replace("(anonymous namespace)::", "")
+    if s.startswith("void "):
+        s = s[5:]
+    depth = 0
+    for i, ch in enumerate(s):                   # cut at the '(' that opens the parameter list (outside the template brackets)
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return s[:i]
+    return s
 
 
 def check(rc, what):

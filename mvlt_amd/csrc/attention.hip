@@ -260,7 +260,7 @@ template <typename T, int NKT> int launch_fwd_n(const mvlt_attn_args& a, hipStre
   const int groups = a.B * a.H;
   const int grid = 8 * ((groups + 7) / 8) * nq;
   hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, NKT>), dim3(grid), dim3(NT), lds, s, a, nq, q_per_wg);
+  MVLT_LAUNCH((attn_fwd_kernel<T, NKT>), dim3(grid), dim3(NT), lds, s, a, nq, q_per_wg);
   return mvlt_check_launch("mvlt_sr_attention_fwd");
 }
 
@@ -595,10 +595,10 @@ template <int NKT, int NW> int launch_fwd2_nw(const mvlt_attn_args& a, hipStream
   const int grid = 8 * ((groups + 7) / 8) * nq;
   if (a.M == MP) {
     hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKT, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_fwd2_kernel<NKT, false, NW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
+    MVLT_LAUNCH((attn_fwd2_kernel<NKT, false, NW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
   } else {
     hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKT, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_fwd2_kernel<NKT, true, NW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
+    MVLT_LAUNCH((attn_fwd2_kernel<NKT, true, NW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
   }
   return mvlt_check_launch("mvlt_sr_attention_fwd");
 }
@@ -1161,17 +1161,17 @@ template <typename T, int NW, int TPW> int launch_bwd_n(const mvlt_attn_bwd_args
 #ifdef MVLT_ATTN_BWD_VAR                       // A/B builds only (tools/build_alt.sh NAME attention.hip -DMVLT_ATTN_BWD_VAR=1): VAR 1 produces no dQ and wrong dK / dV
       {
         hipFuncSetAttribute((const void*)attn_bwd_dma_kernel<NW, TPW, MVLT_ATTN_BWD_VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        hipLaunchKernelGGL((attn_bwd_dma_kernel<NW, TPW, MVLT_ATTN_BWD_VAR>), dim3(grid), dim3(NW * 64), lds2, s, a, nq, q_per_wg);
+        MVLT_LAUNCH((attn_bwd_dma_kernel<NW, TPW, MVLT_ATTN_BWD_VAR>), dim3(grid), dim3(NW * 64), lds2, s, a, nq, q_per_wg);
         return mvlt_check_launch("mvlt_sr_attention_bwd");
       }
 #endif
       hipFuncSetAttribute((const void*)attn_bwd_dma_kernel<NW, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-      hipLaunchKernelGGL((attn_bwd_dma_kernel<NW, TPW>), dim3(grid), dim3(NW * 64), lds2, s, a, nq, q_per_wg);
+      MVLT_LAUNCH((attn_bwd_dma_kernel<NW, TPW>), dim3(grid), dim3(NW * 64), lds2, s, a, nq, q_per_wg);
       return mvlt_check_launch("mvlt_sr_attention_bwd");
     }
   } else {                                             // fp32 parity path
     hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NW, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_bwd_kernel<T, NW, TPW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
+    MVLT_LAUNCH((attn_bwd_kernel<T, NW, TPW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
     return mvlt_check_launch("mvlt_sr_attention_bwd");
   }
 }

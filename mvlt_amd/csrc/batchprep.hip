@@ -129,7 +129,7 @@ extern "C" int mvlt_grid_mask_flags(uint8_t* flags, int B, int gh, int gw, int n
   MVLT_REQUIRE(flags && B >= 0 && gh > 0 && gw > 0 && gh * gw <= MAXP, "mvlt_grid_mask_flags: bad arguments (at most %d patches per sample)", MAXP);
   MVLT_REQUIRE(num_mask >= 0 && num_mask <= gh * gw && (mode == 0 || mode == 1), "mvlt_grid_mask_flags: bad num_mask / mode");
   if (B == 0) return MVLT_OK;
-  hipLaunchKernelGGL(grid_flags_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, flags, gh, gw, num_mask, mode, seed, sample0);
+  MVLT_LAUNCH(grid_flags_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, flags, gh, gw, num_mask, mode, seed, sample0);
   return mvlt_check_launch("mvlt_grid_mask_flags");
 }
 
@@ -140,7 +140,7 @@ extern "C" int mvlt_grid_mask_apply(const float* image, const uint8_t* flags, fl
   const long n4 = (long)B * C * H * W / 4;
   if (n4 == 0) return MVLT_OK;
   const long blocks = (n4 + NT - 1) / NT;
-  hipLaunchKernelGGL(grid_apply_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(NT), 0, (hipStream_t)stream, image, flags, masked, n4,
+  MVLT_LAUNCH(grid_apply_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(NT), 0, (hipStream_t)stream, image, flags, masked, n4,
                      C, H, W, patch, fill);
   return mvlt_check_launch("mvlt_grid_mask_apply");
 }
@@ -151,7 +151,7 @@ extern "C" int mvlt_token_mask(const long* ori_ids, long* input_ids, long* label
   const long n = (long)B * T;
   if (n == 0) return MVLT_OK;
   // r < T  <=>  r / 2^24 < p for p = 0.15 / 0.8 / 0.9 (fashion_gen.py:390-398)
-  hipLaunchKernelGGL(token_mask_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, ori_ids, input_ids, labels, n, T, seed,
+  MVLT_LAUNCH(token_mask_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, ori_ids, input_ids, labels, n, T, seed,
                      sample0, vocab, 2516583, 13421773, 15099495);
   return mvlt_check_launch("mvlt_token_mask");
 }
@@ -160,7 +160,7 @@ extern "C" int mvlt_keep_mask(uint8_t* keep, long n, float drop_p, uint64_t seed
   MVLT_REQUIRE(keep && n >= 0 && drop_p >= 0.f && drop_p < 1.f && ((uintptr_t)keep & 7) == 0, "mvlt_keep_mask: bad arguments");
   if (n == 0) return MVLT_OK;
   const long groups = (n + 7) / 8;
-  hipLaunchKernelGGL(keep_mask_kernel, dim3((unsigned)((groups + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, keep, n, (uint32_t)(drop_p * 65536.0f), seed,
+  MVLT_LAUNCH(keep_mask_kernel, dim3((unsigned)((groups + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, keep, n, (uint32_t)(drop_p * 65536.0f), seed,
                      call);
   return mvlt_check_launch("mvlt_keep_mask");
 }
@@ -168,6 +168,6 @@ extern "C" int mvlt_keep_mask(uint8_t* keep, long n, float drop_p, uint64_t seed
 extern "C" int mvlt_droppath_scales(float* out, const float* rates, int nrate, int per, uint64_t seed, uint64_t call, void* stream) {
   MVLT_REQUIRE(out && rates && nrate >= 0 && per >= 0, "mvlt_droppath_scales: bad arguments");
   if (nrate * per == 0) return MVLT_OK;
-  hipLaunchKernelGGL(droppath_scales_kernel, dim3((unsigned)((nrate * per + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, out, rates, nrate, per, seed, call);
+  MVLT_LAUNCH(droppath_scales_kernel, dim3((unsigned)((nrate * per + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, out, rates, nrate, per, seed, call);
   return mvlt_check_launch("mvlt_droppath_scales");
 }

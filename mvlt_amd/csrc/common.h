@@ -58,6 +58,16 @@ template <bool NTF, typename V> __device__ __forceinline__ V ld_g(const V* p) {
 void mvlt_set_error(const char* fmt, ...);
 int mvlt_check_launch(const char* what);
 
+// Every kernel launch of the library goes through MVLT_LAUNCH, which remembers WHICH instantiation was launched last (its host-side function pointer, one
+// store; the name is looked up and demangled only when asked for): mvlt_last_kernel() hands it to the caller, so that bench.py's `roofline` entries name the kernel that actually ran instead of a literal
+// (after a dispatch change the prose could silently lie).
+void mvlt_note_kernel(const void* host_function);
+#define MVLT_LAUNCH(K, ...)                  \
+  do {                                       \
+    mvlt_note_kernel((const void*)(K));      \
+    hipLaunchKernelGGL(K, __VA_ARGS__);      \
+  } while (0)
+
 #define MVLT_REQUIRE(cond, ...)                 \
   do {                                          \
     if (!(cond)) {                              \

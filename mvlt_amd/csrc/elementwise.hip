@@ -661,8 +661,8 @@ extern "C" int mvlt_bert_embed_fwd(const long* ids, const float* word, const flo
   if (rows <= 0) return MVLT_OK;
   const float inv_keep = 1.0f / (1.0f - drop_p);
   dim3 grid((rows + 3) / 4), block(NT);
-  if (dtype == 0) hipLaunchKernelGGL((bert_embed_fwd_kernel<bf16, 768>), grid, block, 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta, keep, inv_keep, (bf16*)y, mean, rstd, rows, T, eps);
-  else hipLaunchKernelGGL((bert_embed_fwd_kernel<float, 768>), grid, block, 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta, keep, inv_keep, (float*)y, mean, rstd, rows, T, eps);
+  if (dtype == 0) MVLT_LAUNCH((bert_embed_fwd_kernel<bf16, 768>), grid, block, 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta, keep, inv_keep, (bf16*)y, mean, rstd, rows, T, eps);
+  else MVLT_LAUNCH((bert_embed_fwd_kernel<float, 768>), grid, block, 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta, keep, inv_keep, (float*)y, mean, rstd, rows, T, eps);
   return mvlt_check_launch("mvlt_bert_embed_fwd");
 }
 
@@ -679,8 +679,8 @@ extern "C" int mvlt_bert_embed_bwd(const void* dy, const long* ids, const float*
   const int nbatch = rows / T;
   if (nsplit > (nbatch + 15) / 16) nsplit = (nbatch + 15) / 16;
   dim3 grid(T * nsplit), block(1024);
-  if (dtype == 0) hipLaunchKernelGGL((bert_embed_bwd_kernel<bf16, 768, 1024>), grid, block, 0, (hipStream_t)stream, (const bf16*)dy, ids, word, pos, type0, gamma, keep, inv_keep, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T);
-  else hipLaunchKernelGGL((bert_embed_bwd_kernel<float, 768, 1024>), grid, block, 0, (hipStream_t)stream, (const float*)dy, ids, word, pos, type0, gamma, keep, inv_keep, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T);
+  if (dtype == 0) MVLT_LAUNCH((bert_embed_bwd_kernel<bf16, 768, 1024>), grid, block, 0, (hipStream_t)stream, (const bf16*)dy, ids, word, pos, type0, gamma, keep, inv_keep, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T);
+  else MVLT_LAUNCH((bert_embed_bwd_kernel<float, 768, 1024>), grid, block, 0, (hipStream_t)stream, (const float*)dy, ids, word, pos, type0, gamma, keep, inv_keep, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, rows, T);
   return mvlt_check_launch("mvlt_bert_embed_bwd");
 }
 
@@ -691,14 +691,14 @@ extern "C" int mvlt_patchify(const float* img, void* out, int B, int Cin, int H,
   if (k == 4 && Cin == 3 && W % 4 == 0 && (size_t)12 * (W + 4) * sizeof(float) <= 65536 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)out & 15) == 0) {
     const size_t lds = (size_t)12 * (W + 4) * sizeof(float);
     dim3 sgrid((unsigned)(B * (H / 4))), sblock(NT);
-    if (dtype == 0) hipLaunchKernelGGL((patchify_strip_kernel<bf16>), sgrid, sblock, lds, (hipStream_t)stream, img, (bf16*)out, H, W);
-    else hipLaunchKernelGGL((patchify_strip_kernel<float>), sgrid, sblock, lds, (hipStream_t)stream, img, (float*)out, H, W);
+    if (dtype == 0) MVLT_LAUNCH((patchify_strip_kernel<bf16>), sgrid, sblock, lds, (hipStream_t)stream, img, (bf16*)out, H, W);
+    else MVLT_LAUNCH((patchify_strip_kernel<float>), sgrid, sblock, lds, (hipStream_t)stream, img, (float*)out, H, W);
     return mvlt_check_launch("mvlt_patchify");
   }
   long total = (long)B * (H / k) * (W / k) * Cin * k;
   dim3 grid(grid_for(total, 16384)), block(NT);
-  if (dtype == 0) hipLaunchKernelGGL((patchify_kernel<bf16>), grid, block, 0, (hipStream_t)stream, img, (bf16*)out, B, Cin, H, W, k);
-  else hipLaunchKernelGGL((patchify_kernel<float>), grid, block, 0, (hipStream_t)stream, img, (float*)out, B, Cin, H, W, k);
+  if (dtype == 0) MVLT_LAUNCH((patchify_kernel<bf16>), grid, block, 0, (hipStream_t)stream, img, (bf16*)out, B, Cin, H, W, k);
+  else MVLT_LAUNCH((patchify_kernel<float>), grid, block, 0, (hipStream_t)stream, img, (float*)out, B, Cin, H, W, k);
   return mvlt_check_launch("mvlt_patchify");
 }
 
@@ -707,8 +707,8 @@ extern "C" int mvlt_resize_bilinear_tokens(const float* in, int ld_in, float* ou
   MVLT_REQUIRE(in && out && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && C > 0 && ld_in >= C && ld_out >= C, "mvlt_resize_bilinear_tokens: bad arguments");
   const long n = (long)Hout * Wout * C;
   const float sh = (float)Hin / (float)Hout, sw = (float)Win / (float)Wout;
-  if (adjoint) hipLaunchKernelGGL((resize_tokens_kernel<true>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, in, ld_in, out, ld_out, Hin, Win, Hout, Wout, C, sh, sw);
-  else hipLaunchKernelGGL((resize_tokens_kernel<false>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, in, ld_in, out, ld_out, Hin, Win, Hout, Wout, C, sh, sw);
+  if (adjoint) MVLT_LAUNCH((resize_tokens_kernel<true>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, in, ld_in, out, ld_out, Hin, Win, Hout, Wout, C, sh, sw);
+  else MVLT_LAUNCH((resize_tokens_kernel<false>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, in, ld_in, out, ld_out, Hin, Win, Hout, Wout, C, sh, sw);
   return mvlt_check_launch("mvlt_resize_bilinear_tokens");
 }
 
@@ -726,22 +726,22 @@ extern "C" int mvlt_resize_bilinear_tokens_multi(const float* const* in, const i
     if (n > nmax) nmax = n;
   }
   const dim3 grid(grid_for(nmax), (unsigned)count);
-  if (adjoint) hipLaunchKernelGGL((resize_tokens_multi_kernel<true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((resize_tokens_multi_kernel<false>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+  if (adjoint) MVLT_LAUNCH((resize_tokens_multi_kernel<true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+  else MVLT_LAUNCH((resize_tokens_multi_kernel<false>), grid, dim3(NT), 0, (hipStream_t)stream, a);
   return mvlt_check_launch("mvlt_resize_bilinear_tokens_multi");
 }
 
 extern "C" int mvlt_gelu_bwd(const void* dy, const void* h, void* out, long n, int dtype, void* stream) {
   MVLT_REQUIRE(dy && h && out && n >= 0 && (dtype == 0 || dtype == 1), "mvlt_gelu_bwd: bad arguments");
   if (n == 0) return MVLT_OK;
-  if (dtype == 0) hipLaunchKernelGGL((gelu_bwd_kernel<bf16>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)h, (bf16*)out, n);
-  else hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, (const float*)dy, (const float*)h, (float*)out, n);
+  if (dtype == 0) MVLT_LAUNCH((gelu_bwd_kernel<bf16>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)h, (bf16*)out, n);
+  else MVLT_LAUNCH((gelu_bwd_kernel<float>), dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, (const float*)dy, (const float*)h, (float*)out, n);
   return mvlt_check_launch("mvlt_gelu_bwd");
 }
 
 extern "C" int mvlt_masked_select(const long* labels, int n, long ignore_index, int* idx, int* count, void* stream) {
   MVLT_REQUIRE(labels && idx && count && n >= 0, "mvlt_masked_select: bad arguments");
-  hipLaunchKernelGGL(masked_select_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, n, ignore_index, idx, count);
+  MVLT_LAUNCH(masked_select_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, n, ignore_index, idx, count);
   return mvlt_check_launch("mvlt_masked_select");
 }
 
@@ -752,8 +752,8 @@ extern "C" int mvlt_gather_rows(const void* src, const int* idx, void* dst, int 
   if (rows <= 0) return MVLT_OK;
   dim3 grid(grid_for((long)rows * (C / pc))), block(NT);
   RowMap m = host_rowmap(src_map);
-  if (dtype == 0) hipLaunchKernelGGL((gather_rows_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16*)src, idx, (bf16*)dst, rows, C, ld_src, m);
-  else hipLaunchKernelGGL((gather_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, idx, (float*)dst, rows, C, ld_src, m);
+  if (dtype == 0) MVLT_LAUNCH((gather_rows_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16*)src, idx, (bf16*)dst, rows, C, ld_src, m);
+  else MVLT_LAUNCH((gather_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, idx, (float*)dst, rows, C, ld_src, m);
   return mvlt_check_launch("mvlt_gather_rows");
 }
 
@@ -764,8 +764,8 @@ extern "C" int mvlt_scatter_rows(const void* src, const int* idx, void* dst, int
   if (rows <= 0) return MVLT_OK;
   dim3 grid(grid_for((long)rows * (C / pc))), block(NT);
   RowMap m = host_rowmap(dst_map);
-  if (dtype == 0) hipLaunchKernelGGL((scatter_rows_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16*)src, idx, (bf16*)dst, rows, C, ld_dst, m, accumulate);
-  else hipLaunchKernelGGL((scatter_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, idx, (float*)dst, rows, C, ld_dst, m, accumulate);
+  if (dtype == 0) MVLT_LAUNCH((scatter_rows_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16*)src, idx, (bf16*)dst, rows, C, ld_dst, m, accumulate);
+  else MVLT_LAUNCH((scatter_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, idx, (float*)dst, rows, C, ld_dst, m, accumulate);
   return mvlt_check_launch("mvlt_scatter_rows");
 }
 
@@ -774,8 +774,8 @@ extern "C" int mvlt_cross_entropy_fwd(const void* logits, const long* labels, lo
   MVLT_REQUIRE(logits && labels && lse && loss_sum && count && V > 0 && ld >= V, "mvlt_cross_entropy_fwd: bad arguments");
   if (rows <= 0) return MVLT_OK;
   dim3 grid(rows), block(NT);
-  if (dtype == 0) hipLaunchKernelGGL((ce_fwd_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16*)logits, labels, ignore_index, lse, loss_sum, count, rows, V, ld);
-  else hipLaunchKernelGGL((ce_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)logits, labels, ignore_index, lse, loss_sum, count, rows, V, ld);
+  if (dtype == 0) MVLT_LAUNCH((ce_fwd_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16*)logits, labels, ignore_index, lse, loss_sum, count, rows, V, ld);
+  else MVLT_LAUNCH((ce_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)logits, labels, ignore_index, lse, loss_sum, count, rows, V, ld);
   return mvlt_check_launch("mvlt_cross_entropy_fwd");
 }
 
@@ -785,24 +785,24 @@ extern "C" int mvlt_cross_entropy_bwd(const void* logits, const long* labels, lo
   if (rows <= 0) return MVLT_OK;
   dim3 grid(rows), block(NT);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == 0 && out_dtype == 0) hipLaunchKernelGGL((ce_bwd_kernel<bf16, bf16>), grid, block, 0, s, (const bf16*)logits, labels, ignore_index, lse, gscale, count, (bf16*)dlogits, rows, V, ld, ldd);
-  else if (dtype == 1 && out_dtype == 0) hipLaunchKernelGGL((ce_bwd_kernel<float, bf16>), grid, block, 0, s, (const float*)logits, labels, ignore_index, lse, gscale, count, (bf16*)dlogits, rows, V, ld, ldd);
-  else if (dtype == 1 && out_dtype == 1) hipLaunchKernelGGL((ce_bwd_kernel<float, float>), grid, block, 0, s, (const float*)logits, labels, ignore_index, lse, gscale, count, (float*)dlogits, rows, V, ld, ldd);
-  else hipLaunchKernelGGL((ce_bwd_kernel<bf16, float>), grid, block, 0, s, (const bf16*)logits, labels, ignore_index, lse, gscale, count, (float*)dlogits, rows, V, ld, ldd);
+  if (dtype == 0 && out_dtype == 0) MVLT_LAUNCH((ce_bwd_kernel<bf16, bf16>), grid, block, 0, s, (const bf16*)logits, labels, ignore_index, lse, gscale, count, (bf16*)dlogits, rows, V, ld, ldd);
+  else if (dtype == 1 && out_dtype == 0) MVLT_LAUNCH((ce_bwd_kernel<float, bf16>), grid, block, 0, s, (const float*)logits, labels, ignore_index, lse, gscale, count, (bf16*)dlogits, rows, V, ld, ldd);
+  else if (dtype == 1 && out_dtype == 1) MVLT_LAUNCH((ce_bwd_kernel<float, float>), grid, block, 0, s, (const float*)logits, labels, ignore_index, lse, gscale, count, (float*)dlogits, rows, V, ld, ldd);
+  else MVLT_LAUNCH((ce_bwd_kernel<bf16, float>), grid, block, 0, s, (const bf16*)logits, labels, ignore_index, lse, gscale, count, (float*)dlogits, rows, V, ld, ldd);
   return mvlt_check_launch("mvlt_cross_entropy_bwd");
 }
 
 extern "C" int mvlt_smooth_l1_fwd(const float* pred, const float* target, long n, float* loss_sum, void* stream) {
   MVLT_REQUIRE(pred && target && loss_sum && n > 0 && n % 4 == 0 && (((uintptr_t)pred | (uintptr_t)target) & 15) == 0,
                "mvlt_smooth_l1_fwd: bad arguments (n multiple of 4, 16-byte aligned)");
-  hipLaunchKernelGGL(smooth_l1_sum_kernel, dim3(grid_for(n / 4, 2048)), dim3(NT), 0, (hipStream_t)stream, pred, target, n, loss_sum);
+  MVLT_LAUNCH(smooth_l1_sum_kernel, dim3(grid_for(n / 4, 2048)), dim3(NT), 0, (hipStream_t)stream, pred, target, n, loss_sum);
   return mvlt_check_launch("mvlt_smooth_l1_fwd");
 }
 
 extern "C" int mvlt_smooth_l1_bwd(const float* pred, const float* target, long n, const float* gscale, float* grad, void* stream) {
   MVLT_REQUIRE(pred && target && gscale && grad && n > 0 && n % 4 == 0 && (((uintptr_t)pred | (uintptr_t)target | (uintptr_t)grad) & 15) == 0,
                "mvlt_smooth_l1_bwd: bad arguments (n multiple of 4, 16-byte aligned)");
-  hipLaunchKernelGGL(smooth_l1_grad_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, pred, target, n, gscale, 1.0f / (float)n, grad);
+  MVLT_LAUNCH(smooth_l1_grad_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, pred, target, n, gscale, 1.0f / (float)n, grad);
   return mvlt_check_launch("mvlt_smooth_l1_bwd");
 }
 
@@ -810,14 +810,14 @@ extern "C" int mvlt_adamw_step(float* p, const float* g, float* m, float* v, voi
                                const uint8_t* decay_mask, void* stream) {
   MVLT_REQUIRE(p && g && m && v && hp && n >= 0 && n % 4 == 0, "mvlt_adamw_step: bad arguments (n must be a multiple of 4)");
   if (n == 0) return MVLT_OK;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, hp, decay_mask);
+  MVLT_LAUNCH(adamw_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, hp, decay_mask);
   return mvlt_check_launch("mvlt_adamw_step");
 }
 
 extern "C" int mvlt_cast_bf16(const float* src, void* dst, long n, void* stream) {
   MVLT_REQUIRE(src && dst && n >= 0 && n % 4 == 0, "mvlt_cast_bf16: bad arguments (n must be a multiple of 4)");
   if (n == 0) return MVLT_OK;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, src, (bf16*)dst, n);
+  MVLT_LAUNCH(cast_f32_bf16_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, src, (bf16*)dst, n);
   return mvlt_check_launch("mvlt_cast_bf16");
 }
 
@@ -826,30 +826,30 @@ extern "C" int mvlt_row_scale(const void* x, const float* scale, int rows_per_sc
   MVLT_REQUIRE(dtype == 0 || dtype == 1, "mvlt_row_scale: bad dtype");
   if (M == 0) return MVLT_OK;
   const long n = M * C, per = (long)rows_per_scale * C;
-  if (dtype == 0) hipLaunchKernelGGL((row_scale_kernel<bf16>), dim3(grid_for(n / 8, 8192)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, scale, per, n, (bf16*)out);
-  else hipLaunchKernelGGL((row_scale_kernel<float>), dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, (const float*)x, scale, per, n, (float*)out);
+  if (dtype == 0) MVLT_LAUNCH((row_scale_kernel<bf16>), dim3(grid_for(n / 8, 8192)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, scale, per, n, (bf16*)out);
+  else MVLT_LAUNCH((row_scale_kernel<float>), dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)stream, (const float*)x, scale, per, n, (float*)out);
   return mvlt_check_launch("mvlt_row_scale");
 }
 
 extern "C" int mvlt_head_grad_prep(const float* dlogits, int B, int n, int n_pad, void* dl, float* db1, float* db2, int dtype, void* stream) {
   MVLT_REQUIRE(dlogits && dl && db1 && B > 0 && n > 0 && n_pad >= n && n_pad <= 256 && (dtype == 0 || dtype == 1), "mvlt_head_grad_prep: bad arguments (n_pad <= 256)");
-  if (dtype == 0) hipLaunchKernelGGL((head_grad_prep_kernel<bf16>), dim3(1), dim3(NT), 0, (hipStream_t)stream, dlogits, B, n, n_pad, (bf16*)dl, db1, db2);
-  else hipLaunchKernelGGL((head_grad_prep_kernel<float>), dim3(1), dim3(NT), 0, (hipStream_t)stream, dlogits, B, n, n_pad, (float*)dl, db1, db2);
+  if (dtype == 0) MVLT_LAUNCH((head_grad_prep_kernel<bf16>), dim3(1), dim3(NT), 0, (hipStream_t)stream, dlogits, B, n, n_pad, (bf16*)dl, db1, db2);
+  else MVLT_LAUNCH((head_grad_prep_kernel<float>), dim3(1), dim3(NT), 0, (hipStream_t)stream, dlogits, B, n, n_pad, (float*)dl, db1, db2);
   return mvlt_check_launch("mvlt_head_grad_prep");
 }
 
 extern "C" int mvlt_weight_prep(const mvlt_prep_desc* descs, const int* blk_start, int ndesc, int total_blocks, int dtype, void* stream) {
   MVLT_REQUIRE(descs && blk_start && ndesc > 0 && total_blocks > 0, "mvlt_weight_prep: bad arguments");
-  if (dtype == 0) hipLaunchKernelGGL((weight_prep_kernel<bf16>), dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, descs, blk_start, ndesc);
-  else hipLaunchKernelGGL((weight_prep_kernel<float>), dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, descs, blk_start, ndesc);
+  if (dtype == 0) MVLT_LAUNCH((weight_prep_kernel<bf16>), dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, descs, blk_start, ndesc);
+  else MVLT_LAUNCH((weight_prep_kernel<float>), dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, descs, blk_start, ndesc);
   return mvlt_check_launch("mvlt_weight_prep");
 }
 
 extern "C" int mvlt_transpose_cast(const float* in, void* out, int R, int Ccols, int ld_out, int dtype, void* stream) {
   MVLT_REQUIRE(in && out && R > 0 && Ccols > 0 && ld_out >= R, "mvlt_transpose_cast: bad arguments");
   dim3 grid((Ccols + 31) / 32, (R + 31) / 32), block(NT);
-  if (dtype == 0) hipLaunchKernelGGL((transpose_cast_kernel<bf16>), grid, block, 0, (hipStream_t)stream, in, (bf16*)out, R, Ccols, ld_out);
-  else hipLaunchKernelGGL((transpose_cast_kernel<float>), grid, block, 0, (hipStream_t)stream, in, (float*)out, R, Ccols, ld_out);
+  if (dtype == 0) MVLT_LAUNCH((transpose_cast_kernel<bf16>), grid, block, 0, (hipStream_t)stream, in, (bf16*)out, R, Ccols, ld_out);
+  else MVLT_LAUNCH((transpose_cast_kernel<float>), grid, block, 0, (hipStream_t)stream, in, (float*)out, R, Ccols, ld_out);
   return mvlt_check_launch("mvlt_transpose_cast");
 }
 
@@ -857,7 +857,7 @@ extern "C" int mvlt_loss_compose(const float* const* losses, const float* weight
   MVLT_REQUIRE(losses && weights && out && total, "mvlt_loss_compose: null argument");
   LossPtrs a;
   for (int i = 0; i < 5; ++i) { a.p[i] = losses[i]; a.w[i] = weights[i]; }
-  hipLaunchKernelGGL(loss_compose_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out, total);
+  MVLT_LAUNCH(loss_compose_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out, total);
   return mvlt_check_launch("mvlt_loss_compose");
 }
 
@@ -867,7 +867,7 @@ extern "C" int mvlt_add_column_sums(const float* in, long rows, int cols, int ld
   MVLT_REQUIRE(cols <= 1024, "mvlt_add_column_sums: at most 1024 columns, got %d", cols);
   long nwg = rows / 64 < 32 ? (rows + 63) / 64 : 32;
   const int rows_per_wg = (int)((rows + nwg - 1) / nwg);
-  hipLaunchKernelGGL(add_column_sums_kernel, dim3((unsigned)((rows + rows_per_wg - 1) / rows_per_wg)), dim3(1024), 0, (hipStream_t)stream, in, rows, cols, ld, dst0, n0,
+  MVLT_LAUNCH(add_column_sums_kernel, dim3((unsigned)((rows + rows_per_wg - 1) / rows_per_wg)), dim3(1024), 0, (hipStream_t)stream, in, rows, cols, ld, dst0, n0,
                      dst1, rows_per_wg);
   return mvlt_check_launch("mvlt_add_column_sums");
 }

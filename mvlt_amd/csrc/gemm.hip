@@ -1566,7 +1566,7 @@ template <int W> int launch_conv3_wgrad(const mvlt_gemm_tn_args& a, hipStream_t 
   splits = (ntiles + tps - 1) / tps;
   dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * n_o * n_c)), block(NTHREADS);
   hipFuncSetAttribute((const void*)conv3_wgrad_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((conv3_wgrad_kernel<W>), grid, block, lds, s, a, tps, n_o, n_c, splits);
+  MVLT_LAUNCH((conv3_wgrad_kernel<W>), grid, block, lds, s, a, tps, n_o, n_c, splits);
   return mvlt_check_launch("mvlt_gemm_tn");
 }
 
@@ -2081,7 +2081,7 @@ template <int EPI, int HM, int HN0, int HN1, bool RAG = false> void launch_nt_p8
   (void)once;
   const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = (a.N + BNT - 1) / BNT;
   dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n)), block(512);
-  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI, HM, HN0, HN1, RAG>), grid, block, LDS, s, a);
+  MVLT_LAUNCH((gemm_nt_p8_kernel<EPI, HM, HN0, HN1, RAG>), grid, block, LDS, s, a);
 }
 template <int HM, int HN0, int HN1> bool dispatch_nt_p8(const mvlt_gemm_nt_args& a, int epi, hipStream_t s) {
   switch (epi) {
@@ -2245,7 +2245,7 @@ template <int W, int BN, int EPI> void launch_conv3_nt(const mvlt_gemm_nt_args& 
   const int tiles_m = a.M / BM, tiles_n = (a.N + BN - 1) / BN;
   dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n)), block(NTHREADS);
   hipFuncSetAttribute((const void*)conv3_nt_kernel<W, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((conv3_nt_kernel<W, BN, EPI>), grid, block, lds, s, a);
+  MVLT_LAUNCH((conv3_nt_kernel<W, BN, EPI>), grid, block, lds, s, a);
 }
 template <int W> bool dispatch_conv3_nt(const mvlt_gemm_nt_args& a, int epi, hipStream_t s) {
   const bool wide = a.N % 192 == 0 && a.N % 128 != 0 && (epi == 1 || epi == 5) && a.c_map.mode == 0;
@@ -2364,21 +2364,21 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
                    a->post_mean && a->post_rstd && a->post_ld % 8 == 0 && ((uintptr_t)a->post_y & 15) == 0 && ((uintptr_t)a->post_gamma & 15) == 0,
                    "mvlt_gemm_nt: post_y needs bf16 operands, a residual (R), N == 64 or 128, identity row maps, 16-byte aligned outputs");
       if (lds2 < stage + 2048) lds2 = stage + 2048;
-      if (narrow) hipLaunchKernelGGL((gemm_nt_dma_kernel<64, 0, 8, 64>), grid, block, lds2, s, *a, ns);
-      else hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 0, 8, 64>), grid, block, lds2, s, *a, ns);
+      if (narrow) MVLT_LAUNCH((gemm_nt_dma_kernel<64, 0, 8, 64>), grid, block, lds2, s, *a, ns);
+      else MVLT_LAUNCH((gemm_nt_dma_kernel<128, 0, 8, 64>), grid, block, lds2, s, *a, ns);
       return mvlt_check_launch("mvlt_gemm_nt");
     }
 #define MVLT_NT_LAUNCH_E(BN_, AM_, BK_)                                                                                 \
   do {                                                                                                               \
     switch (epi) {                                                                                                   \
-      case 1: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 1, BK_>), grid, block, lds2, s, *a, ns); break;            \
-      case 2: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 2, BK_>), grid, block, lds2, s, *a, ns); break;            \
-      case 3: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 3, BK_>), grid, block, lds2, s, *a, ns); break;            \
-      case 4: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 4, BK_>), grid, block, lds2, s, *a, ns); break;            \
-      case 5: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 5, BK_>), grid, block, lds2, s, *a, ns); break;            \
-      case 6: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 6, BK_>), grid, block, lds2, s, *a, ns); break;            \
-      case 7: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 7, BK_>), grid, block, lds2, s, *a, ns); break;            \
-      default: hipLaunchKernelGGL((gemm_nt_dma_kernel<BN_, AM_, 0, BK_>), grid, block, lds2, s, *a, ns);                  \
+      case 1: MVLT_LAUNCH((gemm_nt_dma_kernel<BN_, AM_, 1, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      case 2: MVLT_LAUNCH((gemm_nt_dma_kernel<BN_, AM_, 2, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      case 3: MVLT_LAUNCH((gemm_nt_dma_kernel<BN_, AM_, 3, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      case 4: MVLT_LAUNCH((gemm_nt_dma_kernel<BN_, AM_, 4, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      case 5: MVLT_LAUNCH((gemm_nt_dma_kernel<BN_, AM_, 5, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      case 6: MVLT_LAUNCH((gemm_nt_dma_kernel<BN_, AM_, 6, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      case 7: MVLT_LAUNCH((gemm_nt_dma_kernel<BN_, AM_, 7, BK_>), grid, block, lds2, s, *a, ns); break;            \
+      default: MVLT_LAUNCH((gemm_nt_dma_kernel<BN_, AM_, 0, BK_>), grid, block, lds2, s, *a, ns);                  \
     }                                                                                                                \
   } while (0)
 #define MVLT_NT_LAUNCH(BN_, BK_)                                                                                     \
@@ -2434,19 +2434,19 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
       size_t lds3 = (size_t)ns_lds * (BM + 192) * ROW_BYTES;
       const size_t stage192 = (size_t)4 * 32 * 100 * sizeof(float);
       if (lds3 < stage192) lds3 = stage192;
-      if (a->a_map.mode == 0 && epi == 1) hipLaunchKernelGGL((gemm_nt_dma_kernel<192, 0, 1, 64>), grid192, block, lds3, s, *a, ns);
-      else if (a->a_map.mode == 0) hipLaunchKernelGGL((gemm_nt_dma_kernel<192, 0, 5, 64>), grid192, block, lds3, s, *a, ns);
-      else if (epi == 1) hipLaunchKernelGGL((gemm_nt_dma_kernel<192, 2, 1, 64>), grid192, block, lds3, s, *a, ns);
-      else hipLaunchKernelGGL((gemm_nt_dma_kernel<192, 2, 5, 64>), grid192, block, lds3, s, *a, ns);
+      if (a->a_map.mode == 0 && epi == 1) MVLT_LAUNCH((gemm_nt_dma_kernel<192, 0, 1, 64>), grid192, block, lds3, s, *a, ns);
+      else if (a->a_map.mode == 0) MVLT_LAUNCH((gemm_nt_dma_kernel<192, 0, 5, 64>), grid192, block, lds3, s, *a, ns);
+      else if (epi == 1) MVLT_LAUNCH((gemm_nt_dma_kernel<192, 2, 1, 64>), grid192, block, lds3, s, *a, ns);
+      else MVLT_LAUNCH((gemm_nt_dma_kernel<192, 2, 5, 64>), grid192, block, lds3, s, *a, ns);
     } else if (narrow) MVLT_NT_LAUNCH(64, 64);
-    else if (bkd == 32 && epi == 3) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 0, 3, 32>), grid, block, lds2, s, *a, ns);
-    else if (bkd == 32) hipLaunchKernelGGL((gemm_nt_dma_kernel<128, 0, 4, 32>), grid, block, lds2, s, *a, ns);
+    else if (bkd == 32 && epi == 3) MVLT_LAUNCH((gemm_nt_dma_kernel<128, 0, 3, 32>), grid, block, lds2, s, *a, ns);
+    else if (bkd == 32) MVLT_LAUNCH((gemm_nt_dma_kernel<128, 0, 4, 32>), grid, block, lds2, s, *a, ns);
     else MVLT_NT_LAUNCH(128, 64);
 #undef MVLT_NT_LAUNCH_E
 #undef MVLT_NT_LAUNCH
   } else {
-    if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<float, 64>), grid, block, lds, s, *a, nbuf);
-    else hipLaunchKernelGGL((gemm_nt_kernel<float, 128>), grid, block, lds, s, *a, nbuf);
+    if (narrow) MVLT_LAUNCH((gemm_nt_kernel<float, 64>), grid, block, lds, s, *a, nbuf);
+    else MVLT_LAUNCH((gemm_nt_kernel<float, 128>), grid, block, lds, s, *a, nbuf);
   }
   return mvlt_check_launch("mvlt_gemm_nt");
 }
@@ -2513,12 +2513,12 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
         const size_t lds = (size_t)4 * TBK * 128 * 2 + 64 * 64 * 2;
         static bool once = (hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<64, 64, 3, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
         (void)once;
-        hipLaunchKernelGGL((gemm_tn_dma_kernel<64, 64, 3, 4, true>), grid, block, lds, s, *a, m_per_split, 1, 1, splits);
+        MVLT_LAUNCH((gemm_tn_dma_kernel<64, 64, 3, 4, true>), grid, block, lds, s, *a, m_per_split, 1, 1, splits);
       } else {
         const size_t lds = (size_t)2 * TBK * 256 * 2 + 64 * 128 * 2;
         static bool once = (hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<128, 128, 3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
         (void)once;
-        hipLaunchKernelGGL((gemm_tn_dma_kernel<128, 128, 3, 2, true>), grid, block, lds, s, *a, m_per_split, 1, 1, splits);
+        MVLT_LAUNCH((gemm_tn_dma_kernel<128, 128, 3, 2, true>), grid, block, lds, s, *a, m_per_split, 1, 1, splits);
       }
       return mvlt_check_launch("mvlt_gemm_tn");
     }
@@ -2546,10 +2546,10 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
 #define MVLT_TN_LAUNCH(BMT_, BN_, NS_)                                                                                          \
   do {                                                                                                                         \
     if (a->b_map.mode == 0 && a->b_map.rows_per_batch == 0 && a->a_map.rows_per_batch == 0)                                                        \
-      hipLaunchKernelGGL((gemm_tn_dma_kernel<BMT_, BN_, 3, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits);                           \
-    else if (a->b_map.mode == 0) hipLaunchKernelGGL((gemm_tn_dma_kernel<BMT_, BN_, 0, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits); \
-    else if (a->b_map.mode == 1) hipLaunchKernelGGL((gemm_tn_dma_kernel<BMT_, BN_, 1, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits); \
-    else hipLaunchKernelGGL((gemm_tn_dma_kernel<BMT_, BN_, 2, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits);                         \
+      MVLT_LAUNCH((gemm_tn_dma_kernel<BMT_, BN_, 3, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits);                           \
+    else if (a->b_map.mode == 0) MVLT_LAUNCH((gemm_tn_dma_kernel<BMT_, BN_, 0, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits); \
+    else if (a->b_map.mode == 1) MVLT_LAUNCH((gemm_tn_dma_kernel<BMT_, BN_, 1, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits); \
+    else MVLT_LAUNCH((gemm_tn_dma_kernel<BMT_, BN_, 2, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits);                         \
   } while (0)
     if (bmt == 128 && bn == 128) MVLT_TN_LAUNCH(128, 128, 2);
     else if (bmt == 128) MVLT_TN_LAUNCH(128, 64, 3);
@@ -2574,11 +2574,11 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
   const size_t lds = (size_t)(BM + bn) * rowb + BM * sizeof(float);
   dim3 grid((unsigned)t1, (unsigned)t2, (unsigned)splits), block(NTHREADS);
   if (a->dtype == 0) {
-    if (narrow) hipLaunchKernelGGL((gemm_tn_kernel<bf16, 64>), grid, block, lds, s, *a, m_per_split);
-    else hipLaunchKernelGGL((gemm_tn_kernel<bf16, 128>), grid, block, lds, s, *a, m_per_split);
+    if (narrow) MVLT_LAUNCH((gemm_tn_kernel<bf16, 64>), grid, block, lds, s, *a, m_per_split);
+    else MVLT_LAUNCH((gemm_tn_kernel<bf16, 128>), grid, block, lds, s, *a, m_per_split);
   } else {
-    if (narrow) hipLaunchKernelGGL((gemm_tn_kernel<float, 64>), grid, block, lds, s, *a, m_per_split);
-    else hipLaunchKernelGGL((gemm_tn_kernel<float, 128>), grid, block, lds, s, *a, m_per_split);
+    if (narrow) MVLT_LAUNCH((gemm_tn_kernel<float, 64>), grid, block, lds, s, *a, m_per_split);
+    else MVLT_LAUNCH((gemm_tn_kernel<float, 128>), grid, block, lds, s, *a, m_per_split);
   }
   return mvlt_check_launch("mvlt_gemm_tn");
 }

@@ -833,11 +833,11 @@ extern "C" int mvlt_col_stats(const float* z, int ldz, long M, int C, float* sum
   if (vec4_ok(z, ldz, C)) {
     int rows_per_wg = reduce_rows_per_wg(M, C, RNT, RWGS);
     int grid = (int)((M + rows_per_wg - 1) / rows_per_wg);
-    hipLaunchKernelGGL((col_reduce4_kernel<0, RNT>), dim3(grid), dim3(RNT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, (const float*)nullptr, 0, nullptr, nullptr, M, C, sum, sumsq, rows_per_wg);
+    MVLT_LAUNCH((col_reduce4_kernel<0, RNT>), dim3(grid), dim3(RNT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, (const float*)nullptr, 0, nullptr, nullptr, M, C, sum, sumsq, rows_per_wg);
     return mvlt_check_launch("mvlt_col_stats");
   }
   int grid = (int)((M + 63) / 64); if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(grid), dim3(NT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, nullptr, 0, nullptr, nullptr, (int)M, C, sum, sumsq);
+  MVLT_LAUNCH((col_reduce_kernel<0>), dim3(grid), dim3(NT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, nullptr, 0, nullptr, nullptr, (int)M, C, sum, sumsq);
   return mvlt_check_launch("mvlt_col_stats");
 }
 
@@ -845,7 +845,7 @@ extern "C" int mvlt_bn_finalize(const float* sum, const float* sumsq, int copies
                                 float* running_mean, float* running_var, void* stream) {
   MVLT_REQUIRE(sum && sumsq && mean && rstd && M > 0 && C > 0 && copies >= 1, "mvlt_bn_finalize: bad arguments");
   MVLT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mvlt_bn_finalize: running_mean and running_var go together");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sum, sumsq, copies, (int)M, C, eps, momentum, mean, rstd, running_mean, running_var);
+  MVLT_LAUNCH(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sum, sumsq, copies, (int)M, C, eps, momentum, mean, rstd, running_mean, running_var);
   return mvlt_check_launch("mvlt_bn_finalize");
 }
 
@@ -864,13 +864,13 @@ extern "C" int mvlt_bn_norm(const void* z_, int ldz, int z_dtype, const float* m
   {
     if (y32_ && y32_dtype == 2) {
       MVLT_REQUIRE(ld32 % 8 == 0, "mvlt_bn_norm: an fp16 y needs a row stride that is a multiple of 8");
-      hipLaunchKernelGGL((bn_norm8_kernel<_Float16>), dim3(grid_for(M * (C / 8))), dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, mean, rstd, gamma, beta, M, C, (_Float16*)y32_, ld32, (bf16*)y16, ld16);
-    } else hipLaunchKernelGGL((bn_norm8_kernel<float>), dim3(grid_for(M * (C / 8))), dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
+      MVLT_LAUNCH((bn_norm8_kernel<_Float16>), dim3(grid_for(M * (C / 8))), dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, mean, rstd, gamma, beta, M, C, (_Float16*)y32_, ld32, (bf16*)y16, ld16);
+    } else MVLT_LAUNCH((bn_norm8_kernel<float>), dim3(grid_for(M * (C / 8))), dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
   }
   else if (y32_ && y32_dtype == 2) { mvlt_set_error("mvlt_bn_norm: an fp16 y exists with an fp16 z on the 8-wide path only (C, strides multiples of 8, 16-byte aligned)"); return MVLT_ERR_UNSUPPORTED; }
-  else if (z_dtype == 2) hipLaunchKernelGGL((bn_norm_kernel<bf16, _Float16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
-  else if (op_dtype == 0) hipLaunchKernelGGL((bn_norm_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
-  else hipLaunchKernelGGL((bn_norm_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (float*)y16, ld16);
+  else if (z_dtype == 2) MVLT_LAUNCH((bn_norm_kernel<bf16, _Float16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
+  else if (op_dtype == 0) MVLT_LAUNCH((bn_norm_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (bf16*)y16, ld16);
+  else MVLT_LAUNCH((bn_norm_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, z, ldz, mean, rstd, gamma, beta, M, C, y32, ld32, (float*)y16, ld16);
   return mvlt_check_launch("mvlt_bn_norm");
 }
 
@@ -885,10 +885,10 @@ extern "C" int mvlt_bn_finalize_norm(const void* z_, int ldz, const float* sum, 
                "mvlt_bn_finalize_norm: fp16 z, C a multiple of 8 and <= 256, row strides multiples of 8, 16-byte aligned tensors (the bf16 training path of the MIM decoder)");
   const dim3 grid(grid_for(M * (C / 8)));
   if (y32_ && y32_dtype == 2)
-    hipLaunchKernelGGL((bn_fin_norm8_kernel<_Float16>), grid, dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, sum, sumsq, copies, M, eps, momentum, mean, rstd, running_mean, running_var,
+    MVLT_LAUNCH((bn_fin_norm8_kernel<_Float16>), grid, dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, sum, sumsq, copies, M, eps, momentum, mean, rstd, running_mean, running_var,
                        gamma, beta, M, C, (_Float16*)y32_, ld32, (bf16*)y16, ld16);
   else
-    hipLaunchKernelGGL((bn_fin_norm8_kernel<float>), grid, dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, sum, sumsq, copies, M, eps, momentum, mean, rstd, running_mean, running_var,
+    MVLT_LAUNCH((bn_fin_norm8_kernel<float>), grid, dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, sum, sumsq, copies, M, eps, momentum, mean, rstd, running_mean, running_var,
                        gamma, beta, M, C, (float*)y32_, ld32, (bf16*)y16, ld16);
   return mvlt_check_launch("mvlt_bn_finalize_norm");
 }
@@ -912,7 +912,7 @@ extern "C" int mvlt_bn_bwd_reduce(const void* dy_, int lddy, const void* z_, int
     const bf16* dyh = (const bf16*)dy_;
     const _Float16* zh = (const _Float16*)z_;
 #define MVLT_RED_LAUNCH(NT_, TDY_, TZ_, DY_, Z_) \
-    hipLaunchKernelGGL((col_reduce4_kernel<1, NT_, TDY_, TZ_>), dim3(grid), dim3(NT_), lds, (hipStream_t)stream, Z_, ldz, DY_, lddy, mean, rstd, M, C, s1, s2, rows_per_wg)
+    MVLT_LAUNCH((col_reduce4_kernel<1, NT_, TDY_, TZ_>), dim3(grid), dim3(NT_), lds, (hipStream_t)stream, Z_, ldz, DY_, lddy, mean, rstd, M, C, s1, s2, rows_per_wg)
     const bool wide = z_dtype == 2 && C % 64 == 0 && ldz % 8 == 0 && ((uintptr_t)z_ & 15) == 0 && ((uintptr_t)dy_ & 15) == 0 && lddy % (dy_dtype == 0 ? 8 : 4) == 0;
     if (wide) {
       const int nt8 = C == 64 ? 512 : C == 192 ? 768 : 1024;           // whole waves per 64-column group
@@ -920,7 +920,7 @@ extern "C" int mvlt_bn_bwd_reduce(const void* dy_, int lddy, const void* z_, int
       long rows8 = (M + RWGS - 1) / RWGS;
       rows8 = (rows8 + 4 * rpp8 - 1) / (4 * rpp8) * (4 * rpp8);
       const int grid8 = (int)((M + rows8 - 1) / rows8);
-#define MVLT_RED8(NT_, TDY_, DY_) hipLaunchKernelGGL((col_reduce8_kernel<NT_, TDY_>), dim3(grid8), dim3(NT_), lds, (hipStream_t)stream, zh, ldz, DY_, lddy, mean, rstd, M, C, s1, s2, (int)rows8)
+#define MVLT_RED8(NT_, TDY_, DY_) MVLT_LAUNCH((col_reduce8_kernel<NT_, TDY_>), dim3(grid8), dim3(NT_), lds, (hipStream_t)stream, zh, ldz, DY_, lddy, mean, rstd, M, C, s1, s2, (int)rows8)
       if (dy_dtype == 0) { if (nt8 == 512) MVLT_RED8(512, bf16, dyh); else if (nt8 == 768) MVLT_RED8(768, bf16, dyh); else MVLT_RED8(1024, bf16, dyh); }
       else { if (nt8 == 512) MVLT_RED8(512, float, dy); else if (nt8 == 768) MVLT_RED8(768, float, dy); else MVLT_RED8(1024, float, dy); }
 #undef MVLT_RED8
@@ -937,7 +937,7 @@ extern "C" int mvlt_bn_bwd_reduce(const void* dy_, int lddy, const void* z_, int
   }
   MVLT_REQUIRE(dy_dtype == 1 && z_dtype == 1, "mvlt_bn_bwd_reduce: bf16 dy / fp16 z need the vectorised path (16-byte aligned mean / rstd)");
   int grid = (int)((M + 63) / 64); if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(grid), dim3(NT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, (int)M, C, s1, s2);
+  MVLT_LAUNCH((col_reduce_kernel<1>), dim3(grid), dim3(NT), 2 * C * sizeof(float), (hipStream_t)stream, z, ldz, dy, lddy, mean, rstd, (int)M, C, s1, s2);
   return mvlt_check_launch("mvlt_bn_bwd_reduce");
 }
 
@@ -958,14 +958,14 @@ extern "C" int mvlt_bn_bwd_apply(const void* dy_, int lddy, const void* z_, int 
   const bool wide = z_dtype == 2 && C % 8 == 0 && ldz % 8 == 0 && lddz % 8 == 0 && lddy % (dy_dtype == 0 ? 8 : 4) == 0 && al16(dy_) && al16(z_) && al16(dz_bf16) && al16(mean) &&
                     al16(rstd) && al16(gamma) && al16(s1) && al16(s2);
   const dim3 grid8(grid_for(M * (C / 8)));
-  if (wide && dy_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply8_kernel<bf16>), grid8, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, zh, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
-  else if (wide) hipLaunchKernelGGL((bn_bwd_apply8_kernel<float>), grid8, dim3(NT), 0, (hipStream_t)stream, dy, lddy, zh, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
-  else if (z_dtype == 2 && dy_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, bf16, _Float16>), grid, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, zh, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
-  else if (z_dtype == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, float, _Float16>), grid, dim3(NT), 0, (hipStream_t)stream, dy, lddy, zh, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
-  else if (op_dtype == 0 && dy_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
-  else if (op_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
-  else if (dy_dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (float*)dz_bf16, lddz, g_beta, g_gamma);
-  else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), grid, dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (float*)dz_bf16, lddz, g_beta, g_gamma);
+  if (wide && dy_dtype == 0) MVLT_LAUNCH((bn_bwd_apply8_kernel<bf16>), grid8, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, zh, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else if (wide) MVLT_LAUNCH((bn_bwd_apply8_kernel<float>), grid8, dim3(NT), 0, (hipStream_t)stream, dy, lddy, zh, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else if (z_dtype == 2 && dy_dtype == 0) MVLT_LAUNCH((bn_bwd_apply_kernel<bf16, bf16, _Float16>), grid, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, zh, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else if (z_dtype == 2) MVLT_LAUNCH((bn_bwd_apply_kernel<bf16, float, _Float16>), grid, dim3(NT), 0, (hipStream_t)stream, dy, lddy, zh, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else if (op_dtype == 0 && dy_dtype == 0) MVLT_LAUNCH((bn_bwd_apply_kernel<bf16, bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else if (op_dtype == 0) MVLT_LAUNCH((bn_bwd_apply_kernel<bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (bf16*)dz_bf16, lddz, g_beta, g_gamma);
+  else if (dy_dtype == 0) MVLT_LAUNCH((bn_bwd_apply_kernel<float, bf16>), grid, dim3(NT), 0, (hipStream_t)stream, dyh, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (float*)dz_bf16, lddz, g_beta, g_gamma);
+  else MVLT_LAUNCH((bn_bwd_apply_kernel<float>), grid, dim3(NT), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma, s1, s2, M, C, (float*)dz_bf16, lddz, g_beta, g_gamma);
   return mvlt_check_launch("mvlt_bn_bwd_apply");
 }
 
@@ -977,9 +977,9 @@ extern "C" int mvlt_ew_mul(float* out, int ldo, const void* a_, int lda, const v
                (!out_bf16 || ld16 % 4 == 0), "mvlt_ew_mul: bad arguments");
   MVLT_REQUIRE(!accumulate || out, "mvlt_ew_mul: accumulate needs the fp32 output");
   if (M <= 0) return MVLT_OK;
-  if (in_dtype == 2) hipLaunchKernelGGL((ew_mul_kernel<bf16, _Float16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, (const _Float16*)a_, lda, (const _Float16*)b_, ldb, (const _Float16*)c_, ldc, M, C, accumulate, (bf16*)out_bf16, ld16);
-  else if (op_dtype == 0) hipLaunchKernelGGL((ew_mul_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, c, ldc, M, C, accumulate, (bf16*)out_bf16, ld16);
-  else hipLaunchKernelGGL((ew_mul_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, c, ldc, M, C, accumulate, (float*)out_bf16, ld16);
+  if (in_dtype == 2) MVLT_LAUNCH((ew_mul_kernel<bf16, _Float16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, (const _Float16*)a_, lda, (const _Float16*)b_, ldb, (const _Float16*)c_, ldc, M, C, accumulate, (bf16*)out_bf16, ld16);
+  else if (op_dtype == 0) MVLT_LAUNCH((ew_mul_kernel<bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, c, ldc, M, C, accumulate, (bf16*)out_bf16, ld16);
+  else MVLT_LAUNCH((ew_mul_kernel<float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, c, ldc, M, C, accumulate, (float*)out_bf16, ld16);
   return mvlt_check_launch("mvlt_ew_mul");
 }
 
@@ -990,9 +990,9 @@ extern "C" int mvlt_ew_mul3_bwd(const void* dy, int lddy, const void* a_, const 
   /* da / db / dc take dy's dtype */
   MVLT_REQUIRE(dy && a && b && c && da && db && dc && C % 4 == 0 && lddy % 4 == 0 && ld % 4 == 0 && ld >= C && (dy_dtype == 0 || dy_dtype == 1), "mvlt_ew_mul3_bwd: bad arguments");
   if (M <= 0) return MVLT_OK;
-  if (in_dtype == 2) hipLaunchKernelGGL((ew_mul3_bwd_kernel<bf16, bf16, _Float16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, lddy, (const _Float16*)a_, (const _Float16*)b_, (const _Float16*)c_, ld, (bf16*)da, (bf16*)db, (bf16*)dc, M, C);
-  else if (dy_dtype == 0) hipLaunchKernelGGL((ew_mul3_bwd_kernel<bf16, bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, lddy, a, b, c, ld, (bf16*)da, (bf16*)db, (bf16*)dc, M, C);
-  else hipLaunchKernelGGL((ew_mul3_bwd_kernel<float, float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const float*)dy, lddy, a, b, c, ld, (float*)da, (float*)db, (float*)dc, M, C);
+  if (in_dtype == 2) MVLT_LAUNCH((ew_mul3_bwd_kernel<bf16, bf16, _Float16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, lddy, (const _Float16*)a_, (const _Float16*)b_, (const _Float16*)c_, ld, (bf16*)da, (bf16*)db, (bf16*)dc, M, C);
+  else if (dy_dtype == 0) MVLT_LAUNCH((ew_mul3_bwd_kernel<bf16, bf16>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy, lddy, a, b, c, ld, (bf16*)da, (bf16*)db, (bf16*)dc, M, C);
+  else MVLT_LAUNCH((ew_mul3_bwd_kernel<float, float>), dim3(grid_for(M * (C / 4))), dim3(NT), 0, (hipStream_t)stream, (const float*)dy, lddy, a, b, c, ld, (float*)da, (float*)db, (float*)dc, M, C);
   return mvlt_check_launch("mvlt_ew_mul3_bwd");
 }
 
@@ -1001,24 +1001,24 @@ extern "C" int mvlt_upsample_fwd(const float* x, int ldx, int B, int H, int W, i
   MVLT_REQUIRE(!nchw || out_dtype == 1, "mvlt_upsample_fwd: NCHW output is fp32");
   long total = (long)B * H * scale * W * scale * C;
   if (nchw && (long)B * C * H * scale < (1L << 31) && W <= 64 && (W * scale) % 4 == 0 && W * scale <= 256 && ((uintptr_t)out & 15) == 0) {
-    hipLaunchKernelGGL(upsample_fwd_nchw4_kernel, dim3((unsigned)((B * C * H * scale + 7) / 8)), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (float*)out,
+    MVLT_LAUNCH(upsample_fwd_nchw4_kernel, dim3((unsigned)((B * C * H * scale + 7) / 8)), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (float*)out,
                        B * C * H * scale);
     return mvlt_check_launch("mvlt_upsample_fwd");
   }
   if (nchw && (long)B * C * H * scale < (1L << 31)) {
-    hipLaunchKernelGGL(upsample_fwd_nchw_kernel, dim3((unsigned)((B * C * H * scale + 7) / 8)), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (float*)out,
+    MVLT_LAUNCH(upsample_fwd_nchw_kernel, dim3((unsigned)((B * C * H * scale + 7) / 8)), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (float*)out,
                        B * C * H * scale);
     return mvlt_check_launch("mvlt_upsample_fwd");
   }
   if (!nchw && C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 7) == 0) {
     const int chunks = (W * scale * (C / 4) + NT - 1) / NT;
     const unsigned grid = (unsigned)((long)B * H * scale * chunks);
-    if (out_dtype == 0) hipLaunchKernelGGL((upsample_fwd_row_kernel<bf16>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (bf16*)out, ldo, chunks);
-    else hipLaunchKernelGGL((upsample_fwd_row_kernel<float>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (float*)out, ldo, chunks);
+    if (out_dtype == 0) MVLT_LAUNCH((upsample_fwd_row_kernel<bf16>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (bf16*)out, ldo, chunks);
+    else MVLT_LAUNCH((upsample_fwd_row_kernel<float>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, (float*)out, ldo, chunks);
     return mvlt_check_launch("mvlt_upsample_fwd");
   }
-  if (out_dtype == 0) hipLaunchKernelGGL((upsample_fwd_kernel<bf16>), dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, x, ldx, B, H, W, C, scale, (bf16*)out, ldo, nchw);
-  else hipLaunchKernelGGL((upsample_fwd_kernel<float>), dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, x, ldx, B, H, W, C, scale, (float*)out, ldo, nchw);
+  if (out_dtype == 0) MVLT_LAUNCH((upsample_fwd_kernel<bf16>), dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, x, ldx, B, H, W, C, scale, (bf16*)out, ldo, nchw);
+  else MVLT_LAUNCH((upsample_fwd_kernel<float>), dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, x, ldx, B, H, W, C, scale, (float*)out, ldo, nchw);
   return mvlt_check_launch("mvlt_upsample_fwd");
 }
 
@@ -1031,9 +1031,9 @@ extern "C" int mvlt_upsample_bwd(const void* dy_, int lddy, int nchw, int B, int
     MVLT_REQUIRE(!nchw && dx_dtype == 1 && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy_ & 7) == 0 && ((uintptr_t)dx_ & 15) == 0,
                  "mvlt_upsample_bwd: bf16 dy needs the pixel-major layout, fp32 dx, C / ld multiples of 4");
     const int chunks = (W * (C / 4) + NT - 1) / NT;
-    if (scale == 2) hipLaunchKernelGGL((upsample_bwd_row_s_kernel<bf16, 2>), dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy_, lddy, H, W,
+    if (scale == 2) MVLT_LAUNCH((upsample_bwd_row_s_kernel<bf16, 2>), dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy_, lddy, H, W,
                                        C, (float*)dx_, lddx, accumulate, chunks);
-    else hipLaunchKernelGGL(upsample_bwd_row_kernel<bf16>, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy_, lddy, H, W, C, scale,
+    else MVLT_LAUNCH(upsample_bwd_row_kernel<bf16>, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)dy_, lddy, H, W, C, scale,
                             (float*)dx_, lddx, accumulate, chunks);
     return mvlt_check_launch("mvlt_upsample_bwd");
   }
@@ -1045,24 +1045,24 @@ extern "C" int mvlt_upsample_bwd(const void* dy_, int lddy, int nchw, int B, int
     const size_t lds = (size_t)W * scale * sizeof(float);
     const bool v4 = (W * scale) % 4 == 0 && W * scale <= 256 && ((uintptr_t)dy & 15) == 0;
     if (dx_dtype == 0) {
-      if (v4) hipLaunchKernelGGL(upsample_bwd_nchw4_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)stream, dy, H, W, C, scale, (bf16*)dx_, lddx, accumulate);
-      else hipLaunchKernelGGL(upsample_bwd_nchw_kernel<bf16>, grid, dim3(NT), lds, (hipStream_t)stream, dy, H, W, C, scale, (bf16*)dx_, lddx, accumulate);
+      if (v4) MVLT_LAUNCH(upsample_bwd_nchw4_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)stream, dy, H, W, C, scale, (bf16*)dx_, lddx, accumulate);
+      else MVLT_LAUNCH(upsample_bwd_nchw_kernel<bf16>, grid, dim3(NT), lds, (hipStream_t)stream, dy, H, W, C, scale, (bf16*)dx_, lddx, accumulate);
     } else {
-      if (v4) hipLaunchKernelGGL(upsample_bwd_nchw4_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, dy, H, W, C, scale, dx, lddx, accumulate);
-      else hipLaunchKernelGGL(upsample_bwd_nchw_kernel<float>, grid, dim3(NT), lds, (hipStream_t)stream, dy, H, W, C, scale, dx, lddx, accumulate);
+      if (v4) MVLT_LAUNCH(upsample_bwd_nchw4_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, dy, H, W, C, scale, dx, lddx, accumulate);
+      else MVLT_LAUNCH(upsample_bwd_nchw_kernel<float>, grid, dim3(NT), lds, (hipStream_t)stream, dy, H, W, C, scale, dx, lddx, accumulate);
     }
     return mvlt_check_launch("mvlt_upsample_bwd");
   }
   MVLT_REQUIRE(dx_dtype == 1, "mvlt_upsample_bwd: bf16 dx needs the row-buffered NCHW path (W * scale * 4 <= 64 KB)");
   if (!nchw && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0) {
     const int chunks = (W * (C / 4) + NT - 1) / NT;
-    if (scale == 2) hipLaunchKernelGGL((upsample_bwd_row_s_kernel<float, 2>), dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, H, W, C, dx, lddx,
+    if (scale == 2) MVLT_LAUNCH((upsample_bwd_row_s_kernel<float, 2>), dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, H, W, C, dx, lddx,
                                        accumulate, chunks);
-    else hipLaunchKernelGGL(upsample_bwd_row_kernel<float>, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, H, W, C, scale, dx, lddx,
+    else MVLT_LAUNCH(upsample_bwd_row_kernel<float>, dim3((unsigned)((long)B * H * chunks)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, H, W, C, scale, dx, lddx,
                             accumulate, chunks);
     return mvlt_check_launch("mvlt_upsample_bwd");
   }
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, nchw, B, H, W, C, scale, dx, lddx, accumulate);
+  MVLT_LAUNCH(upsample_bwd_kernel, dim3(grid_for(total, 16384)), dim3(NT), 0, (hipStream_t)stream, dy, lddy, nchw, B, H, W, C, scale, dx, lddx, accumulate);
   return mvlt_check_launch("mvlt_upsample_bwd");
 }
 
@@ -1072,7 +1072,7 @@ extern "C" int mvlt_upsample_l1_fwd(const float* x, int ldx, int B, int H, int W
                "mvlt_upsample_l1_fwd: needs W <= 64, W * scale a multiple of 4 and <= 256, 16-byte aligned target");
   const int nrows = B * C * H * scale;
   const int groups = (nrows + 7) / 8;
-  hipLaunchKernelGGL(upsample_l1_fwd_kernel, dim3((unsigned)(groups < 2048 ? groups : 2048)), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, target, nrows, loss_sum);
+  MVLT_LAUNCH(upsample_l1_fwd_kernel, dim3((unsigned)(groups < 2048 ? groups : 2048)), dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, target, nrows, loss_sum);
   return mvlt_check_launch("mvlt_upsample_l1_fwd");
 }
 
@@ -1082,7 +1082,7 @@ extern "C" int mvlt_upsample_l1_bwd(const float* x, int ldx, int B, int H, int W
   MVLT_REQUIRE(W <= 64 && (W * scale) % 4 == 0 && W * scale <= 256 && ((uintptr_t)target & 15) == 0, "mvlt_upsample_l1_bwd: needs W <= 64, W * scale a multiple of 4 and <= 256");
   const float inv_n = 1.0f / ((float)B * C * H * scale * W * scale);
   const dim3 grid((unsigned)(B * C * H));
-  if (dx_dtype == 0) hipLaunchKernelGGL(upsample_l1_bwd_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, target, gscale, inv_n, (bf16*)dx, lddx);
-  else hipLaunchKernelGGL(upsample_l1_bwd_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, target, gscale, inv_n, (float*)dx, lddx);
+  if (dx_dtype == 0) MVLT_LAUNCH(upsample_l1_bwd_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, target, gscale, inv_n, (bf16*)dx, lddx);
+  else MVLT_LAUNCH(upsample_l1_bwd_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, x, ldx, H, W, C, scale, target, gscale, inv_n, (float*)dx, lddx);
   return mvlt_check_launch("mvlt_upsample_l1_bwd");
 }

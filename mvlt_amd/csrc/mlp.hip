@@ -1232,11 +1232,11 @@ template <int C> int launch_wgrad(const mvlt_mlp_args& a, hipStream_t s) {
     constexpr int NW = C == 64 ? 4 : 8;
     const size_t lds_t = lds + ((MVLT_GELU_LUT & 1) ? GELU_LUT_BYTES : 0);
     hipFuncSetAttribute((const void*)mlp_wgrad2_kernel<C, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
-    hipLaunchKernelGGL((mlp_wgrad2_kernel<C, NW>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NW * 64), lds_t, s, a, m_per_split, splits, ny);
+    MVLT_LAUNCH((mlp_wgrad2_kernel<C, NW>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NW * 64), lds_t, s, a, m_per_split, splits, ny);
     return mvlt_check_launch("mvlt_mlp_bwd_dw");
   }
   hipFuncSetAttribute((const void*)mlp_wgrad_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((mlp_wgrad_kernel<C>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NT), lds, s, a, m_per_split, splits, ny);
+  MVLT_LAUNCH((mlp_wgrad_kernel<C>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NT), lds, s, a, m_per_split, splits, ny);
   return mvlt_check_launch("mvlt_mlp_bwd_dw");
 }
 
@@ -1253,11 +1253,11 @@ template <int C, int MODE> int launch(const mvlt_mlp_args& a, hipStream_t s) {
     if ((MVLT_GELU_LUT >> (MODE == 1 ? 1 : 2)) & 1) l2 += GELU_LUT_BYTES;
     if (l2 < stage) l2 = stage;
     hipFuncSetAttribute((const void*)mlp_pipe_kernel<C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-    hipLaunchKernelGGL((mlp_pipe_kernel<C, MODE>), dim3((a.M + BM - 1) / BM), dim3(NT), l2, s, a);
+    MVLT_LAUNCH((mlp_pipe_kernel<C, MODE>), dim3((a.M + BM - 1) / BM), dim3(NT), l2, s, a);
     return mvlt_check_launch(MODE == 0 ? "mvlt_mlp_fwd" : "mvlt_mlp_bwd_dx");
   }
   hipFuncSetAttribute((const void*)mlp_fused_kernel<C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((mlp_fused_kernel<C, MODE>), dim3((a.M + BM - 1) / BM), dim3(NT), lds, s, a);
+  MVLT_LAUNCH((mlp_fused_kernel<C, MODE>), dim3((a.M + BM - 1) / BM), dim3(NT), lds, s, a);
   return mvlt_check_launch(MODE == 0 ? "mvlt_mlp_fwd" : "mvlt_mlp_bwd_dx");
 }
 

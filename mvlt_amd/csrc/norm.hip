@@ -466,7 +466,7 @@ template <typename T, typename TY, int G, int ITS, int RU> void launch_fwd_fixed
   static const int cap = getenv("MVLT_LN_GRID") ? atoi(getenv("MVLT_LN_GRID")) : 8192;
   long grid = ((long)a.rows + GROUPS * RU - 1) / (GROUPS * RU);
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL((ln_fwd_fixed_kernel<T, TY, G, ITS, RU>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+  MVLT_LAUNCH((ln_fwd_fixed_kernel<T, TY, G, ITS, RU>), dim3((unsigned)grid), dim3(NT), 0, s, a);
 }
 
 template <typename T, typename TY> int launch_fwd(const mvlt_layernorm_args& a_in, hipStream_t s) {
@@ -491,10 +491,10 @@ template <typename T, typename TY> int launch_fwd(const mvlt_layernorm_args& a_i
   int grid = (a.rows + groups - 1) / groups;
   if (grid > 8192) grid = 8192;
   switch (g) {
-    case 8: hipLaunchKernelGGL((ln_fwd_kernel<T, TY, 8>), dim3(grid), dim3(NT), 0, s, a); break;
-    case 16: hipLaunchKernelGGL((ln_fwd_kernel<T, TY, 16>), dim3(grid), dim3(NT), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((ln_fwd_kernel<T, TY, 32>), dim3(grid), dim3(NT), 0, s, a); break;
-    default: hipLaunchKernelGGL((ln_fwd_kernel<T, TY, 64>), dim3(grid), dim3(NT), 0, s, a); break;
+    case 8: MVLT_LAUNCH((ln_fwd_kernel<T, TY, 8>), dim3(grid), dim3(NT), 0, s, a); break;
+    case 16: MVLT_LAUNCH((ln_fwd_kernel<T, TY, 16>), dim3(grid), dim3(NT), 0, s, a); break;
+    case 32: MVLT_LAUNCH((ln_fwd_kernel<T, TY, 32>), dim3(grid), dim3(NT), 0, s, a); break;
+    default: MVLT_LAUNCH((ln_fwd_kernel<T, TY, 64>), dim3(grid), dim3(NT), 0, s, a); break;
   }
   return mvlt_check_launch("mvlt_layernorm_fwd");
 }
@@ -521,7 +521,7 @@ template <typename T, typename TX, typename TDX> int launch_bwd(const mvlt_layer
   do {                                                                                                               \
     static const hipError_t attr = hipFuncSetAttribute((const void*)KERN_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     MVLT_REQUIRE(lds <= 65536 || attr == hipSuccess, "mvlt_layernorm_bwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr)); \
-    hipLaunchKernelGGL(KERN_, dim3(grid), dim3(NT_), lds, s, a);                                                     \
+    MVLT_LAUNCH(KERN_, dim3(grid), dim3(NT_), lds, s, a);                                                     \
   } while (0)
 #define MVLT_LN_BWD_N(G_, NT_)                                                                                       \
   do {                                                                                                               \
@@ -562,8 +562,8 @@ extern "C" int mvlt_layernorm_fwd(const mvlt_layernorm_args* a, void* stream) {
 extern "C" int mvlt_fold_copies(float* arena, int copies, long stride, const int* dst_index, int j0, int j1, float* dst, void* stream) {
   MVLT_REQUIRE(arena && dst_index && dst && copies >= 1 && j0 >= 0 && j1 >= j0 && stride >= j1, "mvlt_fold_copies: bad arguments");
   if (j1 == j0) return MVLT_OK;
-  if (copies >= 32) hipLaunchKernelGGL(fold_copies_wide_kernel, dim3((j1 - j0 + 63) / 64), dim3(1024), 0, (hipStream_t)stream, arena, copies, stride, dst_index, j0, j1, dst);
-  else hipLaunchKernelGGL(fold_copies_kernel, dim3((j1 - j0 + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, arena, copies, stride, dst_index, j0, j1, dst);
+  if (copies >= 32) MVLT_LAUNCH(fold_copies_wide_kernel, dim3((j1 - j0 + 63) / 64), dim3(1024), 0, (hipStream_t)stream, arena, copies, stride, dst_index, j0, j1, dst);
+  else MVLT_LAUNCH(fold_copies_kernel, dim3((j1 - j0 + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, arena, copies, stride, dst_index, j0, j1, dst);
   return mvlt_check_launch("mvlt_fold_copies");
 }
 
@@ -598,7 +598,7 @@ extern "C" int mvlt_batch_sum(const void* in, float* out, int B, int R, int C, l
   if (R == 0) return MVLT_OK;
   long total = (long)R * (C / 8);
   int grid = (int)((total + 15) / 16);
-  if (dtype == 0) hipLaunchKernelGGL((batch_sum_kernel<bf16>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const bf16*)in, out, B, R, C, batch_stride_rows, ld, acc2, split);
-  else hipLaunchKernelGGL((batch_sum_kernel<float>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const float*)in, out, B, R, C, batch_stride_rows, ld, acc2, split);
+  if (dtype == 0) MVLT_LAUNCH((batch_sum_kernel<bf16>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const bf16*)in, out, B, R, C, batch_stride_rows, ld, acc2, split);
+  else MVLT_LAUNCH((batch_sum_kernel<float>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const float*)in, out, B, R, C, batch_stride_rows, ld, acc2, split);
   return mvlt_check_launch("mvlt_batch_sum");
 }

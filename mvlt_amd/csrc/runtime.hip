@@ -2,6 +2,8 @@
 #include "common.h"
 #include "../../include/mvlt_hip.h"
 #include <stdarg.h>
+#include <stdlib.h>
+#include <cxxabi.h>
 
 static thread_local char g_err[512] = "";
 
@@ -22,6 +24,24 @@ int mvlt_check_launch(const char* what) {
 }
 
 extern "C" const char* mvlt_last_error(void) { return g_err; }
+
+// the instantiation MVLT_LAUNCH launched last on this thread: the runtime's name for the host function pointer, demangled
+// ("void (anonymous namespace)::mlp_wgrad2_kernel<64, 4>(mvlt_mlp_args, int, int, int)")
+static thread_local const void* g_last_kernel = nullptr;
+static thread_local char g_last_kernel_name[512] = "";
+void mvlt_note_kernel(const void* host_function) { g_last_kernel = host_function; }
+extern "C" const char* mvlt_last_kernel(void) {
+  g_last_kernel_name[0] = 0;
+  if (!g_last_kernel) return g_last_kernel_name;
+  const char* mangled = hipKernelNameRefByPtr(g_last_kernel, nullptr);
+  if (!mangled) return g_last_kernel_name;
+  int status = 0;
+  char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+  snprintf(g_last_kernel_name, sizeof(g_last_kernel_name), "%s", (status == 0 && dem) ? dem : mangled);
+  free(dem);
+  return g_last_kernel_name;
+}
+
 // Bumped whenever an exported signature or argument struct changes (include/mvlt_hip.h MVLT_ABI_VERSION; mvlt_amd/_lib.py refuses a library whose
 // number differs from the binding's: a stale build loaded through MVLT_HIP_LIB would otherwise be called with shifted positional arguments).
 extern "C" int mvlt_abi_version(void) { return MVLT_ABI_VERSION; }

@@ -22,6 +22,8 @@ import torch.nn as nn
 
 # test switch: issue every collective even at world size 1 (a one-GPU box then exercises the RCCL calls of the N > 1 path)
 _FORCE = bool(os.environ.get("MVLT_DP_FORCE_COLLECTIVES"))
+# A/B + test switch: wait for every collective at the end of the backward and step all parameters in one AdamW launch (round 4's behaviour)
+_ONE_LAUNCH = bool(os.environ.get("MVLT_ADAMW_ONE_LAUNCH"))
 
 
 class DataParallel(nn.Module):
@@ -44,6 +46,7 @@ class DataParallel(nn.Module):
         self.active = self.world > 1 or (_FORCE and dist.is_initialized())
         self._works = []
         self._pending = []                      # announced ranges not yet on the wire (see _range_ready)
+        self._finishing = False
         self._synced_init = False
         module.store.on_backward_done = self._finish
         module.store.on_range_ready = self._range_ready
@@ -109,12 +112,13 @@ class DataParallel(nn.Module):
 
     def _aborted(self, store):
         """a backward pass raised after announcing ranges: wait for what is in flight and forget it (the next pass starts clean)"""
-        for w, _, _ in self._works:
+        for w in [x[0] for x in self._works] + [x[0] for x in store.grad_works]:
             try:
                 w.wait()
             except RuntimeError:
                 pass
         self._works = []
+        store.grad_works = []
         self._pending = []
 
     MIN_BYTES = 16 << 20                        # pending gradient bytes that start a collective
@@ -136,12 +140,14 @@ class DataParallel(nn.Module):
         self._pending = []
 
     def _reduce(self, store, lo, hi):
+        """one collective: (work, lo, hi, G view, payload tensor or None, early) -- early = issued while the backward was still running"""
         g = store.G[lo:hi]
+        early = not self._finishing
         if self.grad_payload is torch.float32:
-            self._works.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None, None))
+            self._works.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), lo, hi, g, None, early))
         else:
             t = g.to(self.grad_payload)                  # half the bytes on the links; written back (widened) once the collective is done
-            self._works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), g, t))
+            self._works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), lo, hi, g, t, early))
 
     def _range_ready(self, store, lo, hi):
         """called by the backward schedule when G[lo:hi] is final on the compute stream: queued, and sent once MIN_BYTES are pending"""
@@ -161,12 +167,17 @@ class DataParallel(nn.Module):
             if lo > cur:
                 self._pending.append((cur, lo))
             cur = max(cur, hi)
-        self._flush(store)
-        for w, g, t in self._works:
-            w.wait()
-            if t is not None:
-                g.copy_(t)
-        self._works = []
+        self._finishing = True
+        try:
+            self._flush(store)
+        finally:
+            self._finishing = False
+        # The fused optimizer is the next reader of G (engine.BF16Scaler sets scale_in_optimizer around backward + step): the collectives are handed
+        # over un-waited -- FusedAdamW.step steps the ranges whose collectives went out during the backward (pvlt_tiny: 57 of 153 MB) while the tail
+        # (the tied word-embedding table, final only with the last kernel of the pass) is still on the wire, then the tail.  Anyone else gets final gradients.
+        store.grad_works, self._works = self._works, []
+        if not (store.scale_in_optimizer and not _ONE_LAUNCH):
+            store.wait_grads()
         store._ranges_done = []
         store.scale_grads(1.0 / self.world)          # DDP's mean; folded into the fused AdamW kernel when that is the optimizer
 

@@ -18,6 +18,40 @@ def _unwrap(model):
     return model.module if hasattr(model, "module") and not hasattr(model, "store") else model
 
 
+def phased_ranges(S):
+    """The element ranges of the flat buffers in the order the optimizer may step them.  Without gradient collectives in flight: the whole buffer.
+    With them (mvlt_amd.dist.DataParallel hands them over un-waited when this optimizer is the next reader): first the ranges whose collectives were
+    issued DURING the backward pass -- by now (mostly) complete -- then the ones issued at its end, each group after `wait()` on its works (a
+    stream-side wait for RCCL: the host keeps enqueuing).  The first launch then runs while the tail is still on the wire; element-wise AdamW makes the
+    result bit-identical to one launch over everything.  Anything the collectives do not cover exactly once falls back to wait-all + one range."""
+    works, S.grad_works = S.grad_works, []
+    if not works:
+        yield 0, S.total
+        return
+    def finish(ws):
+        for w, lo, hi, g, t, early in ws:
+            w.wait()
+            if t is not None:
+                g.copy_(t)
+    cov = sorted((lo, hi) for _, lo, hi, _, _, _ in works)
+    exact = cov[0][0] == 0 and cov[-1][1] == S.total and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
+    groups = [[x for x in works if x[5]], [x for x in works if not x[5]]]
+    if not exact or not groups[0] or not groups[1]:
+        finish(works)
+        yield 0, S.total
+        return
+    for ws in groups:
+        finish(ws)
+        merged = []
+        for lo, hi in sorted((x[1], x[2]) for x in ws):
+            if merged and merged[-1][1] == lo:
+                merged[-1][1] = hi
+            else:
+                merged.append([lo, hi])
+        for lo, hi in merged:
+            yield lo, hi
+
+
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
         model = _unwrap(model)
@@ -86,7 +120,8 @@ class FusedAdamW(torch.optim.Optimizer):
             self._hp.copy_(self._hp_pin[k], non_blocking=True)
             ev = self._hp_ev[k] = self._hp_ev[k] or torch.cuda.Event()
             ev.record()
-        ops.adamw_step(S.P, S.G, self._m, self._v, S.C, S.total, self._hp, self._wd_mask)
+        for lo, hi in phased_ranges(S):
+            ops.adamw_step(S.P[lo:hi], S.G[lo:hi], self._m[lo:hi], self._v[lo:hi], None if S.C is None else S.C[lo:hi], hi - lo, self._hp, self._wd_mask[lo:hi])
         # W^T / permuted conv operand copies are refreshed by the next forward; the plain bf16 copy S.C is already current,
         # which holds as long as nothing else writes the parameters before that forward (FlatStore.versions() notices)
         S.force_dirty = True

@@ -144,6 +144,10 @@ class FlatStore:
         self._ranges_done = []
         self.scale_in_optimizer = False   # set by engine.BF16Scaler around backward + FusedAdamW.step: that kernel applies `pending_grad_scale`
         self.pending_grad_scale = 1.0     # factor still owed to G (1/world after a data-parallel SUM all-reduce)
+        # gradient collectives still in flight when the backward pass returned: [(work, lo, hi, g_view, payload or None, early)].  Only set while
+        # `scale_in_optimizer` (the fused optimizer is the next reader: it steps the ranges whose collectives are done while the tail is on the
+        # wire, FusedAdamW.step); every other reader of G goes through wait_grads() first.
+        self.grad_works = []
 
     # ------------------------------------------------------------------ layout
     def _index(self):
@@ -315,6 +319,7 @@ class FlatStore:
         second and later optimizer steps correct: during the forward `.grad` still aliases G from the previous step."""
         # accumulate only if a trainable parameter's .grad aliases its slice of G; frozen parameters (requires_grad=False, .grad stays
         # None for ever) and parameters the optimizer's zero_grad does not cover say nothing about the caller's intent (ADVICE r2)
+        self.wait_grads()                 # collectives of a pass nobody stepped (no-op normally)
         live = [(n, q) for n, q in self.fn_params if q.requires_grad]
         alias = [q.grad is not None and q.grad.data_ptr() == self.grad(n).data_ptr() for n, q in live]
         if not any(alias):
@@ -505,8 +510,17 @@ class FlatStore:
         else:
             self.G.mul_(factor)
 
+    def wait_grads(self):
+        """block (the stream, for RCCL; the host, for gloo) until every gradient collective handed over by the data-parallel wrapper is done"""
+        works, self.grad_works = self.grad_works, []
+        for w, lo, hi, g, t, early in works:
+            w.wait()
+            if t is not None:
+                g.copy_(t)
+
     def apply_pending_scale(self):
         """make G itself carry the owed factor (anything that READS gradients before the optimizer step: clipping, logging)"""
+        self.wait_grads()
         if self.pending_grad_scale != 1.0:
             self.G.mul_(self.pending_grad_scale)
             self.pending_grad_scale = 1.0

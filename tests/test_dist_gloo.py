@@ -133,6 +133,79 @@ def test_bf16_gradient_payload_world2():
     assert res[0][1] == pytest.approx(res[1][1])
 
 
+def _worker_phased(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mvlt_amd.dist import DataParallel
+        from mvlt_amd.optim import phased_ranges
+
+        def adamw(P, G, M, V, lo, hi, gscale, step=1, lr=1e-2, b1=0.9, b2=0.999, eps=1e-8, wd=0.05):
+            g = G[lo:hi] * gscale
+            M[lo:hi].mul_(b1).add_(g, alpha=1 - b1)
+            V[lo:hi].mul_(b2).addcmul_(g, g, value=1 - b2)
+            P[lo:hi].mul_(1 - lr * wd).addcdiv_(M[lo:hi] / (1 - b1 ** step), (V[lo:hi] / (1 - b2 ** step)).sqrt_().add_(eps), value=-lr)
+
+        out = {}
+        for mode in ("phased", "one"):
+            torch.manual_seed(3)
+            m = _Toy()
+            for p in m.parameters():
+                p.data.normal_()
+            S = m.store
+            S.materialize(torch.device("cpu"))
+            dp = DataParallel(m, broadcast_buffers=False)
+            dp.MIN_BYTES = 256                              # the toy's stages are a few hundred bytes: two of them start a collective
+            dp._sync_init()
+            S.G.copy_(torch.randn(S.total, generator=torch.Generator().manual_seed(11 + rank)))
+            S.scale_in_optimizer = mode == "phased"         # what engine.BF16Scaler sets around backward + FusedAdamW.step
+            for i in (3, 2):
+                S.announce_stage(i)                         # these go out DURING the pass
+            S._finalize()                                   # ... everything else at its end
+            handed = [(lo, hi, early) for _, lo, hi, _, _, early in S.grad_works]
+            M, V = torch.zeros_like(S.P), torch.zeros_like(S.P)
+            gscale = S.pending_grad_scale if mode == "phased" else 1.0
+            ranges = list(phased_ranges(S))
+            for lo, hi in ranges:
+                adamw(S.P, S.G, M, V, lo, hi, gscale)
+            S.scale_in_optimizer = False
+            S.pending_grad_scale = 1.0
+            out[mode] = (S.P.clone(), ranges, handed, not S.grad_works)
+        same = bool(torch.equal(out["phased"][0], out["one"][0]))
+        q.put((rank, same, out["phased"][1], out["phased"][2], out["one"][1], out["one"][2], out["phased"][3], int(m.store.total)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_phased_optimizer_step_world2():
+    """VERDICT r4 #5b: with the fused optimizer as the next reader the wrapper hands its collectives over UN-WAITED and `phased_ranges` steps the ranges
+    whose collectives went out during the backward first (after their wait), the tail after its own wait -- at least two ranges, covering the buffer
+    exactly once; the parameters equal, bit for bit, what wait-all + one range gives (element-wise AdamW restated in torch: the HIP kernel needs a GPU;
+    tests/test_dist_gpu.py repeats this with the real kernel).  Outside the optimizer's scope the wrapper still returns final gradients."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_phased, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, ranges, handed, ranges_one, handed_one, drained, total in res:
+        assert same, "phased step differs from the one-range step"
+        assert len(ranges) >= 2 and sorted(ranges)[0][0] == 0 and sorted(ranges)[-1][1] == total
+        srt = sorted(ranges)
+        assert all(a[1] == b[0] for a, b in zip(srt, srt[1:])), ranges
+        assert any(e for _, _, e in handed) and any(not e for _, _, e in handed), handed
+        early_cov = sorted((lo, hi) for lo, hi, e in handed if e)
+        n_early = len(ranges) - sum(1 for lo, hi, e in handed if not e)          # ranges stepped before the tail's wait
+        assert n_early >= 1 and ranges[0][0] == early_cov[0][0]                   # the early collectives' ranges come first
+        assert ranges_one == [(0, total)] and handed_one == [], (ranges_one, handed_one)
+        assert drained
+
+
 # ------------------------------------------------------------------------------------------------------------------------------------
 # World 4 / 8 with the REAL parameter layouts (VERDICT r3 #6b): what travels when, in which order, and what is left for the end of the pass
 def _worker_real(rank, world, port, q, variant, payload):
@@ -271,3 +344,58 @@ def test_bench_spawn_ranks_plumbing(monkeypatch):
     calls.clear()
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
     assert bench.spawn_ranks(8) == 2 and not calls
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_spawn_ranks_plumbing_for_2_and_4(monkeypatch, n):
+    """the driver's N = 2 / 4 points of the scaling curve through `python bench.py --gpus N` (VERDICT r4 #5c): N ranks on 127.0.0.1, no forced
+    collectives, the caller's arguments passed on"""
+    import subprocess
+    import sys
+    import bench
+    calls = []
+
+    class _R:
+        returncode = 0
+
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(subprocess, "run", lambda cmd, env=None, **k: (calls.append((cmd, env)), _R())[1])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", str(n), "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("MVLT_DP_FORCE_COLLECTIVES", raising=False)
+    assert bench.spawn_ranks(n) == 0
+    (cmd, env), = calls
+    assert f"--nproc-per-node={n}" in cmd and "--nnodes=1" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index(os.path.abspath(bench.__file__)) + 1:] == ["--gpus", str(n), "--steps", "20", "--warmup", "5"]
+    assert "MVLT_DP_FORCE_COLLECTIVES" not in env and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+@pytest.mark.parametrize("world,local", [(2, 1), (4, 3), (8, 5)])
+def test_bench_rank_binds_its_own_device_before_anything_else(monkeypatch, world, local):
+    """Under a launcher every rank must bind LOCAL_RANK's GPU BEFORE its first allocation, its process group and its first kernel -- a rank that
+    allocates on the default device first leaves 8 contexts on GPU 0 (and RCCL then binds the wrong device).  bench.main() is run with the GPU
+    entry points replaced by recorders: the first thing it does to the GPU runtime is set_device(LOCAL_RANK)."""
+    import sys
+    import bench
+
+    class _Stop(Exception):
+        pass
+
+    events = []
+
+    def bind(d):
+        events.append(("set_device", d))
+        raise _Stop()
+
+    monkeypatch.setenv("WORLD_SIZE", str(world))
+    monkeypatch.setenv("RANK", str(local))
+    monkeypatch.setenv("LOCAL_RANK", str(local))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1"])
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", bind)
+    monkeypatch.setattr(dist, "init_process_group", lambda *a, **k: events.append(("init_process_group",)))
+    for fn in ("empty", "zeros", "randn", "rand", "full", "tensor"):
+        orig = getattr(torch, fn)
+        monkeypatch.setattr(torch, fn, (lambda o, f: lambda *a, **k: (events.append((f, k.get("device"))), o(*a, **k))[1])(orig, fn))
+    with pytest.raises(_Stop):
+        bench.main()
+    assert events == [("set_device", local)], events

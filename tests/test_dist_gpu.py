@@ -74,16 +74,28 @@ def _worker(rank, world, port, kind, q):
         opt = FusedAdamW(core, lr=1e-3, weight_decay=0.05)
         batch = _batch(rank)
         S = core.store
-        if kind == "ours_scaler":
+        launches = []
+        if kind.startswith("ours_scaler"):
+            from mvlt_amd import ops as _ops
+            _adamw = _ops.adamw_step
+            _ops.adamw_step = lambda p_, *a_, **k_: (launches.append(p_.numel()), _adamw(p_, *a_, **k_))[1]
             # the engine's own path: BF16Scaler runs backward + FusedAdamW.step with the 1/world factor riding in the optimizer kernel
             # (G keeps the rank SUM; nothing may be owed once the call returns)
             from mvlt_amd.engine import BF16Scaler, train_step
             total, _ = train_step(model, batch, 1, True)
             for p_ in model.parameters():
                 p_.grad = None
+            p_before = S.P.clone()
             BF16Scaler()(total, opt)
-            assert S.pending_grad_scale == 1.0 and not S.scale_in_optimizer
+            _ops.adamw_step = _adamw                 # (the single-process reference below steps through the plain entry)
+            assert S.pending_grad_scale == 1.0 and not S.scale_in_optimizer and not S.grad_works
             g_mine = (S.G / world).cpu()
+            # the same step as ONE launch over everything, on the same (now final) gradient sums, moments from zero, the optimizer's own scalar row
+            # (it still holds lr, betas, bias corrections and the 1/world gradient scale of this step): must equal the phased step bit for bit
+            p_one, m_one, v_one = p_before.clone(), torch.zeros_like(S.P), torch.zeros_like(S.P)
+            _adamw(p_one, S.G, m_one, v_one, None if S.C is None else torch.empty_like(S.C), S.total, opt._hp, opt._wd_mask)
+            torch.cuda.synchronize()
+            same_as_one_launch = bool(torch.equal(p_one, S.P) and torch.equal(m_one, opt._m) and torch.equal(v_one, opt._v))
         else:
             _grads(model, batch)
             S.sync_grads()
@@ -111,7 +123,10 @@ def _worker(rank, world, port, kind, q):
         # gradient is ~0 -- e.g. the key half of attn.kv.bias -- into O(lr) differences: the bound is 5 % of the update's norm)
         upd = sum(((ref.state_dict()[k].double() - v.double().cuda()) ** 2).sum() for k, v in p_init.items() if v.is_floating_point()).sqrt()
         e_p = ((S.P.double() - ref.store.P.double()).norm() / upd).item()
-        q.put(dict(rank=rank, e_g=e_g, e_p=e_p, p_sum=float(S.P.double().sum()), p_abs=float(S.P.double().abs().sum())))
+        import hashlib
+        q.put(dict(rank=rank, e_g=e_g, e_p=e_p, p_sum=float(S.P.double().sum()), p_abs=float(S.P.double().abs().sum()),
+                   p_sha=hashlib.sha256(S.P.cpu().numpy().tobytes()).hexdigest(), launches=launches, total=S.total,
+                   same_as_one_launch=same_as_one_launch if kind == "ours_scaler" else None))
     finally:
         dist.destroy_process_group()
 
@@ -134,6 +149,32 @@ def test_two_ranks_average_gradients_like_ddp(kind, parity):
         assert parity(f"dp-{kind}/grad-rank{r['rank']}", r["e_g"], 1e-5), r
         assert parity(f"dp-{kind}/params-after-step-rank{r['rank']}", r["e_p"], 5e-2), r
     assert abs(r0["p_sum"] - r1["p_sum"]) <= 1e-9 * r0["p_abs"]           # both ranks hold the same parameters after the step
+
+
+def _run_kind(kind):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_phased_adamw_equals_one_launch_bit_for_bit():
+    """VERDICT r4 #5b with the real model and the real kernel: FusedAdamW steps the ranges whose collectives went out during the backward in a first
+    launch (after their wait) and the tail in a second; parameters and moments equal, bit for bit, those of ONE launch over everything on the same
+    gradient sums, and both ranks end with identical parameters."""
+    res = _run_kind("ours_scaler")
+    for r in res:
+        assert r["same_as_one_launch"], (r["rank"], r["launches"])
+        assert len(r["launches"]) >= 2 and sum(r["launches"]) == r["total"], r["launches"]
+    assert res[0]["p_sha"] == res[1]["p_sha"]
 
 
 def test_bench_self_launch_runs_the_rccl_path():
