@@ -290,8 +290,39 @@ def other_configs(device):
                     "pairs_s": round(B * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warm,
                     "step_tflops_reference_equivalent": round(B * steps / dt * gflop / 1e3, 1),
                     "mfma_frac_reference_equivalent": round(B * steps / dt * gflop / 1e3 / PEAK_BF16_TFLOPS, 4), "epoch_avg_loss": round(st["total_loss"], 4)}
+        if key == "finetune":
+            del model, opt
+            continue
+        # the eval callers' forward (evaluate_vl: model.eval(), no_grad, masked-row MLM head; BatchNorms of the MIM decoder folded into their convs) on the
+        # pre-train model at batch 64 of configuration #4 -- and below on the headline model at batch 256
         del model, opt, batch
         torch.cuda.empty_cache()
+    torch.manual_seed(4321)
+    lt = dict(mlm=1, itm=1, t2i=1, cls=0)
+    model = pvlt.pvlt_tiny(pretrained=False, token_hidden_size=768, num_text_tokens=128, loss_type=lt, pretrained_pth=None, drop_path_rate=0.1,
+                           drop_rate=0.0, num_classes=1000, in_chans=3).cuda(device).eval()
+    batch = synth_batch(256, 256, 128, device, 99)
+
+    def fwd(n):
+        with torch.no_grad():
+            for _ in range(n):
+                model(batch["image"], batch["input_ids"], mlm_labels=batch["mlm_labels"])
+
+    fwd(3)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    fwd(10)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / 10
+    n_sel = int((batch["mlm_labels"] != -1).sum())
+    fl = (FWD_ALL - FWD_MLM) + FWD_MLM * n_sel / (256 * 128)                  # executed forward FLOPs per pair (MLM head on the selected rows)
+    out["eval_forward"] = {"workload": "pvlt_tiny MVLT eval forward (evaluate_vl's model call: eval mode, no_grad, masked-row MLM head), 256x256 + 128 tokens, batch 256, bf16",
+                           "pairs_s": round(256 / dt, 1), "ms_per_batch": round(1e3 * dt, 3),
+                           "executed_gflop_per_pair": round(fl / 1e9, 2), "tflops_executed": round(256 / dt * fl / 1e12, 1),
+                           "mfma_frac_executed": round(256 / dt * fl / 1e12 / PEAK_BF16_TFLOPS, 4),
+                           "tflops_reference_equivalent": round(256 / dt * FWD_ALL / 1e12, 1)}
+    del model, batch
+    torch.cuda.empty_cache()
     return out
 
 
