@@ -480,9 +480,6 @@ __device__ __forceinline__ void nt_epilogue_lean(const mvlt_gemm_nt_args& p, f32
       if (!FULL && !ok[sl][it]) continue;
       const int rl = it * RPI + lane / CPR;
       const f32x4 v0 = *(const f32x4*)(stage + rl * LDW + ch * 8), v1 = *(const f32x4*)(stage + rl * LDW + ch * 8 + 4);
-#if defined(MVLT_P8_ABL) && MVLT_P8_ABL == 2      // timing ablation: the LDS staging alone
-      if (p.M > 0) { asm volatile("" ::"v"(v0), "v"(v1)); continue; }
-#endif
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += bias8[e];
@@ -1898,11 +1895,8 @@ __device__ __forceinline__ void nt_epilogue_w80(const mvlt_gemm_nt_args& p, f32x
   }
 }
 
-// the residual epilogue of the 80-column wave tile (120 accumulator registers + 80 of prefetched rows) has no room for the persistent form's live state
-template <int EPI, int HN0, int HN1> constexpr bool p8_persistent() { return !(EPI == 2 && HN0 + HN1 == 5); }
 template <int EPI, int HM, int HN0, int HN1, bool RAG = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p) {
-  constexpr bool PERS = p8_persistent<EPI, HN0, HN1>();
   // RAG: M and / or N are not whole tiles (the MLM logits: ~1500 selected rows x 30522 words).  The loader then points the rows past the end at
   // the last valid row -- their products are never stored: the epilogue runs with its bound checks -- which costs nothing inside the K-loop.
   constexpr int WMT = 2 * HM, WNT = HN0 + HN1;                    // accumulator tiles per wave
@@ -1916,68 +1910,42 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_m = RAG ? (p.M + BMT - 1) / BMT : p.M / BMT, tiles_n = RAG ? (p.N + BNT - 1) / BNT : p.N / BNT;
-  // PERSISTENT workgroups (round 5): the grid is one workgroup per CU and workgroup w walks the tile slots w, w + grid, w + 2 grid, ... (the grid is a
-  // multiple of 8, so a workgroup keeps its XCD: slot b belongs to XCD b % 8, the n-tiles of an m-tile stay neighbours on one XCD's L2).  Behind the
-  // K-loop of a tile the FIRST k-tile of the workgroup's next tile is requested (buffer 0) BEFORE the epilogue starts, whose staging lives in buffer 1
-  // (+ a few KB behind it): the launches of this model are 1.5-10 tiles per CU with K-loops of 5-32 k-tiles, and every tile used to pay a workgroup
-  // launch, its address set-up and a cold DMA pipeline (HBM / L2 latency before the first MFMA) in front of a loop of a few microseconds.
-  const int slots = 8 * ((tiles_m + 7) / 8) * tiles_n;
-  auto slot_tile = [&](int b, int& tm, int& tn) {
-    const int xcd = b & 7, bslot = b >> 3;
-    tm = (bslot / tiles_n) * 8 + xcd;              // the n-tiles of an m-tile are neighbours on one XCD
-    tn = bslot % tiles_n;
-    return tm < tiles_m;
-  };
-  auto next_slot = [&](int b) {                    // the next slot of this workgroup that holds a tile (slots past the last m-tile of a group of 8 are empty)
-    int tm, tn;
-    for (b += gridDim.x; b < slots; b += gridDim.x)
-      if (slot_tile(b, tm, tn)) return b;
-    return slots;
-  };
-  int bid = blockIdx.x, tile_m, tile_n;
-  if (!slot_tile(bid, tile_m, tile_n)) bid = next_slot(bid);
-  if (bid >= slots) return;
-  slot_tile(bid, tile_m, tile_n);
-  int m0 = tile_m * BMT, n0 = tile_n * BNT;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, bslot = bid >> 3;
+  const int tile_m = (bslot / tiles_n) * 8 + xcd, tile_n = bslot % tiles_n;      // the n-tiles of an m-tile are neighbours on one XCD
+  if (tile_m >= tiles_m) return;
+  const int m0 = tile_m * BMT, n0 = tile_n * BNT;
   const unsigned smem_lds = (unsigned)(uintptr_t)smem;
   const int nk = p.K >> 6;
 
   // ---- loader: DMA instruction i of a half-tile covers its rows 64 i .. 64 i + 63, thread -> (row (tid >> 3) + 64 i, slot tid & 7); the slot holds
   //      source chunk slot ^ ((row >> 1) & 7) (the read-side swizzle, an involution; rows 64 apart share the mask).  Source address = a scalar
   //      base per (operand, half, k-tile) + a per-thread 32-bit offset per instruction.
-  const int lrow_c = tid >> 3;
-  const int chunk_c = (tid & 7) ^ ((lrow_c >> 1) & 7);
+  const int lrow = tid >> 3;
+  const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
   const unsigned a_rs = 2u * (unsigned)p.lda, b_rs = 2u * (unsigned)p.ldb;
   unsigned a_voff[A_IT], a_voff1[RAG ? A_IT : 1], b_voff0[B_IT0], b_voff1[B_IT1];
-  const char *a_base, *b_base;
-  auto set_tile = [&](int tm0, int tn0) {          // per-thread source offsets (they depend on the tile only through RAG's clamping) and the scalar bases
-    // recomputed per tile from an opaque copy of the thread's row: kept live across the epilogue instead, these ~10 registers pushed the residual
-    // epilogue (64 registers of prefetched rows) over the 256 of two waves per SIMD (140 B of scratch at 192 x 320)
-    int lrow = lrow_c, chunk = chunk_c;
-    asm volatile("" : "+v"(lrow), "+v"(chunk));
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int lr = lrow + 64 * i, w_ = lr / (HM * 16), rem = lr - w_ * (HM * 16);
-      const int trow = w_ * (WMT * 16) + rem;                     // row inside the tile, half 0; half 1 is HM * 16 rows further
-      a_voff[i] = (unsigned)(RAG ? min(trow, p.M - 1 - tm0) : trow) * a_rs + chunk * 16;
-      if (RAG) a_voff1[i] = (unsigned)min(trow + HM * 16, p.M - 1 - tm0) * a_rs + chunk * 16;
-    }
+  for (int i = 0; i < A_IT; ++i) {
+    const int lr = lrow + 64 * i, w_ = lr / (HM * 16), rem = lr - w_ * (HM * 16);
+    const int trow = w_ * (WMT * 16) + rem;                     // row inside the tile, half 0; half 1 is HM * 16 rows further
+    a_voff[i] = (unsigned)(RAG ? min(trow, p.M - 1 - m0) : trow) * a_rs + chunk * 16;
+    if (RAG) a_voff1[i] = (unsigned)min(trow + HM * 16, p.M - 1 - m0) * a_rs + chunk * 16;
+  }
 #pragma unroll
-    for (int i = 0; i < B_IT0; ++i) {
-      const int lr = lrow + 64 * i, w_ = lr / (HN0 * 16), rem = lr - w_ * (HN0 * 16);
-      const int trow = w_ * (WNT * 16) + rem;
-      b_voff0[i] = (unsigned)(RAG ? min(trow, p.N - 1 - tn0) : trow) * b_rs + chunk * 16;
-    }
+  for (int i = 0; i < B_IT0; ++i) {
+    const int lr = lrow + 64 * i, w_ = lr / (HN0 * 16), rem = lr - w_ * (HN0 * 16);
+    const int trow = w_ * (WNT * 16) + rem;
+    b_voff0[i] = (unsigned)(RAG ? min(trow, p.N - 1 - n0) : trow) * b_rs + chunk * 16;
+  }
 #pragma unroll
-    for (int i = 0; i < B_IT1; ++i) {
-      const int lr = lrow + 64 * i, w_ = lr / (HN1 * 16), rem = lr - w_ * (HN1 * 16);
-      const int trow = w_ * (WNT * 16) + HN0 * 16 + rem;
-      b_voff1[i] = (unsigned)(RAG ? min(trow, p.N - 1 - tn0) : trow) * b_rs + chunk * 16;
-    }
-    a_base = (const char*)p.A + (size_t)tm0 * a_rs;
-    b_base = (const char*)p.B + (size_t)tn0 * b_rs;
-  };
-  set_tile(m0, n0);
+  for (int i = 0; i < B_IT1; ++i) {
+    const int lr = lrow + 64 * i, w_ = lr / (HN1 * 16), rem = lr - w_ * (HN1 * 16);
+    const int trow = w_ * (WNT * 16) + HN0 * 16 + rem;
+    b_voff1[i] = (unsigned)(RAG ? min(trow, p.N - 1 - n0) : trow) * b_rs + chunk * 16;
+  }
+  const char* const a_base = (const char*)p.A + (size_t)m0 * a_rs;
+  const char* const b_base = (const char*)p.B + (size_t)n0 * b_rs;
   const unsigned dst_wave = smem_lds + wave * 1024;
   // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1 (compile-time at every call site)
   auto stage = [&](int which, int t, int buf) {
@@ -2008,37 +1976,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p)
   };
 
   // ---- fragment geometry: lane (fr, fg) reads row fr of a 16-row tile, chunk (ks * 4 + fg) ^ ((fr >> 1) & 7)
-  //      (32-bit LDS byte offsets, re-derived per tile from an opaque copy of the lane id so that they are not live across the epilogue)
-  unsigned fa_base, fb0_base, fb1_base, koff0, koff1;
-  auto set_frag = [&]() {
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int fr = ln & 15, fg = ln >> 4;
-    const int sw = (fr >> 1) & 7;
-    fa_base = (wr * HM * 16 + fr) * 128;
-    fb0_base = OFF_B0 + (wc * HN0 * 16 + fr) * 128;
-    fb1_base = OFF_B1 + (wc * HN1 * 16 + fr) * 128;
-    koff0 = ((fg ^ sw) & 7) << 4;
-    koff1 = (((4 + fg) ^ sw) & 7) << 4;
-  };
+  const int fr = lane & 15, fg = lane >> 4;
+  const int sw = (fr >> 1) & 7;
+  const char* const fa_base = smem + (wr * HM * 16 + fr) * 128;
+  const char* const fb0_base = smem + OFF_B0 + (wc * HN0 * 16 + fr) * 128;
+  const char* const fb1_base = smem + OFF_B1 + (wc * HN1 * 16 + fr) * 128;
+  const int koff0 = ((fg ^ sw) & 7) << 4, koff1 = (((4 + fg) ^ sw) & 7) << 4;
 
   f32x4 acc[WMT][WNT];
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   u32x4 fa[2][HM], fb0[2][HN0], fb1[2][HN1];
 
 #define MVLT_LDA(BUFI, MH)                                                                                         \
   _Pragma("unroll") for (int i = 0; i < HM; ++i) {                                                                 \
-    fa[0][i] = *(const u32x4*)(smem + fa_base + (BUFI) * BUF + (MH) * OFF_A1 + i * 2048 + koff0);                         \
-    fa[1][i] = *(const u32x4*)(smem + fa_base + (BUFI) * BUF + (MH) * OFF_A1 + i * 2048 + koff1);                         \
+    fa[0][i] = *(const u32x4*)(fa_base + (BUFI) * BUF + (MH) * OFF_A1 + i * 2048 + koff0);                         \
+    fa[1][i] = *(const u32x4*)(fa_base + (BUFI) * BUF + (MH) * OFF_A1 + i * 2048 + koff1);                         \
   }
 #define MVLT_LDB0(BUFI)                                                                                            \
   _Pragma("unroll") for (int j = 0; j < HN0; ++j) {                                                                \
-    fb0[0][j] = *(const u32x4*)(smem + fb0_base + (BUFI) * BUF + j * 2048 + koff0);                                       \
-    fb0[1][j] = *(const u32x4*)(smem + fb0_base + (BUFI) * BUF + j * 2048 + koff1);                                       \
+    fb0[0][j] = *(const u32x4*)(fb0_base + (BUFI) * BUF + j * 2048 + koff0);                                       \
+    fb0[1][j] = *(const u32x4*)(fb0_base + (BUFI) * BUF + j * 2048 + koff1);                                       \
   }
 #define MVLT_LDB1(BUFI)                                                                                            \
   _Pragma("unroll") for (int j = 0; j < HN1; ++j) {                                                                \
-    fb1[0][j] = *(const u32x4*)(smem + fb1_base + (BUFI) * BUF + j * 2048 + koff0);                                       \
-    fb1[1][j] = *(const u32x4*)(smem + fb1_base + (BUFI) * BUF + j * 2048 + koff1);                                       \
+    fb1[0][j] = *(const u32x4*)(fb1_base + (BUFI) * BUF + j * 2048 + koff0);                                       \
+    fb1[1][j] = *(const u32x4*)(fb1_base + (BUFI) * BUF + j * 2048 + koff1);                                       \
   }
 #define MVLT_MMA(MH, JBASE, HN, FB)                                                                                \
   do {                                                                                                             \
@@ -2050,6 +2015,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p)
               __builtin_bit_cast(bf16x8, fa[ks][i]), __builtin_bit_cast(bf16x8, FB[ks][j]), acc[(MH) * HM + i][(JBASE) + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
   } while (0)
+
+  // ---- prologue: k-tile 0 whole, and the first three half-tiles of k-tile 1, in the loop's own issue order (B0, A0, B1, A1)
+  stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+  if (nk > 1) { stage(2, 1, 1); stage(0, 1, 1); stage(3, 1, 1); }
+  wait_tile(nk > 1);
+  MVLT_BAR();
+  if (wr == 1) MVLT_BAR();                        // the second wave row runs half a phase behind the first
 
   auto ktile = [&](auto bufc, int t) {
     constexpr int B = decltype(bufc)::value;
@@ -2084,84 +2056,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p)
     MVLT_MMA(1, 0, HN0, fb0);
     MVLT_BAR();
   };
-  // ---- first tile: k-tile 0 whole, in the loop's own issue order (B0, A0, B1, A1)
-  stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
-  for (;;) {
-    // k-tile 0 of this tile is in flight or has landed (requested above, or behind the previous tile's K-loop); now the first three half-tiles of
-    // k-tile 1 (buffer 1 is free: the previous epilogue's staging ended at the barrier that closes it)
-    if (nk > 1) { stage(2, 1, 1); stage(0, 1, 1); stage(3, 1, 1); }
-    set_frag();
-    wait_tile(nk > 1);                              // (conservative behind an epilogue: the counter also holds that epilogue's stores, which are older)
-    MVLT_BAR();
-    if (wr == 1) MVLT_BAR();                        // the second wave row runs half a phase behind the first
-#pragma unroll
-    for (int i = 0; i < WMT; ++i)
-#pragma unroll
-      for (int j = 0; j < WNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < nk; t += 2) {
-      ktile(std::integral_constant<int, 0>{}, t);
-      if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
-    }
-    if (wr == 0) MVLT_BAR();
-    MVLT_BAR();                                      // every wave is out of the loop: both buffers are free
-    const int em0 = m0, en0 = n0;
-    if (PERS) bid = next_slot(bid);
-    const bool more = PERS && bid < slots;           // workgroup-uniform
-    // (the residual epilogue holds 64 registers of prefetched rows: with the loader state live beside them it spills; there the request follows the epilogue,
-    //  which still saves the workgroup launch and the address set-up of a tile)
-    constexpr bool PREF = EPI != 2;
-    if (more) {
-      slot_tile(bid, tile_m, tile_n);
-      m0 = tile_m * BMT;
-      n0 = tile_n * BNT;
-      if (PREF) {
-        set_tile(m0, n0);
-        stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);    // the next tile's first k-tile travels while this tile's epilogue runs
-      }
-    }
-    // (whole tiles only: the bound checks go, -20 us on the GELU' launches; not for the residual epilogue, which measured 9 us SLOWER without them --
-    //  49152 x 512 x 2048 + R 120 -> 129 us, same box, two passes: its prefetched rows are then requested in a different order)
-#if defined(MVLT_P8_ABL) && MVLT_P8_ABL == 1      // timing ablation: no epilogue at all
-    if (p.M > 0) {
-#pragma unroll
-      for (int i = 0; i < WMT; ++i)
-#pragma unroll
-        for (int j = 0; j < WNT; ++j) asm volatile("" ::"v"(acc[i][j]));
-    } else
-#endif
-    if constexpr (WNT == 4) nt_epilogue_lean<128, EPI, WMT, 4, EPI != 2 && !RAG>(p, acc, smem + BUF, em0, en0, wave, lane);
-    else nt_epilogue_w80<EPI, WMT>(p, acc, smem + BUF, em0, en0, wave, lane);
-    if (!more) break;
-    MVLT_BAR();                                      // every wave is done with the staging area before k-tile 1 lands on it
-    if (!PREF) {
-      set_tile(m0, n0);
-      stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
-    }
+  for (int t = 0; t < nk; t += 2) {
+    ktile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
   }
+  if (wr == 0) MVLT_BAR();
+  MVLT_BAR();                                      // every wave is out of the loop: the epilogue may reuse the LDS
 #undef MVLT_LDA
 #undef MVLT_LDB0
 #undef MVLT_LDB1
 #undef MVLT_MMA
+  // (whole tiles only: the bound checks go, -20 us on the GELU' launches; not for the residual epilogue, which measured 9 us SLOWER without them --
+  //  49152 x 512 x 2048 + R 120 -> 129 us, same box, two passes: its prefetched rows are then requested in a different order)
+  if constexpr (WNT == 4) nt_epilogue_lean<128, EPI, WMT, 4, EPI != 2 && !RAG>(p, acc, smem, m0, n0, wave, lane);
+  else nt_epilogue_w80<EPI, WMT>(p, acc, smem, m0, n0, wave, lane);
 }
 
 template <int EPI, int HM, int HN0, int HN1, bool RAG = false> void launch_nt_p8(const mvlt_gemm_nt_args& a, hipStream_t s) {
   constexpr int BMT = 64 * HM, BNT = 64 * (HN0 + HN1);
-  constexpr int BUF = (2 * (2 * HM * 16) + 64 * (HN0 + HN1)) * 128;          // one k-tile buffer {A0, A1, B0, B1}
-  constexpr int LDS_EPI = 8 * 32 * (16 * (HN0 + HN1) + 4) * 4;               // epilogue staging: starts at buffer 1 (buffer 0 receives the next tile's first k-tile meanwhile)
-  constexpr int LDS = 2 * BUF > BUF + LDS_EPI ? 2 * BUF : BUF + LDS_EPI;
-  static_assert(LDS <= 160 * 1024, "k-tile buffers + epilogue staging exceed the LDS");
+  constexpr int LDS_LOOP = 2 * (2 * (2 * HM * 16) + 64 * (HN0 + HN1)) * 128;
+  constexpr int LDS_EPI = 8 * 32 * (16 * (HN0 + HN1) + 4) * 4;
+  constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
   static bool once = (hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<EPI, HM, HN0, HN1, RAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess);
   (void)once;
   const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = (a.N + BNT - 1) / BNT;
-  const int slots = 8 * ((tiles_m + 7) / 8) * tiles_n;
-  // one persistent workgroup per CU (a multiple of 8: a workgroup's slots stay on its XCD); MVLT_NT_P8_GRID = 0 restores one workgroup per tile
-  static const int cus = [] {
-    if (const char* e = getenv("MVLT_NT_P8_GRID")) return atoi(e);
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n / 8 * 8;
-  }();
-  dim3 grid((unsigned)((p8_persistent<EPI, HN0, HN1>() && cus > 0 && slots > cus) ? cus : slots)), block(512);
+  dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n)), block(512);
   MVLT_LAUNCH((gemm_nt_p8_kernel<EPI, HM, HN0, HN1, RAG>), grid, block, LDS, s, a);
 }
 template <int HM, int HN0, int HN1> bool dispatch_nt_p8(const mvlt_gemm_nt_args& a, int epi, hipStream_t s) {
