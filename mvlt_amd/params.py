@@ -128,6 +128,7 @@ class FlatStore:
         self.compute_dtype = compute_dtype
         self.device = None
         self.P = self.G = self.C = None
+        self._views = {}
         self.offsets = OrderedDict()      # name -> (offset, numel, shape)
         self.params = OrderedDict()       # name -> Parameter (unique)
         self.total = 0
@@ -203,19 +204,30 @@ class FlatStore:
             self.materialize(device)
 
     # ------------------------------------------------------------------ views
+    # (the views are cached per flat buffer: a step asks for ~1000 of them, and slicing + view cost ~1 us each on the host -- tools/host_profile.py)
+    def _view(self, kind, buf, name):
+        cache = self._views.get(kind)
+        if cache is None or cache[0] is not buf:
+            cache = self._views[kind] = (buf, {})
+        v = cache[1].get(name)
+        if v is None:
+            off, n, shape = self.offsets[name]
+            v = cache[1][name] = buf[off:off + n].view(shape)
+        return v
+
     def master(self, name):
-        off, n, shape = self.offsets[name]
-        return self.P[off:off + n].view(shape)
+        return self._view("P", self.P, name)
 
     def grad(self, name):
+        # NOT cached: the backward hands these views to autograd, whose AccumulateGrad adopts a returned tensor as `.grad` only when nobody else holds it --
+        # a cached (shared) view is cloned instead, and `.grad` then no longer aliases G (234 copies per step in sync_grads, and the accumulate / zero
+        # logic of begin_backward sees foreign tensors)
         off, n, shape = self.offsets[name]
         return self.G[off:off + n].view(shape)
 
     def comp(self, name):
         """parameter in the compute dtype, reference layout"""
-        off, n, shape = self.offsets[name]
-        src = self.C if self.C is not None else self.P
-        return src[off:off + n].view(shape)
+        return self._view("C", self.C if self.C is not None else self.P, name)
 
     # ------------------------------------------------------------------ operand copies
     def versions(self):
