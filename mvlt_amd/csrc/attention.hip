@@ -259,7 +259,7 @@ template <typename T, int NKT> int launch_fwd_n(const mvlt_attn_args& a, hipStre
   const int nq = (a.N + q_per_wg - 1) / q_per_wg;
   const int groups = a.B * a.H;
   const int grid = 8 * ((groups + 7) / 8) * nq;
-  hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  mvlt_max_lds<(attn_fwd_kernel<T, NKT>)>();
   MVLT_LAUNCH((attn_fwd_kernel<T, NKT>), dim3(grid), dim3(NT), lds, s, a, nq, q_per_wg);
   return mvlt_check_launch("mvlt_sr_attention_fwd");
 }
@@ -594,10 +594,10 @@ template <int NKT, int NW> int launch_fwd2_nw(const mvlt_attn_args& a, hipStream
   nq = (a.N + q_per_wg - 1) / q_per_wg;
   const int grid = 8 * ((groups + 7) / 8) * nq;
   if (a.M == MP) {
-    hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKT, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    mvlt_max_lds<(attn_fwd2_kernel<NKT, false, NW>)>();
     MVLT_LAUNCH((attn_fwd2_kernel<NKT, false, NW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
   } else {
-    hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKT, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    mvlt_max_lds<(attn_fwd2_kernel<NKT, true, NW>)>();
     MVLT_LAUNCH((attn_fwd2_kernel<NKT, true, NW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
   }
   return mvlt_check_launch("mvlt_sr_attention_fwd");
@@ -828,10 +828,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_kernel(mvlt
 // Row fragments (A operands of S / dP) are 16-byte reads of those tiles, the transposed fragments (B operands of dV / dK,
 // k = queries) are ds_read_b64_tr_b16 of the same tiles; D = rowsum(dO * O) is computed by every wave for itself from
 // LDS (no workgroup barrier), dQ leaves through an LDS tile as 16-byte row stores one iteration later.
-template <int NW, int TPW, int VAR = 0>
+template <int NW, int TPW>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(mvlt_attn_bwd_args p, int nq_chunks, int q_per_wg) {
-  // VAR (round-5 experiments, compile-time MVLT_ATTN_BWD_VAR, never in the product build; docs/experiments_r5.md 2): 1 = the key-split half of a split backward, timing only -- dK / dV alone, D taken from memory (no O tile, no
-  // per-wave rowsum), no dS park, no dQ product, one barrier per tile; 2 = the transposed dO / Q fragments read once per tile instead of once per key tile
+  // (round 5 bounded a split backward with two timing variants of this template -- the key-split half alone; the transposed fragments read once per
+  //  query tile -- and rejected it: docs/experiments_r5.md 2, code in commit 2c01256)
   typedef bf16 T;
   constexpr int NTH = NW * 64;
   constexpr int MP = NW * TPW * 16;           // padded keys (multiple of 32)
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
     const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + slot * STAGE + wave * 1024);
     glds16(ok ? (const void*)(Qg + (long)q * p.ldq + l_chunk * 8) : (const void*)zsrc, dst);
     glds16(ok ? (const void*)(dOg + (long)q * p.ldo + l_chunk * 8) : (const void*)zsrc, dst + TILE);
-    if (VAR != 1) glds16(ok ? (const void*)(Og + (long)q * p.ldo + l_chunk * 8) : (const void*)zsrc, dst + 2 * TILE);
+    glds16(ok ? (const void*)(Og + (long)q * p.ldo + l_chunk * 8) : (const void*)zsrc, dst + 2 * TILE);
   };
   issue(q_begin, 0);
   float lse_cur = (lane < 32 && q_begin + lane < q_end) ? Lg[q_begin + lane] : 0.f;
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
     // before the loop back-edge, and the deferred dQ store below then read two or four stale rows about once in 100 launches
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                   // (A) tile q0 landed; previous tile's dS / dQ tiles are complete
-    if (VAR != 1 && q_prev >= 0 && tid < 256) {        // deferred dQ store of the previous tile: 16 B per thread
+    if (q_prev >= 0 && tid < 256) {                    // deferred dQ store of the previous tile: 16 B per thread
       const int r = tid >> 3, c = tid & 7;
       if (q_prev + r < q_end) st_g<MVLT_NT_ATTN>((u32x4*)(dQg + (long)(q_prev + r) * p.ldq + c * 8), *(const u32x4*)(sdQ + r * HD + c * 8));
     }
@@ -955,12 +955,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
     const char* tO = tQ + 2 * TILE;
 
     // ---- per-wave D = rowsum(dO * O) and lse into this wave's scratch
-    if (VAR == 1) {
-      if (lane < 32) { myD[lane] = lse_now; myL[lane] = lse_now * l2e; }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } else {
+    {
       float dsum = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -992,14 +987,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
         dof[qs][s].v = *(const bf16x8*)(tdO + qs * 16 * 128 + roff[s]);
       }
 
-    Frag<T> hdot[VAR == 2 ? 4 : 1], hqt[VAR == 2 ? 4 : 1];
-    if (VAR == 2) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        hdot[dt].v = __builtin_bit_cast(bf16x8, tr_frag16(tdO + toffs[dt]));
-        hqt[dt].v = __builtin_bit_cast(bf16x8, tr_frag16(tQ + toffs[dt]));
-      }
-    }
     // ---- per owned key tile: S, dP -> P, dS ; dV += P^T dO ; dK += dS^T Q ; park dS in LDS
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -1021,23 +1008,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
           float dsv = pv * (pacc[r] - dv[qs][r]) * p.scale;
           pfrag.v[qs * 4 + r] = (T)pv;
           dsfrag.v[qs * 4 + r] = (T)dsv;
-          if (VAR != 1) sdS[ql * KS + key] = (T)dsv;
+          sdS[ql * KS + key] = (T)dsv;
         }
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         // B operands (n = d): k-slot (fg, j) <-> q = 16 (j>>2) + 4 fg + (j&3): two transposed 8-byte reads, 16 rows apart
         Frag<T> dotf, qtf;
-        if (VAR == 2) { dotf = hdot[dt]; qtf = hqt[dt]; }
-        else {
-          dotf.v = __builtin_bit_cast(bf16x8, tr_frag16(tdO + toffs[dt]));
-          qtf.v = __builtin_bit_cast(bf16x8, tr_frag16(tQ + toffs[dt]));
-        }
+        dotf.v = __builtin_bit_cast(bf16x8, tr_frag16(tdO + toffs[dt]));
+        qtf.v = __builtin_bit_cast(bf16x8, tr_frag16(tQ + toffs[dt]));
         mma16(dVacc[t][dt], pfrag, dotf);              // dV[key = tile*16 + 4 fg + r][d = 16 dt + fr]
         mma16(dKacc[t][dt], dsfrag, qtf);
       }
     }
-    if (VAR == 1) { q_prev = q0; continue; }
     __syncthreads();                                   // (C) every wave's dS columns are parked
 
     // ---- dQ[32 x 64] = dS[32 x MP] K[MP x 64]: 8 output tiles (16 x 16) dealt round-robin to the waves -> sdQ
@@ -1082,7 +1065,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
     q_prev = q0;
   }
   __syncthreads();
-  if (VAR != 1 && q_prev >= 0 && tid < 256) {
+  if (q_prev >= 0 && tid < 256) {
     const int r = tid >> 3, c = tid & 7;
     if (q_prev + r < q_end) st_g<MVLT_NT_ATTN>((u32x4*)(dQg + (long)(q_prev + r) * p.ldq + c * 8), *(const u32x4*)(sdQ + r * HD + c * 8));
   }
@@ -1158,19 +1141,12 @@ template <typename T, int NW, int TPW> int launch_bwd_n(const mvlt_attn_bwd_args
     {
       const size_t lds2 = (size_t)(HD * (MP + 8) + 32 * (MP + 8)) * 2 + 2 * 3 * 4096 + 4096 + 2 * NW * 32 * sizeof(float);
       MVLT_REQUIRE(lds2 <= 160 * 1024, "mvlt_sr_attention_bwd: LDS %zu B > 160 KB", lds2);
-#ifdef MVLT_ATTN_BWD_VAR                       // A/B builds only (tools/build_alt.sh NAME attention.hip -DMVLT_ATTN_BWD_VAR=1): VAR 1 produces no dQ and wrong dK / dV
-      {
-        hipFuncSetAttribute((const void*)attn_bwd_dma_kernel<NW, TPW, MVLT_ATTN_BWD_VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        MVLT_LAUNCH((attn_bwd_dma_kernel<NW, TPW, MVLT_ATTN_BWD_VAR>), dim3(grid), dim3(NW * 64), lds2, s, a, nq, q_per_wg);
-        return mvlt_check_launch("mvlt_sr_attention_bwd");
-      }
-#endif
-      hipFuncSetAttribute((const void*)attn_bwd_dma_kernel<NW, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      mvlt_max_lds<(attn_bwd_dma_kernel<NW, TPW>)>();
       MVLT_LAUNCH((attn_bwd_dma_kernel<NW, TPW>), dim3(grid), dim3(NW * 64), lds2, s, a, nq, q_per_wg);
       return mvlt_check_launch("mvlt_sr_attention_bwd");
     }
   } else {                                             // fp32 parity path
-    hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NW, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    mvlt_max_lds<(attn_bwd_kernel<T, NW, TPW>)>();
     MVLT_LAUNCH((attn_bwd_kernel<T, NW, TPW>), dim3(grid), dim3(NW * 64), lds, s, a, nq, q_per_wg);
     return mvlt_check_launch("mvlt_sr_attention_bwd");
   }

@@ -68,6 +68,13 @@ void mvlt_note_kernel(const void* host_function);
     hipLaunchKernelGGL(K, __VA_ARGS__);      \
   } while (0)
 
+// dynamic-LDS ceiling of a kernel instantiation raised to the 160 KB of a CU ONCE (the per-launch hipFuncSetAttribute calls of rounds 1-4 cost host time on
+// ~55 launches per step); what a launch occupies is still the size it asks for
+template <auto K> inline void mvlt_max_lds() {
+  static const hipError_t e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)e;
+}
+
 #define MVLT_REQUIRE(cond, ...)                 \
   do {                                          \
     if (!(cond)) {                              \
@@ -185,59 +192,9 @@ __device__ __forceinline__ void gelu_poly_both1(float x, float& g, float& dg) {
   dg = __builtin_fmaf(xc * 0.39894228040143267794f, e, ph);
 }
 
-// Packed-f16 forms (round 5; MVLT_GELU_H16 bit 0: GELU' of the fused-MLP input-gradient kernels, bit 1: GELU of the fused-MLP forward,
-// bit 2: the EPI 3 / EPI 4 epilogues of the stage 3-4 GEMMs).  Two activations per instruction on v_pk_*_f16, which share the VALU with an MFMA
-// stream better than f32 ops do (profiles/r03_valu_rates.txt: 16 x {mfma + 4 v_pk_fma_f16} 16.3 ticks against 21.5 for the same 8 element-ops as
-// v_fma_f32).  A monomial Horner in x^2 does NOT survive binary16 (coefficients 3e-8 .. 0.4, or O(4) with alternating signs once rescaled:
-// 3e-2 absolute error); in the CENTRED variable t = (x/4)^2 - 1/2 in [-1/2, 1/2] the coefficients are 0.2 .. 0.6 (Phi) / 0.2 .. 4.9 (GELU') with
-// partial sums of the size of the result, and with the LAST Horner step and the final x * r + 1/2 in f32 (v_fma_mix_f32: f16 operands, f32
-// arithmetic) the error against erf-GELU over every bf16 input and 4 M random f32 inputs is |delta GELU| <= 4.2e-4, |delta Phi| <= 2.9e-4,
-// |delta GELU'| <= 8.2e-4 -- inside the 1e-3 of the table form (tools/probes/gelu_f16_probe.py -> profiles/r05_gelu_f16_probe.txt, which
-// emulates exactly this instruction sequence; the fit and the clamp come from it).  17 instructions per PAIR (forward) / 17 (GELU' + product)
-// against 21 / 23 scalar-f32 ones.  The Phi clamp is the f16 value whose evaluated Phi(-c) is the smallest positive number (1.06e-6: the tail of
-// GELU is x * 1e-6 with the right sign).
-#ifndef MVLT_GELU_H16
-#define MVLT_GELU_H16 0
-#endif
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-#define MVLT_H2(v) h16x2{(_Float16)(v), (_Float16)(v)}
-__device__ __forceinline__ void gelu_h16_t(float h0, float h1, float clamp, h16x2& xc, h16x2& t) {
-  const h16x2 x = __builtin_convertvector(f32x2{h0, h1}, h16x2);                                  // v_cvt_pk_f16_f32 (RNE; saturates to inf, clamped next)
-  xc = __builtin_elementwise_min(__builtin_elementwise_max(x, MVLT_H2(-clamp)), MVLT_H2(clamp));
-  const h16x2 q = xc * MVLT_H2(0.25f);
-  t = __builtin_elementwise_fma(q, q, MVLT_H2(-0.5f));
-}
-// Phi(h0), Phi(h1)
-__device__ __forceinline__ void gelu_h16_phi2(float h0, float h1, float& p0, float& p1) {
-  h16x2 xc, t;
-  gelu_h16_t(h0, h1, 3.9234375953674316f, xc, t);
-  h16x2 r = MVLT_H2(-4.082031e-01f);
-  r = __builtin_elementwise_fma(r, t, MVLT_H2(5.527344e-01f));
-  r = __builtin_elementwise_fma(r, t, MVLT_H2(-4.079590e-01f));
-  r = __builtin_elementwise_fma(r, t, MVLT_H2(3.386230e-01f));
-  r = __builtin_elementwise_fma(r, t, MVLT_H2(-2.929688e-01f));
-  r = __builtin_elementwise_fma(r, t, MVLT_H2(2.246094e-01f));
-  r = __builtin_elementwise_fma(r, t, MVLT_H2(-1.687012e-01f));
-  const float r0 = __builtin_fmaf((float)r[0], (float)t[0], 1.759438962e-01f), r1 = __builtin_fmaf((float)r[1], (float)t[1], 1.759438962e-01f);
-  p0 = __builtin_fmaf((float)xc[0], r0, 0.5f);
-  p1 = __builtin_fmaf((float)xc[1], r1, 0.5f);
-}
-// GELU'(h0), GELU'(h1)
-__device__ __forceinline__ void gelu_h16_dg2(float h0, float h1, float& d0, float& d1) {
-  h16x2 xc, t;
-  gelu_h16_t(h0, h1, 4.0f, xc, t);
-  h16x2 r = MVLT_H2(-4.179688e+00f);
-  r = __builtin_elementwise_fma(r, t, MVLT_H2(4.882812e+00f));
-  r = __builtin_elementwise_fma(r, t, MVLT_H2(-2.460938e+00f));
-  r = __builtin_elementwise_fma(r, t, MVLT_H2(1.345703e+00f));
-  r = __builtin_elementwise_fma(r, t, MVLT_H2(-8.984375e-01f));
-  r = __builtin_elementwise_fma(r, t, MVLT_H2(4.687500e-01f));
-  r = __builtin_elementwise_fma(r, t, MVLT_H2(-2.277832e-01f));
-  const float r0 = __builtin_fmaf((float)r[0], (float)t[0], 1.831848323e-01f), r1 = __builtin_fmaf((float)r[1], (float)t[1], 1.831848323e-01f);
-  d0 = __builtin_fmaf((float)xc[0], r0, 0.5f);
-  d1 = __builtin_fmaf((float)xc[1], r1, 0.5f);
-}
-
+// (Round 5 built packed-f16 forms of the two polynomials -- centred variable t = (x/4)^2 - 1/2, last Horner step in f32: |dGELU| <= 4.2e-4, |dGELU'| <= 8.2e-4,
+//  17 instead of 21-23 instructions per pair -- and measured no gain in the fused-MLP kernels (docs/experiments_r5.md 1; code: commit 75ee330;
+//  error certificate: tools/probes/gelu_f16_probe.py -> profiles/r05_gelu_f16_probe.txt).  Not kept in the product.)
 __device__ __forceinline__ void gelu_fast_parts2(f32x2 x, f32x2& xc2, f32x2& e, f32x2& sg) {
   const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -7.0f, 7.0f), __builtin_amdgcn_fmed3f(x[1], -7.0f, 7.0f)};
   xc2 = xc * xc;

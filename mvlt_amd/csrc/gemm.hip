@@ -1565,7 +1565,7 @@ template <int W> int launch_conv3_wgrad(const mvlt_gemm_tn_args& a, hipStream_t 
   const int tps = (ntiles + splits - 1) / splits;
   splits = (ntiles + tps - 1) / tps;
   dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * n_o * n_c)), block(NTHREADS);
-  hipFuncSetAttribute((const void*)conv3_wgrad_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  mvlt_max_lds<(conv3_wgrad_kernel<W>)>();
   MVLT_LAUNCH((conv3_wgrad_kernel<W>), grid, block, lds, s, a, tps, n_o, n_c, splits);
   return mvlt_check_launch("mvlt_gemm_tn");
 }
@@ -2244,7 +2244,7 @@ template <int W, int BN, int EPI> void launch_conv3_nt(const mvlt_gemm_nt_args& 
   if (lds < stage) lds = stage;
   const int tiles_m = a.M / BM, tiles_n = (a.N + BN - 1) / BN;
   dim3 grid((unsigned)(8 * ((tiles_m + 7) / 8) * tiles_n)), block(NTHREADS);
-  hipFuncSetAttribute((const void*)conv3_nt_kernel<W, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  mvlt_max_lds<(conv3_nt_kernel<W, BN, EPI>)>();
   MVLT_LAUNCH((conv3_nt_kernel<W, BN, EPI>), grid, block, lds, s, a);
 }
 template <int W> bool dispatch_conv3_nt(const mvlt_gemm_nt_args& a, int epi, hipStream_t s) {

@@ -662,11 +662,6 @@ __global__ __launch_bounds__(NT, (C == 64 && MODE == 1) ? MVLT_PIPE_WAVES_64_1 :
           gelu_lut_one2<MODE>(lut0, h0, h1, a0, a1);
           g0 = (MODE == 0 ? h0 : dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half]) * a0;
           g1 = (MODE == 0 ? h1 : dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half + 1]) * a1;
-        } else if ((MVLT_GELU_H16 >> ((C == 128 ? 2 : 0) + (MODE == 1 ? 0 : 1))) & 1) {      // packed-f16 polynomial (common.h); bits: C = 64 dx, fwd, C = 128 dx, fwd
-          float a0, a1;
-          if (MODE == 0) gelu_h16_phi2(h0, h1, a0, a1); else gelu_h16_dg2(h0, h1, a0, a1);
-          g0 = (MODE == 0 ? h0 : dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half]) * a0;
-          g1 = (MODE == 0 ? h1 : dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half + 1]) * a1;
         } else if (MODE == 0) { g0 = gelu_fast1(h0); g1 = gelu_fast1(h1); }
         else {
           g0 = dgacc[MODE == 1 ? PAR : 0][h][mt][2 * half] * gelu_fast_grad1(h0);
@@ -1231,11 +1226,11 @@ template <int C> int launch_wgrad(const mvlt_mlp_args& a, hipStream_t s) {
   if (!a.row_scale || a.rows_per_scale % 64 == 0) {      // tile-uniform DropPath factor: the round-3 kernel (other sample lengths -- 96-px inputs, T = 20 -- take the round-2 one below)
     constexpr int NW = C == 64 ? 4 : 8;
     const size_t lds_t = lds + ((MVLT_GELU_LUT & 1) ? GELU_LUT_BYTES : 0);
-    hipFuncSetAttribute((const void*)mlp_wgrad2_kernel<C, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+    mvlt_max_lds<(mlp_wgrad2_kernel<C, NW>)>();
     MVLT_LAUNCH((mlp_wgrad2_kernel<C, NW>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NW * 64), lds_t, s, a, m_per_split, splits, ny);
     return mvlt_check_launch("mvlt_mlp_bwd_dw");
   }
-  hipFuncSetAttribute((const void*)mlp_wgrad_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  mvlt_max_lds<(mlp_wgrad_kernel<C>)>();
   MVLT_LAUNCH((mlp_wgrad_kernel<C>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NT), lds, s, a, m_per_split, splits, ny);
   return mvlt_check_launch("mvlt_mlp_bwd_dw");
 }
@@ -1252,11 +1247,11 @@ template <int C, int MODE> int launch(const mvlt_mlp_args& a, hipStream_t s) {
     size_t l2 = (size_t)2 * (MODE == 1 ? 2 : 1) * 32 * 2 * C + (size_t)2 * C * 64 + (size_t)a.hid * 4;
     if ((MVLT_GELU_LUT >> (MODE == 1 ? 1 : 2)) & 1) l2 += GELU_LUT_BYTES;
     if (l2 < stage) l2 = stage;
-    hipFuncSetAttribute((const void*)mlp_pipe_kernel<C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+    mvlt_max_lds<(mlp_pipe_kernel<C, MODE>)>();
     MVLT_LAUNCH((mlp_pipe_kernel<C, MODE>), dim3((a.M + BM - 1) / BM), dim3(NT), l2, s, a);
     return mvlt_check_launch(MODE == 0 ? "mvlt_mlp_fwd" : "mvlt_mlp_bwd_dx");
   }
-  hipFuncSetAttribute((const void*)mlp_fused_kernel<C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  mvlt_max_lds<(mlp_fused_kernel<C, MODE>)>();
   MVLT_LAUNCH((mlp_fused_kernel<C, MODE>), dim3((a.M + BM - 1) / BM), dim3(NT), lds, s, a);
   return mvlt_check_launch(MODE == 0 ? "mvlt_mlp_fwd" : "mvlt_mlp_bwd_dx");
 }

@@ -15,6 +15,7 @@ RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 MVLT_DP
 bash tools/l1_stalls.sh > /dev/null 2>&1; cp gpurun_out/l1_stalls.txt gpurun_out/${tag}_l1_stalls.txt 2>/dev/null
 bash tools/step_traffic.sh $tag > /dev/null 2>&1
 python3 tools/gemm_shapes.py > gpurun_out/${tag}_gemm_shapes.txt 2>&1
+(python3 tools/host_time.py; python3 tools/host_waits.py 20) 2>&1 | grep -E "^host|^pretrain:|^finetune:" > gpurun_out/${tag}_host_time.txt
 bash tools/pmc_collect.sh $tag > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   out=gpurun_out/pmc_${tag}_$c; rm -rf "$out"; mkdir -p "$out"

@@ -26,3 +26,13 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"host enqueue {1e3 * (t1 - t0) / N:.2f} ms/step; GPU-bound total {1e3 * (t2 - t0) / N:.2f} ms/step")
+# what one launch costs the host: 2000 tiny launches through the C ABI (a 4-element cast), queue never drained
+from mvlt_amd import ops
+src, dst = torch.zeros(4, device=dev), torch.zeros(4, device=dev, dtype=torch.bfloat16)
+for _ in range(100): ops.cast_bf16(src, dst, 4)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(2000): ops.cast_bf16(src, dst, 4)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+print(f"host cost of one launch through ops.* (ctypes + hipLaunchKernel, tiny kernel): {1e6 * (t1 - t0) / 2000:.1f} us; x 377 launches = {377 * 1e3 * (t1 - t0) / 2000:.2f} ms/step")
