@@ -48,20 +48,20 @@ g = lambda k: f"{R[k][0]} | {R[k][1]:.0f} | {R[k][2]:.1f} %"
 us = lambda k: fam.get(k, [0, 0.0])[1]
 t31 = f"""### 3.1 One steady-state step: {n_launch} launches, kernels busy {busy_ms:.2f} ms (`profiles/{tag}_step_launches.txt`)
 
-(The span from the step's first kernel to the optimizer's end is {span_ms:.2f} ms under `rocprofv3 --kernel-trace` -- {busy_pct:.1f} % busy: the traced host thread needs longer to
-enqueue a step than the GPU needs to run it, `docs/experiments_r4.md` 9.  Unprofiled the bench step equals the sum of the kernel durations.)
+(The span from the step's first kernel to the optimizer's end is {span_ms:.2f} ms under `rocprofv3 --kernel-trace` -- {busy_pct:.1f} % busy; {n_aten} of the launches are ATen kernels, {n_copy} `copyBuffer`.
+Unprofiled the bench step equals the sum of the kernel durations.  This round's collection box is ~2 % slower than round 4's: the per-family differences to `r04_step_launches.txt` are that spread, no kernel changed.)
 
 | kernel family | launches | us / step | share | bound by (evidence) |
 |---|---|---|---|---|
 | `gemm_tn_dma_kernel` (weight gradients; 8 launches carry the input gradient too) | {g('gemm_tn_dma')} | MFMA-bound shapes 0.24-0.38 of peak (3.2), the K <= 128 shapes HBM (4.5-5.6 TB/s); split reductions cost outputs x splits / 0.3 ns (`experiments_r4.md` 2) |
 | `gemm_nt_dma_kernel` (128-wide NT GEMMs: K <= 128 projections, gathers, small heads) | {g('gemm_nt_dma')} | HBM for K = 64 / 128 (`proj64` sibling: 0.60-0.70 of 8 TB/s); TA / L1 path for the rest (`r03_l1_stalls.txt`) |
-| `gemm_nt_p8_kernel` (8-wave / 8-phase NT GEMMs, stage 3-4, MLM logits) | {g('gemm_nt_p8')} | K-loop ~1.45 PFLOP/s while a round is full; launches 0.23-0.57 of peak: whole-round quantisation + an epilogue nothing overlaps; the activation-storing launches within 1.4 x of their HBM floor (3.2, 3.3) |
+| `gemm_nt_p8_kernel` (8-wave / 8-phase NT GEMMs, stage 3-4, MLM logits) | {g('gemm_nt_p8')} | K-loops alone 1.1-1.6 PFLOP/s (epilogue compiled out, `r05_p8_epilogue_ablation.txt`); the launches 0.23-0.57 of peak: whole-round quantisation + a VALU-bound epilogue (~15 instructions per output at two waves per SIMD) that a persistent grid does not hide (3.3, `experiments_r5.md` 3) |
 | `mlp_pipe_kernel` (fused MLP forward / input gradient, stages 1-2) | {g('mlp_pipe')} | VALU (GELU: 10 instructions per hidden element) + MFMA, partly overlapped: MFMA-busy 0.28-0.35, VALU-active 0.26-0.35 (`{tag}_mfma_counters.csv`) |
 | `mlp_wgrad2_kernel` (fused MLP weight gradients) | {g('mlp_wgrad2')} | VALU + MFMA add up (`roofline`: {_rf:.3f} algorithmic / {2 * _rf:.2f} executed); LDS table gather 0.43 conflicts (inherent, `experiments_r4.md` 4) |
 | LayerNorm forward / backward (standalone launches) | {g('ln')} | HBM + Infinity Cache: 4.5-7.8 TB/s algorithmic (streaming passes over the fp32 residual stream); round 3 / first half of round 4: 2238 us (`experiments_r4.md` 7) |
 | `conv3_nt_kernel` (MIM conv3x3 forward / dgrad) | {g('conv3_nt')} | MFMA / LDS-DMA: 1.0-1.24 PFLOP/s (0.41-0.50), MFMA-busy 0.48 |
 | MIM decoder non-GEMM (BatchNorm, upsample, products, fused loss) | {g('mim')} | HBM streaming, fp16 z and product factors (first half of round 4: 1482 us, `experiments_r4.md` 8) |
-| `attn_bwd_dma_kernel` | {g('attn_bwd')} | dependent chain per 32-query tile at two waves per SIMD: MFMA-busy 0.23, waits 0.37 + 0.26; stage 1 = 2.4 x its HBM floor |
+| `attn_bwd_dma_kernel` | {g('attn_bwd')} | dependent chain per 32-query tile at two waves per SIMD (256 registers): MFMA-busy 0.23, waits 0.37 + 0.26; stage 1 = 2.4 x its HBM floor; a split into dQ + dK / dV kernels cannot win (`experiments_r5.md` 2); prologue + flush 21 % / 9 % of the launch at stages 4 / 3 |
 | `conv3_wgrad_kernel` | {g('conv3_wgrad')} | 1.02 PFLOP/s (0.41), MFMA-busy 0.41 |
 | `attn_fwd2_kernel` | {g('attn_fwd2')} | Q / O streaming at stage 1 (77-80 us vs ~55 us floor), K / V staging at stages 3-4 |
 | AdamW {us('adamw'):.0f}, BERT-embedding bwd / fwd {us('bert_embed_bwd'):.0f} / {us('bert_embed_fwd'):.0f}, weight prep {us('weight_prep'):.0f}, cross entropy {us('ce_fwd') + us('ce_bwd'):.0f}, gradient-copy folds {us('fold_copies'):.0f}, ATen leftovers ({R.get('aten', (0, 0, 0))[0]} launches) {us('aten'):.0f}, other helpers | {rest_n} | {rest_us:.0f} | {100 * rest_us / total:.1f} % | HBM (AdamW: 1.2 GB at 5.7-6.4 TB/s; the embedding backward: 25 M fp32 atomics at 0.3 per ns) |
@@ -83,6 +83,25 @@ def S(key):
     raise KeyError(key)
 
 
+# the previous round's time of the same launch, from ITS committed per-shape file (last column of 3.2)
+prev_tag = "r%02d" % (int(tag[1:]) - 1)
+prev_shapes = {}
+_pp = os.path.join(ROOT, "profiles", f"{prev_tag}_gemm_shapes.txt")
+if os.path.exists(_pp):
+    for _l in open(_pp):
+        mm = re.match(r"\s*([\d.]+) ms\s+x\s+(\d+)\s+([\d.]+) us\s+(?:([\d.]+) TF/s\s+)?(.*)$", _l)
+        if mm:
+            prev_shapes[" ".join(mm.group(5).split())] = float(mm.group(3))
+
+
+def PV(*keys):
+    out = []
+    for key in keys:
+        v = next((u for k, u in prev_shapes.items() if k.startswith(key)), None)
+        out.append("-" if v is None else f"{v:.1f}")
+    return " / ".join(out)
+
+
 def r(key, flops=None):
     n, us_, tf = S(key)
     if tf is None and flops:
@@ -92,12 +111,12 @@ def r(key, flops=None):
 
 def line(label, kern, key, floor, r3, flops=None):
     us_, tf = r(key, flops)
-    return f"| {label} | {kern} | {us_:.1f} | {tf:.0f} | {tf / 2500:.2f} | {floor} | {r3} |"
+    return f"| {label} | {kern} | {us_:.1f} | {tf:.0f} | {tf / 2500:.2f} | {floor} | {PV(key)} |"
 
 
 def line2(label, kern, key_a, key_b, floor, r3):
     (ua, ta), (ub, tb) = r(key_a), r(key_b)
-    return f"| {label} | {kern} | {ua:.1f} / {ub:.1f} | {ta:.0f} / {tb:.0f} | {ta / 2500:.2f} / {tb / 2500:.2f} | {floor} | {r3} |"
+    return f"| {label} | {kern} | {ua:.1f} / {ub:.1f} | {ta:.0f} / {tb:.0f} | {ta / 2500:.2f} / {tb / 2500:.2f} | {floor} | {PV(key_a, key_b)} |"
 
 
 rows = [
@@ -108,7 +127,7 @@ rows = [
     line("stage-3 fc1 dgrad 98304 x 320 x 1280", "p8 192 x 320", "gemm_nt 98304 320 1280 A:- C:- act0 bfloat16", 50, 106.2),
 ]
 a, b = r("gemm_tn 98304 1280 320"), r("gemm_tn 98304 320 1280")
-rows.append(f"| stage-3 dW2 / dW1 (TN, 98304 rows) | tn 128 x 128 | {a[0]:.1f} / {b[0]:.1f} | {a[1]:.0f} / {b[1]:.0f} | {a[1] / 2500:.2f} / {b[1] / 2500:.2f} | 50 | 134.0 / 121.0 |")
+rows.append(f"| stage-3 dW2 / dW1 (TN, 98304 rows) | tn 128 x 128 | {a[0]:.1f} / {b[0]:.1f} | {a[1]:.0f} / {b[1]:.0f} | {a[1] / 2500:.2f} / {b[1] / 2500:.2f} | 50 | {PV('gemm_tn 98304 1280 320', 'gemm_tn 98304 320 1280')} |")
 rows += [
     line("stage-4 fc1 + GELU 49152 x 2048 x 512", "p8 256 x 256", "gemm_nt 49152 2048 512 A:- C:- b act1", 72, 150.3),
     line2("stage-4 fc2 + fp32 residual 49152 x 512 x 2048 (fp32 out / bf16 out)", "p8 192 x 256", "gemm_nt 49152 512 2048 A:- C:- b act0 R float32",
@@ -117,46 +136,50 @@ rows += [
     line("stage-4 fc1 dgrad 49152 x 512 x 2048", "p8 192 x 256", "gemm_nt 49152 512 2048 A:- C:- act0 bfloat16", 40, 91.8),
 ]
 a, b = r("gemm_tn 49152 2048 512"), r("gemm_tn 49152 512 2048")
-rows.append(f"| stage-4 dW2 / dW1 (TN, 49152 rows) | tn 128 x 128 | {a[0]:.1f} / {b[0]:.1f} | {a[1]:.0f} / {b[1]:.0f} | {a[1] / 2500:.2f} / {b[1] / 2500:.2f} | 40 | 131.0 / 112.0 |")
-twelve = sum(r(k)[0] for k in ("gemm_nt 98304 1280 320 A:- C:- b act1", "gemm_nt 98304 320 1280 A:- C:- b act0 R float32", "gemm_nt 98304 1280 320 A:- C:- act2",
+rows.append(f"| stage-4 dW2 / dW1 (TN, 49152 rows) | tn 128 x 128 | {a[0]:.1f} / {b[0]:.1f} | {a[1]:.0f} / {b[1]:.0f} | {a[1] / 2500:.2f} / {b[1] / 2500:.2f} | 40 | {PV('gemm_tn 49152 2048 512', 'gemm_tn 49152 512 2048')} |")
+TWELVE = ("gemm_nt 98304 1280 320 A:- C:- b act1", "gemm_nt 98304 320 1280 A:- C:- b act0 R float32", "gemm_nt 98304 1280 320 A:- C:- act2",
                                "gemm_nt 98304 320 1280 A:- C:- act0 bfloat16", "gemm_tn 98304 1280 320", "gemm_tn 98304 320 1280",
                                "gemm_nt 49152 2048 512 A:- C:- b act1", "gemm_nt 49152 512 2048 A:- C:- b act0 R float32", "gemm_nt 49152 2048 512 A:- C:- act2",
-                               "gemm_nt 49152 512 2048 A:- C:- act0 bfloat16", "gemm_tn 49152 2048 512", "gemm_tn 49152 512 2048"))
-rows.append(f"| **the twelve MLP launches of a stage-3 + a stage-4 block** | | **{twelve:.0f}** | | | | **1623** (VERDICT r3 target 1200) |")
+                               "gemm_nt 49152 512 2048 A:- C:- act0 bfloat16", "gemm_tn 49152 2048 512", "gemm_tn 49152 512 2048")
+twelve = sum(r(k)[0] for k in TWELVE)
+_pt = [next((u for kk, u in prev_shapes.items() if kk.startswith(k)), None) for k in TWELVE]
+twelve_prev = f"{sum(_pt):.0f}" if all(v is not None for v in _pt) else "-"
+rows.append(f"| **the twelve MLP launches of a stage-3 + a stage-4 block** | | **{twelve:.0f}** | | | | **{twelve_prev}** (VERDICT r4 target 1200: not reachable with an f32 GELU epilogue on this tile, 3.3) |")
 cf, cd, cw = r("gemm_nt 262144 192 1728 A:m2r3 C:- act0 float16"), r("gemm_nt 262144 192 1728 A:m2r3 C:- act0 bfloat16"), r("gemm_tn 262144 192 1728")
-rows.append(f"| MIM conv3x3 192 -> 192 @ 32 x 32 forward (fp16 z + BN statistics) / dgrad (bf16) | conv3_nt | {cf[0]:.1f} / {cd[0]:.1f} | {cf[1]:.0f} / {cd[1]:.0f} | {cf[1] / 2500:.2f} / {cd[1] / 2500:.2f} | 40 | 178.1 / 145.9 |")
-rows.append(f"| its weight gradient | conv3_wgrad | {cw[0]:.1f} | {cw[1]:.0f} | {cw[1] / 2500:.2f} | 32 | 180.3 |")
+rows.append(f"| MIM conv3x3 192 -> 192 @ 32 x 32 forward (fp16 z + BN statistics) / dgrad (bf16) | conv3_nt | {cf[0]:.1f} / {cd[0]:.1f} | {cf[1]:.0f} / {cd[1]:.0f} | {cf[1] / 2500:.2f} / {cd[1] / 2500:.2f} | 40 | {PV('gemm_nt 262144 192 1728 A:m2r3 C:- act0 float16', 'gemm_nt 262144 192 1728 A:m2r3 C:- act0 bfloat16')} |")
+rows.append(f"| its weight gradient | conv3_wgrad | {cw[0]:.1f} | {cw[1]:.0f} | {cw[1] / 2500:.2f} | 32 | {PV('gemm_tn 262144 192 1728')} |")
 rows.append(line("MLM logits 1490 x 30522 x 768 (fp32 out)", "p8 256 x 256, ragged", "gemm_nt 1490 30522 768", 37, 157.6))
 GF1, GF2 = 2.0 * 1081344 * 64 * 512, 2.0 * 294912 * 128 * 1024       # one GEMM unit of the fused MLP
 f1, x1, w1 = S("mlp_fwd 1081344 64 512")[1], S("mlp_bwd_dx 1081344 64 512")[1], S("mlp_bwd_dw 1081344 64 512")[1]
 f2, x2, w2 = S("mlp_fwd 294912 128 1024")[1], S("mlp_bwd_dx 294912 128 1024")[1], S("mlp_bwd_dw 294912 128 1024")[1]
 tfs = lambda units, gf, us_: units * gf / us_ / 1e6
 rows.append(f"| fused MLP stage 1 (M = 1081344, C = 64, hidden 512): forward / input gradient (+ `norm2` backward) / weight gradients | mlp_pipe / mlp_wgrad2 | {f1:.1f} / {x1:.1f} / {w1:.1f} | "
-            f"{tfs(2, GF1, f1):.0f} / {tfs(3, GF1, x1):.0f} / {tfs(4, GF1, w1):.0f} executed | {tfs(2, GF1, f1) / 2500:.2f} / {tfs(3, GF1, x1) / 2500:.2f} / {tfs(4, GF1, w1) / 2500:.2f} executed | 50-100 | 291 / 409 / 355 |")
+            f"{tfs(2, GF1, f1):.0f} / {tfs(3, GF1, x1):.0f} / {tfs(4, GF1, w1):.0f} executed | {tfs(2, GF1, f1) / 2500:.2f} / {tfs(3, GF1, x1) / 2500:.2f} / {tfs(4, GF1, w1) / 2500:.2f} executed | 50-100 | {PV('mlp_fwd 1081344 64 512', 'mlp_bwd_dx 1081344 64 512', 'mlp_bwd_dw 1081344 64 512')} |")
 rows.append(f"| fused MLP stage 2 (M = 294912, C = 128, hidden 1024) | same | {f2:.1f} / {x2:.1f} / {w2:.1f} | {tfs(2, GF2, f2):.0f} / {tfs(3, GF2, x2):.0f} / {tfs(4, GF2, w2):.0f} executed | "
-            f"{tfs(2, GF2, f2) / 2500:.2f} / {tfs(3, GF2, x2) / 2500:.2f} / {tfs(4, GF2, w2) / 2500:.2f} executed | 30-60 | 235 / 353 / 357 |")
+            f"{tfs(2, GF2, f2) / 2500:.2f} / {tfs(3, GF2, x2) / 2500:.2f} / {tfs(4, GF2, w2) / 2500:.2f} executed | 30-60 | {PV('mlp_fwd 294912 128 1024', 'mlp_bwd_dx 294912 128 1024', 'mlp_bwd_dw 294912 128 1024')} |")
 ab = [S(f"sr_attention_bwd 256 {h} {n} 192")[1] for h, n in ((1, 4224), (2, 1152), (5, 384), (8, 192))]
 af = [S(f"sr_attention_fwd 256 {h} {n} 192")[1] for h, n in ((1, 4224), (2, 1152), (5, 384), (8, 192))]
 fl = [256 * h * n * 192 * 64 * 2.0 for h, n in ((1, 4224), (2, 1152), (5, 384), (8, 192))]
 rows.append("| SR attention backward, stages 1 / 2 / 3 / 4 | attn_bwd_dma | " + " / ".join(f"{x:.1f}" for x in ab) + " | " + " / ".join(f"{5 * f / x / 1e6:.0f}" for f, x in zip(fl, ab)) + " | " +
-            " / ".join(f"{5 * f / x / 1e6 / 2500:.2f}" for f, x in zip(fl, ab)) + " | 100 / 27 / 27 / 27 | 240.7 / 129.1 / 140.7 / 140.9 |")
+            " / ".join(f"{5 * f / x / 1e6 / 2500:.2f}" for f, x in zip(fl, ab)) + " | 95 / 56 / 60 / 64 | " + PV(*[f"sr_attention_bwd 256 {h} {n} 192" for h, n in ((1, 4224), (2, 1152), (5, 384), (8, 192))]) + " |")
 rows.append("| SR attention forward, stages 1-4 | attn_fwd2 | " + " / ".join(f"{x:.1f}" for x in af) + " | " + " / ".join(f"{2 * f / x / 1e6:.0f}" for f, x in zip(fl, af)) + " | " +
-            " / ".join(f"{2 * f / x / 1e6 / 2500:.2f}" for f, x in zip(fl, af)) + " | 55 / 15 / 15 / 15 | 82.3 / 52.0 / 47.3 / 50.7 |")
+            " / ".join(f"{2 * f / x / 1e6 / 2500:.2f}" for f, x in zip(fl, af)) + " | 46 / 28 / 30 / 32 | " + PV(*[f"sr_attention_fwd 256 {h} {n} 192" for h, n in ((1, 4224), (2, 1152), (5, 384), (8, 192))]) + " |")
 d1, d2 = S("gemm_tn 1081344 64 64")[1], S("gemm_tn 294912 128 128")[1]
 b1, b2 = (1081344 * 64 * 2 * 3 + 0.0) / d1 / 1e6, (294912 * 128 * 2 * 3 + 0.0) / d2 / 1e6
 rows.append(f"| q / proj weight + input gradient in one pass, stage 1 (1081344 x 64 x 64) / stage 2 (294912 x 128 x 128) | tn 64 x 64 / 128 x 128 + DG | {d1:.1f} / {d2:.1f} | HBM: {b1:.1f} / {b2:.1f} TB/s | "
-            f"{b1 / 8:.2f} / {b2 / 8:.2f} of 8 TB/s | 66 / 36 | 102.5 / 68.8 (two launches) |")
+            f"{b1 / 8:.2f} / {b2 / 8:.2f} of 8 TB/s | 66 / 36 | {PV('gemm_tn 1081344 64 64', 'gemm_tn 294912 128 128')} |")
 bench = json.loads(open(P("bench_n1.json")).read().strip().split("\n")[-1])
 bo = bench["flops"]["blocks_only"]
 t32 = f"""### 3.2 The MFMA-carrying launches (`profiles/{tag}_gemm_shapes.txt`: every distinct launch of the step re-timed alone with the step's arguments; {tot_line})
 
-fraction = 2 M N K / time / 2.5 PFLOP/s; "HBM floor" = algorithmic bytes / 6.3 TB/s.
+fraction = 2 M N K / time / 2.5 PFLOP/s; "HBM floor" = algorithmic bytes / 6.3 TB/s (attention: Q, dO, O, dQ + K / V + dK / dV + lse in bf16 -- round 4's table
+had left the K / V / dK / dV streams out of the stage 2-4 floors and showed 27 / 15 us there).
 
-| launch (M x N x K, epilogue) | kernel / tile | us | TFLOP/s | fraction | HBM floor us | round 3 us |
+| launch (M x N x K, epilogue) | kernel / tile | us | TFLOP/s | fraction | HBM floor us | round {int(tag[1:]) - 1} us (`profiles/{prev_tag}_gemm_shapes.txt`, another box) |
 |---|---|---|---|---|---|---|
 """ + "\n".join(rows) + f"""
 
-Blocks-only MFMA fraction (north_star's figure, `flops.blocks_only` of the bench line): **{bo['mfma_frac']:.3f}** ({bo['ms_per_step']:.2f} ms for 6.15 TFLOP; round 3: 0.165; target 0.40
+Blocks-only MFMA fraction (north_star's figure, `flops.blocks_only` of the bench line): **{bo['mfma_frac']:.3f}** ({bo['ms_per_step']:.2f} ms for 6.15 TFLOP; round 4: 0.182 builder / 0.180 driver, round 3: 0.165; target 0.40
 -- the ceiling argument of round 3 stands: in stages 1-2, half of the block FLOPs, the VALU floor of the activation alone is 1.6-2.7 x the MFMA time of the GEMMs
 around it, `docs/experiments_r1-r3.md` B "Instruction issue rates").
 """
@@ -170,23 +193,23 @@ ks_calls, ks_avg_us = int(ks[0]), float(ks[2]) / 1e3
 mw, cal = tj["mlp_dw64"], tj["calib_cast"]
 pairs = lambda x: f"{x:,.0f}".replace(",", " ")
 t6 = f"""**The line of the final build** (`profiles/{tag}_bench_n1.json`, command `python bench.py`, sources `{tj['_source_hash']}`): **{pairs(bench['value'])} pairs/s, {bench['ms_per_step']:.2f} ms/step**
-(round 3's driver line: 11 428 / 22.40; the first half of this round: 11 903 / 21.51).  The boxes of the pool differ by +-2.5 %: the final tree (and its last few predecessors, which differ by < 0.05 ms) measured 20.2 .. 21.3 ms on nine boxes of the last afternoon (20.19, 20.31, 20.56, 20.66, 20.68, 20.86, 21.09, 21.15, 21.33); every A/B below is same-box.  Same-box A/Bs of this round add up to -1.75 ms (-8 %): 8-phase NT GEMMs -0.15, polynomial GELU' + whole-tile
-epilogues + K = 320 launches on them -0.12, weight + input gradient in one pass -0.15, pipelined C = 128 input gradient -0.04 (first half); LayerNorm backward without LDS
-atomics -0.38, fp16 pre-BatchNorm conv outputs and product factors -0.25, attention-backward dK / dV flush -0.06, bf16 stage outputs from the fc2 epilogue, MLM logits on the 8-phase
-kernel, `weight_prep` from the bf16 copy, embedding backward together -0.15, BatchNorm statistics finalised inside the normalisation launch -0.145 (second half,
-`docs/experiments_r4.md` 7-10).  Loss trajectory unchanged (epoch average 10.67, same synthetic batch).
+(round 4: driver 12 532 / 20.43, builder's box 12 704 / 20.15; round 3's driver line: 11 428 / 22.40).  The boxes of the pool differ by +-2.5 %: the final tree measured 20.2 .. 20.9 ms on the boxes of this
+round.  Round 5 changed no hot kernel (`docs/experiments_r5.md`: five kernel-level attempts measured same-box, none faster), so the step is round 4's within that spread; what changed in the LINE is that
+its roofline entries are named by the library (`mvlt_last_kernel()` after the timed launches), `share_of_step` is computed from the measured launch and step times, a `limiter` text is attached only to the
+instantiation it was written for, the top instantiation of the kernel trace (`gemm_tn_dma_kernel<128, 128, 3, 2, false>` on the stage-3 fc2 weight-gradient shape) is a third sibling, `other_configs` carries an
+MFMA fraction and an eval-forward entry.  Loss trajectory unchanged (epoch average {bench['config']['epoch_avg_loss']:.2f}, same synthetic batch).
 
 | field | value | how to recompute it |
 |---|---|---|
 | `value`, `ms_per_step` | {pairs(bench['value'])} pairs/s, {bench['ms_per_step']:.3f} ms | 256 pairs x 20 steps / wall time between `torch.cuda.synchronize()`s around `train_one_epoch_vl`; kernel sum of one step: {busy_ms:.2f} ms (`{tag}_step_launches.txt`) |
 | `flops.blocks_only` | {bo['ms_per_step']:.2f} ms, {bo['tflops']:.1f} TFLOP/s, **{bo['mfma_frac']:.3f}** | HIP events around the Block kernels of every stage, fwd + bwd, two extra iterations; 3 x 8.003 GFLOP x 256 / {bo['ms_per_step']:.2f} ms / 2.5 PFLOP/s |
 | `flops.mfma_frac_executed` | {fl_['mfma_frac_executed']:.3f} | {fl_['executed_gflop_per_pair']:.2f} GFLOP/pair executed (MLM head on the selected rows of 32768 only; + 2.32 fc1 recomputed) x {pairs(bench['value'])} / 2.5 PFLOP/s |
-| `roofline` (kernel `mlp_wgrad2_kernel<64, 4>`, the launch VERDICT r3 named) | achieved {rf['achieved']:.1f} TFLOP/s, **frac {rf['frac']:.3f}**, {rf['ms_per_launch']:.3f} ms | algorithmic FLOPs 2 x 2 M C hid = 4 x 1081344 x 64 x 512 = 141.73 GFLOP / {rf['ms_per_launch']:.3f} ms (HIP events, 20 launches, torch's current stream = the launch stream); `{tag}_kernel_stats.csv`: {ks_avg_us:.1f} us average over {ks_calls} calls (in-step + this timing) -> {141.73392 / ks_avg_us * 1e3:.1f} TFLOP/s = {141.73392 / ks_avg_us * 1e3 / 2500:.3f}; executed FLOPs are twice the algorithmic ones (h and dg recomputed on chip) |
+| `roofline` (kernel as reported by the library: `{rf['kernel'].split(' (bf16)')[0]}`, the launch VERDICT r3 named) | achieved {rf['achieved']:.1f} TFLOP/s, **frac {rf['frac']:.3f}**, {rf['ms_per_launch']:.3f} ms; {rf['share_of_step']} | algorithmic FLOPs 2 x 2 M C hid = 4 x 1081344 x 64 x 512 = 141.73 GFLOP / {rf['ms_per_launch']:.3f} ms (HIP events, 20 launches, torch's current stream = the launch stream); `{tag}_kernel_stats.csv`: {ks_avg_us:.1f} us average over {ks_calls} calls (in-step + this timing) -> {141.73e9 / (ks_avg_us * 1e-6) / 1e12:.1f} TFLOP/s = {141.73e9 / (ks_avg_us * 1e-6) / 1e12 / 2500:.3f}; executed FLOPs are twice the algorithmic ones (h and dg recomputed on chip) |
 | `roofline.traffic` | {rf['traffic'] / 1e6:.1f} MB per launch | `{tag}_roofline_traffic.json`: 2 x FETCH_SIZE ({mw['fetch_size_kib']:,.0f} KiB) + WRITE_SIZE ({mw['write_size_kib']:,.0f} KiB), separate `--pmc` passes over `tools/roofline_launch.py`, {mw['dispatches']} dispatches; calibration in the same run: torch's fp32 -> bf16 cast of a 262144 x 192 tensor reads {cal['read_bytes'] / 1e6:.2f} MB (expected {cal['expected_read_bytes'] / 1e6:.2f}) and writes {cal['write_bytes'] / 1e6:.2f} ({cal['expected_write_bytes'] / 1e6:.2f}); algorithmic bytes 276.8 MB -> {rf['traffic'] / 276.824064e6:.2f} x (the partial-sum flushes) |
-| `roofline.siblings` | conv3x3 192 -> 192: {sib[0]['achieved']:.0f} TFLOP/s = **{sib[0]['frac']:.2f}**, {sib[0]['traffic'] / 1e6:.1f} MB; K = 64 projection: {sib[1]['achieved'] / 1e3:.2f} TB/s = **{sib[1]['frac']:.2f}** of 8 TB/s, {sib[1]['traffic'] / 1e6:.0f} MB | 173.9 GFLOP / {sib[0]['ms_per_launch']:.4f} ms; 276.8 MB / {sib[1]['ms_per_launch']:.4f} ms |
-| `step.hbm_gb_per_step` | {st['hbm_gb_per_step']:.2f} GB, {st['hbm_tb_per_s']:.2f} TB/s | `{tag}_step_traffic.txt`: FETCH_SIZE x 2 + WRITE_SIZE over 6 whole steps of the bench process, per kernel (round 3: 66.65; first half of round 4: 66.05) |
+| `roofline.siblings` | conv3x3 192 -> 192 (`{sib[0]['kernel'].split(' (bf16)')[0]}`): {sib[0]['achieved']:.0f} TFLOP/s = **{sib[0]['frac']:.2f}**, {sib[0]['traffic'] / 1e6:.1f} MB; K = 64 projection (`{sib[1]['kernel'].split(' (bf16)')[0]}`): {sib[1]['achieved'] / 1e3:.2f} TB/s = **{sib[1]['frac']:.2f}** of 8 TB/s, {sib[1]['traffic'] / 1e6:.0f} MB; stage-3 fc2 weight gradient (`{sib[2]['kernel'].split(' (bf16)')[0]}`, the trace's top instantiation): {sib[2]['achieved']:.0f} TFLOP/s = **{sib[2]['frac']:.2f}**, {sib[2]['ms_per_launch'] * 1e3:.1f} us, {(sib[2]['traffic'] or 0) / 1e6:.1f} MB against {sib[2]['algorithmic_bytes'] / 1e6:.1f} MB algorithmic | {sib[0]['algorithmic_flops'] / 1e9:.1f} GFLOP / {sib[0]['ms_per_launch']:.4f} ms; {sib[1]['algorithmic_bytes'] / 1e6:.1f} MB / {sib[1]['ms_per_launch']:.4f} ms; {sib[2]['algorithmic_flops'] / 1e9:.1f} GFLOP / {sib[2]['ms_per_launch']:.4f} ms |
+| `step.hbm_gb_per_step` | {st['hbm_gb_per_step']:.2f} GB, {st['hbm_tb_per_s']:.2f} TB/s | `{tag}_step_traffic.txt`: FETCH_SIZE x 2 + WRITE_SIZE over 6 whole steps of the bench process, per kernel (round 4: 63.19, round 3: 66.65) |
 | `cpu_baseline` | {cb['value']:.1f} pairs/s train step, {cb.get('forward_loss_value', 0):.1f} forward + loss, {cb['cores']} cores, `kind: {cb['kind']}` | the oracle at config #1 shapes (4 pairs, fp32), ~20 s sample on the box's host cores; a reported baseline, not a target |
-| `other_configs` | medium384_b64 **{pairs(oc['medium384_b64']['pairs_s'])} pairs/s** ({oc['medium384_b64']['ms_per_step']:.1f} ms), finetune **{pairs(oc['finetune']['pairs_s'])} pairs/s** ({oc['finetune']['ms_per_step']:.1f} ms) | BASELINE configurations #4 / #5 at one GPU, 5 + 10 / 20 + 20 iterations of the same engine entry behind the headline (round 3, builder-run: 1 570 / 13 600) |
+| `other_configs` | medium384_b64 **{pairs(oc['medium384_b64']['pairs_s'])} pairs/s** ({oc['medium384_b64']['ms_per_step']:.1f} ms, {oc['medium384_b64']['mfma_frac_reference_equivalent']:.3f} of peak reference-equivalent), finetune **{pairs(oc['finetune']['pairs_s'])} pairs/s** ({oc['finetune']['ms_per_step']:.1f} ms, {oc['finetune']['mfma_frac_reference_equivalent']:.3f}), eval forward **{pairs(oc['eval_forward']['pairs_s'])} pairs/s** ({oc['eval_forward']['ms_per_batch']:.2f} ms per batch of 256, {oc['eval_forward']['mfma_frac_executed']:.3f} executed) | BASELINE configurations #4 / #5 at one GPU, 5 + 10 / 5 + 20 iterations of the same engine entry behind the headline; the eval callers' model call (eval mode, no_grad, masked-row MLM head, BatchNorms folded) 3 + 10 times |
 """
 
 p = os.path.join(ROOT, "DESIGN.md")

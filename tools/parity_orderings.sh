@@ -1,7 +1,7 @@
 #!/bin/bash
 # the model-level parity tests under other arithmetic orderings of the same build -- Block.norm2 inside the fused-MLP prologue instead of the
 # proj epilogue (MVLT_NO_PROJ_LN=1), the sigmoid-form GELU instead of the polynomials (a second library built with -DMVLT_GELU_POLY=0), 128-wide GEMMs instead of
-# the 8-phase ones (MVLT_NT_P8=0): the tightest margins of each run.   gpurun -- 'bash tools/parity_orderings.sh > gpurun_out/r04_parity_orderings.txt'
+# the 8-phase ones (MVLT_NT_P8=0): the tightest margins of each run.  The sigmoid build: bash tools/build_alt.sh sigm gemm.hip,mlp.hip -DMVLT_GELU_POLY=0   gpurun -- 'bash tools/parity_orderings.sh > gpurun_out/rNN_parity_orderings.txt'
 cd "${GRAFT_REPO_ROOT:-.}"
 run() {
   echo "=== $1"
@@ -10,7 +10,7 @@ run() {
 }
 run "default build" "MVLT_DUMMY=1"
 run "MVLT_NO_PROJ_LN=1" "MVLT_NO_PROJ_LN=1"
-run "MVLT_NT_P8=0 MVLT_NO_LIN_FUSE=1 MVLT_MLP_PIPE128=0 (round-3 kernel selection)" "MVLT_NT_P8=0 MVLT_NO_LIN_FUSE=1 MVLT_MLP_PIPE128=0"
+run "MVLT_NT_P8=0 MVLT_NO_LIN_FUSE=1 (128-wide GEMMs instead of the 8-phase ones, weight and input gradients as two launches)" "MVLT_NT_P8=0 MVLT_NO_LIN_FUSE=1"
 run "MVLT_MIM_FP32_Z=1 MVLT_NO_OUT_OP=1 (fp32 pre-BatchNorm conv outputs, fp32 stage outputs + cast pass)" "MVLT_MIM_FP32_Z=1 MVLT_NO_OUT_OP=1"
 [ -f ab/libmvlt_sigm.so ] && run "sigmoid-form GELU build (ab/libmvlt_sigm.so)" "MVLT_HIP_LIB=ab/libmvlt_sigm.so"
 [ -f ab/libmvlt_sigm.so ] && run "sigmoid-form GELU build + MVLT_NO_PROJ_LN=1" "MVLT_HIP_LIB=ab/libmvlt_sigm.so MVLT_NO_PROJ_LN=1"
