@@ -22,8 +22,9 @@ extern "C" {
 /* Version of this header: bumped whenever an exported signature or an argument struct changes.  mvlt_abi_version() returns the number the library was
  * built with; a binding compares it with the number it was written against (mvlt_amd/_lib.py ABI_VERSION) before any other call.
  *   2 (round 5): positional signatures of mvlt_batch_sum / mvlt_bn_norm / mvlt_bn_bwd_reduce / mvlt_bn_bwd_apply / mvlt_ew_mul / mvlt_ew_mul3_bwd as of
- *                round 4's second half (the number had stayed 1 through those changes: ADVICE r4) */
-#define MVLT_ABI_VERSION 2
+ *                round 4's second half (the number had stayed 1 through those changes: ADVICE r4)
+ *   3 (round 5): mvlt_gemm_tn_args.partials / partials_bytes; mvlt_last_kernel() */
+#define MVLT_ABI_VERSION 3
 const char* mvlt_last_error(void);
 int mvlt_abi_version(void);
 /* the kernel instantiation the library launched last on the calling thread, as the HIP runtime names it, demangled (e.g. "void (anonymous
@@ -111,6 +112,12 @@ typedef struct mvlt_gemm_tn_args {
    * N1 == N2 == 64 or 128, trans_c == 0: the q / proj projections of stages 1-2 (reference libs/pvlt.py:98,118 and their autograd) read dY
    * once for both gradients instead of once per gradient (138 MB per Linear at stage 1). */
   const void* dgrad_wt; void* dgrad_out; int dgrad_ld;
+  /* optional scratch for a reduction WITHOUT atomics (round 5): when the output is whole 256 x 256 tiles, 16 .. 64 of them, M a multiple of 64 with enough rows per split
+   * (the fc1 / fc2 weight gradients of a stage-4 block: 2048 x 512 over 49152 rows), bf16 operands, plain rows, trans_c == 0, the 8-wave / 8-phase TN kernel stores every
+   * m-split's tile to partials[split][N1][N2] in bf16 and an ordered fold adds them to C: deterministic (bit-identical from launch to launch), 114 us against 132 us.
+   * partials_bytes >= 32 MiB covers every qualifying shape (splits x N1 x N2 = 256 x 65536 elements); NULL or too small = the atomic path.  One bf16 rounding per split's
+   * partial sum: max-norm error 2e-3 of the gradient instead of 1e-5. */
+  void* partials; long partials_bytes;
 } mvlt_gemm_tn_args;
 int mvlt_gemm_tn(const mvlt_gemm_tn_args* args, void* stream);
 

@@ -52,7 +52,8 @@ class GemmTNArgs(C.Structure):
                 ("M", c_int), ("N1", c_int), ("N2", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int),
                 ("dtype", c_int), ("a_map", RowMap), ("b_map", RowMap),
                 ("colsum_a", c_void_p), ("splits", c_int), ("colsum_b", c_void_p), ("trans_c", c_int),
-                ("c_taps", c_int), ("c_seg", c_int), ("dgrad_wt", c_void_p), ("dgrad_out", c_void_p), ("dgrad_ld", c_int)]
+                ("c_taps", c_int), ("c_seg", c_int), ("dgrad_wt", c_void_p), ("dgrad_out", c_void_p), ("dgrad_ld", c_int),
+                ("partials", c_void_p), ("partials_bytes", c_long)]
 
 
 class LayerNormArgs(C.Structure):
@@ -106,7 +107,7 @@ class MlpArgs(C.Structure):
 lib.mvlt_last_error.restype = C.c_char_p
 lib.mvlt_last_kernel.restype = C.c_char_p
 lib.mvlt_sizeof.argtypes = [C.c_char_p]
-ABI_VERSION = 2          # include/mvlt_hip.h MVLT_ABI_VERSION this binding was written against
+ABI_VERSION = 3          # include/mvlt_hip.h MVLT_ABI_VERSION this binding was written against
 if lib.mvlt_abi_version() != ABI_VERSION:
     raise ImportError(f"ABI mismatch: {LIB_PATH} is version {lib.mvlt_abi_version()}, the binding is version {ABI_VERSION} (stale build? run python -m mvlt_amd.build)")
 for _name, _cls in (("mvlt_rowmap", RowMap), ("mvlt_prep_desc", PrepDesc), ("mvlt_gemm_nt_args", GemmNTArgs), ("mvlt_gemm_tn_args", GemmTNArgs),

@@ -2100,6 +2100,314 @@ template <int HM, int HN0, int HN1> bool dispatch_nt_p8(const mvlt_gemm_nt_args&
   return false;
 }
 
+// ------------------------------------------------------------------------------------------------ TN (weight gradients), bf16, 8 waves, 8-phase loop
+// C[N1, N2] += A[M, N1]^T B[M, N2] on the schedule of gemm_nt_p8_kernel: the reduction runs over the ROWS of both operands (k-tile = 64 rows), the
+// operand tiles keep their natural [m][n] layout in LDS (LDS-DMA cannot transpose) and the MFMA fragments -- 8 consecutive m of one n per lane --
+// come from two ds_read_b64_tr_b16 each, as in gemm_tn_dma_kernel.  Half h of A holds the columns {wr * 2 HM 16 + h * HM 16 + c} of both wave rows
+// as a [64 m][2 HM 16] image, half h of B the columns of all four wave columns as [64 m][4 HNh 16]; row pitches 128 / 256 / 384 B, the 16-byte
+// chunks of a row XOR-ed (on the source side) with a hash of the row so that the eight rows a 32-lane transposed read touches (m .. m+3, m+8 ..
+// m+11) fall into eight different 32-byte bank windows: pitch 256 -> (row & 3) | bit 3 of the row; pitch 128 and 384 (both 4 windows mod 8 per
+// row) -> bit 1 | bit 3.  Tiles: 256 x 256 (2048 x 512 at stage 4) and 128 x 320 (1280 x 320 at stage 3); an output whose 320-multiple side is N1 is
+// computed as its transpose (operands swapped by the host, the MFMA operand order flipped so that a lane's 16 consecutive outputs stay contiguous
+// in memory).  The m range is split over workgroups (one per CU), partial tiles meet by fp32 atomics; bias gradients = ones-fragment MFMAs,
+// taken in turns by the workgroups that share an operand column range.
+template <int PITCH> __device__ __forceinline__ int tn_hash(int row) {
+  return PITCH == 256 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+}
+template <int HM, int HN0, int HN1, bool TRANS>
+__global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p, int kt_per, int t1, int t2, int splits, bf16* part) {
+  constexpr int WMT = 2 * HM, WNT = HN0 + HN1;
+  constexpr int AC = 2 * HM * 16, BC0 = 4 * HN0 * 16, BC1 = 4 * HN1 * 16;          // columns of the A / B0 / B1 half-tiles
+  constexpr int PA = AC * 2, PB0 = BC0 * 2, PB1 = BC1 * 2;                         // row pitches in bytes
+  constexpr int A_IT = 64 * PA / 8192, B_IT0 = 64 * PB0 / 8192, B_IT1 = 64 * PB1 / 8192;
+  static_assert((PA == 128 || PA == 256) && (PB0 == 256 || PB0 == 384) && PB1 == 256, "half-tile pitches with a bank hash");
+  constexpr int OFF_A1 = 64 * PA, OFF_B0 = 2 * 64 * PA, OFF_B1 = OFF_B0 + 64 * PB0, BUF = OFF_B1 + 64 * PB1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  // all output tiles of one m-split on ONE XCD (workgroup b runs on XCD b % 8): the operand rows pass that L2 once
+  const int txy = t1 * t2;
+  int bz, xy;
+  if (splits >= 8) {
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    const int zq = kq / txy;
+    xy = kq - zq * txy;
+    bz = zq * 8 + xcd;
+    if (bz >= splits) return;
+  } else {
+    bz = blockIdx.x / txy;
+    xy = blockIdx.x - bz * txy;
+  }
+  const int bx = xy % t1, by = xy / t1;
+  const int n1_0 = bx * (2 * WMT * 16), n2_0 = by * (4 * WNT * 16);
+  const int nkt = p.M >> 6;
+  const int kt0 = bz * kt_per;
+  const int nk = min(kt_per, nkt - kt0);
+  if (nk <= 0) return;
+  const unsigned smem_lds = (unsigned)(uintptr_t)smem;
+  const unsigned a_rs = 2u * (unsigned)p.lda, b_rs = 2u * (unsigned)p.ldb;
+
+  // ---- loader: chunk q = tid + 512 i of a half-tile = (row q / CPR, slot q % CPR); the slot holds source chunk slot ^ (hash(row) << 1)
+  unsigned a_voff[A_IT], b_voff0[B_IT0], b_voff1[B_IT1];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    constexpr int CPR = PA / 16;
+    const int q = tid + 512 * i, row = q / CPR, lc = ((q - row * CPR) ^ (tn_hash<PA>(row) << 1)) * 8;
+    const int w_ = lc / (HM * 16);
+    a_voff[i] = (unsigned)row * a_rs + 2u * (unsigned)(w_ * (WMT * 16) + (lc - w_ * (HM * 16)));
+  }
+#pragma unroll
+  for (int i = 0; i < B_IT0; ++i) {
+    constexpr int CPR = PB0 / 16;
+    const int q = tid + 512 * i, row = q / CPR, lc = ((q - row * CPR) ^ (tn_hash<PB0>(row) << 1)) * 8;
+    const int w_ = lc / (HN0 * 16);
+    b_voff0[i] = (unsigned)row * b_rs + 2u * (unsigned)(w_ * (WNT * 16) + (lc - w_ * (HN0 * 16)));
+  }
+#pragma unroll
+  for (int i = 0; i < B_IT1; ++i) {
+    constexpr int CPR = PB1 / 16;
+    const int q = tid + 512 * i, row = q / CPR, lc = ((q - row * CPR) ^ (tn_hash<PB1>(row) << 1)) * 8;
+    const int w_ = lc / (HN1 * 16);
+    b_voff1[i] = (unsigned)row * b_rs + 2u * (unsigned)(w_ * (WNT * 16) + HN0 * 16 + (lc - w_ * (HN1 * 16)));
+  }
+  const char* const a_base = (const char*)p.A + (size_t)(kt0 * 64) * a_rs + (size_t)n1_0 * 2;
+  const char* const b_base = (const char*)p.B + (size_t)(kt0 * 64) * b_rs + (size_t)n2_0 * 2;
+  const unsigned dst_wave = smem_lds + wave * 1024;
+  auto stage = [&](int which, int t, int buf) {
+    if (which < 2) {
+      const char* sb = a_base + (size_t)(t * 64) * a_rs + which * (HM * 16 * 2);
+      const unsigned dst = dst_wave + buf * BUF + which * OFF_A1;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) glds16_s(sb, a_voff[i], dst + i * 8192);
+    } else if (which == 2) {
+      const char* sb = b_base + (size_t)(t * 64) * b_rs;
+      const unsigned dst = dst_wave + buf * BUF + OFF_B0;
+#pragma unroll
+      for (int i = 0; i < B_IT0; ++i) glds16_s(sb, b_voff0[i], dst + i * 8192);
+    } else {
+      const char* sb = b_base + (size_t)(t * 64) * b_rs;
+      const unsigned dst = dst_wave + buf * BUF + OFF_B1;
+#pragma unroll
+      for (int i = 0; i < B_IT1; ++i) glds16_s(sb, b_voff1[i], dst + i * 8192);
+    }
+  };
+  constexpr int INFL = B_IT0 + A_IT + B_IT1;          // DMA instructions per thread in the three youngest half-tiles (B0, A0, B1)
+
+  // ---- fragment geometry (transposed reads): lane (g, L) supplies k-row 8 g + (L >> 2) and the row 4 below, 8-byte piece L & 3 of a 16-column
+  //      window; the k32 step ks adds 32 rows
+  const int g = lane >> 4, L = lane & 15;
+  const int frow = 8 * g + (L >> 2);
+  int aoff[HM], boff0[HN0], boff1[HN1];
+#pragma unroll
+  for (int i = 0; i < HM; ++i) aoff[i] = frow * PA + (((wr * HM + i) ^ tn_hash<PA>(frow)) << 5) + ((L & 3) << 3);
+#pragma unroll
+  for (int j = 0; j < HN0; ++j) boff0[j] = OFF_B0 + frow * PB0 + (((wc * HN0 + j) ^ tn_hash<PB0>(frow)) << 5) + ((L & 3) << 3);
+#pragma unroll
+  for (int j = 0; j < HN1; ++j) boff1[j] = OFF_B1 + frow * PB1 + (((wc * HN1 + j) ^ tn_hash<PB1>(frow)) << 5) + ((L & 3) << 3);
+
+  f32x4 acc[WMT][WNT];
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradients: column sums of A (colsum_a) or of B (colsum_b) by one MFMA against an all-ones fragment.  The A fragments of accumulator row tile
+  // i are read by the four waves of a wave row: wave wc takes i == wc; the B fragments of column tile j by the two wave rows: j & 1 == wr.
+  f32x4 csa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 csb[(WNT + 1) / 2];
+#pragma unroll
+  for (int j = 0; j < (WNT + 1) / 2; ++j) csb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+  const bool do_csa = p.colsum_a != nullptr, do_csb = p.colsum_b != nullptr;
+  u32x4 fa[2][HM], fb0[2][HN0], fb1[2][HN1];
+
+#define MVLT_TLDA(BUFI, MH)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < HM; ++i) {                                                                 \
+    fa[0][i] = tr_frag(smem + (BUFI) * BUF + (MH) * OFF_A1 + aoff[i], PA);                                         \
+    fa[1][i] = tr_frag(smem + (BUFI) * BUF + (MH) * OFF_A1 + aoff[i] + 32 * PA, PA);                               \
+  }
+#define MVLT_TLDB0(BUFI)                                                                                           \
+  _Pragma("unroll") for (int j = 0; j < HN0; ++j) {                                                                \
+    fb0[0][j] = tr_frag(smem + (BUFI) * BUF + boff0[j], PB0);                                                      \
+    fb0[1][j] = tr_frag(smem + (BUFI) * BUF + boff0[j] + 32 * PB0, PB0);                                           \
+  }
+#define MVLT_TLDB1(BUFI)                                                                                           \
+  _Pragma("unroll") for (int j = 0; j < HN1; ++j) {                                                                \
+    fb1[0][j] = tr_frag(smem + (BUFI) * BUF + boff1[j], PB1);                                                      \
+    fb1[1][j] = tr_frag(smem + (BUFI) * BUF + boff1[j] + 32 * PB1, PB1);                                           \
+  }
+#define MVLT_TMMA(MH, JBASE, HN, FB)                                                                               \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                 \
+    _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                                 \
+      _Pragma("unroll") for (int j = 0; j < (HN); ++j) {                                                           \
+        f32x4& c_ = acc[(MH) * HM + i][(JBASE) + j];                                                               \
+        if (TRANS) c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FB[ks][j]), __builtin_bit_cast(bf16x8, fa[ks][i]), c_, 0, 0, 0); \
+        else c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks][i]), __builtin_bit_cast(bf16x8, FB[ks][j]), c_, 0, 0, 0);       \
+      }
+#define MVLT_TCSA(MH)                                                                                              \
+  if (csa_now) {                                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+      _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                               \
+        if (i == wc) csa[MH] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks][i]), ones, csa[MH], 0, 0, 0); \
+  }
+#define MVLT_TCSB(JBASE, HN, FB)                                                                                   \
+  if (csb_now) {                                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+      _Pragma("unroll") for (int j = 0; j < (HN); ++j)                                                             \
+        if ((((JBASE) + j) & 1) == wr) csb[((JBASE) + j) >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, FB[ks][j]), csb[((JBASE) + j) >> 1], 0, 0, 0); \
+  }
+
+  stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+  if (nk > 1) { stage(2, 1, 1); stage(0, 1, 1); stage(3, 1, 1); wait_vm<INFL>(); }
+  else wait_vm<0>();
+  MVLT_BAR();
+  if (wr == 1) MVLT_BAR();
+
+  auto ktile = [&](auto bufc, int t) {
+    constexpr int B = decltype(bufc)::value;
+    const bool csa_now = do_csa && (t % t2) == by, csb_now = do_csb && (t % t1) == bx;       // the workgroups sharing A (B) columns take turns
+    MVLT_TLDB0(B)
+    __builtin_amdgcn_sched_barrier(0);
+    MVLT_TLDA(B, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nk) stage(1, t + 1, B ^ 1);
+    wait_lgkm<(4 * HM < 15 ? 4 * HM : 15)>();     // the B0 reads (two 8-byte reads per fragment, issued first) are back (the counter has 4 bits)
+    MVLT_BAR();
+    __builtin_amdgcn_s_setprio(1);
+    MVLT_TMMA(0, 0, HN0, fb0)
+    MVLT_TCSA(0)
+    MVLT_TCSB(0, HN0, fb0)
+    __builtin_amdgcn_s_setprio(0);
+    MVLT_BAR();
+    MVLT_TLDB1(B)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nk) stage(2, t + 2, B);
+    MVLT_BAR();
+    __builtin_amdgcn_s_setprio(1);
+    MVLT_TMMA(0, HN0, HN1, fb1)
+    MVLT_TCSB(HN0, HN1, fb1)
+    __builtin_amdgcn_s_setprio(0);
+    MVLT_BAR();
+    MVLT_TLDA(B, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nk) stage(0, t + 2, B);
+    MVLT_BAR();
+    __builtin_amdgcn_s_setprio(1);
+    MVLT_TMMA(1, HN0, HN1, fb1)
+    MVLT_TCSA(1)
+    __builtin_amdgcn_s_setprio(0);
+    MVLT_BAR();
+    if (t + 2 < nk) { stage(3, t + 2, B); wait_vm<INFL>(); }
+    else wait_vm<0>();
+    MVLT_BAR();
+    __builtin_amdgcn_s_setprio(1);
+    MVLT_TMMA(1, 0, HN0, fb0)
+    __builtin_amdgcn_s_setprio(0);
+    MVLT_BAR();
+  };
+  for (int t = 0; t < nk; t += 2) {
+    ktile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
+  }
+  if (wr == 0) MVLT_BAR();
+#undef MVLT_TLDA
+#undef MVLT_TLDB0
+#undef MVLT_TLDB1
+#undef MVLT_TMMA
+#undef MVLT_TCSA
+#undef MVLT_TCSB
+  const int fr = lane & 15, fg = lane >> 4;
+  if (do_csa && fr == 0 && wc < HM) {            // csa[mh][r]: column n1 = tile (mh * HM + wc), row 4 fg + r of it (identical in every lane column)
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&p.colsum_a[n1_0 + wr * (WMT * 16) + (mh * HM + wc) * 16 + 4 * fg + r], csa[mh][r]);
+  }
+  if (do_csb && fg == 0) {                        // csb[j >> 1][0]: column n2 = tile j, lane column fr
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+      if ((j & 1) == wr) atomicAdd(&p.colsum_b[n2_0 + wc * (WNT * 16) + j * 16 + fr], csb[j >> 1][0]);
+  }
+  if (part) {
+    // PARTIAL-TILE mode (round 5): no atomics.  The split's tile goes to part[split][N1][N2] in bf16 -- the MFMA operands are flipped (TRANS instantiation), so a lane owns
+    // four consecutive n2 of one n1: one 8-byte store per accumulator tile -- and tn_fold_kernel adds the splits' tiles into C in a fixed order (deterministic).
+    static_assert(TRANS, "partial tiles are stored from the flipped accumulator layout");
+    bf16* const P = part + (size_t)bz * p.N1 * p.N2;
+    // through a per-wave LDS tile [16 n1][WNT * 16 n2] so that the partial tile leaves as whole 16-byte pieces of contiguous rows (8-byte pieces 32 B apart cost 22 us per launch)
+    constexpr int LDP = WNT * 16 + 8;              // bf16 elements per staged row (16 B of padding)
+    constexpr int CPR = WNT * 2;                   // 16-byte chunks per row
+    MVLT_BAR();                                    // every wave is out of the loop: the k-tile buffers are free
+    bf16* const st = (bf16*)smem + wave * 16 * LDP;
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const bf16x2 lo = __builtin_convertvector(f32x2{acc[i][j][0], acc[i][j][1]}, bf16x2), hi = __builtin_convertvector(f32x2{acc[i][j][2], acc[i][j][3]}, bf16x2);
+        *(u32x2*)(st + fr * LDP + j * 16 + 4 * fg) = u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = lane; q < 16 * CPR; q += 64) {
+        const int row = q / CPR, ch = q - row * CPR;
+        const int n1 = n1_0 + wr * (WMT * 16) + i * 16 + row, n2 = n2_0 + wc * (WNT * 16) + ch * 8;
+        st_g<MVLT_NT_GEMM>((u32x4*)(P + (size_t)n1 * p.N2 + n2), *(const u32x4*)(st + row * LDP + ch * 8));
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (TRANS) {                              // acc[r] = C[n2 tile j row 4 fg + r][n1 tile i column fr], stored transposed: consecutive lanes = consecutive n1
+          const int n2 = n2_0 + wc * (WNT * 16) + j * 16 + 4 * fg + r, n1 = n1_0 + wr * (WMT * 16) + i * 16 + fr;
+          atomicAdd(&p.C[(long)n2 * p.ldc + n1], acc[i][j][r]);
+        } else {
+          const int n1 = n1_0 + wr * (WMT * 16) + i * 16 + 4 * fg + r, n2 = n2_0 + wc * (WNT * 16) + j * 16 + fr;
+          atomicAdd(&p.C[(long)n1 * p.ldc + n2], acc[i][j][r]);
+        }
+      }
+}
+
+// C[n1][n2] += sum over the splits of part[split][n1][n2] (bf16 partial tiles of gemm_tn_p8_kernel), eight consecutive n2 per thread, splits in order
+__global__ __launch_bounds__(256) void tn_fold_kernel(const bf16* __restrict__ part, int splits, int N1, int N2, float* __restrict__ C, int ldc) {
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per = (long)N1 * N2;
+  if (g * 8 >= per) return;
+  const int n1 = (int)((g * 8) / N2), n2 = (int)((g * 8) - (long)n1 * N2);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < splits; ++z) {
+    const bf16x8 v = __builtin_bit_cast(bf16x8, ld_g<MVLT_NT_LD>((const u32x4*)(part + (size_t)z * per + g * 8)));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+  }
+  float* dst = C + (long)n1 * ldc + n2;
+  f32x4 a = *(const f32x4*)dst, b = *(const f32x4*)(dst + 4);
+  *(f32x4*)dst = f32x4{a[0] + s[0], a[1] + s[1], a[2] + s[2], a[3] + s[3]};
+  *(f32x4*)(dst + 4) = f32x4{b[0] + s[4], b[1] + s[5], b[2] + s[6], b[3] + s[7]};
+}
+
+template <int HM, int HN0, int HN1> int launch_tn_p8_partial(const mvlt_gemm_tn_args& a, hipStream_t s) {
+  constexpr int BM1 = 64 * HM, BN2 = 64 * (HN0 + HN1);
+  constexpr int LDS = 2 * 64 * 2 * (2 * (2 * HM * 16) + BN2);
+  mvlt_max_lds<(gemm_tn_p8_kernel<HM, HN0, HN1, true>)>();
+  const int t1 = a.N1 / BM1, t2 = a.N2 / BN2, nkt = a.M / 64;
+  int splits = 256 / (t1 * t2);                   // one workgroup per CU (the caller's scratch is sized for exactly this)
+  if (splits > nkt) splits = nkt;
+  const int kt_per = (nkt + splits - 1) / splits;
+  splits = (nkt + kt_per - 1) / kt_per;
+  void* const scratch = a.partials;              // [splits][N1][N2] bf16, the caller's (mvlt_gemm_tn checked its size)
+  dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * t1 * t2)), block(512);
+  MVLT_LAUNCH((gemm_tn_p8_kernel<HM, HN0, HN1, true>), grid, block, LDS, s, a, kt_per, t1, t2, splits, (bf16*)scratch);
+  const long groups = (long)a.N1 * a.N2 / 8;
+  MVLT_LAUNCH(tn_fold_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, (const bf16*)scratch, splits, a.N1, a.N2, a.C, a.ldc);
+  return mvlt_check_launch("mvlt_gemm_tn");
+}
+
 // ------------------------------------------------------------------------------------------------ conv3x3 forward / dgrad, LDS halo
 // C[pixel][n] = sum over taps t and channels c of x[pixel + tap t][c] * B[n][t*cin + c]: the MIM decoder's conv3x3 (and its input
 // gradient, the same gather with flipped taps) as the NT GEMM with a_map mode 2.  In gemm_nt_dma_kernel every k-step fetches its own
@@ -2489,6 +2797,16 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
   //  removed it again: its main loop ran at 1.1-1.16 PFLOP/s, but one workgroup per CU means 16 m-splits of the 2048 x 512 outputs, and the fp32
   //  atomics that combine the splits complete at ~0.3 floats per ns chip-wide whatever their scope or coalescing: 55 us of tail per launch,
   //  147 us against the 122 us of the 128 x 128 tiles below with their 8 splits and a second workgroup per CU to hide the tail.  DESIGN.md 6.)
+  // whole 256 x 256 output tiles, 16 .. 64 of them (= 16 .. 4 m-splits for one workgroup per CU), and a scratch buffer from the caller: the 8-wave / 8-phase TN loop with
+  // bf16 partial tiles + an ordered fold instead of fp32 atomics (gemm_tn_p8_kernel; MVLT_TN_P8=0 keeps the atomic path).  Fewer tiles mean more splits than the fold is
+  // worth (8 tiles: 75 us either way), more do not occur in this model.
+  static const bool tnp8 = !(getenv("MVLT_TN_P8") && atoi(getenv("MVLT_TN_P8")) == 0);
+  if (tnp8 && a->partials && a->dtype == 0 && a->a_map.mode == 0 && a->b_map.mode == 0 && a->a_map.rows_per_batch == 0 && a->b_map.rows_per_batch == 0 && a->c_taps <= 1 &&
+      !a->trans_c && !a->dgrad_out && a->M % 64 == 0 && a->N1 % 256 == 0 && a->N2 % 256 == 0 && a->ldc % 4 == 0 && ((uintptr_t)a->C & 15) == 0 && ((uintptr_t)a->partials & 15) == 0) {
+    const int tiles = (a->N1 / 256) * (a->N2 / 256), nkt = a->M / 64;
+    if (tiles >= 16 && tiles <= 64 && nkt / (256 / tiles) >= 16 && a->partials_bytes >= (long)(256 / tiles) * a->N1 * a->N2 * 2)
+      return launch_tn_p8_partial<4, 2, 2>(*a, s);
+  }
   if (a->dtype == 0 && a->M < (1 << 24)) {
     // LDS-DMA kernel: A tile 128 or 64 wide, B tile 128 or 64 wide; ~1024 workgroups, splits a multiple of the 8 XCDs
     // outputs of at most 128 x 128 take 64 x 64 tiles: every output cache line receives one atomic request per m-split, those

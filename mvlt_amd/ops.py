@@ -45,10 +45,11 @@ def weight_prep(desc_dev, blk_dev, ndesc, total_blocks, dtype):
           "mvlt_weight_prep")
 
 
-def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, colsum=None, splits=0, taps=0, seg=0, dgrad=None):
+def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, colsum=None, splits=0, taps=0, seg=0, dgrad=None, partials=None):
     """C[N1,N2] += A[M,N1]^T @ B[M,N2] (fp32 atomics); colsum[N1] += A.sum(0).  taps > 1: logical column tap*seg + c is
     accumulated at column c*taps + tap (conv weight gradients straight into the [out][cin][kh][kw] layout).
-    dgrad = (W^T [N2][N1] bf16, out [M, N2] bf16): the Linear's input gradient out = A @ W from the same pass over A (N1 == N2 in {64, 128})."""
+    dgrad = (W^T [N2][N1] bf16, out [M, N2] bf16): the Linear's input gradient out = A @ W from the same pass over A (N1 == N2 in {64, 128}).
+    partials = a scratch tensor of >= 32 MiB: outputs of 16 .. 64 whole 256 x 256 tiles are reduced without atomics (deterministic; bf16 partial tiles + an ordered fold)."""
     assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype == torch.float32
     if colsum is not None:
         assert colsum.dtype == torch.float32
@@ -72,6 +73,8 @@ def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, co
         a = L.GemmTNArgs(ptr(B), ptr(A), ptr(C_out), M, N2, N1, ldb, lda, ldc, DT[A.dtype], b_map, a_map, None, splits, ptr(colsum), 1, 0, 0)
     else:
         a = L.GemmTNArgs(ptr(A), ptr(B), ptr(C_out), M, N1, N2, lda, ldb, ldc, DT[A.dtype], a_map, b_map, ptr(colsum), splits, None, 0, taps, seg)
+        if partials is not None:       # scratch for the atomic-free reduction of whole 256 x 256 output tiles (mvlt_gemm_tn_args.partials); ignored for other shapes
+            a.partials, a.partials_bytes = ptr(partials), partials.numel() * partials.element_size()
     check(L.lib.mvlt_gemm_tn(C.byref(a), stream_ptr()), "mvlt_gemm_tn")
     return C_out
 

@@ -522,6 +522,14 @@ class FlatStore:
         else:
             self.G.mul_(factor)
 
+    def tn_partials(self):
+        """32 MiB of persistent scratch for the atomic-free reduction of the weight-gradient GEMMs whose outputs are 16 .. 64 whole 256 x 256 tiles (the stage-4 MLP;
+        mvlt_gemm_tn_args.partials): every qualifying shape needs splits x N1 x N2 = 256 x 65536 bf16 elements"""
+        t = getattr(self, "_tn_partials", None)
+        if t is None or t.device != self.G.device:
+            t = self._tn_partials = torch.empty(256 * 65536, dtype=torch.bfloat16, device=self.G.device)
+        return t
+
     def wait_grads(self):
         """block (the stream, for RCCL; the host, for gloo) until every gradient collective handed over by the data-parallel wrapper is done"""
         works, self.grad_works = self.grad_works, []

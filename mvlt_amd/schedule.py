@@ -526,11 +526,11 @@ class TrunkStep:
             self._dy2_pre = None
             if dy2 is None:
                 dy2 = self._scaled(dx, bs["s2"], N)
-            ops.gemm_tn(dy2, bs["gact"], self.g(p + "mlp.fc2.weight"), M, C, hid, C, hid, hid, colsum=self.g(p + "mlp.fc2.bias"))
+            ops.gemm_tn(dy2, bs["gact"], self.g(p + "mlp.fc2.weight"), M, C, hid, C, hid, hid, colsum=self.g(p + "mlp.fc2.bias"), partials=self.S.tn_partials())
             dh = _empty((M, hid), dt, dev)
             ops.gemm_nt(dy2, self.wT(p + "mlp.fc2.weight"), dh, M, hid, C, C, C, hid, act=2, H=bs["hpre"])
             bs["gact"] = bs["hpre"] = None
-            ops.gemm_tn(dh, bs["xn2"], self.g(p + "mlp.fc1.weight"), M, hid, C, hid, C, C, colsum=self.g(p + "mlp.fc1.bias"))
+            ops.gemm_tn(dh, bs["xn2"], self.g(p + "mlp.fc1.weight"), M, hid, C, hid, C, C, colsum=self.g(p + "mlp.fc1.bias"), partials=self.S.tn_partials())
             ops.gemm_nt(dh, self.wT(p + "mlp.fc1.weight"), dxn2, M, C, hid, hid, hid, C)
             del dh
         # dx += LN2 backward = d(x_mid); the same kernel writes its DropPath-scaled copy, the gradient of the attention branch

@@ -297,6 +297,33 @@ def test_gemm_tn(ops, dtype, M, N1, N2):
     assert maxrel(out, 2 * ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,N1,N2", [(49152, 512, 2048), (49152, 2048, 512), (16384, 1024, 1024)])
+def test_gemm_tn_partial_tiles_reduce_without_atomics(ops, M, N1, N2):
+    """Weight gradients whose output is 16 .. 64 whole 256 x 256 tiles (the stage-4 MLP) with a scratch buffer: the 8-wave / 8-phase TN kernel stores bf16 partial tiles
+    and an ordered fold adds them to C (mvlt_gemm_tn_args.partials) -- ACCUMULATING into C like the atomic path, within 5e-3 of the fp32 reference (one bf16 rounding per
+    m-split), bias gradient included, bit-identical from launch to launch (the atomic path is not), and the launched kernel is the partial-tile one."""
+    from mvlt_amd._lib import last_kernel
+    dt = torch.bfloat16
+    A, B = rnd(M, N1, dtype=dt, scale=0.5), rnd(M, N2, dtype=dt, seed=1, scale=0.5)
+    ref = A.float().t() @ B.float()
+    scratch = torch.empty(256 * 65536, device=dev(), dtype=dt)
+    outs = []
+    for _ in range(2):
+        Cw, cs = torch.full((N1, N2), 3.0, device=dev()), torch.zeros(N1, device=dev())
+        ops.gemm_tn(A, B, Cw, M, N1, N2, N1, N2, N2, colsum=cs, partials=scratch)
+        torch.cuda.synchronize()
+        assert "tn_fold_kernel" in last_kernel()
+        outs.append((Cw, cs))
+    assert maxrel(outs[0][0] - 3.0, ref) < 5e-3
+    assert maxrel(outs[0][1], A.float().sum(0)) < 1e-3
+    assert torch.equal(outs[0][0], outs[1][0])
+    # a scratch that is too small, or none: the atomic kernel, same answer to fp32-atomic accuracy
+    Cw = torch.zeros(N1, N2, device=dev())
+    ops.gemm_tn(A, B, Cw, M, N1, N2, N1, N2, N2, partials=scratch[:1024])
+    torch.cuda.synchronize()
+    assert "gemm_tn_dma_kernel" in last_kernel() and maxrel(Cw, ref) < 1e-3
+
+
 def test_gemm_tn_fused_input_gradient_is_never_skipped_silently(ops):
     """every launch path of mvlt_gemm_tn that cannot produce dgrad_out must refuse -- a silently unwritten input gradient is a wrong
     gradient.  fp32 operands (the generic kernel) with dgrad_out raise; a row-strided dX view (a column slice of a wider buffer) keeps its
