@@ -31,6 +31,8 @@ for line in open(P("step_launches.txt")).read().split("\n")[2:]:
     elif "at::" in name or "rocclr" in name:
         k = "aten"
     else:
+        if name.startswith(("gemm_tn_p8", "tn_fold")):
+            name = "gemm_tn_dma(p8)" + name
         k = next((x for x in ("gemm_tn_dma", "gemm_nt_p8", "gemm_nt_dma", "mlp_pipe", "mlp_wgrad2", "attn_bwd", "attn_fwd2", "conv3_nt", "conv3_wgrad", "adamw",
                               "bert_embed_bwd", "bert_embed_fwd", "weight_prep", "ce_fwd", "ce_bwd", "fold_copies") if name.startswith(x)), "other")
     a = fam.setdefault(k, [0, 0.0])
@@ -49,11 +51,11 @@ us = lambda k: fam.get(k, [0, 0.0])[1]
 t31 = f"""### 3.1 One steady-state step: {n_launch} launches, kernels busy {busy_ms:.2f} ms (`profiles/{tag}_step_launches.txt`)
 
 (The span from the step's first kernel to the optimizer's end is {span_ms:.2f} ms under `rocprofv3 --kernel-trace` -- {busy_pct:.1f} % busy; {n_aten} of the launches are ATen kernels, {n_copy} `copyBuffer`.
-Unprofiled the bench step equals the sum of the kernel durations.  This round's collection box is ~2 % slower than round 4's: the per-family differences to `r04_step_launches.txt` are that spread, no kernel changed.)
+Unprofiled the bench step equals the sum of the kernel durations.  This round's collection box is ~2 % slower than round 4's: the per-family differences to `r04_step_launches.txt` are that spread; the one kernel change of the round is the stage-4 weight-gradient pair (`gemm_tn_p8_kernel` + `tn_fold_kernel`).)
 
 | kernel family | launches | us / step | share | bound by (evidence) |
 |---|---|---|---|---|
-| `gemm_tn_dma_kernel` (weight gradients; 8 launches carry the input gradient too) | {g('gemm_tn_dma')} | MFMA-bound shapes 0.24-0.38 of peak (3.2), the K <= 128 shapes HBM (4.5-5.6 TB/s); split reductions cost outputs x splits / 0.3 ns (`experiments_r4.md` 2) |
+| `gemm_tn_dma_kernel` + `gemm_tn_p8_kernel` / `tn_fold_kernel` (weight gradients; 8 launches carry the input gradient too; the 4 stage-4 MLP ones reduce without atomics) | {g('gemm_tn_dma')} | MFMA-bound shapes 0.24-0.38 of peak (3.2), the K <= 128 shapes HBM (4.5-5.6 TB/s); split reductions cost outputs x splits / 0.3 ns (`experiments_r4.md` 2) |
 | `gemm_nt_dma_kernel` (128-wide NT GEMMs: K <= 128 projections, gathers, small heads) | {g('gemm_nt_dma')} | HBM for K = 64 / 128 (`proj64` sibling: 0.60-0.70 of 8 TB/s); TA / L1 path for the rest (`r03_l1_stalls.txt`) |
 | `gemm_nt_p8_kernel` (8-wave / 8-phase NT GEMMs, stage 3-4, MLM logits) | {g('gemm_nt_p8')} | K-loops alone 1.1-1.6 PFLOP/s (epilogue compiled out, `r05_p8_epilogue_ablation.txt`); the launches 0.23-0.57 of peak: whole-round quantisation + a VALU-bound epilogue (~15 instructions per output at two waves per SIMD) that a persistent grid does not hide (3.3, `experiments_r5.md` 3) |
 | `mlp_pipe_kernel` (fused MLP forward / input gradient, stages 1-2) | {g('mlp_pipe')} | VALU (GELU: 10 instructions per hidden element) + MFMA, partly overlapped: MFMA-busy 0.28-0.35, VALU-active 0.26-0.35 (`{tag}_mfma_counters.csv`) |
@@ -136,7 +138,7 @@ rows += [
     line("stage-4 fc1 dgrad 49152 x 512 x 2048", "p8 192 x 256", "gemm_nt 49152 512 2048 A:- C:- act0 bfloat16", 40, 91.8),
 ]
 a, b = r("gemm_tn 49152 2048 512"), r("gemm_tn 49152 512 2048")
-rows.append(f"| stage-4 dW2 / dW1 (TN, 49152 rows) | tn 128 x 128 | {a[0]:.1f} / {b[0]:.1f} | {a[1]:.0f} / {b[1]:.0f} | {a[1] / 2500:.2f} / {b[1] / 2500:.2f} | 40 | {PV('gemm_tn 49152 2048 512', 'gemm_tn 49152 512 2048')} |")
+rows.append(f"| stage-4 dW2 / dW1 (TN, 49152 rows; bf16 partial tiles + fold, no atomics) | tn p8 256 x 256 + fold | {a[0]:.1f} / {b[0]:.1f} | {a[1]:.0f} / {b[1]:.0f} | {a[1] / 2500:.2f} / {b[1] / 2500:.2f} | 40 | {PV('gemm_tn 49152 2048 512', 'gemm_tn 49152 512 2048')} |")
 TWELVE = ("gemm_nt 98304 1280 320 A:- C:- b act1", "gemm_nt 98304 320 1280 A:- C:- b act0 R float32", "gemm_nt 98304 1280 320 A:- C:- act2",
                                "gemm_nt 98304 320 1280 A:- C:- act0 bfloat16", "gemm_tn 98304 1280 320", "gemm_tn 98304 320 1280",
                                "gemm_nt 49152 2048 512 A:- C:- b act1", "gemm_nt 49152 512 2048 A:- C:- b act0 R float32", "gemm_nt 49152 2048 512 A:- C:- act2",
@@ -194,7 +196,7 @@ mw, cal = tj["mlp_dw64"], tj["calib_cast"]
 pairs = lambda x: f"{x:,.0f}".replace(",", " ")
 t6 = f"""**The line of the final build** (`profiles/{tag}_bench_n1.json`, command `python bench.py`, sources `{tj['_source_hash']}`): **{pairs(bench['value'])} pairs/s, {bench['ms_per_step']:.2f} ms/step**
 (round 4: driver 12 532 / 20.43, builder's box 12 704 / 20.15; round 3's driver line: 11 428 / 22.40).  The boxes of the pool differ by +-2.5 %: the final tree measured 20.2 .. 20.9 ms on the boxes of this
-round.  Round 5 changed no hot kernel (`docs/experiments_r5.md`: five kernel-level attempts measured same-box, none faster), so the step is round 4's within that spread; what changed in the LINE is that
+round.  Round 5 changed one hot path (the stage-4 MLP weight gradients without atomics: -0.09 ms same-box; `docs/experiments_r5.md`: five other kernel-level attempts measured same-box, none faster), so the step is round 4's within that spread; what changed in the LINE is that
 its roofline entries are named by the library (`mvlt_last_kernel()` after the timed launches), `share_of_step` is computed from the measured launch and step times, a `limiter` text is attached only to the
 instantiation it was written for, the top instantiation of the kernel trace (`gemm_tn_dma_kernel<128, 128, 3, 2, false>` on the stage-3 fc2 weight-gradient shape) is a third sibling, `other_configs` carries an
 MFMA fraction and an eval-forward entry.  Loss trajectory unchanged (epoch average {bench['config']['epoch_avg_loss']:.2f}, same synthetic batch).
