@@ -77,6 +77,53 @@ def test_full_batch_engine_iteration_matches_chunked_eval(parity):
     assert all(torch.isfinite(p).all() for p in model.parameters())          # the AdamW step of that iteration
 
 
+@pytest.mark.parametrize("name,img,batch_size,lt", [("pvlt_medium", 384, 64, dict(mlm=1, itm=1, t2i=1, cls=0)),
+                                                    ("pvlt_tiny", 256, 256, dict(mlm=0, itm=0, t2i=0, cls=1))], ids=["config4_medium384_b64", "config5_finetune_b256"])
+def test_other_configs_full_size_iteration_matches_chunked_eval(parity, name, img, batch_size, lt):
+    """BASELINE configurations #4 (pvlt_medium, 384 px: 272 keys per query, 18 stage-3 blocks) and #5 (the CLS-head fine-tune step) at the sizes `bench.py`'s
+    `other_configs` runs them (round 5; the fixtures pin them at B = 4): one `train_one_epoch_vl` iteration whose per-head losses equal what the same pairs give as
+    eval-mode batches of 4 -- every kernel variant these shapes select (attention with 272 keys on the 6-wave backward, the ragged-free 128-wide GEMMs at 45056 rows,
+    the recognition heads) against the configuration the goldens do pin."""
+    import engine_grid_masking as E
+    from mvlt_amd import pvlt
+    from mvlt_amd.engine import BF16Scaler
+    from mvlt_amd.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    torch.manual_seed(78)
+    model = getattr(pvlt, name)(pretrained=False, token_hidden_size=768, num_text_tokens=T, loss_type=lt, pretrained_pth=None, drop_path_rate=0.1, drop_rate=0.0,
+                                num_classes=1000, in_chans=3).cuda()
+    Bc = batch_size
+    batch = bench.synth_batch(Bc, img, T, dev, 4321)
+    model.eval()
+    acc = dict(mlm=0.0, itm=0.0, sup=0.0, sub=0.0)
+    n_sel = 0
+    with torch.no_grad():
+        for c in range(0, Bc, 4):
+            out = model(batch["image"][c:c + 4], batch["input_ids"][c:c + 4])
+            if lt["mlm"]:
+                lab = batch["mlm_labels"][c:c + 4].reshape(-1)
+                acc["mlm"] += F.cross_entropy(out["mlm_logits"].reshape(-1, 30522).float(), lab, ignore_index=-1, reduction="sum").item()
+                n_sel += int((lab != -1).sum())
+                acc["itm"] += F.cross_entropy(out["itm_logits"].reshape(-1, 2).float(), batch["itm_labels"][c:c + 4].reshape(-1), reduction="sum").item()
+            if lt["cls"]:
+                acc["sup"] += F.cross_entropy(out["sup_cls_logits"].reshape(-1, 48).float(), batch["sup_cls_labels"][c:c + 4].reshape(-1), reduction="sum").item()
+                acc["sub"] += F.cross_entropy(out["sub_cls_logits"].reshape(-1, 122).float(), batch["sub_cls_labels"][c:c + 4].reshape(-1), reduction="sum").item()
+    nblk = sum(model.depths)
+    model.injected_masks = dict(bert=torch.ones(Bc, T, 768), droppath=[torch.ones(Bc)] * nblk, droppath2=[torch.ones(Bc)] * nblk)
+    opt = FusedAdamW(model, lr=1e-5, weight_decay=0.01)
+    with contextlib.redirect_stdout(io.StringIO()):
+        stats = E.train_one_epoch_vl(model, None, [batch], opt, dev, 0, BF16Scaler(), None, None, None, True, False, argparse.Namespace(loss_type=lt))
+    torch.cuda.synchronize()
+    assert stats["total_loss"] == stats["total_loss"] and abs(stats["total_loss"]) < 1e4
+    if lt["mlm"]:
+        assert parity(f"{name}-{img}/loss_mlm vs eval chunks", abs(stats["loss_mlm"] - acc["mlm"] / n_sel) / (acc["mlm"] / n_sel), 2e-2), (stats["loss_mlm"], acc["mlm"] / n_sel)
+        assert parity(f"{name}-{img}/loss_itm vs eval chunks", abs(stats["loss_itm"] - acc["itm"] / Bc) / (acc["itm"] / Bc), 2e-2), (stats["loss_itm"], acc["itm"] / Bc)
+    if lt["cls"]:
+        assert parity(f"{name}-{img}/loss_sup_cls vs eval chunks", abs(stats["loss_sup_cls"] - acc["sup"] / Bc) / (acc["sup"] / Bc), 2e-2), (stats["loss_sup_cls"], acc["sup"] / Bc)
+        assert parity(f"{name}-{img}/loss_sub_cls vs eval chunks", abs(stats["loss_sub_cls"] - acc["sub"] / Bc) / (acc["sub"] / Bc), 2e-2), (stats["loss_sub_cls"], acc["sub"] / Bc)
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
 def test_full_batch_step_is_repeatable(parity):
     from mvlt_amd.engine import train_step
     dev = torch.device("cuda:0")
