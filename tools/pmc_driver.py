@@ -57,6 +57,11 @@ def main():
     dh4, w14 = torch.randn(M4, H4, device=dev).to(bf), (torch.randn(C4, H4, device=dev) * H4 ** -0.5).to(bf)
     dx4 = torch.empty(M4, C4, device=dev, dtype=bf)
     todo.append(lambda: ops.gemm_nt(dh4, w14, dx4, M4, C4, H4, H4, H4, C4))
+    # round 5: the stage-4 fc2 weight gradient on the 8-phase TN loop with bf16 partial tiles + fold (gemm_tn_p8_kernel, tn_fold_kernel), and the same shape on the atomic kernel
+    dy4, g4 = torch.randn(M4, C4, device=dev).to(bf), torch.randn(M4, H4, device=dev).to(bf)
+    dw4, db4, scr = torch.zeros(C4, H4, device=dev), torch.zeros(C4, device=dev), torch.empty(256 * 65536, device=dev, dtype=bf)
+    todo.append(lambda: ops.gemm_tn(dy4, g4, dw4, M4, C4, H4, C4, H4, H4, colsum=db4, partials=scr))
+    todo.append(lambda: ops.gemm_tn(dy4, g4, dw4, M4, C4, H4, C4, H4, H4, colsum=db4))
     M1 = B * 4224
     dq, xn = torch.randn(M1, 64, device=dev).to(bf), torch.randn(M1, 64, device=dev).to(bf)
     wqt = (torch.randn(64, 64, device=dev) * 0.125).to(bf)
