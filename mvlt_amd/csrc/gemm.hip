@@ -1114,7 +1114,7 @@ template <int W> struct DmaTile {
 // registers (wave w owns output columns [w C/4, (w + 1) C/4)); the result leaves through an LDS tile as whole 16-byte row pieces one
 // iteration later (so that its stores are a tile time old when the next counted vmcnt wait sees them).
 template <int BMT, int BN, int BMODE, int NS, bool DG = false>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_args p, int m_per_split, int t1, int t2, int splits) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_args p, int m_per_split, int t1, int t2, int splits, bf16* part = nullptr) {
   using TA = DmaTile<BMT>;
   using TB = DmaTile<BN>;
   static_assert(!DG || (BMODE == 3 && BMT == BN && !MVLT_TN_EARLY), "dgrad rides on the plain-row single-tile kernels");
@@ -1391,6 +1391,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_a
     __syncthreads();
     if (do_colsum && tid < BMT && n1_0 + tid < p.N1) atomicAdd(&p.colsum_a[n1_0 + tid], s_cs[tid]);
     if (do_colsum_b && tid < BN && n2_0 + tid < p.N2) atomicAdd(&p.colsum_b[n2_0 + tid], s_cs[tid]);
+  }
+  if (part) {
+    // PARTIAL-TILE mode (round 5; the host chooses it for outputs that many m-splits meet on: the q / proj weight gradients of stages 3-4 spent 14-21 us of 53-56 us in
+    // 5.7-8.4 M fp32 atomics): this split's tile goes to part[split][N1][N2] in bf16 -- 16 rows at a time through a per-wave LDS tile, out as 16-byte pieces of contiguous
+    // rows -- and tn_fold_kernel adds the splits in order (deterministic).  N2 % 8 == 0 (host), rows past N1 and 8-column pieces past N2 are not stored.
+    constexpr int LDP = WN + 8;
+    __syncthreads();                                    // every wave is done with the operand tiles (and the column sums) this overlays
+    bf16* const st = (bf16*)smem + wave * 16 * LDP;
+    bf16* const P = part + (size_t)bz * p.N1 * p.N2;
+#pragma unroll
+    for (int i = 0; i < TM_; ++i) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < TN_; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[(4 * fg + r) * LDP + j * 16 + fr] = (bf16)acc[i][j][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = lane; q < 16 * (WN / 8); q += 64) {
+        const int row = q / (WN / 8), ch = q - row * (WN / 8);
+        const int n1 = n1_0 + wm * WM + i * 16 + row, n2 = n2_0 + wn * WN + ch * 8;
+        if (n1 < p.N1 && n2 < p.N2) st_g<MVLT_NT_GEMM>((u32x4*)(P + (size_t)n1 * p.N2 + n2), *(const u32x4*)(st + row * LDP + ch * 8));
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < TM_; ++i)
@@ -2373,22 +2400,37 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p,
       }
 }
 
-// C[n1][n2] += sum over the splits of part[split][n1][n2] (bf16 partial tiles of gemm_tn_p8_kernel), eight consecutive n2 per thread, splits in order
+// C[n1][n2] += sum over the splits of part[split][n1][n2] (bf16 partial tiles of gemm_tn_p8_kernel / gemm_tn_dma_kernel).  A workgroup covers 32 groups of eight consecutive n2;
+// its 256 threads are 32 groups x 8 split subsets (a 320 x 320 output over 56 splits is only 12800 groups: one thread per group left 200 CUs idle and ran the 56 loads of a
+// group one behind the other), the subsets meet in LDS and are added in a FIXED order: the result does not depend on timing.
 __global__ __launch_bounds__(256) void tn_fold_kernel(const bf16* __restrict__ part, int splits, int N1, int N2, float* __restrict__ C, int ldc) {
-  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[8][32][9];
+  const int eg = threadIdx.x & 31, sk = threadIdx.x >> 5;
+  const long g = (long)blockIdx.x * 32 + eg;
   const long per = (long)N1 * N2;
-  if (g * 8 >= per) return;
-  const int n1 = (int)((g * 8) / N2), n2 = (int)((g * 8) - (long)n1 * N2);
+  const bool ok = g * 8 < per;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int z = 0; z < splits; ++z) {
-    const bf16x8 v = __builtin_bit_cast(bf16x8, ld_g<MVLT_NT_LD>((const u32x4*)(part + (size_t)z * per + g * 8)));
+  if (ok) {
+    for (int z = sk; z < splits; z += 8) {
+      const bf16x8 v = __builtin_bit_cast(bf16x8, ld_g<MVLT_NT_LD>((const u32x4*)(part + (size_t)z * per + g * 8)));
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
   }
-  float* dst = C + (long)n1 * ldc + n2;
-  f32x4 a = *(const f32x4*)dst, b = *(const f32x4*)(dst + 4);
-  *(f32x4*)dst = f32x4{a[0] + s[0], a[1] + s[1], a[2] + s[2], a[3] + s[3]};
-  *(f32x4*)(dst + 4) = f32x4{b[0] + s[4], b[1] + s[5], b[2] + s[6], b[3] + s[7]};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[sk][eg][e] = s[e];
+  __syncthreads();
+  if (sk == 0 && ok) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += red[k][eg][e];
+    const int n1 = (int)((g * 8) / N2), n2 = (int)((g * 8) - (long)n1 * N2);
+    float* dst = C + (long)n1 * ldc + n2;
+    const f32x4 a = *(const f32x4*)dst, b = *(const f32x4*)(dst + 4);
+    *(f32x4*)dst = f32x4{a[0] + s[0], a[1] + s[1], a[2] + s[2], a[3] + s[3]};
+    *(f32x4*)(dst + 4) = f32x4{b[0] + s[4], b[1] + s[5], b[2] + s[6], b[3] + s[7]};
+  }
 }
 
 template <int HM, int HN0, int HN1> int launch_tn_p8_partial(const mvlt_gemm_tn_args& a, hipStream_t s) {
@@ -2404,7 +2446,7 @@ template <int HM, int HN0, int HN1> int launch_tn_p8_partial(const mvlt_gemm_tn_
   dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * t1 * t2)), block(512);
   MVLT_LAUNCH((gemm_tn_p8_kernel<HM, HN0, HN1, true>), grid, block, LDS, s, a, kt_per, t1, t2, splits, (bf16*)scratch);
   const long groups = (long)a.N1 * a.N2 / 8;
-  MVLT_LAUNCH(tn_fold_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, (const bf16*)scratch, splits, a.N1, a.N2, a.C, a.ldc);
+  MVLT_LAUNCH(tn_fold_kernel, dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, s, (const bf16*)scratch, splits, a.N1, a.N2, a.C, a.ldc);
   return mvlt_check_launch("mvlt_gemm_tn");
 }
 
@@ -2831,12 +2873,12 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
         const size_t lds = (size_t)4 * TBK * 128 * 2 + 64 * 64 * 2;
         static bool once = (hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<64, 64, 3, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
         (void)once;
-        MVLT_LAUNCH((gemm_tn_dma_kernel<64, 64, 3, 4, true>), grid, block, lds, s, *a, m_per_split, 1, 1, splits);
+        MVLT_LAUNCH((gemm_tn_dma_kernel<64, 64, 3, 4, true>), grid, block, lds, s, *a, m_per_split, 1, 1, splits, (bf16*)nullptr);
       } else {
         const size_t lds = (size_t)2 * TBK * 256 * 2 + 64 * 128 * 2;
         static bool once = (hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<128, 128, 3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
         (void)once;
-        MVLT_LAUNCH((gemm_tn_dma_kernel<128, 128, 3, 2, true>), grid, block, lds, s, *a, m_per_split, 1, 1, splits);
+        MVLT_LAUNCH((gemm_tn_dma_kernel<128, 128, 3, 2, true>), grid, block, lds, s, *a, m_per_split, 1, 1, splits, (bf16*)nullptr);
       }
       return mvlt_check_launch("mvlt_gemm_tn");
     }
@@ -2861,19 +2903,29 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
     const int ns = (bmt + bn == 256) ? 2 : (bmt + bn == 192) ? 3 : 4;      // 64 / 72 / 64 KB of LDS: 2 workgroups per CU
     const size_t lds = (size_t)ns * TBK * (bmt + bn) * 2;
     dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * t1 * t2)), block(NTHREADS);
+    // many splits meeting on a mid-sized output (>= 24 splits: the C x C weight gradients of stages 3-4, 9-16 tiles x 32-56 splits): bf16 partial tiles into the caller's scratch
+    // + an ordered fold instead of the atomics (14-21 us of a 53-56 us launch, profiles/r05_tn_small_atomics_ablation.txt).  Fewer splits: the atomics are cheaper than a fold launch.
+    static const int part_min = getenv("MVLT_TN_PART_MIN") ? atoi(getenv("MVLT_TN_PART_MIN")) : 24;
+    bf16* const part = (tnp8 && a->partials && splits >= part_min && !a->trans_c && a->c_taps <= 1 && a->N2 % 8 == 0 && a->ldc % 4 == 0 && ((uintptr_t)a->C & 15) == 0 &&
+                        ((uintptr_t)a->partials & 15) == 0 && (long)splits * a->N1 * a->N2 * 2 <= a->partials_bytes && (long)a->N1 * a->N2 >= 65536)
+                           ? (bf16*)a->partials : nullptr;
 #define MVLT_TN_LAUNCH(BMT_, BN_, NS_)                                                                                          \
   do {                                                                                                                         \
     if (a->b_map.mode == 0 && a->b_map.rows_per_batch == 0 && a->a_map.rows_per_batch == 0)                                                        \
-      MVLT_LAUNCH((gemm_tn_dma_kernel<BMT_, BN_, 3, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits);                           \
-    else if (a->b_map.mode == 0) MVLT_LAUNCH((gemm_tn_dma_kernel<BMT_, BN_, 0, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits); \
-    else if (a->b_map.mode == 1) MVLT_LAUNCH((gemm_tn_dma_kernel<BMT_, BN_, 1, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits); \
-    else MVLT_LAUNCH((gemm_tn_dma_kernel<BMT_, BN_, 2, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits);                         \
+      MVLT_LAUNCH((gemm_tn_dma_kernel<BMT_, BN_, 3, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits, part);                     \
+    else if (a->b_map.mode == 0) MVLT_LAUNCH((gemm_tn_dma_kernel<BMT_, BN_, 0, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits, part); \
+    else if (a->b_map.mode == 1) MVLT_LAUNCH((gemm_tn_dma_kernel<BMT_, BN_, 1, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits, part); \
+    else MVLT_LAUNCH((gemm_tn_dma_kernel<BMT_, BN_, 2, NS_>), grid, block, lds, s, *a, m_per_split, t1, t2, splits, part);                   \
   } while (0)
     if (bmt == 128 && bn == 128) MVLT_TN_LAUNCH(128, 128, 2);
     else if (bmt == 128) MVLT_TN_LAUNCH(128, 64, 3);
     else if (bn == 128) MVLT_TN_LAUNCH(64, 128, 3);
     else MVLT_TN_LAUNCH(64, 64, 4);
 #undef MVLT_TN_LAUNCH
+    if (part) {
+      const long groups = (long)a->N1 * a->N2 / 8;
+      MVLT_LAUNCH(tn_fold_kernel, dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, s, (const bf16*)part, splits, a->N1, a->N2, a->C, a->ldc);
+    }
     return mvlt_check_launch("mvlt_gemm_tn");
   }
   const bool narrow = a->N2 <= 64;

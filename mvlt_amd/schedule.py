@@ -550,7 +550,8 @@ class TrunkStep:
             ops.gemm_tn(dy1, bs["ao"], self.g(p + "attn.proj.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.proj.bias"),
                         dgrad=(self.wT(p + "attn.proj.weight"), dao.view(M, C)))
         else:
-            ops.gemm_tn(dy1, bs["ao"], self.g(p + "attn.proj.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.proj.bias"))
+            # (stages 3-4: 9-16 output tiles x 32-56 m-splits -- reduced through bf16 partial tiles + a fold instead of atomics: mvlt_gemm_tn_args.partials)
+            ops.gemm_tn(dy1, bs["ao"], self.g(p + "attn.proj.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.proj.bias"), partials=self.S.tn_partials())
             ops.gemm_nt(dy1, self.wT(p + "attn.proj.weight"), dao, M, C, C, C, C, C)
         Mk = bs["Mk"]
         dq = _empty((B, N, C), dt, dev)
@@ -570,17 +571,17 @@ class TrunkStep:
             ops.gemm_tn(dq, bs["xn1"], self.g(p + "attn.q.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.q.bias"),
                         dgrad=(self.wT(p + "attn.q.weight"), dxn1.view(M, C)))
         else:
-            ops.gemm_tn(dq, bs["xn1"], self.g(p + "attn.q.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.q.bias"))
+            ops.gemm_tn(dq, bs["xn1"], self.g(p + "attn.q.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.q.bias"), partials=self.S.tn_partials())
             ops.gemm_nt(dq, self.wT(p + "attn.q.weight"), dxn1, M, C, C, C, C, C)
         gkvw, gkvb = self.g(p + "attn.kv.weight"), self.g(p + "attn.kv.bias")
         wkvT = self.wT(p + "attn.kv.weight")
         if r > 1:
             HWr, pm = bs["HWr"], bs["pm"]
             # text keys come straight from LN1(x)[text rows]
-            ops.gemm_tn(dkv, bs["xn1"], gkvw, B * T, 2 * C, C, 2 * C, C, C, a_map=rowmap(T, Mk, HWr), b_map=rowmap(T, N, HW), colsum=gkvb)
+            ops.gemm_tn(dkv, bs["xn1"], gkvw, B * T, 2 * C, C, 2 * C, C, C, a_map=rowmap(T, Mk, HWr), b_map=rowmap(T, N, HW), colsum=gkvb, partials=self.S.tn_partials())
             ops.gemm_nt(dkv, wkvT, dxn1, B * T, C, 2 * C, 2 * C, 2 * C, C, a_map=rowmap(T, Mk, HWr), c_map=rowmap(T, N, HW), R=dxn1)
             # image keys: kv <- LN(sr conv(LN1(x)[image rows]))
-            ops.gemm_tn(dkv, bs["kvin"], gkvw, B * HWr, 2 * C, C, 2 * C, C, C, a_map=rowmap(HWr, Mk, 0), colsum=gkvb)
+            ops.gemm_tn(dkv, bs["kvin"], gkvw, B * HWr, 2 * C, C, 2 * C, C, C, a_map=rowmap(HWr, Mk, 0), colsum=gkvb, partials=self.S.tn_partials())
             dkvin = _empty((B * HWr, C), dt, dev)
             ops.gemm_nt(dkv, wkvT, dkvin, B * HWr, C, 2 * C, 2 * C, 2 * C, C, a_map=rowmap(HWr, Mk, 0))
             dsr = _empty((B * HWr, C), dt, dev)
@@ -590,7 +591,7 @@ class TrunkStep:
             conv_wgrad(self.S, p + "attn.sr.weight", dsr, bs["xn1"], B * HWr, C, K, C, C, pm, r * r, C, colsum=self.g(p + "attn.sr.bias"))
             ops.gemm_nt(dsr, self.wKT(p + "attn.sr.weight"), dxn1, B * HWr, K, C, C, C, C, c_map=pm, R=dxn1)
         else:
-            ops.gemm_tn(dkv, bs["xn1"], gkvw, M, 2 * C, C, 2 * C, C, C, colsum=gkvb)
+            ops.gemm_tn(dkv, bs["xn1"], gkvw, M, 2 * C, C, 2 * C, C, C, colsum=gkvb, partials=self.S.tn_partials())
             ops.gemm_nt(dkv, wkvT, dxn1, M, C, 2 * C, 2 * C, 2 * C, C, R=dxn1)
         # the block below (processed next) scales this gradient by its own MLP-branch DropPath factor first thing when its MLP is not the
         # fused kernel (stages 3-4): norm1's backward writes that scaled copy in the same pass

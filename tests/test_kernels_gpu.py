@@ -324,6 +324,27 @@ def test_gemm_tn_partial_tiles_reduce_without_atomics(ops, M, N1, N2):
     assert "gemm_tn_dma_kernel" in last_kernel() and maxrel(Cw, ref) < 1e-3
 
 
+@pytest.mark.parametrize("M,N1,N2", [(98304, 320, 320), (49152, 512, 512), (40000, 328, 512)])
+def test_gemm_tn_partial_tiles_on_the_128_wide_kernel(ops, M, N1, N2):
+    """The 128 x 128 weight-gradient kernel in partial-tile mode (many m-splits on a mid-sized output: the q / proj gradients of stages 3-4): accumulates into C within 5e-3 of
+    the fp32 product, ragged tiles and a ragged last split included, bit-identical from launch to launch, the bias gradient unchanged."""
+    from mvlt_amd._lib import last_kernel
+    dt = torch.bfloat16
+    A, B = rnd(M, N1, dtype=dt, scale=0.5), rnd(M, N2, dtype=dt, seed=1, scale=0.5)
+    ref = A.float().t() @ B.float()
+    scratch = torch.empty(256 * 65536, device=dev(), dtype=dt)
+    outs = []
+    for _ in range(2):
+        Cw, cs = torch.full((N1, N2), -2.0, device=dev()), torch.zeros(N1, device=dev())
+        ops.gemm_tn(A, B, Cw, M, N1, N2, N1, N2, N2, colsum=cs, partials=scratch)
+        torch.cuda.synchronize()
+        assert "tn_fold_kernel" in last_kernel()
+        outs.append((Cw, cs))
+    assert maxrel(outs[0][0] + 2.0, ref) < 5e-3
+    assert maxrel(outs[0][1], A.float().sum(0)) < 1e-3
+    assert torch.equal(outs[0][0], outs[1][0])
+
+
 def test_gemm_tn_fused_input_gradient_is_never_skipped_silently(ops):
     """every launch path of mvlt_gemm_tn that cannot produce dgrad_out must refuse -- a silently unwritten input gradient is a wrong
     gradient.  fp32 operands (the generic kernel) with dgrad_out raise; a row-strided dX view (a column slice of a wider buffer) keeps its

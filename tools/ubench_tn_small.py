@@ -14,5 +14,6 @@ def timeit(fn, reps=20):
 for M, N1, N2 in ((98304, 320, 320), (49152, 512, 512), (49152, 1024, 512), (98304, 1280, 320), (98304, 320, 1280), (294912, 128, 128), (262144, 192, 192)):
     A = (torch.randn(M, N1, device=dev) * 0.5).to(bf); B = (torch.randn(M, N2, device=dev) * 0.5).to(bf)
     Cw, cs = torch.zeros(N1, N2, device=dev), torch.zeros(N1, device=dev)
-    t = timeit(lambda: ops.gemm_tn(A, B, Cw, M, N1, N2, N1, N2, N2, colsum=cs))
+    scr = torch.empty(256 * 65536, device=dev, dtype=bf)
+    t = timeit(lambda: ops.gemm_tn(A, B, Cw, M, N1, N2, N1, N2, N2, colsum=cs, partials=scr))
     print(f"{M} x {N1} x {N2}: {t:.1f} us  {2.0 * M * N1 * N2 / t / 1e6:.0f} TF/s")
