@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_a
 // a fragment are consecutive in one image row, so a tap is a constant row offset; out-of-image halo rows come from the zero page).
 // 25 KB through the DMA path per 4.7 MFLOP: ~22 B/clk/CU at full MFMA rate.
 template <int W>
-__global__ __launch_bounds__(NTHREADS, 2) void conv3_wgrad_kernel(mvlt_gemm_tn_args p, int tiles_per_split, int n_o, int n_c, int splits) {
+__global__ __launch_bounds__(NTHREADS, 2) void conv3_wgrad_kernel(mvlt_gemm_tn_args p, int tiles_per_split, int n_o, int n_c, int splits, bf16* part) {
   using TA = DmaTile<64>;
   constexpr int R = 64 / W;                         // image rows per 64-pixel k-tile
   constexpr int HW2 = W + 2, HR = (R + 2) * HW2;    // halo rows (one pixel each, 64 channels = 128 B)
@@ -1563,6 +1563,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_wgrad_kernel(mvlt_gemm_tn_a
     }
   }
   const int fr = lane & 15, fg = lane >> 4;
+  if (part) {
+    // PARTIAL-TILE mode (round 5): the flush of the 64 x 9 x 64 blocks was 35 % of this kernel family (18.6 M fp32 atomics at 192 -> 192 / 32 x 32: 193 us with, 155 us without
+    // them; 64 -> 64: 75 / 32 us -- profiles/r05_conv_wgrad_atomics_ablation.txt).  The split's block goes to part[split][N1][N2] in bf16 -- 16 output rows at a time through a
+    // per-wave LDS tile [16][9 taps x 32 columns], out as 16-byte pieces (64 contiguous bytes per row and tap) -- and tn_fold_kernel adds the splits in order.
+    constexpr int LDP = 9 * 32 + 8;
+    __syncthreads();                                    // every wave is done with the dz tiles / halos this overlays
+    bf16* const st = (bf16*)smem + wave * 16 * LDP;
+    bf16* const P = part + (size_t)bz * p.N1 * p.N2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[(4 * fg + r) * LDP + t * 32 + j * 16 + fr] = (bf16)acc[i][t][j][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int q = lane + 64 * k, row = q / 36, rem = q - row * 36, t = rem >> 2, pc = rem & 3;
+        const int n1 = o0 + wm * 32 + i * 16 + row, n2 = t * cin + c0 + wn * 32 + pc * 8;
+        st_g<MVLT_NT_GEMM>((u32x4*)(P + (size_t)n1 * p.N2 + n2), *(const u32x4*)(st + row * LDP + t * 32 + pc * 8));
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1576,6 +1605,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_wgrad_kernel(mvlt_gemm_tn_a
           atomicAdd(&p.C[(long)n1 * p.ldc + n2], acc[i][t][j][r]);
         }
 }
+
+__global__ void tn_fold_kernel(const bf16* __restrict__ part, int splits, int N1, int N2, float* __restrict__ C, int ldc);      // below, with the 8-phase TN kernel
 
 template <int W> int launch_conv3_wgrad(const mvlt_gemm_tn_args& a, hipStream_t s) {
   constexpr int R = 64 / W, HR = (R + 2) * (W + 2), H_IT = (HR * 8 + NTHREADS - 1) / NTHREADS;
@@ -1593,7 +1624,16 @@ template <int W> int launch_conv3_wgrad(const mvlt_gemm_tn_args& a, hipStream_t 
   splits = (ntiles + tps - 1) / tps;
   dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * n_o * n_c)), block(NTHREADS);
   mvlt_max_lds<(conv3_wgrad_kernel<W>)>();
-  MVLT_LAUNCH((conv3_wgrad_kernel<W>), grid, block, lds, s, a, tps, n_o, n_c, splits);
+  // the caller's scratch takes the splits' blocks (bf16) and an ordered fold adds them to C: no atomics (MVLT_TN_P8=0 keeps them)
+  static const bool part_ok = !(getenv("MVLT_TN_P8") && atoi(getenv("MVLT_TN_P8")) == 0);
+  bf16* const part = (part_ok && a.partials && splits >= 4 && ((uintptr_t)a.partials & 15) == 0 && (long)splits * a.N1 * a.N2 * 2 <= a.partials_bytes && a.ldc % 4 == 0 &&
+                      ((uintptr_t)a.C & 15) == 0 && lds >= (size_t)4 * 16 * (9 * 32 + 8) * 2)
+                         ? (bf16*)a.partials : nullptr;
+  MVLT_LAUNCH((conv3_wgrad_kernel<W>), grid, block, lds, s, a, tps, n_o, n_c, splits, part);
+  if (part) {
+    const long groups = (long)a.N1 * a.N2 / 8;
+    MVLT_LAUNCH(tn_fold_kernel, dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, s, (const bf16*)part, splits, a.N1, a.N2, a.C, a.ldc);
+  }
   return mvlt_check_launch("mvlt_gemm_tn");
 }
 

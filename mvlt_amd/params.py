@@ -523,11 +523,11 @@ class FlatStore:
             self.G.mul_(factor)
 
     def tn_partials(self):
-        """32 MiB of persistent scratch for the atomic-free reduction of the weight-gradient GEMMs whose outputs are 16 .. 64 whole 256 x 256 tiles (the stage-4 MLP;
-        mvlt_gemm_tn_args.partials): every qualifying shape needs splits x N1 x N2 = 256 x 65536 bf16 elements"""
+        """64 MiB of persistent scratch for the atomic-free reduction of the weight-gradient GEMMs (mvlt_gemm_tn_args.partials): bf16 partial tiles [splits][N1][N2].  The
+        stage-4 MLP needs 256 x 65536 elements (32 MiB), the MIM decoder's largest conv (192 -> 192 at 32 x 32: 56 splits x 192 x 1728) 37 MiB; what does not fit takes atomics."""
         t = getattr(self, "_tn_partials", None)
         if t is None or t.device != self.G.device:
-            t = self._tn_partials = torch.empty(256 * 65536, dtype=torch.bfloat16, device=self.G.device)
+            t = self._tn_partials = torch.empty(512 * 65536, dtype=torch.bfloat16, device=self.G.device)
         return t
 
     def wait_grads(self):

@@ -53,7 +53,7 @@ def conv_wgrad(S, name, dz, xin, M, cout, K, ld_dz, ld_in, bmap, taps, cin, cols
         kk = int(round(taps ** 0.5))
         S.grad(name).add_(dWk.view(cout, kk, kk, cin).permute(0, 3, 1, 2))
         return
-    ops.gemm_tn(dz, xin, S.grad_taps(name, cout, taps, cin), M, cout, K, ld_dz, ld_in, K, b_map=bmap, colsum=colsum)
+    ops.gemm_tn(dz, xin, S.grad_taps(name, cout, taps, cin), M, cout, K, ld_dz, ld_in, K, b_map=bmap, colsum=colsum, partials=S.tn_partials())
 
 
 def _step_rng(model):

@@ -1249,6 +1249,18 @@ def test_conv3x3_wgrad_lds_halo(ops, side, Cin, Cout, Bsz, tokens_extra):
     assert rel(dW, ref) < 5e-3
     ops.gemm_tn(dY, X, dW, M, Cout, 9 * Cin, Cout, Cin, 9 * Cin, b_map=amap)
     assert rel(dW, 2 * ref) < 5e-3
+    # the same through bf16 partial tiles + the ordered fold instead of atomics (mvlt_gemm_tn_args.partials): accumulates, agrees, and repeats bit for bit
+    from mvlt_amd._lib import last_kernel
+    scratch = torch.empty(512 * 65536, device=dev(), dtype=torch.bfloat16)
+    outs = []
+    for _ in range(2):
+        dWp = torch.full_like(dW, 0.5)
+        ops.gemm_tn(dY, X, dWp, M, Cout, 9 * Cin, Cout, Cin, 9 * Cin, b_map=amap, partials=scratch)
+        torch.cuda.synchronize()
+        outs.append(dWp)
+    if "tn_fold_kernel" in last_kernel():                     # (few pixels = fewer than four splits: the atomic flush stays)
+        assert torch.equal(outs[0], outs[1])
+    assert rel(outs[0] - 0.5, ref) < 6e-3
 
 
 @pytest.mark.parametrize("side,Cin,Cout,Bsz,tokens_extra,variant",

@@ -20,7 +20,8 @@ for side, cin, cout, tok, cnt in ((32, 192, 192, 1024, 2), (32, 64, 64, 1024, 2)
     M = B * side * side
     x = torch.randn(B, tok, cin, device=dev).to(bf); dz = torch.randn(M, cout, device=dev).to(bf)
     dW = torch.zeros(cout, 9 * cin, device=dev)
-    t = timeit(lambda: ops.gemm_tn(dz, x, dW, M, cout, 9 * cin, cout, cin, 9 * cin, b_map=conv3map(side, side, tok, cin)))
+    scr = torch.empty(512 * 65536, device=dev, dtype=bf)      # mvlt_gemm_tn_args.partials: bf16 partial blocks + ordered fold (MVLT_TN_P8=0: fp32 atomics)
+    t = timeit(lambda: ops.gemm_tn(dz, x, dW, M, cout, 9 * cin, cout, cin, 9 * cin, b_map=conv3map(side, side, tok, cin), partials=scr))
     tot += cnt * t
     print(f'{side}x{side} {cin:>3}->{cout:<3} x{cnt}: {t*1e3:7.1f} us  {2.0*M*cout*9*cin/t/1e9:6.0f} TF/s')
 print(f'per step: {tot:.3f} ms')
