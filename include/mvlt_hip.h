@@ -24,7 +24,7 @@ extern "C" {
  *   2 (round 5): positional signatures of mvlt_batch_sum / mvlt_bn_norm / mvlt_bn_bwd_reduce / mvlt_bn_bwd_apply / mvlt_ew_mul / mvlt_ew_mul3_bwd as of
  *                round 4's second half (the number had stayed 1 through those changes: ADVICE r4)
  *   3 (round 5): mvlt_gemm_tn_args.partials / partials_bytes; mvlt_last_kernel() */
-#define MVLT_ABI_VERSION 3
+#define MVLT_ABI_VERSION 4
 const char* mvlt_last_error(void);
 int mvlt_abi_version(void);
 /* the kernel instantiation the library launched last on the calling thread, as the HIP runtime names it, demangled (e.g. "void (anonymous
@@ -308,7 +308,8 @@ int mvlt_transpose_cast(const float* in, void* out, int R, int C, int ld_out, in
  * operands) or a 3-D strided gather-cast (dst[i0*ds0 + i1*ds1 + i2*ds2] = src[src_off + i0*ss0 + i1*ss1 + i2*ss2]: the
  * [out][kh][kw][cin] / flipped-tap re-orderings of the conv weights of reference libs/pvlt.py:104,168 and
  * libs/vl_heads.py:107-165).  blk_start[ndesc + 1] = prefix sums of the workgroups each descriptor needs
- * (kind 0 / 2: ceil(R/64)*ceil(C/64), kind 1: ceil(d0*d1*d2 / 256)). */
+ * (kind 0 / 2: ceil(R/64)*ceil(C/64), kind 1: ceil(d0*d1*d2 / 256)); blk_desc[total_blocks] (nullable, ABI 4) = the descriptor
+ * index of every workgroup, i.e. the inverse of blk_start: with it a workgroup finds its descriptor by two scalar loads instead of a search. */
 typedef struct mvlt_prep_desc {
   const float* src; void* dst;
   int kind;                 /* 0 = transpose, 1 = gather, 2 = transpose of a bf16 source (src points at bf16; C % 8 == 0, ld_out % 8 == 0, bf16 dst) */
@@ -318,7 +319,7 @@ typedef struct mvlt_prep_desc {
   int ds0, ds1, ds2;
 } mvlt_prep_desc;
 int mvlt_weight_prep(const mvlt_prep_desc* descs /* device */, const int* blk_start /* device, [ndesc + 1] */, int ndesc,
-                     int total_blocks, int dtype /* of every dst */, void* stream);
+                     int total_blocks, const int* blk_desc /* device, [total_blocks] or NULL */, int dtype /* of every dst */, void* stream);
 
 /* ---- fused MLP for the narrow stages (mvlt_amd/csrc/mlp.hip), bf16 operands, C = 64 or 128 ------------------------
  * Replaces fc1 -> nn.GELU -> fc2 (+ DropPath + residual) of reference libs/pvlt.py:65-71,142 and their autograd: the

@@ -39,9 +39,10 @@ def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias
     return C_out
 
 
-def weight_prep(desc_dev, blk_dev, ndesc, total_blocks, dtype):
+def weight_prep(desc_dev, blk_dev, ndesc, total_blocks, dtype, blk_desc=None):
     """desc_dev: uint8 device tensor holding ndesc packed mvlt_prep_desc; blk_dev: int32 device tensor [ndesc + 1]."""
-    check(L.lib.mvlt_weight_prep(C.c_void_p(desc_dev.data_ptr()), C.c_void_p(blk_dev.data_ptr()), ndesc, total_blocks, DT[dtype], stream_ptr()),
+    check(L.lib.mvlt_weight_prep(C.c_void_p(desc_dev.data_ptr()), C.c_void_p(blk_dev.data_ptr()), ndesc, total_blocks,
+                                 C.c_void_p(blk_desc.data_ptr() if blk_desc is not None else None), DT[dtype], stream_ptr()),
           "mvlt_weight_prep")
 
 

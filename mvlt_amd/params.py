@@ -252,7 +252,7 @@ class FlatStore:
             self._build_prep(transposed, conv_perm, conv3)
             self._prep_key = key
         if self._prep_n:
-            ops.weight_prep(self._prep_desc, self._prep_blk, self._prep_n, self._prep_blocks, self.compute_dtype)
+            ops.weight_prep(self._prep_desc, self._prep_blk, self._prep_n, self._prep_blocks, self.compute_dtype, self._prep_blk_desc)
         self._cast_version = ver
         self.force_dirty = False
         self.refresh_count += 1      # consumers that cache their own derived copies key on this
@@ -320,6 +320,8 @@ class FlatStore:
             starts.append(starts[-1] + b)
         self._prep_blk = torch.tensor(starts, dtype=torch.int32, device=dev)
         self._prep_blocks = starts[-1]
+        # block -> descriptor (the inverse of the prefix sums): the kernel's workgroups look themselves up with two scalar loads
+        self._prep_blk_desc = torch.repeat_interleave(torch.arange(len(blocks), dtype=torch.int32), torch.tensor(blocks)).to(torch.int32).to(dev)
 
     # ------------------------------------------------------------------ gradients
     def begin_backward(self):

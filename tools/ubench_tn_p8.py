@@ -12,7 +12,7 @@ def timeit(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for M, N1, N2 in ((49152, 512, 2048), (49152, 2048, 512), (49152, 512, 512), (49152, 1024, 512), (98304, 1280, 320)):
+for M, N1, N2 in ((49152, 512, 2048), (49152, 2048, 512), (49152, 512, 512), (49152, 1024, 512), (98304, 1280, 320), (98304, 320, 1280)):
     A = (torch.randn(M, N1, device=dev) * 0.5).to(bf); B = (torch.randn(M, N2, device=dev) * 0.5).to(bf)
     ref = A.float().t() @ B.float()
     scr = torch.empty(256 * 65536, device=dev, dtype=bf)      # mvlt_gemm_tn_args.partials (MVLT_TN_P8=0: ignored, fp32 atomics)
