@@ -718,7 +718,7 @@ def test_patchify_matches_conv(ops, dtype):
 
 
 def test_masked_select_bit_exact(ops):
-    for n, frac in ((128 * 4, 0.05), (32768, 0.04), (1000, 0.0), (5000, 1.0), (1, 1.0)):
+    for n, frac in ((128 * 4, 0.05), (32768, 0.04), (1000, 0.0), (5000, 1.0), (1, 1.0), (65536, 0.5), (1025, 0.5), (70001, 0.3)):
         lab = torch.where(torch.rand(n, device=dev()) < frac, torch.randint(0, 30522, (n,), device=dev()), torch.full((n,), -1, device=dev()))
         idx = torch.full((n,), -7, device=dev(), dtype=torch.int32)
         cnt = torch.zeros(1, device=dev(), dtype=torch.int32)

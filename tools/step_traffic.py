@@ -38,5 +38,5 @@ if __name__ == "__main__":
     tot = sum(r[0] for r in rows)
     print(f"total HBM bytes per step (all launches of the bench process, setup included, over the {steps} steps it ran): {tot / 1e9:.2f} GB   [source_hash={source_hash()}]")
     print(f"{'MB/step':>9} {'read':>8} {'written':>8} {'us/step':>9} {'TB/s':>6} {'calls':>6}  kernel")
-    for t, rb, wb, us, c, n in rows[:45]:
+    for t, rb, wb, us, c, n in rows:
         print(f"{t / 1e6:9.1f} {rb / 1e6:8.1f} {wb / 1e6:8.1f} {us:9.1f} {t / us / 1e6 if us else 0:6.2f} {c:6.1f}  {n}")
