@@ -51,11 +51,11 @@ us = lambda k: fam.get(k, [0, 0.0])[1]
 t31 = f"""### 3.1 One steady-state step: {n_launch} launches, kernels busy {busy_ms:.2f} ms (`profiles/{tag}_step_launches.txt`)
 
 (The span from the step's first kernel to the optimizer's end is {span_ms:.2f} ms under `rocprofv3 --kernel-trace` -- {busy_pct:.1f} % busy; {n_aten} of the launches are ATen kernels, {n_copy} `copyBuffer`.
-Unprofiled the bench step equals the sum of the kernel durations.  This round's collection box is ~2 % slower than round 4's: the per-family differences to `r04_step_launches.txt` are that spread; the one kernel change of the round is the stage-4 weight-gradient pair (`gemm_tn_p8_kernel` + `tn_fold_kernel`).)
+Unprofiled the bench step equals the sum of the kernel durations.  The boxes of the pool differ by up to 5 % (19.6-20.6 ms for this build): family differences to `r04_step_launches.txt` below that are spread; the kernel changes of the round are the weight-gradient families (`gemm_tn_*` + `tn_fold_kernel`, `conv3_wgrad_kernel`: split reductions without atomics) and the helper row (cross entropy, label selection, weight prep).)
 
 | kernel family | launches | us / step | share | bound by (evidence) |
 |---|---|---|---|---|
-| `gemm_tn_dma_kernel` + `gemm_tn_p8_kernel` / `tn_fold_kernel` (weight gradients; 8 launches carry the input gradient too; the 4 stage-4 MLP ones reduce without atomics) | {g('gemm_tn_dma')} | MFMA-bound shapes 0.24-0.38 of peak (3.2), the K <= 128 shapes HBM (4.5-5.6 TB/s); split reductions cost outputs x splits / 0.3 ns (`experiments_r4.md` 2) |
+| `gemm_tn_dma_kernel` + `gemm_tn_p8_kernel` / `tn_fold_kernel` (weight gradients; 8 launches carry the input gradient too; the stage-4 MLP ones and every launch with >= 24 m-splits reduce through bf16 partial tiles + the fold, whose launches -- the conv3x3 ones included -- are counted here) | {g('gemm_tn_dma')} | MFMA-bound shapes 0.24-0.38 of peak (3.2), the K <= 128 shapes HBM (4.5-5.6 TB/s); where atomics remain a split reduction costs outputs x splits / 0.3 ns (`experiments_r4.md` 2) |
 | `gemm_nt_dma_kernel` (128-wide NT GEMMs: K <= 128 projections, gathers, small heads) | {g('gemm_nt_dma')} | HBM for K = 64 / 128 (`proj64` sibling: 0.60-0.70 of 8 TB/s); TA / L1 path for the rest (`r03_l1_stalls.txt`) |
 | `gemm_nt_p8_kernel` (8-wave / 8-phase NT GEMMs, stage 3-4, MLM logits) | {g('gemm_nt_p8')} | K-loops alone 1.1-1.6 PFLOP/s (epilogue compiled out, `r05_p8_epilogue_ablation.txt`); the launches 0.23-0.57 of peak: whole-round quantisation + a VALU-bound epilogue (~15 instructions per output at two waves per SIMD) that a persistent grid does not hide (3.3, `experiments_r5.md` 3) |
 | `mlp_pipe_kernel` (fused MLP forward / input gradient, stages 1-2) | {g('mlp_pipe')} | VALU (GELU: 10 instructions per hidden element) + MFMA, partly overlapped: MFMA-busy 0.28-0.35, VALU-active 0.26-0.35 (`{tag}_mfma_counters.csv`) |
@@ -64,7 +64,7 @@ Unprofiled the bench step equals the sum of the kernel durations.  This round's 
 | `conv3_nt_kernel` (MIM conv3x3 forward / dgrad) | {g('conv3_nt')} | MFMA / LDS-DMA: 1.0-1.24 PFLOP/s (0.41-0.50), MFMA-busy 0.48 |
 | MIM decoder non-GEMM (BatchNorm, upsample, products, fused loss) | {g('mim')} | HBM streaming, fp16 z and product factors (first half of round 4: 1482 us, `experiments_r4.md` 8) |
 | `attn_bwd_dma_kernel` | {g('attn_bwd')} | dependent chain per 32-query tile at two waves per SIMD (256 registers): MFMA-busy 0.23, waits 0.37 + 0.26; stage 1 = 2.4 x its HBM floor; a split into dQ + dK / dV kernels cannot win (`experiments_r5.md` 2); prologue + flush 21 % / 9 % of the launch at stages 4 / 3 |
-| `conv3_wgrad_kernel` | {g('conv3_wgrad')} | 1.02 PFLOP/s (0.41), MFMA-busy 0.41 |
+| `conv3_wgrad_kernel` (bf16 partial blocks, folded by `tn_fold_kernel`: round 4 with the atomic flush 1005 us) | {g('conv3_wgrad')} | MFMA / LDS: the loop alone ran at ~1.5 PFLOP/s in the flush ablation (`r05_conv_wgrad_atomics_ablation.txt`) |
 | `attn_fwd2_kernel` | {g('attn_fwd2')} | Q / O streaming at stage 1 (77-80 us vs ~55 us floor), K / V staging at stages 3-4 |
 | AdamW {us('adamw'):.0f}, BERT-embedding bwd / fwd {us('bert_embed_bwd'):.0f} / {us('bert_embed_fwd'):.0f}, weight prep {us('weight_prep'):.0f}, cross entropy {us('ce_fwd') + us('ce_bwd'):.0f}, gradient-copy folds {us('fold_copies'):.0f}, ATen leftovers ({R.get('aten', (0, 0, 0))[0]} launches) {us('aten'):.0f}, other helpers | {rest_n} | {rest_us:.0f} | {100 * rest_us / total:.1f} % | HBM (AdamW: 1.2 GB at 5.7-6.4 TB/s; the embedding backward: 25 M fp32 atomics at 0.3 per ns) |
 """
