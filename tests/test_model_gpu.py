@@ -350,6 +350,50 @@ def test_mim_decoder_hip_vs_torch_twin(dtype, tol, img, B):
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
 
 
+def test_weight_prep_copies_equal_their_definitions_on_both_lookup_paths():
+    """mvlt_weight_prep refreshes every derived weight copy in one launch (W^T dgrad operands, [out][kh][kw][cin] conv layouts, flipped dgrad taps): each copy against its
+    definition from the fp32 master (reference libs/pvlt.py:104,168, libs/vl_heads.py:107-165 keep one layout and let cuDNN / cuBLAS permute), with the host's
+    block -> descriptor table and with the per-workgroup search the kernel falls back to without it."""
+    from mvlt_amd import pvlt, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = pvlt.pvlt_tiny(pretrained=False, token_hidden_size=768, num_text_tokens=16, loss_type=dict(mlm=1, itm=1, t2i=1, cls=1),
+                           pretrained_pth=None, drop_path_rate=0.0, drop_rate=0.0, num_classes=1000, in_chans=3).cuda(dev)
+    S = model.store
+    S.ensure(dev)
+    S.force_dirty = True
+    S.refresh(model._transposed, model._conv_perm, model._conv3)
+    torch.cuda.synchronize()
+    dt = S.compute_dtype
+    names = [k for k in S.extra if "::" in k]
+    assert len([k for k in names if k.endswith("::T")]) > 40 and any(k.endswith("::F") for k in names) and any(k.endswith("::KT") for k in names)
+
+    def check():
+        for k in names:
+            name, suffix = k.rsplit("::", 1)
+            w = S.master(name).to(dt)
+            got = S.extra[k]
+            if suffix == "T" and w.dim() == 2 and name != "t2i_head.score.0.weight":
+                R, Cc = w.shape
+                assert torch.equal(got[:, :R], w.t()) and (got[:, R:] == 0).all(), k
+            elif suffix == "K":
+                out, cin, kh, kw = w.shape
+                assert torch.equal(got, w.permute(0, 2, 3, 1).reshape(out, kh * kw * cin)), k
+            elif suffix == "KT":
+                out, cin, kh, kw = w.shape
+                assert torch.equal(got, w.permute(2, 3, 1, 0).reshape(kh * kw * cin, out)), k
+            elif suffix == "F":
+                out, cin, kh, kw = w.shape
+                assert torch.equal(got, w.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, kh * kw * out)), k
+
+    check()
+    for k in names:
+        S.extra[k].zero_()
+    ops.weight_prep(S._prep_desc, S._prep_blk, S._prep_n, S._prep_blocks, dt, None)       # no table: the search path
+    torch.cuda.synchronize()
+    check()
+
+
 def test_deep_variant_train_step_runs():
     """pvlt_medium (3/4/18/3 blocks): one bf16 train step end to end -- sizes that depend on the depth (the LayerNorm
     gradient accumulator arena, the weight-prep table) must follow the model, not the tiny configuration."""
