@@ -23,8 +23,9 @@ extern "C" {
  * built with; a binding compares it with the number it was written against (mvlt_amd/_lib.py ABI_VERSION) before any other call.
  *   2 (round 5): positional signatures of mvlt_batch_sum / mvlt_bn_norm / mvlt_bn_bwd_reduce / mvlt_bn_bwd_apply / mvlt_ew_mul / mvlt_ew_mul3_bwd as of
  *                round 4's second half (the number had stayed 1 through those changes: ADVICE r4)
- *   3 (round 5): mvlt_gemm_tn_args.partials / partials_bytes; mvlt_last_kernel() */
-#define MVLT_ABI_VERSION 4
+ *   3 (round 5): mvlt_gemm_tn_args.partials / partials_bytes; mvlt_last_kernel()
+ *   4: mvlt_weight_prep blk_desc      5: mvlt_gemm_tn_args.defer_fold, mvlt_tn_fold_flush() */
+#define MVLT_ABI_VERSION 5
 const char* mvlt_last_error(void);
 int mvlt_abi_version(void);
 /* the kernel instantiation the library launched last on the calling thread, as the HIP runtime names it, demangled (e.g. "void (anonymous
@@ -120,8 +121,14 @@ typedef struct mvlt_gemm_tn_args {
    * trans_c == 0, c_taps <= 1.  A launch whose splits x N1 x N2 x 2 bytes exceed partials_bytes, or partials == NULL, takes the atomic path; 64 MiB covers every launch of
    * the BASELINE configurations (the largest: 56 splits x 192 x 1728 = 37 MiB). */
   void* partials; long partials_bytes;
+  /* 1: leave this launch's partial tiles in the scratch (each deferring launch takes the next free region of it) and fold them together with the next ones -- up to 32 per fold
+   * launch; the library folds by itself when its table or the scratch is full or when a non-deferring launch needs the scratch, and when the caller says
+   * mvlt_tn_fold_flush(): REQUIRED before anything reads a gradient a deferring launch produced.  0: fold right behind the GEMM (ABI 5). */
+  int defer_fold;
 } mvlt_gemm_tn_args;
 int mvlt_gemm_tn(const mvlt_gemm_tn_args* args, void* stream);
+/* fold every deferred partial-tile reduction now (one launch on the stream their producers ran on); nothing pending: no launch */
+int mvlt_tn_fold_flush(void* stream);
 
 /* y = LayerNorm(x) * gamma + beta (+ add[(row % add_rows)] ) over the last dim C; rows addressed through maps.
  * Replaces nn.LayerNorm at reference libs/pvlt.py:105,141,142,169,208 and libs/vl_heads.py:33 (eps differs per

@@ -53,7 +53,7 @@ class GemmTNArgs(C.Structure):
                 ("dtype", c_int), ("a_map", RowMap), ("b_map", RowMap),
                 ("colsum_a", c_void_p), ("splits", c_int), ("colsum_b", c_void_p), ("trans_c", c_int),
                 ("c_taps", c_int), ("c_seg", c_int), ("dgrad_wt", c_void_p), ("dgrad_out", c_void_p), ("dgrad_ld", c_int),
-                ("partials", c_void_p), ("partials_bytes", c_long)]
+                ("partials", c_void_p), ("partials_bytes", c_long), ("defer_fold", c_int)]
 
 
 class LayerNormArgs(C.Structure):
@@ -107,7 +107,7 @@ class MlpArgs(C.Structure):
 lib.mvlt_last_error.restype = C.c_char_p
 lib.mvlt_last_kernel.restype = C.c_char_p
 lib.mvlt_sizeof.argtypes = [C.c_char_p]
-ABI_VERSION = 4          # include/mvlt_hip.h MVLT_ABI_VERSION this binding was written against
+ABI_VERSION = 5          # include/mvlt_hip.h MVLT_ABI_VERSION this binding was written against
 if lib.mvlt_abi_version() != ABI_VERSION:
     raise ImportError(f"ABI mismatch: {LIB_PATH} is version {lib.mvlt_abi_version()}, the binding is version {ABI_VERSION} (stale build? run python -m mvlt_amd.build)")
 for _name, _cls in (("mvlt_rowmap", RowMap), ("mvlt_prep_desc", PrepDesc), ("mvlt_gemm_nt_args", GemmNTArgs), ("mvlt_gemm_tn_args", GemmTNArgs),
@@ -125,7 +125,7 @@ EXPORTS = ["mvlt_last_error", "mvlt_last_kernel", "mvlt_abi_version", "mvlt_size
            "mvlt_ew_mul", "mvlt_upsample_fwd", "mvlt_upsample_bwd", "mvlt_mlp_fwd", "mvlt_mlp_bwd_dx", "mvlt_mlp_bwd_dw",
            "mvlt_grid_mask_flags", "mvlt_grid_mask_apply", "mvlt_token_mask", "mvlt_resize_bilinear_tokens", "mvlt_resize_bilinear_tokens_multi", "mvlt_gelu_bwd",
            "mvlt_keep_mask", "mvlt_droppath_scales", "mvlt_loss_compose", "mvlt_add_column_sums",
-           "mvlt_upsample_l1_fwd", "mvlt_upsample_l1_bwd"]
+           "mvlt_upsample_l1_fwd", "mvlt_upsample_l1_bwd", "mvlt_tn_fold_flush"]
 
 DT = {torch.bfloat16: 0, torch.float32: 1}
 

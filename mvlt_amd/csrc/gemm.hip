@@ -1608,6 +1608,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_wgrad_kernel(mvlt_gemm_tn_a
 
 __global__ void tn_fold_kernel(const bf16* __restrict__ part, int splits, int N1, int N2, float* __restrict__ C, int ldc);      // below, with the 8-phase TN kernel
 
+// ---- deferred folds (mvlt_gemm_tn_args.defer_fold): a fold is a ~8 us memory-bound launch between two long MFMA-bound ones (30 per step, 2.5 TB/s).  A deferring caller's
+// partial tiles stay in its scratch -- each launch takes the next free region -- and up to FOLD_MAX of them are folded by ONE launch of tn_fold_multi_kernel: when the table or
+// the scratch is full, when a non-deferring launch wants the scratch, or when the caller says mvlt_tn_fold_flush (before anything reads the gradients).  Same stream throughout.
+constexpr int FOLD_MAX = 32;
+struct FoldDesc { const bf16* part; float* C; int splits, N1, N2, ldc, wg0; };
+struct FoldBatch { FoldDesc d[FOLD_MAX]; int n, total_wgs; };
+__global__ void tn_fold_multi_kernel(FoldBatch b);
+struct FoldPending {
+  FoldBatch b = {};
+  void* scratch = nullptr;
+  long used = 0;
+  hipStream_t stream = nullptr;
+};
+FoldPending g_fp;
+void fold_flush() {
+  if (g_fp.b.n > 0) {
+    g_fp.b.total_wgs = g_fp.b.d[g_fp.b.n - 1].wg0 + (int)(((long)g_fp.b.d[g_fp.b.n - 1].N1 * g_fp.b.d[g_fp.b.n - 1].N2 / 8 + 31) / 32);
+    MVLT_LAUNCH(tn_fold_multi_kernel, dim3((unsigned)g_fp.b.total_wgs), dim3(256), 0, g_fp.stream, g_fp.b);
+  }
+  g_fp.b.n = 0;
+  g_fp.used = 0;
+}
+// the scratch region of this launch's partial tiles, or nullptr when they do not fit
+bf16* fold_acquire(const mvlt_gemm_tn_args& a, long need, hipStream_t s) {
+  if (!a.partials || ((uintptr_t)a.partials & 15) || need > a.partials_bytes) return nullptr;
+  if (g_fp.b.n > 0 && (!a.defer_fold || g_fp.scratch != a.partials || g_fp.stream != s || g_fp.b.n == FOLD_MAX || g_fp.used + need > a.partials_bytes)) fold_flush();
+  if (!a.defer_fold) return (bf16*)a.partials;
+  g_fp.scratch = a.partials;
+  g_fp.stream = s;
+  return (bf16*)((char*)a.partials + g_fp.used);
+}
+void fold_launch(const mvlt_gemm_tn_args& a, const bf16* part, int splits, hipStream_t s) {
+  const long groups = (long)a.N1 * a.N2 / 8;
+  if (!a.defer_fold) {
+    MVLT_LAUNCH(tn_fold_kernel, dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, s, part, splits, a.N1, a.N2, a.C, a.ldc);
+    return;
+  }
+  FoldDesc& d = g_fp.b.d[g_fp.b.n];
+  d.part = part; d.C = a.C; d.splits = splits; d.N1 = a.N1; d.N2 = a.N2; d.ldc = a.ldc;
+  d.wg0 = g_fp.b.n == 0 ? 0 : g_fp.b.d[g_fp.b.n - 1].wg0 + (int)(((long)g_fp.b.d[g_fp.b.n - 1].N1 * g_fp.b.d[g_fp.b.n - 1].N2 / 8 + 31) / 32);
+  ++g_fp.b.n;
+  g_fp.used += ((long)splits * a.N1 * a.N2 * 2 + 255) & ~255L;
+}
+
 template <int W> int launch_conv3_wgrad(const mvlt_gemm_tn_args& a, hipStream_t s) {
   constexpr int R = 64 / W, HR = (R + 2) * (W + 2), H_IT = (HR * 8 + NTHREADS - 1) / NTHREADS;
   const size_t lds = (size_t)2 * (DmaTile<64>::BYTES + H_IT * NTHREADS * 16);
@@ -1626,14 +1670,10 @@ template <int W> int launch_conv3_wgrad(const mvlt_gemm_tn_args& a, hipStream_t 
   mvlt_max_lds<(conv3_wgrad_kernel<W>)>();
   // the caller's scratch takes the splits' blocks (bf16) and an ordered fold adds them to C: no atomics (MVLT_TN_P8=0 keeps them)
   static const bool part_ok = !(getenv("MVLT_TN_P8") && atoi(getenv("MVLT_TN_P8")) == 0);
-  bf16* const part = (part_ok && a.partials && splits >= 4 && ((uintptr_t)a.partials & 15) == 0 && (long)splits * a.N1 * a.N2 * 2 <= a.partials_bytes && a.ldc % 4 == 0 &&
-                      ((uintptr_t)a.C & 15) == 0 && lds >= (size_t)4 * 16 * (9 * 32 + 8) * 2)
-                         ? (bf16*)a.partials : nullptr;
+  bf16* const part = (part_ok && a.partials && splits >= 4 && a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0 && lds >= (size_t)4 * 16 * (9 * 32 + 8) * 2)
+                         ? fold_acquire(a, (long)splits * a.N1 * a.N2 * 2, s) : nullptr;
   MVLT_LAUNCH((conv3_wgrad_kernel<W>), grid, block, lds, s, a, tps, n_o, n_c, splits, part);
-  if (part) {
-    const long groups = (long)a.N1 * a.N2 / 8;
-    MVLT_LAUNCH(tn_fold_kernel, dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, s, (const bf16*)part, splits, a.N1, a.N2, a.C, a.ldc);
-  }
+  if (part) fold_launch(a, part, splits, s);
   return mvlt_check_launch("mvlt_gemm_tn");
 }
 
@@ -2443,10 +2483,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p,
 // C[n1][n2] += sum over the splits of part[split][n1][n2] (bf16 partial tiles of gemm_tn_p8_kernel / gemm_tn_dma_kernel).  A workgroup covers 32 groups of eight consecutive n2;
 // its 256 threads are 32 groups x 8 split subsets (a 320 x 320 output over 56 splits is only 12800 groups: one thread per group left 200 CUs idle and ran the 56 loads of a
 // group one behind the other), the subsets meet in LDS and are added in a FIXED order: the result does not depend on timing.
-__global__ __launch_bounds__(256) void tn_fold_kernel(const bf16* __restrict__ part, int splits, int N1, int N2, float* __restrict__ C, int ldc) {
+__device__ __forceinline__ void tn_fold_body(const bf16* __restrict__ part, int splits, int N1, int N2, float* __restrict__ C, int ldc, int blk) {
   __shared__ float red[8][32][9];
   const int eg = threadIdx.x & 31, sk = threadIdx.x >> 5;
-  const long g = (long)blockIdx.x * 32 + eg;
+  const long g = (long)blk * 32 + eg;
   const long per = (long)N1 * N2;
   const bool ok = g * 8 < per;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -2473,6 +2513,18 @@ __global__ __launch_bounds__(256) void tn_fold_kernel(const bf16* __restrict__ p
   }
 }
 
+__global__ __launch_bounds__(256) void tn_fold_kernel(const bf16* __restrict__ part, int splits, int N1, int N2, float* __restrict__ C, int ldc) {
+  tn_fold_body(part, splits, N1, N2, C, ldc, blockIdx.x);
+}
+// several folds in one launch: workgroup b belongs to the descriptor whose [wg0, next wg0) holds it
+__global__ __launch_bounds__(256) void tn_fold_multi_kernel(FoldBatch b) {
+  int i = 0;
+#pragma unroll 1
+  for (int k = 1; k < b.n; ++k) if ((int)blockIdx.x >= b.d[k].wg0) i = k;
+  const FoldDesc& d = b.d[i];
+  tn_fold_body(d.part, d.splits, d.N1, d.N2, d.C, d.ldc, (int)blockIdx.x - d.wg0);
+}
+
 template <int HM, int HN0, int HN1> int launch_tn_p8_partial(const mvlt_gemm_tn_args& a, hipStream_t s) {
   constexpr int BM1 = 64 * HM, BN2 = 64 * (HN0 + HN1);
   constexpr int LDS = 2 * 64 * 2 * (2 * (2 * HM * 16) + BN2);
@@ -2482,11 +2534,10 @@ template <int HM, int HN0, int HN1> int launch_tn_p8_partial(const mvlt_gemm_tn_
   if (splits > nkt) splits = nkt;
   const int kt_per = (nkt + splits - 1) / splits;
   splits = (nkt + kt_per - 1) / kt_per;
-  void* const scratch = a.partials;              // [splits][N1][N2] bf16, the caller's (mvlt_gemm_tn checked its size)
+  bf16* const scratch = fold_acquire(a, (long)splits * a.N1 * a.N2 * 2, s);      // [splits][N1][N2] bf16 in the caller's scratch (mvlt_gemm_tn checked its size)
   dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * t1 * t2)), block(512);
-  MVLT_LAUNCH((gemm_tn_p8_kernel<HM, HN0, HN1, true>), grid, block, LDS, s, a, kt_per, t1, t2, splits, (bf16*)scratch);
-  const long groups = (long)a.N1 * a.N2 / 8;
-  MVLT_LAUNCH(tn_fold_kernel, dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, s, (const bf16*)scratch, splits, a.N1, a.N2, a.C, a.ldc);
+  MVLT_LAUNCH((gemm_tn_p8_kernel<HM, HN0, HN1, true>), grid, block, LDS, s, a, kt_per, t1, t2, splits, scratch);
+  fold_launch(a, scratch, splits, s);
   return mvlt_check_launch("mvlt_gemm_tn");
 }
 
@@ -2841,6 +2892,12 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   return mvlt_check_launch("mvlt_gemm_nt");
 }
 
+extern "C" int mvlt_tn_fold_flush(void* stream) {
+  (void)stream;                                   // the pending folds run on the stream their producers ran on
+  fold_flush();
+  return mvlt_check_launch("mvlt_tn_fold_flush");
+}
+
 extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
   MVLT_REQUIRE(a && a->A && a->B && a->C, "mvlt_gemm_tn: null operand");
   MVLT_REQUIRE(a->M >= 0 && a->N1 > 0 && a->N2 > 0, "mvlt_gemm_tn: bad shape");
@@ -2947,8 +3004,8 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
     // + an ordered fold instead of the atomics (14-21 us of a 53-56 us launch, profiles/r05_tn_small_atomics_ablation.txt).  Fewer splits: the atomics are cheaper than a fold launch.
     static const int part_min = getenv("MVLT_TN_PART_MIN") ? atoi(getenv("MVLT_TN_PART_MIN")) : 24;
     bf16* const part = (tnp8 && a->partials && splits >= part_min && !a->trans_c && a->c_taps <= 1 && a->N2 % 8 == 0 && a->ldc % 4 == 0 && ((uintptr_t)a->C & 15) == 0 &&
-                        ((uintptr_t)a->partials & 15) == 0 && (long)splits * a->N1 * a->N2 * 2 <= a->partials_bytes && (long)a->N1 * a->N2 >= 65536)
-                           ? (bf16*)a->partials : nullptr;
+                        (long)a->N1 * a->N2 >= 65536)
+                           ? fold_acquire(*a, (long)splits * a->N1 * a->N2 * 2, s) : nullptr;
 #define MVLT_TN_LAUNCH(BMT_, BN_, NS_)                                                                                          \
   do {                                                                                                                         \
     if (a->b_map.mode == 0 && a->b_map.rows_per_batch == 0 && a->a_map.rows_per_batch == 0)                                                        \
@@ -2962,10 +3019,7 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
     else if (bn == 128) MVLT_TN_LAUNCH(64, 128, 3);
     else MVLT_TN_LAUNCH(64, 64, 4);
 #undef MVLT_TN_LAUNCH
-    if (part) {
-      const long groups = (long)a->N1 * a->N2 / 8;
-      MVLT_LAUNCH(tn_fold_kernel, dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, s, (const bf16*)part, splits, a->N1, a->N2, a->C, a->ldc);
-    }
+    if (part) fold_launch(*a, part, splits, s);
     return mvlt_check_launch("mvlt_gemm_tn");
   }
   const bool narrow = a->N2 <= 64;

@@ -39,6 +39,11 @@ def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias
     return C_out
 
 
+def tn_fold_flush():
+    """fold every partial-tile reduction that gemm_tn(defer_fold=True) left pending (one launch; none pending: none)"""
+    check(L.lib.mvlt_tn_fold_flush(stream_ptr()), "mvlt_tn_fold_flush")
+
+
 def weight_prep(desc_dev, blk_dev, ndesc, total_blocks, dtype, blk_desc=None):
     """desc_dev: uint8 device tensor holding ndesc packed mvlt_prep_desc; blk_dev: int32 device tensor [ndesc + 1]."""
     check(L.lib.mvlt_weight_prep(C.c_void_p(desc_dev.data_ptr()), C.c_void_p(blk_dev.data_ptr()), ndesc, total_blocks,
@@ -46,7 +51,7 @@ def weight_prep(desc_dev, blk_dev, ndesc, total_blocks, dtype, blk_desc=None):
           "mvlt_weight_prep")
 
 
-def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, colsum=None, splits=0, taps=0, seg=0, dgrad=None, partials=None):
+def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, colsum=None, splits=0, taps=0, seg=0, dgrad=None, partials=None, defer_fold=False):
     """C[N1,N2] += A[M,N1]^T @ B[M,N2] (fp32 atomics); colsum[N1] += A.sum(0).  taps > 1: logical column tap*seg + c is
     accumulated at column c*taps + tap (conv weight gradients straight into the [out][cin][kh][kw] layout).
     dgrad = (W^T [N2][N1] bf16, out [M, N2] bf16): the Linear's input gradient out = A @ W from the same pass over A (N1 == N2 in {64, 128}).
@@ -77,6 +82,7 @@ def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, co
         a = L.GemmTNArgs(ptr(A), ptr(B), ptr(C_out), M, N1, N2, lda, ldb, ldc, DT[A.dtype], a_map, b_map, ptr(colsum), splits, None, 0, taps, seg)
         if partials is not None:       # scratch for the atomic-free reduction of whole 256 x 256 output tiles (mvlt_gemm_tn_args.partials); ignored for other shapes
             a.partials, a.partials_bytes = ptr(partials), partials.numel() * partials.element_size()
+            a.defer_fold = 1 if defer_fold else 0       # the caller promises tn_fold_flush() before anything reads C_out
     check(L.lib.mvlt_gemm_tn(C.byref(a), stream_ptr()), "mvlt_gemm_tn")
     return C_out
 

@@ -21,6 +21,7 @@ import torch.nn as nn
 from . import ops
 
 _EARLY_FOLDS = bool(os.environ.get("MVLT_EARLY_FOLDS"))        # A/B switch: gradient-copy folds after every backward stage also without a data-parallel wrapper
+_TN_SCRATCH_MIB = int(os.environ.get("MVLT_TN_SCRATCH_MIB", "256"))      # scratch of the weight-gradient partial tiles (deferred folds keep several launches' tiles in it)
 _PREP_FP32_SRC = bool(os.environ.get("MVLT_PREP_FP32_SRC"))     # A/B switch: transposed weight copies read the fp32 masters (rounds 1-3)
 ALIGN = 8
 
@@ -334,6 +335,9 @@ class FlatStore:
         # accumulate only if a trainable parameter's .grad aliases its slice of G; frozen parameters (requires_grad=False, .grad stays
         # None for ever) and parameters the optimizer's zero_grad does not cover say nothing about the caller's intent
         self.wait_grads()                 # collectives of a pass nobody stepped (no-op normally)
+        if self.G.is_cuda:
+            from . import ops
+            ops.tn_fold_flush()           # folds a pass that raised left pending (no-op normally)
         live = [(n, q) for n, q in self.fn_params if q.requires_grad]
         alias = [q.grad is not None and q.grad.data_ptr() == self.grad(n).data_ptr() for n, q in live]
         if not any(alias):
@@ -452,6 +456,8 @@ class FlatStore:
         from . import ops
         if early and self.on_range_ready is None and not _EARLY_FOLDS:
             return
+        if self.G.is_cuda:
+            ops.tn_fold_flush()              # deferred partial-tile folds of the weight-gradient GEMMs (their conv outputs land in the tap arena folded next)
         if getattr(self, "_tap_lo", None) is not None:
             ops.fold_copies(self._tap_arena, 1, self._tap_arena.numel(), self._tap_index, self._tap_lo, self._tap_hi, self.G)
             self._tap_lo = self._tap_hi = None
@@ -525,11 +531,11 @@ class FlatStore:
             self.G.mul_(factor)
 
     def tn_partials(self):
-        """64 MiB of persistent scratch for the atomic-free reduction of the weight-gradient GEMMs (mvlt_gemm_tn_args.partials): bf16 partial tiles [splits][N1][N2].  The
+        """256 MiB of persistent scratch for the atomic-free reduction of the weight-gradient GEMMs (mvlt_gemm_tn_args.partials): bf16 partial tiles [splits][N1][N2].  The
         stage-4 MLP needs 256 x 65536 elements (32 MiB), the MIM decoder's largest conv (192 -> 192 at 32 x 32: 56 splits x 192 x 1728) 37 MiB; what does not fit takes atomics."""
         t = getattr(self, "_tn_partials", None)
         if t is None or t.device != self.G.device:
-            t = self._tn_partials = torch.empty(512 * 65536, dtype=torch.bfloat16, device=self.G.device)
+            t = self._tn_partials = torch.empty(_TN_SCRATCH_MIB * 8 * 65536, dtype=torch.bfloat16, device=self.G.device)
         return t
 
     def wait_grads(self):

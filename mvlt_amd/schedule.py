@@ -41,6 +41,9 @@ WGRAD_TAPS = bool(os.environ.get("MVLT_WGRAD_TAPS"))
 WGRAD_ADD = bool(os.environ.get("MVLT_WGRAD_ADD"))
 
 
+_DEFER_FOLD = os.environ.get("MVLT_TN_DEFER_FOLD", "1") != "0"     # the weight-gradient folds batched into a few launches (FlatStore.fold_copies flushes); 0 = one fold per GEMM
+
+
 def conv_wgrad(S, name, dz, xin, M, cout, K, ld_dz, ld_in, bmap, taps, cin, colsum=None):
     """weight gradient of a gathered-row convolution into the G slice of nn.Conv2d's (out, cin, kh, kw) weight `name`: accumulated in
     the gather's (out, kh, kw, cin) order in the store's tap arena, which S.fold_copies() adds to G at the (out, cin, kh, kw) places"""
@@ -53,7 +56,7 @@ def conv_wgrad(S, name, dz, xin, M, cout, K, ld_dz, ld_in, bmap, taps, cin, cols
         kk = int(round(taps ** 0.5))
         S.grad(name).add_(dWk.view(cout, kk, kk, cin).permute(0, 3, 1, 2))
         return
-    ops.gemm_tn(dz, xin, S.grad_taps(name, cout, taps, cin), M, cout, K, ld_dz, ld_in, K, b_map=bmap, colsum=colsum, partials=S.tn_partials())
+    ops.gemm_tn(dz, xin, S.grad_taps(name, cout, taps, cin), M, cout, K, ld_dz, ld_in, K, b_map=bmap, colsum=colsum, partials=S.tn_partials(), defer_fold=_DEFER_FOLD)
 
 
 def _step_rng(model):
@@ -526,11 +529,11 @@ class TrunkStep:
             self._dy2_pre = None
             if dy2 is None:
                 dy2 = self._scaled(dx, bs["s2"], N)
-            ops.gemm_tn(dy2, bs["gact"], self.g(p + "mlp.fc2.weight"), M, C, hid, C, hid, hid, colsum=self.g(p + "mlp.fc2.bias"), partials=self.S.tn_partials())
+            ops.gemm_tn(dy2, bs["gact"], self.g(p + "mlp.fc2.weight"), M, C, hid, C, hid, hid, colsum=self.g(p + "mlp.fc2.bias"), partials=self.S.tn_partials(), defer_fold=_DEFER_FOLD)
             dh = _empty((M, hid), dt, dev)
             ops.gemm_nt(dy2, self.wT(p + "mlp.fc2.weight"), dh, M, hid, C, C, C, hid, act=2, H=bs["hpre"])
             bs["gact"] = bs["hpre"] = None
-            ops.gemm_tn(dh, bs["xn2"], self.g(p + "mlp.fc1.weight"), M, hid, C, hid, C, C, colsum=self.g(p + "mlp.fc1.bias"), partials=self.S.tn_partials())
+            ops.gemm_tn(dh, bs["xn2"], self.g(p + "mlp.fc1.weight"), M, hid, C, hid, C, C, colsum=self.g(p + "mlp.fc1.bias"), partials=self.S.tn_partials(), defer_fold=_DEFER_FOLD)
             ops.gemm_nt(dh, self.wT(p + "mlp.fc1.weight"), dxn2, M, C, hid, hid, hid, C)
             del dh
         # dx += LN2 backward = d(x_mid); the same kernel writes its DropPath-scaled copy, the gradient of the attention branch
@@ -551,7 +554,7 @@ class TrunkStep:
                         dgrad=(self.wT(p + "attn.proj.weight"), dao.view(M, C)))
         else:
             # (stages 3-4: 9-16 output tiles x 32-56 m-splits -- reduced through bf16 partial tiles + a fold instead of atomics: mvlt_gemm_tn_args.partials)
-            ops.gemm_tn(dy1, bs["ao"], self.g(p + "attn.proj.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.proj.bias"), partials=self.S.tn_partials())
+            ops.gemm_tn(dy1, bs["ao"], self.g(p + "attn.proj.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.proj.bias"), partials=self.S.tn_partials(), defer_fold=_DEFER_FOLD)
             ops.gemm_nt(dy1, self.wT(p + "attn.proj.weight"), dao, M, C, C, C, C, C)
         Mk = bs["Mk"]
         dq = _empty((B, N, C), dt, dev)
@@ -571,17 +574,17 @@ class TrunkStep:
             ops.gemm_tn(dq, bs["xn1"], self.g(p + "attn.q.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.q.bias"),
                         dgrad=(self.wT(p + "attn.q.weight"), dxn1.view(M, C)))
         else:
-            ops.gemm_tn(dq, bs["xn1"], self.g(p + "attn.q.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.q.bias"), partials=self.S.tn_partials())
+            ops.gemm_tn(dq, bs["xn1"], self.g(p + "attn.q.weight"), M, C, C, C, C, C, colsum=self.g(p + "attn.q.bias"), partials=self.S.tn_partials(), defer_fold=_DEFER_FOLD)
             ops.gemm_nt(dq, self.wT(p + "attn.q.weight"), dxn1, M, C, C, C, C, C)
         gkvw, gkvb = self.g(p + "attn.kv.weight"), self.g(p + "attn.kv.bias")
         wkvT = self.wT(p + "attn.kv.weight")
         if r > 1:
             HWr, pm = bs["HWr"], bs["pm"]
             # text keys come straight from LN1(x)[text rows]
-            ops.gemm_tn(dkv, bs["xn1"], gkvw, B * T, 2 * C, C, 2 * C, C, C, a_map=rowmap(T, Mk, HWr), b_map=rowmap(T, N, HW), colsum=gkvb, partials=self.S.tn_partials())
+            ops.gemm_tn(dkv, bs["xn1"], gkvw, B * T, 2 * C, C, 2 * C, C, C, a_map=rowmap(T, Mk, HWr), b_map=rowmap(T, N, HW), colsum=gkvb, partials=self.S.tn_partials(), defer_fold=_DEFER_FOLD)
             ops.gemm_nt(dkv, wkvT, dxn1, B * T, C, 2 * C, 2 * C, 2 * C, C, a_map=rowmap(T, Mk, HWr), c_map=rowmap(T, N, HW), R=dxn1)
             # image keys: kv <- LN(sr conv(LN1(x)[image rows]))
-            ops.gemm_tn(dkv, bs["kvin"], gkvw, B * HWr, 2 * C, C, 2 * C, C, C, a_map=rowmap(HWr, Mk, 0), colsum=gkvb, partials=self.S.tn_partials())
+            ops.gemm_tn(dkv, bs["kvin"], gkvw, B * HWr, 2 * C, C, 2 * C, C, C, a_map=rowmap(HWr, Mk, 0), colsum=gkvb, partials=self.S.tn_partials(), defer_fold=_DEFER_FOLD)
             dkvin = _empty((B * HWr, C), dt, dev)
             ops.gemm_nt(dkv, wkvT, dkvin, B * HWr, C, 2 * C, 2 * C, 2 * C, C, a_map=rowmap(HWr, Mk, 0))
             dsr = _empty((B * HWr, C), dt, dev)
@@ -591,7 +594,7 @@ class TrunkStep:
             conv_wgrad(self.S, p + "attn.sr.weight", dsr, bs["xn1"], B * HWr, C, K, C, C, pm, r * r, C, colsum=self.g(p + "attn.sr.bias"))
             ops.gemm_nt(dsr, self.wKT(p + "attn.sr.weight"), dxn1, B * HWr, K, C, C, C, C, c_map=pm, R=dxn1)
         else:
-            ops.gemm_tn(dkv, bs["xn1"], gkvw, M, 2 * C, C, 2 * C, C, C, colsum=gkvb, partials=self.S.tn_partials())
+            ops.gemm_tn(dkv, bs["xn1"], gkvw, M, 2 * C, C, 2 * C, C, C, colsum=gkvb, partials=self.S.tn_partials(), defer_fold=_DEFER_FOLD)
             ops.gemm_nt(dkv, wkvT, dxn1, M, C, 2 * C, 2 * C, 2 * C, C, R=dxn1)
         # the block below (processed next) scales this gradient by its own MLP-branch DropPath factor first thing when its MLP is not the
         # fused kernel (stages 3-4): norm1's backward writes that scaled copy in the same pass

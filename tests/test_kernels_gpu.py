@@ -345,6 +345,54 @@ def test_gemm_tn_partial_tiles_on_the_128_wide_kernel(ops, M, N1, N2):
     assert torch.equal(outs[0][0], outs[1][0])
 
 
+def test_gemm_tn_deferred_folds_equal_immediate_ones(ops):
+    """mvlt_gemm_tn_args.defer_fold: the partial tiles of several weight-gradient launches stay in the scratch and ONE launch folds them (mvlt_tn_fold_flush, or the library by
+    itself when its 32-entry table or the scratch is full, or when a non-deferring launch needs the scratch).  Bit-identical to folding behind every launch, whatever triggered
+    the fold; C untouched until then."""
+    from mvlt_amd._lib import last_kernel
+    dt = torch.bfloat16
+    shapes = [(49152, 512, 512), (24576, 320, 320), (16384, 2048, 512), (40000, 328, 512)]
+    ops_in = [(rnd(M, N1, dtype=dt, seed=3 * i, scale=0.5), rnd(M, N2, dtype=dt, seed=3 * i + 1, scale=0.5)) for i, (M, N1, N2) in enumerate(shapes)]
+    scratch = torch.empty(2048 * 65536, device=dev(), dtype=dt)
+
+    def run(defer, reps=1, small=None):
+        outs = []
+        for r in range(reps):
+            for (M, N1, N2), (A, B) in zip(shapes, ops_in):
+                Cw = torch.full((N1, N2), 0.25, device=dev())
+                ops.gemm_tn(A, B, Cw, M, N1, N2, N1, N2, N2, partials=scratch if small is None else small, defer_fold=defer)
+                outs.append(Cw)
+        return outs
+
+    want = run(False)
+    torch.cuda.synchronize()
+    got = run(True)
+    torch.cuda.synchronize()
+    assert all(bool((g == 0.25).all()) for g in got)                      # nothing folded yet
+    ops.tn_fold_flush()
+    torch.cuda.synchronize()
+    assert "tn_fold_multi_kernel" in last_kernel()
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    ops.tn_fold_flush()                                                   # nothing pending: no launch, no error
+    # more launches than the table (32) or the scratch holds: the library folds the earlier ones by itself, the last one is still pending
+    got = run(True, reps=5)
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[3], want[3]) and bool((got[-1] == 0.25).all())
+    # a non-deferring launch that needs the scratch folds what is pending first
+    Cn = torch.zeros(512, 512, device=dev())
+    ops.gemm_tn(ops_in[0][0], ops_in[0][1], Cn, 49152, 512, 512, 512, 512, 512, partials=scratch)
+    torch.cuda.synchronize()
+    assert all(torch.equal(g, w) for g, w in zip(got, want * 5)) and torch.equal(Cn + 0.25, want[0])
+    # a scratch that holds two of the partial sets but not three: folded when the next one does not fit
+    small = scratch[: 48 * 512 * 512 * 2 + 4096]
+    got = run(True, small=small)
+    ops.tn_fold_flush()
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert maxrel(g - 0.25, w - 0.25) < 5e-3                          # (the launches that did not fit took the atomic path)
+
+
 def test_gemm_tn_fused_input_gradient_is_never_skipped_silently(ops):
     """every launch path of mvlt_gemm_tn that cannot produce dgrad_out must refuse -- a silently unwritten input gradient is a wrong
     gradient.  fp32 operands (the generic kernel) with dgrad_out raise; a row-strided dX view (a column slice of a wider buffer) keeps its
