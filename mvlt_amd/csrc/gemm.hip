@@ -1633,7 +1633,18 @@ void fold_flush() {
 // the scratch region of this launch's partial tiles, or nullptr when they do not fit
 bf16* fold_acquire(const mvlt_gemm_tn_args& a, long need, hipStream_t s) {
   if (!a.partials || ((uintptr_t)a.partials & 15) || need > a.partials_bytes) return nullptr;
-  if (g_fp.b.n > 0 && (!a.defer_fold || g_fp.scratch != a.partials || g_fp.stream != s || g_fp.b.n == FOLD_MAX || g_fp.used + need > a.partials_bytes)) fold_flush();
+  bool flush = g_fp.b.n > 0 && (!a.defer_fold || g_fp.scratch != a.partials || g_fp.stream != s || g_fp.b.n == FOLD_MAX || g_fp.used + need > a.partials_bytes);
+  // two pending folds into the same gradient would be two unordered read-modify-writes in one launch (the kv weight gradient takes its text rows and its image rows from two
+  // GEMMs): an output that overlaps a pending one folds the pending ones first
+  const float* c_lo = a.C;
+  const float* c_hi = a.C + (size_t)(a.N1 - 1) * a.ldc + a.N2;
+  for (int i = 0; i < g_fp.b.n && !flush; ++i) {
+    const FoldDesc& d = g_fp.b.d[i];
+    const float* d_lo = d.C;
+    const float* d_hi = d.C + (size_t)(d.N1 - 1) * d.ldc + d.N2;
+    if (c_lo < d_hi && d_lo < c_hi) flush = true;
+  }
+  if (flush) fold_flush();
   if (!a.defer_fold) return (bf16*)a.partials;
   g_fp.scratch = a.partials;
   g_fp.stream = s;

@@ -375,6 +375,17 @@ def test_gemm_tn_deferred_folds_equal_immediate_ones(ops):
     for g, w in zip(got, want):
         assert torch.equal(g, w)
     ops.tn_fold_flush()                                                   # nothing pending: no launch, no error
+    # two deferring launches into the SAME gradient (the kv weights take their text rows and their image rows from two GEMMs): folded one after the other, not in one launch
+    (A0, B0), (A1, B1) = (rnd(49152, 512, dtype=dt, seed=40, scale=0.5), rnd(49152, 512, dtype=dt, seed=41, scale=0.5)), ops_in[0]
+    both = []
+    for defer in (False, True):
+        Cw = torch.zeros(512, 512, device=dev())
+        ops.gemm_tn(A0, B0, Cw, 49152, 512, 512, 512, 512, 512, partials=scratch, defer_fold=defer)
+        ops.gemm_tn(A1, B1, Cw[:256], 49152, 256, 512, 512, 512, 512, partials=scratch, defer_fold=defer)      # (an overlapping row range of it)
+        ops.tn_fold_flush()
+        torch.cuda.synchronize()
+        both.append(Cw)
+    assert torch.equal(both[0], both[1])
     # more launches than the table (32) or the scratch holds: the library folds the earlier ones by itself, the last one is still pending
     got = run(True, reps=5)
     torch.cuda.synchronize()
