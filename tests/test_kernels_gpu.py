@@ -1326,6 +1326,8 @@ def test_conv3x3_wgrad_lds_halo(ops, side, Cin, Cout, Bsz, tokens_extra):
                          [(32, 192, 192, 2, 0, "stats"), (32, 192, 192, 1, 0, "plain"), (32, 128, 128, 2, 128, "plain"), (32, 64, 64, 3, 0, "stats"),
                           (16, 128, 64, 5, 128, "plain"), (16, 64, 320, 4, 0, "strided"), (64, 64, 64, 1, 0, "acc"), (32, 64, 128, 2, 0, "acc"),
                           (16, 320, 64, 2, 0, "plain"),          # 320 channels: 5 slices
+                          (16, 128, 128, 3, 0, "plain"), (16, 192, 192, 2, 128, "stats"), (32, 128, 256, 1, 0, "plain"), (32, 64, 192, 2, 0, "strided"),      # 8-wave tiles: W = 16, two N tiles, batch-strided rows
+                          (32, 64, 128, 3, 0, "stats"), (16, 64, 128, 5, 0, "acc"),
                           (8, 64, 64, 3, 0, "plain"), (24, 64, 64, 2, 0, "plain"), (32, 72, 64, 1, 0, "plain")])      # not halo shapes -> generic gather
 def test_conv3x3_nt_lds_halo(ops, side, Cin, Cout, Bsz, tokens_extra, variant):
     """conv3_nt_kernel (mvlt_gemm_nt with the 3x3 gather on A, W in {16, 32, 64}, 64-multiples of channels): the nine taps read their A
