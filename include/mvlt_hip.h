@@ -116,7 +116,7 @@ typedef struct mvlt_gemm_tn_args {
   /* optional scratch for split reductions WITHOUT atomics (round 5): every m-split stores its output tile to partials[split][N1][N2] in bf16 and an ordered fold
    * (tn_fold_kernel) adds the splits to C -- deterministic (bit-identical from launch to launch), one bf16 rounding per split's partial sum (max-norm error 2e-3 of the
    * gradient instead of 1e-5).  Taken by (a) outputs of 16 .. 64 whole 256 x 256 tiles with M a multiple of 64 (the fc1 / fc2 weight gradients of a stage-4 block, 2048 x 512
-   * over 49152 rows: 8-wave / 8-phase TN kernel, 114 against 132 us), (b) the 128-wide kernel when >= 24 m-splits meet on an output of >= 65536 elements (q / proj / kv
+   * over 49152 rows: 8-wave / 8-phase TN kernel, 114 against 132 us), (b) the 128-wide kernel when >= 8 m-splits meet on an output of >= 65536 elements (q / proj / kv
    * weight gradients of stages 3-4: 40-45 against 53-56 us), (c) the conv3x3 weight-gradient kernel with >= 4 m-splits; bf16 operands, plain rows (b_map mode 2 for (c)),
    * trans_c == 0, c_taps <= 1.  A launch whose splits x N1 x N2 x 2 bytes exceed partials_bytes, or partials == NULL, takes the atomic path; 64 MiB covers every launch of
    * the BASELINE configurations (the largest: 56 splits x 192 x 1728 = 37 MiB). */

@@ -3011,9 +3011,10 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
     const int ns = (bmt + bn == 256) ? 2 : (bmt + bn == 192) ? 3 : 4;      // 64 / 72 / 64 KB of LDS: 2 workgroups per CU
     const size_t lds = (size_t)ns * TBK * (bmt + bn) * 2;
     dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * t1 * t2)), block(NTHREADS);
-    // many splits meeting on a mid-sized output (>= 24 splits: the C x C weight gradients of stages 3-4, 9-16 tiles x 32-56 splits): bf16 partial tiles into the caller's scratch
+    // several splits meeting on an output of >= 65536 elements (>= 8: the C x C and the fc weight gradients of stages 3-4; 24 while every fold was a launch of its own -- with the
+    // batched folds 16 / 8 / 4 / 2 all measure 12.98-13.00 k pairs/s against 12.90 at 24): bf16 partial tiles into the caller's scratch
     // + an ordered fold instead of the atomics (14-21 us of a 53-56 us launch, profiles/r05_tn_small_atomics_ablation.txt).  Fewer splits: the atomics are cheaper than a fold launch.
-    static const int part_min = getenv("MVLT_TN_PART_MIN") ? atoi(getenv("MVLT_TN_PART_MIN")) : 24;
+    static const int part_min = getenv("MVLT_TN_PART_MIN") ? atoi(getenv("MVLT_TN_PART_MIN")) : 8;
     bf16* const part = (tnp8 && a->partials && splits >= part_min && !a->trans_c && a->c_taps <= 1 && a->N2 % 8 == 0 && a->ldc % 4 == 0 && ((uintptr_t)a->C & 15) == 0 &&
                         (long)a->N1 * a->N2 >= 65536)
                            ? fold_acquire(*a, (long)splits * a->N1 * a->N2 * 2, s) : nullptr;

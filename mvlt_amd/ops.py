@@ -56,7 +56,7 @@ def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, co
     accumulated at column c*taps + tap (conv weight gradients straight into the [out][cin][kh][kw] layout).
     dgrad = (W^T [N2][N1] bf16, out [M, N2] bf16): the Linear's input gradient out = A @ W from the same pass over A (N1 == N2 in {64, 128}).
     partials = a scratch tensor (64 MiB covers every launch of the model): split reductions leave as bf16 partial tiles + an ordered fold instead of fp32 atomics where the
-    library has that mode (mvlt_gemm_tn_args.partials in include/mvlt_hip.h: whole 256 x 256 tiles, >= 24 m-splits on the 128-wide kernel, conv3x3 weight gradients); deterministic."""
+    library has that mode (mvlt_gemm_tn_args.partials in include/mvlt_hip.h: whole 256 x 256 tiles, >= 8 m-splits on the 128-wide kernel, conv3x3 weight gradients); deterministic."""
     assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype == torch.float32
     if colsum is not None:
         assert colsum.dtype == torch.float32

@@ -51,11 +51,11 @@ us = lambda k: fam.get(k, [0, 0.0])[1]
 t31 = f"""### 3.1 One steady-state step: {n_launch} launches, kernels busy {busy_ms:.2f} ms (`profiles/{tag}_step_launches.txt`)
 
 (The span from the step's first kernel to the optimizer's end is {span_ms:.2f} ms under `rocprofv3 --kernel-trace` -- {busy_pct:.1f} % busy; {n_aten} of the launches are ATen kernels, {n_copy} `copyBuffer`.
-Unprofiled the bench step equals the sum of the kernel durations.  The boxes of the pool differ by up to 5 % (19.5-20.4 ms for this build): family differences to `r04_step_launches.txt` below that are spread; the kernel changes of the round are the weight-gradient families (`gemm_tn_*` + `tn_fold_kernel`, `conv3_wgrad_kernel`: split reductions without atomics) and the helper row (cross entropy, label selection, weight prep).)
+Unprofiled the bench step equals the sum of the kernel durations.  The boxes of the pool differ by up to 5 % (19.4-20.5 ms for this build): family differences to `r04_step_launches.txt` below that are spread; the kernel changes of the round are the weight-gradient families (`gemm_tn_*` + `tn_fold_kernel`, `conv3_wgrad_kernel`: split reductions without atomics) and the helper row (cross entropy, label selection, weight prep).)
 
 | kernel family | launches | us / step | share | bound by (evidence) |
 |---|---|---|---|---|
-| `gemm_tn_dma_kernel` + `gemm_tn_p8_kernel` / `tn_fold_kernel` (weight gradients; 8 launches carry the input gradient too; the stage-4 MLP ones and every launch with >= 24 m-splits reduce through bf16 partial tiles + the batched fold (`tn_fold_multi_kernel`, 4 launches per step, the conv3x3 outputs included: counted here)) | {g('gemm_tn_dma')} | MFMA-bound shapes 0.24-0.38 of peak (3.2), the K <= 128 shapes HBM (4.5-5.6 TB/s); where atomics remain a split reduction costs outputs x splits / 0.3 ns (`experiments_r4.md` 2) |
+| `gemm_tn_dma_kernel` + `gemm_tn_p8_kernel` / `tn_fold_kernel` (weight gradients; 8 launches carry the input gradient too; the stage-4 MLP ones and every launch with >= 8 m-splits reduce through bf16 partial tiles + the batched fold (`tn_fold_multi_kernel`, 5 launches per step, the conv3x3 outputs included: counted here)) | {g('gemm_tn_dma')} | MFMA-bound shapes 0.24-0.38 of peak (3.2), the K <= 128 shapes HBM (4.5-5.6 TB/s); where atomics remain a split reduction costs outputs x splits / 0.3 ns (`experiments_r4.md` 2) |
 | `gemm_nt_dma_kernel` (128-wide NT GEMMs: K <= 128 projections, gathers, small heads) | {g('gemm_nt_dma')} | HBM for K = 64 / 128 (`proj64` sibling: 0.60-0.70 of 8 TB/s); TA / L1 path for the rest (`r03_l1_stalls.txt`) |
 | `gemm_nt_p8_kernel` (8-wave / 8-phase NT GEMMs, stage 3-4, MLM logits) | {g('gemm_nt_p8')} | K-loops alone 1.1-1.6 PFLOP/s (epilogue compiled out, `r05_p8_epilogue_ablation.txt`); the launches 0.23-0.57 of peak: whole-round quantisation + a VALU-bound epilogue (~15 instructions per output at two waves per SIMD) that a persistent grid does not hide (3.3, `experiments_r5.md` 3) |
 | `mlp_pipe_kernel` (fused MLP forward / input gradient, stages 1-2) | {g('mlp_pipe')} | VALU (GELU: 10 instructions per hidden element) + MFMA, partly overlapped: MFMA-busy 0.28-0.35, VALU-active 0.26-0.35 (`{tag}_mfma_counters.csv`) |
