@@ -185,35 +185,40 @@ __global__ __launch_bounds__(1024) void masked_select_loop_kernel(const long* la
   if (threadIdx.x == 0) *count = s_base;
 }
 __global__ __launch_bounds__(1024) void masked_select_kernel(const long* labels, int n, long ignore, int* idx, int* count) {
-  // thread t owns the contiguous labels [t * per, (t + 1) * per), per <= 64: their selection bits in one 64-bit mask (the loads in batches of eight, all in flight),
-  // one block-wide exclusive scan of the 1024 counts, then the indices leave in ascending order.  (Before: 1024 labels per trip, n / 1024 trips of one load + three
-  // barriers each on the only workgroup of the launch -- 40 us for 32768 labels with the chip idle.)
+  // wave w owns the contiguous labels [w * per * 64, (w + 1) * per * 64), per <= 64: row k of it is ONE coalesced 512-byte load (lane l takes label k * 64 + l; the rows in
+  // batches of eight, all in flight), its ballot a wave-uniform 64-bit mask; a selected lane's place = the wave's offset + the selected of the rows before + the selected
+  // lanes below it -- scalar arithmetic on the masks.  One pass, one barrier, ascending order.  (Round 5 first had 64 contiguous labels per THREAD: 21 us for 32768 labels,
+  // every load instruction touching 64 cache lines; before that 1024 labels per trip on one workgroup, a load and three barriers per trip: 40 us.)
   __shared__ int s_wave[16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int per = (n + 1023) / 1024;
-  const int p0 = threadIdx.x * per;
-  unsigned long long mask = 0ull;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int per = (n + 1023) / 1024;                   // rows of 64 labels per wave
+  const long w0 = (long)wave * per * 64;
+  int total = 0;
+  // pass 1: the wave's count (pass 2 recomputes the masks from the same, now cached, loads: up to 64 of them would not stay in scalar registers)
   for (int b = 0; b < per; b += 8) {
     long v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int p = p0 + b + u; v[u] = (b + u < per && p < n) ? labels[p] : ignore; }
+    for (int u = 0; u < 8; ++u) { const long p = w0 + (long)(b + u) * 64 + lane; v[u] = (b + u < per && p < n) ? labels[p] : ignore; }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) if (v[u] != ignore) mask |= 1ull << (b + u);
+    for (int u = 0; u < 8; ++u) total += __popcll(__ballot(v[u] != ignore));
   }
-  const int mine = __popcll(mask);
-  int incl = mine;                                    // inclusive scan over the wave
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-  if (lane == 63) s_wave[wave] = incl;
+  if (lane == 0) s_wave[wave] = total;
   __syncthreads();
-  int off = incl - mine;
-  for (int w = 0; w < wave; ++w) off += s_wave[w];
-  while (mask) {
-    const int b = __ffsll((long long)mask) - 1;
-    idx[off++] = p0 + b;
-    mask &= mask - 1;
+  int off = 0, all = 0;
+  for (int w = 0; w < 16; ++w) { const int c = s_wave[w]; if (w < wave) off += c; all += c; }
+  // pass 2: places
+  for (int b = 0; b < per; b += 8) {
+    long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const long p = w0 + (long)(b + u) * 64 + lane; v[u] = (b + u < per && p < n) ? labels[p] : ignore; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned long long m = __ballot(v[u] != ignore);
+      if (v[u] != ignore) idx[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)(w0 + (long)(b + u) * 64 + lane);
+      off += __popcll(m);
+    }
   }
-  if (threadIdx.x == 1023) *count = off;
+  if (threadIdx.x == 0) *count = all;
 }
 
 // ------------------------------------------------------------------ row gather / scatter-add
