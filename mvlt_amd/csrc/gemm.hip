@@ -1771,7 +1771,7 @@ __global__ __launch_bounds__(NTHREADS, BMT == 256 ? 2 : 1) void gemm_nt_dma_kern
   const int nsplit = p.split_k > 1 ? p.split_k : 1;
   const int kt_per = (nk_all + nsplit - 1) / nsplit;
   const int kt0 = blockIdx.y * kt_per;
-  int kpos = kt0 * BK + chunk * 8, seg = 0, kk = chunk * 8;
+  int kpos = kt0 * BK + chunk * 8, seg = 0, kk = kpos;                   // (a K split of a gathered A starts inside a later segment)
   if constexpr (AMODE != 0) { seg = kk / amap.c_seg; kk -= seg * amap.c_seg; }
   auto issue = [&](int slot) {                                  // tiles are issued in K order
     const bool k_ok = kpos < p.K;
@@ -2747,8 +2747,8 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   MVLT_REQUIRE(!a->row_scale || a->rows_per_scale > 0, "mvlt_gemm_nt: row_scale needs rows_per_scale");
   MVLT_REQUIRE((a->col_sum == nullptr) == (a->col_sumsq == nullptr), "mvlt_gemm_nt: col_sum and col_sumsq come together");
   MVLT_REQUIRE(a->split_k <= 1 || (a->dtype == 0 && a->out_dtype == 1 && a->act == 0 && !a->H && !a->R && !a->row_scale && !a->col_sum &&
-                                   a->a_map.mode == 0 && a->c_map.mode == 0 && a->split_k <= 64),
-               "mvlt_gemm_nt: split_k needs bf16 operands, fp32 C (zeroed by the caller) and a plain epilogue");
+                                   a->c_map.mode == 0 && a->split_k <= 64),
+               "mvlt_gemm_nt: split_k needs bf16 operands, fp32 C (zeroed by the caller) and a plain epilogue (A may be gathered)");
   MVLT_REQUIRE(a->col_copies >= 0, "mvlt_gemm_nt: col_copies < 0");
   MVLT_REQUIRE(!a->r_fp32 || (a->R && a->R != a->C && a->dtype == 0 && a->out_dtype == 0 && a->act == 0 && !a->col_sum && !a->post_y && a->split_k <= 1 && a->c_map.mode == 0 &&
                               a->N % 8 == 0 && a->ldc % 8 == 0 && (((uintptr_t)a->C | (uintptr_t)a->R) & 15) == 0 && a->M < (1 << 24) && !getenv("MVLT_NT_GENERIC_EPI")),

@@ -776,6 +776,29 @@ def test_patchify_matches_conv(ops, dtype):
     assert maxrel(P.float() @ W.reshape(Cout, -1).t(), ref) < TOL[dtype]
 
 
+def test_gemm_nt_split_k_with_patch_gather(ops):
+    """split_k on a gathered A operand (the spatial-reduction conv of stage 1: 8 x 8 patches of 64 channels, K = 4096, only 128 output tiles): the K ranges of the splits start
+    inside later patch segments; partial sums meet in a zeroed fp32 C, bias added once -- against F.conv2d, and against the unsplit launch"""
+    from mvlt_amd._lib import patchmap
+    Bsz, side, Cc, r, T = 4, 64, 64, 8, 16
+    N = side * side + T
+    x = rnd(Bsz, N, Cc, dtype=torch.bfloat16)
+    Wc = rnd(Cc, Cc, r, r, dtype=torch.float32, scale=0.05, seed=2)
+    bias = rnd(Cc, dtype=torch.float32, seed=3)
+    Wk = Wc.permute(0, 2, 3, 1).reshape(Cc, r * r * Cc).to(torch.bfloat16).contiguous()          # [out][kh][kw][cin]
+    sr = side // r
+    HWr = sr * sr
+    pm = patchmap(r, side, N, HWr, sr, Cc)
+    img = x[:, : side * side].float().reshape(Bsz, side, side, Cc).permute(0, 3, 1, 2)
+    ref = F.conv2d(img, Wk.float().view(Cc, r, r, Cc).permute(0, 3, 1, 2), bias, stride=r).permute(0, 2, 3, 1).reshape(Bsz * HWr, Cc)
+    one = torch.empty(Bsz * HWr, Cc, device=dev())
+    ops.gemm_nt(x, Wk, one, Bsz * HWr, Cc, r * r * Cc, Cc, r * r * Cc, Cc, a_map=pm, bias=bias)
+    for sk in (2, 4, 7):
+        out = torch.zeros(Bsz * HWr, Cc, device=dev())
+        ops.gemm_nt(x, Wk, out, Bsz * HWr, Cc, r * r * Cc, Cc, r * r * Cc, Cc, a_map=pm, bias=bias, split_k=sk)
+        assert maxrel(out, ref) < TOL[torch.bfloat16] and maxrel(out, one) < 1e-5, sk
+
+
 def test_masked_select_bit_exact(ops):
     for n, frac in ((128 * 4, 0.05), (32768, 0.04), (1000, 0.0), (5000, 1.0), (1, 1.0), (65536, 0.5), (1025, 0.5), (70001, 0.3)):
         lab = torch.where(torch.rand(n, device=dev()) < frac, torch.randint(0, 30522, (n,), device=dev()), torch.full((n,), -1, device=dev()))
