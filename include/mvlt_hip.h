@@ -24,7 +24,7 @@ extern "C" {
  *   2 (round 5): positional signatures of mvlt_batch_sum / mvlt_bn_norm / mvlt_bn_bwd_reduce / mvlt_bn_bwd_apply / mvlt_ew_mul / mvlt_ew_mul3_bwd as of
  *                round 4's second half (the number had stayed 1 through those changes: ADVICE r4)
  *   3 (round 5): mvlt_gemm_tn_args.partials / partials_bytes; mvlt_last_kernel()
- *   4: mvlt_weight_prep blk_desc      5: mvlt_gemm_tn_args.defer_fold, mvlt_tn_fold_flush() */
+ *   4: mvlt_weight_prep blk_desc      5: mvlt_gemm_tn_args.defer_fold, mvlt_tn_fold_flush(), mvlt_tn_fold_discard() */
 #define MVLT_ABI_VERSION 5
 const char* mvlt_last_error(void);
 int mvlt_abi_version(void);
@@ -129,6 +129,9 @@ typedef struct mvlt_gemm_tn_args {
 int mvlt_gemm_tn(const mvlt_gemm_tn_args* args, void* stream);
 /* fold every deferred partial-tile reduction now (one launch on the stream their producers ran on); nothing pending: no launch */
 int mvlt_tn_fold_flush(void* stream);
+/* forget the pending folds without launching them: a backward pass that raised leaves descriptors of gradients nobody will use (and whose buffers may be gone by the time the
+ * next pass starts) -- the start of a pass discards, it never folds */
+int mvlt_tn_fold_discard(void);
 
 /* y = LayerNorm(x) * gamma + beta (+ add[(row % add_rows)] ) over the last dim C; rows addressed through maps.
  * Replaces nn.LayerNorm at reference libs/pvlt.py:105,141,142,169,208 and libs/vl_heads.py:33 (eps differs per

@@ -2903,6 +2903,12 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   return mvlt_check_launch("mvlt_gemm_nt");
 }
 
+extern "C" int mvlt_tn_fold_discard(void) {
+  g_fp.b.n = 0;                                    // forget the pending folds without launching anything (their producers belong to a pass that was abandoned)
+  g_fp.used = 0;
+  return MVLT_OK;
+}
+
 extern "C" int mvlt_tn_fold_flush(void* stream) {
   (void)stream;                                   // the pending folds run on the stream their producers ran on
   fold_flush();

@@ -44,6 +44,11 @@ def tn_fold_flush():
     check(L.lib.mvlt_tn_fold_flush(stream_ptr()), "mvlt_tn_fold_flush")
 
 
+def tn_fold_discard():
+    """drop the pending deferred folds without running them (the start of a backward pass: whatever is pending then belongs to a pass that was abandoned)"""
+    check(L.lib.mvlt_tn_fold_discard(), "mvlt_tn_fold_discard")
+
+
 def weight_prep(desc_dev, blk_dev, ndesc, total_blocks, dtype, blk_desc=None):
     """desc_dev: uint8 device tensor holding ndesc packed mvlt_prep_desc; blk_dev: int32 device tensor [ndesc + 1]."""
     check(L.lib.mvlt_weight_prep(C.c_void_p(desc_dev.data_ptr()), C.c_void_p(blk_dev.data_ptr()), ndesc, total_blocks,

@@ -337,7 +337,7 @@ class FlatStore:
         self.wait_grads()                 # collectives of a pass nobody stepped (no-op normally)
         if self.G.is_cuda:
             from . import ops
-            ops.tn_fold_flush()           # folds a pass that raised left pending (no-op normally)
+            ops.tn_fold_discard()         # folds a pass that raised left pending (nothing, normally): dropped, never run -- their gradients are void, their buffers may be gone
         live = [(n, q) for n, q in self.fn_params if q.requires_grad]
         alias = [q.grad is not None and q.grad.data_ptr() == self.grad(n).data_ptr() for n, q in live]
         if not any(alias):

@@ -395,6 +395,12 @@ def test_gemm_tn_deferred_folds_equal_immediate_ones(ops):
     ops.gemm_tn(ops_in[0][0], ops_in[0][1], Cn, 49152, 512, 512, 512, 512, 512, partials=scratch)
     torch.cuda.synchronize()
     assert all(torch.equal(g, w) for g, w in zip(got, want * 5)) and torch.equal(Cn + 0.25, want[0])
+    # an abandoned pass: pending folds are dropped, nothing is written
+    got = run(True)
+    ops.tn_fold_discard()
+    ops.tn_fold_flush()
+    torch.cuda.synchronize()
+    assert all(bool((g == 0.25).all()) for g in got)
     # a scratch that holds two of the partial sets but not three: folded when the next one does not fit
     small = scratch[: 48 * 512 * 512 * 2 + 4096]
     got = run(True, small=small)
