@@ -24,8 +24,9 @@ extern "C" {
  *   2 (round 5): positional signatures of mvlt_batch_sum / mvlt_bn_norm / mvlt_bn_bwd_reduce / mvlt_bn_bwd_apply / mvlt_ew_mul / mvlt_ew_mul3_bwd as of
  *                round 4's second half (the number had stayed 1 through those changes: ADVICE r4)
  *   3 (round 5): mvlt_gemm_tn_args.partials / partials_bytes; mvlt_last_kernel()
- *   4: mvlt_weight_prep blk_desc      5: mvlt_gemm_tn_args.defer_fold, mvlt_tn_fold_flush(), mvlt_tn_fold_discard() */
-#define MVLT_ABI_VERSION 5
+ *   4: mvlt_weight_prep blk_desc      5: mvlt_gemm_tn_args.defer_fold, mvlt_tn_fold_flush(), mvlt_tn_fold_discard()
+ *   6 (round 6): mvlt_tn_fold_flush(partials, stream) / mvlt_tn_fold_discard(partials): the pending-fold table is kept per scratch (= per owner) */
+#define MVLT_ABI_VERSION 6
 const char* mvlt_last_error(void);
 int mvlt_abi_version(void);
 /* the kernel instantiation the library launched last on the calling thread, as the HIP runtime names it, demangled (e.g. "void (anonymous
@@ -118,8 +119,9 @@ typedef struct mvlt_gemm_tn_args {
    * gradient instead of 1e-5).  Taken by (a) outputs of 16 .. 64 whole 256 x 256 tiles with M a multiple of 64 (the fc1 / fc2 weight gradients of a stage-4 block, 2048 x 512
    * over 49152 rows: 8-wave / 8-phase TN kernel, 114 against 132 us), (b) the 128-wide kernel when >= 8 m-splits meet on an output of >= 65536 elements (q / proj / kv
    * weight gradients of stages 3-4: 40-45 against 53-56 us), (c) the conv3x3 weight-gradient kernel with >= 4 m-splits; bf16 operands, plain rows (b_map mode 2 for (c)),
-   * trans_c == 0, c_taps <= 1.  A launch whose splits x N1 x N2 x 2 bytes exceed partials_bytes, or partials == NULL, takes the atomic path; 64 MiB covers every launch of
-   * the BASELINE configurations (the largest: 56 splits x 192 x 1728 = 37 MiB). */
+   * trans_c == 0, c_taps <= 1.  A launch whose splits x N1 x N2 x 2 bytes exceed partials_bytes, or partials == NULL, takes the atomic path.  Sizing: the largest single
+   * launch of the BASELINE configurations needs 37 MiB (56 splits x 192 x 1728); with defer_fold several launches SHARE the scratch -- each takes the next free region, the
+   * library folds by itself when the next one does not fit -- so the host side holds 256 MiB per parameter store (MVLT_TN_SCRATCH_MIB): ~4 fold launches per step. */
   void* partials; long partials_bytes;
   /* 1: leave this launch's partial tiles in the scratch (each deferring launch takes the next free region of it) and fold them together with the next ones -- up to 32 per fold
    * launch; the library folds by itself when its table or the scratch is full or when a non-deferring launch needs the scratch, and when the caller says
@@ -127,11 +129,13 @@ typedef struct mvlt_gemm_tn_args {
   int defer_fold;
 } mvlt_gemm_tn_args;
 int mvlt_gemm_tn(const mvlt_gemm_tn_args* args, void* stream);
-/* fold every deferred partial-tile reduction now (one launch on the stream their producers ran on); nothing pending: no launch */
-int mvlt_tn_fold_flush(void* stream);
-/* forget the pending folds without launching them: a backward pass that raised leaves descriptors of gradients nobody will use (and whose buffers may be gone by the time the
- * next pass starts) -- the start of a pass discards, it never folds */
-int mvlt_tn_fold_discard(void);
+/* fold the deferred partial-tile reductions of the scratch `partials` (NULL: of every scratch) now: one launch per scratch on the stream their producers ran on; when `stream`
+ * -- the stream of whoever reads the gradients next -- is another one, it is made to wait for that launch (event).  Nothing pending: no launch.  The table of pending folds is
+ * kept PER SCRATCH under a mutex: two parameter stores (two models in one backward pass, two host threads) never see each other's entries (ABI 6). */
+int mvlt_tn_fold_flush(const void* partials, void* stream);
+/* forget the pending folds of `partials` (NULL: all) without launching them: a backward pass that raised leaves descriptors of gradients nobody will use (and whose buffers
+ * may be gone by the time the next pass starts) -- the start of a pass discards ITS OWN store's entries, it never folds */
+int mvlt_tn_fold_discard(const void* partials);
 
 /* y = LayerNorm(x) * gamma + beta (+ add[(row % add_rows)] ) over the last dim C; rows addressed through maps.
  * Replaces nn.LayerNorm at reference libs/pvlt.py:105,141,142,169,208 and libs/vl_heads.py:33 (eps differs per

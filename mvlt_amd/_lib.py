@@ -107,7 +107,7 @@ class MlpArgs(C.Structure):
 lib.mvlt_last_error.restype = C.c_char_p
 lib.mvlt_last_kernel.restype = C.c_char_p
 lib.mvlt_sizeof.argtypes = [C.c_char_p]
-ABI_VERSION = 5          # include/mvlt_hip.h MVLT_ABI_VERSION this binding was written against
+ABI_VERSION = 6          # include/mvlt_hip.h MVLT_ABI_VERSION this binding was written against
 if lib.mvlt_abi_version() != ABI_VERSION:
     raise ImportError(f"ABI mismatch: {LIB_PATH} is version {lib.mvlt_abi_version()}, the binding is version {ABI_VERSION} (stale build? run python -m mvlt_amd.build)")
 for _name, _cls in (("mvlt_rowmap", RowMap), ("mvlt_prep_desc", PrepDesc), ("mvlt_gemm_nt_args", GemmNTArgs), ("mvlt_gemm_tn_args", GemmTNArgs),

@@ -1,6 +1,7 @@
 // Shared device helpers for the MVLT gfx950 kernels (CDNA4 only: wave64, MFMA, 160 KB LDS).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
@@ -70,9 +71,18 @@ void mvlt_note_kernel(const void* host_function);
 
 // dynamic-LDS ceiling of a kernel instantiation raised to the 160 KB of a CU ONCE (the per-launch hipFuncSetAttribute calls of rounds 1-4 cost host time on
 // ~55 launches per step); what a launch occupies is still the size it asks for
+// -- once per (instantiation, DEVICE): the attribute is per device (a process that later launched on another GPU kept the 64 KB default there).  A failure is
+// remembered on the thread and named by mvlt_check_launch when the launch that needed the room then fails (instead of an opaque "invalid argument").
+void mvlt_note_lds_error(hipError_t e);
 template <auto K> inline void mvlt_max_lds() {
-  static const hipError_t e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)e;
+  static std::atomic<unsigned> done{0};            // bit d: device d has the ceiling raised
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned bit = 1u << (dev & 31);
+  if (done.load(std::memory_order_relaxed) & bit) return;
+  const hipError_t e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) { (void)hipGetLastError(); mvlt_note_lds_error(e); return; }
+  done.fetch_or(bit, std::memory_order_relaxed);
 }
 
 #define MVLT_REQUIRE(cond, ...)                 \

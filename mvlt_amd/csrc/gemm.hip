@@ -16,6 +16,8 @@
                              // GELU' is 10 instructions instead of 19.6 issue units: stage-4 GELU' dgrad 179 -> 157 us, stage-3 204 -> 181 us (same-box A/B, round 4)
 #include "common.h"
 #include <type_traits>
+#include <map>
+#include <mutex>
 #ifndef MVLT_NT_EARLY_DEFAULT
 #define MVLT_NT_EARLY_DEFAULT 0x100  // early slot release in the NT K-loop: logits GEMM 172 -> 163 us, step -0.16 ms (same-box A/B, MVLT_NT_EARLY=0 / 1)
 #endif
@@ -1615,40 +1617,51 @@ constexpr int FOLD_MAX = 32;
 struct FoldDesc { const bf16* part; float* C; int splits, N1, N2, ldc, wg0; };
 struct FoldBatch { FoldDesc d[FOLD_MAX]; int n, total_wgs; };
 __global__ void tn_fold_multi_kernel(FoldBatch b);
+// One pending table PER SCRATCH (= per owner: a FlatStore holds one scratch; ADVICE r5 -- a single process-global table let the start of one model's backward pass discard another
+// model's pending folds, and a launch on another stream reused the scratch while the old stream's fold still read it).  The map and its tables are guarded by g_fold_mu; the launches
+// themselves are asynchronous, so the lock is held for table bookkeeping + one enqueue.
 struct FoldPending {
   FoldBatch b = {};
-  void* scratch = nullptr;
   long used = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t ev = nullptr;                         // recorded behind a fold when ANOTHER stream is about to reuse the scratch / read the gradients
 };
-FoldPending g_fp;
-void fold_flush() {
-  if (g_fp.b.n > 0) {
-    g_fp.b.total_wgs = g_fp.b.d[g_fp.b.n - 1].wg0 + (int)(((long)g_fp.b.d[g_fp.b.n - 1].N1 * g_fp.b.d[g_fp.b.n - 1].N2 / 8 + 31) / 32);
-    MVLT_LAUNCH(tn_fold_multi_kernel, dim3((unsigned)g_fp.b.total_wgs), dim3(256), 0, g_fp.stream, g_fp.b);
+std::mutex g_fold_mu;
+std::map<const void*, FoldPending> g_fold;         // key: mvlt_gemm_tn_args.partials
+int fold_wgs(const FoldDesc& d) { return (int)(((long)d.N1 * d.N2 / 8 + 31) / 32); }
+// fold what is pending in `f` on the stream its producers ran on; `reader` (if it is another stream) is made to wait for that fold
+void fold_flush_locked(FoldPending& f, hipStream_t reader, bool order_reader) {
+  if (f.b.n > 0) {
+    f.b.total_wgs = f.b.d[f.b.n - 1].wg0 + fold_wgs(f.b.d[f.b.n - 1]);
+    MVLT_LAUNCH(tn_fold_multi_kernel, dim3((unsigned)f.b.total_wgs), dim3(256), 0, f.stream, f.b);
+    if (order_reader && reader != f.stream) {
+      if (!f.ev) (void)hipEventCreateWithFlags(&f.ev, hipEventDisableTiming);
+      if (f.ev && hipEventRecord(f.ev, f.stream) == hipSuccess) (void)hipStreamWaitEvent(reader, f.ev, 0);
+    }
   }
-  g_fp.b.n = 0;
-  g_fp.used = 0;
+  f.b.n = 0;
+  f.used = 0;
 }
 // the scratch region of this launch's partial tiles, or nullptr when they do not fit
 bf16* fold_acquire(const mvlt_gemm_tn_args& a, long need, hipStream_t s) {
   if (!a.partials || ((uintptr_t)a.partials & 15) || need > a.partials_bytes) return nullptr;
-  bool flush = g_fp.b.n > 0 && (!a.defer_fold || g_fp.scratch != a.partials || g_fp.stream != s || g_fp.b.n == FOLD_MAX || g_fp.used + need > a.partials_bytes);
+  std::lock_guard<std::mutex> lk(g_fold_mu);
+  FoldPending& f = g_fold[a.partials];
+  bool flush = f.b.n > 0 && (!a.defer_fold || f.stream != s || f.b.n == FOLD_MAX || f.used + need > a.partials_bytes);
   // two pending folds into the same gradient would be two unordered read-modify-writes in one launch (the kv weight gradient takes its text rows and its image rows from two
   // GEMMs): an output that overlaps a pending one folds the pending ones first
   const float* c_lo = a.C;
   const float* c_hi = a.C + (size_t)(a.N1 - 1) * a.ldc + a.N2;
-  for (int i = 0; i < g_fp.b.n && !flush; ++i) {
-    const FoldDesc& d = g_fp.b.d[i];
+  for (int i = 0; i < f.b.n && !flush; ++i) {
+    const FoldDesc& d = f.b.d[i];
     const float* d_lo = d.C;
     const float* d_hi = d.C + (size_t)(d.N1 - 1) * d.ldc + d.N2;
     if (c_lo < d_hi && d_lo < c_hi) flush = true;
   }
-  if (flush) fold_flush();
+  if (flush) fold_flush_locked(f, s, true);        // a launch on another stream writes region 0 only behind the old stream's fold
+  f.stream = s;
   if (!a.defer_fold) return (bf16*)a.partials;
-  g_fp.scratch = a.partials;
-  g_fp.stream = s;
-  return (bf16*)((char*)a.partials + g_fp.used);
+  return (bf16*)((char*)a.partials + f.used);
 }
 void fold_launch(const mvlt_gemm_tn_args& a, const bf16* part, int splits, hipStream_t s) {
   const long groups = (long)a.N1 * a.N2 / 8;
@@ -1656,11 +1669,13 @@ void fold_launch(const mvlt_gemm_tn_args& a, const bf16* part, int splits, hipSt
     MVLT_LAUNCH(tn_fold_kernel, dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, s, part, splits, a.N1, a.N2, a.C, a.ldc);
     return;
   }
-  FoldDesc& d = g_fp.b.d[g_fp.b.n];
+  std::lock_guard<std::mutex> lk(g_fold_mu);
+  FoldPending& f = g_fold[a.partials];
+  FoldDesc& d = f.b.d[f.b.n];
   d.part = part; d.C = a.C; d.splits = splits; d.N1 = a.N1; d.N2 = a.N2; d.ldc = a.ldc;
-  d.wg0 = g_fp.b.n == 0 ? 0 : g_fp.b.d[g_fp.b.n - 1].wg0 + (int)(((long)g_fp.b.d[g_fp.b.n - 1].N1 * g_fp.b.d[g_fp.b.n - 1].N2 / 8 + 31) / 32);
-  ++g_fp.b.n;
-  g_fp.used += ((long)splits * a.N1 * a.N2 * 2 + 255) & ~255L;
+  d.wg0 = f.b.n == 0 ? 0 : f.b.d[f.b.n - 1].wg0 + fold_wgs(f.b.d[f.b.n - 1]);
+  ++f.b.n;
+  f.used += ((long)splits * a.N1 * a.N2 * 2 + 255) & ~255L;
 }
 
 template <int W> int launch_conv3_wgrad(const mvlt_gemm_tn_args& a, hipStream_t s) {
@@ -1919,7 +1934,8 @@ template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_w
 
 // epilogue of the 80-column wave tile (BN 320 = 4 waves x 5 accumulator tiles): a 32-row half of the wave tile is 32 x 10 chunks of 8 columns =
 // 5 chunks per lane.  EPI 1: C = AB^T (+bias); EPI 2: C = (AB^T + bias) * row_scale + R.  Identity or batch-strided c_map, fp32 / bf16 output.
-template <int EPI, int TM>
+// CHK (round 6): the last row tile is ragged (M % 192 != 0: pvlt_medium at 384 px has 45056 rows per stage-3 launch) -- requests are clamped to the last row, rows past M are not stored.
+template <int EPI, int TM, bool CHK = false>
 __device__ __forceinline__ void nt_epilogue_w80(const mvlt_gemm_nt_args& p, f32x4 (&acc)[TM][5], char* smem, int m0, int n0, int wave, int lane) {
   static_assert(EPI == 1 || EPI == 2, "the 80-column wave tile carries the plain and the residual epilogue");
   constexpr int WN = 80, LDW = WN + 4, NH = TM / 2, NIT = 5;
@@ -1947,7 +1963,7 @@ __device__ __forceinline__ void nt_epilogue_w80(const mvlt_gemm_nt_args& p, f32x
     const int sl = half & 1;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int m = m0 + wm * (TM * 16) + half * 32 + rl[it];
+      const int m = CHK ? min(m0 + wm * (TM * 16) + half * 32 + rl[it], p.M - 1) : m0 + wm * (TM * 16) + half * 32 + rl[it];
       long phys = m;
       if (rpb > 0) {
         const int b = fdiv24(m, rpb, inv_rpb);
@@ -1979,6 +1995,7 @@ __device__ __forceinline__ void nt_epilogue_w80(const mvlt_gemm_nt_args& p, f32x
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
+      if (CHK && m0 + wm * (TM * 16) + half * 32 + rl[it] >= p.M) continue;
       const f32x4 v0 = *(const f32x4*)(stage + rl[it] * LDW + cc[it]), v1 = *(const f32x4*)(stage + rl[it] * LDW + cc[it] + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       if (p.bias) {
@@ -2187,7 +2204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(mvlt_gemm_nt_args p)
   // (whole tiles only: the bound checks go, -20 us on the GELU' launches; not for the residual epilogue, which measured 9 us SLOWER without them --
   //  49152 x 512 x 2048 + R 120 -> 129 us, same box, two passes: its prefetched rows are then requested in a different order)
   if constexpr (WNT == 4) nt_epilogue_lean<128, EPI, WMT, 4, EPI != 2 && !RAG>(p, acc, smem, m0, n0, wave, lane);
-  else nt_epilogue_w80<EPI, WMT>(p, acc, smem, m0, n0, wave, lane);
+  else nt_epilogue_w80<EPI, WMT, RAG>(p, acc, smem, m0, n0, wave, lane);
 }
 
 template <int EPI, int HM, int HN0, int HN1, bool RAG = false> void launch_nt_p8(const mvlt_gemm_nt_args& a, hipStream_t s) {
@@ -2871,6 +2888,18 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
         const long rounds = (tiles + 255) / 256;
         if (tiles >= 384 && (double)a->M * a->N >= 0.85 * (double)rounds * 256.0 * 65536.0) { launch_nt_p8<1, 4, 2, 2, true>(*a, s); done = true; }
       }
+      // ragged M on the 192 x 320 tile (round 6; N % 320 == 0, same epilogue rules as the whole-tile form): pvlt_medium at 384 px runs its 18 stage-3 blocks at
+      // M = 45056 = 234.67 x 192 rows -- 235 tiles = ONE round at 92 % -- and took the 128-wide kernels for every N = 320 product (fc2 76 us, fc1 input gradient 66 us,
+      // q / proj 27 us: profiles/r06_medium384_gemm_shapes.txt); taken when the whole rounds of padded tiles are >= 85 % real work
+      if (!done && !c320 && !c256 && !c192 && (ntp8 & 4) && a->N % 320 == 0 && a->N % 256 != 0 && a->M % 192 != 0 && (epi == 1 || (epi == 2 && (a->K >= 640 || (ntp8 & 16))))) {
+        const long tiles = (long)((a->M + 191) / 192) * (a->N / 320);
+        const long rounds = (tiles + 255) / 256;
+        if (tiles >= 192 && (double)a->M * a->N >= 0.85 * (double)rounds * 256.0 * 192.0 * 320.0) {
+          if (epi == 1) launch_nt_p8<1, 3, 3, 2, true>(*a, s);
+          else launch_nt_p8<2, 3, 3, 2, true>(*a, s);
+          done = true;
+        }
+      }
       if (done) return mvlt_check_launch("mvlt_gemm_nt");
       if (c320) done = dispatch_nt_p8<3, 3, 2>(*a, epi, s);
       else if (c256 && (!c192 || c256 <= c192)) done = dispatch_nt_p8<4, 2, 2>(*a, epi, s);
@@ -2903,15 +2932,19 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   return mvlt_check_launch("mvlt_gemm_nt");
 }
 
-extern "C" int mvlt_tn_fold_discard(void) {
-  g_fp.b.n = 0;                                    // forget the pending folds without launching anything (their producers belong to a pass that was abandoned)
-  g_fp.used = 0;
+extern "C" int mvlt_tn_fold_discard(const void* partials) {
+  // forget the pending folds of one scratch (NULL: of every scratch) without launching anything: their producers belong to a pass that was abandoned
+  std::lock_guard<std::mutex> lk(g_fold_mu);
+  for (auto& kv : g_fold)
+    if (!partials || kv.first == partials) { kv.second.b.n = 0; kv.second.used = 0; }
   return MVLT_OK;
 }
 
-extern "C" int mvlt_tn_fold_flush(void* stream) {
-  (void)stream;                                   // the pending folds run on the stream their producers ran on
-  fold_flush();
+extern "C" int mvlt_tn_fold_flush(const void* partials, void* stream) {
+  // the pending folds run on the stream their producers ran on; `stream` -- the stream of whoever reads the gradients next -- waits for them when it is another one
+  std::lock_guard<std::mutex> lk(g_fold_mu);
+  for (auto& kv : g_fold)
+    if (!partials || kv.first == partials) fold_flush_locked(kv.second, (hipStream_t)stream, true);
   return mvlt_check_launch("mvlt_tn_fold_flush");
 }
 

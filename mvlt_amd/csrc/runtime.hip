@@ -14,10 +14,17 @@ void mvlt_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local hipError_t g_lds_err = hipSuccess;
+void mvlt_note_lds_error(hipError_t e) { g_lds_err = e; }
+
 int mvlt_check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
-    mvlt_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    if (g_lds_err != hipSuccess)
+      mvlt_set_error("%s: launch failed: %s (raising the kernel's dynamic-LDS limit to 160 KB had failed on this device: %s)", what, hipGetErrorString(e), hipGetErrorString(g_lds_err));
+    else
+      mvlt_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    g_lds_err = hipSuccess;
     return MVLT_ERR_LAUNCH;
   }
   return MVLT_OK;

@@ -39,14 +39,16 @@ def gemm_nt(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_map=None, c_map=None, bias
     return C_out
 
 
-def tn_fold_flush():
-    """fold every partial-tile reduction that gemm_tn(defer_fold=True) left pending (one launch; none pending: none)"""
-    check(L.lib.mvlt_tn_fold_flush(stream_ptr()), "mvlt_tn_fold_flush")
+def tn_fold_flush(partials=None):
+    """fold the partial-tile reductions that gemm_tn(partials=..., defer_fold=True) left pending in that scratch (None: in every scratch): one launch per scratch on the
+    producers' stream, which the current stream waits for if it is another one; none pending: none"""
+    check(L.lib.mvlt_tn_fold_flush(ptr(partials), stream_ptr()), "mvlt_tn_fold_flush")
 
 
-def tn_fold_discard():
-    """drop the pending deferred folds without running them (the start of a backward pass: whatever is pending then belongs to a pass that was abandoned)"""
-    check(L.lib.mvlt_tn_fold_discard(), "mvlt_tn_fold_discard")
+def tn_fold_discard(partials=None):
+    """drop the pending deferred folds of that scratch (None: all) without running them (the start of a backward pass: whatever its store has pending then belongs to a
+    pass that was abandoned)"""
+    check(L.lib.mvlt_tn_fold_discard(ptr(partials)), "mvlt_tn_fold_discard")
 
 
 def weight_prep(desc_dev, blk_dev, ndesc, total_blocks, dtype, blk_desc=None):
@@ -60,7 +62,7 @@ def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, co
     """C[N1,N2] += A[M,N1]^T @ B[M,N2] (fp32 atomics); colsum[N1] += A.sum(0).  taps > 1: logical column tap*seg + c is
     accumulated at column c*taps + tap (conv weight gradients straight into the [out][cin][kh][kw] layout).
     dgrad = (W^T [N2][N1] bf16, out [M, N2] bf16): the Linear's input gradient out = A @ W from the same pass over A (N1 == N2 in {64, 128}).
-    partials = a scratch tensor (64 MiB covers every launch of the model): split reductions leave as bf16 partial tiles + an ordered fold instead of fp32 atomics where the
+    partials = a scratch tensor (the largest single launch of the model needs 37 MiB; deferring launches share it region by region: FlatStore holds 256 MiB): split reductions leave as bf16 partial tiles + an ordered fold instead of fp32 atomics where the
     library has that mode (mvlt_gemm_tn_args.partials in include/mvlt_hip.h: whole 256 x 256 tiles, >= 8 m-splits on the 128-wide kernel, conv3x3 weight gradients); deterministic."""
     assert A.dtype == B.dtype and A.dtype in DT and C_out.dtype == torch.float32
     if colsum is not None:

@@ -337,7 +337,8 @@ class FlatStore:
         self.wait_grads()                 # collectives of a pass nobody stepped (no-op normally)
         if self.G.is_cuda:
             from . import ops
-            ops.tn_fold_discard()         # folds a pass that raised left pending (nothing, normally): dropped, never run -- their gradients are void, their buffers may be gone
+            if getattr(self, "_tn_partials", None) is not None:
+                ops.tn_fold_discard(self._tn_partials)         # THIS store's folds (the table is kept per scratch) a pass that raised left pending (nothing, normally): dropped, never run -- their gradients are void, their buffers may be gone
         live = [(n, q) for n, q in self.fn_params if q.requires_grad]
         alias = [q.grad is not None and q.grad.data_ptr() == self.grad(n).data_ptr() for n, q in live]
         if not any(alias):
@@ -457,7 +458,7 @@ class FlatStore:
         if early and self.on_range_ready is None and not _EARLY_FOLDS:
             return
         if self.G.is_cuda:
-            ops.tn_fold_flush()              # deferred partial-tile folds of the weight-gradient GEMMs (their conv outputs land in the tap arena folded next)
+            self.tn_fold_flush()             # deferred partial-tile folds of the weight-gradient GEMMs (their conv outputs land in the tap arena folded next)
         if getattr(self, "_tap_lo", None) is not None:
             ops.fold_copies(self._tap_arena, 1, self._tap_arena.numel(), self._tap_index, self._tap_lo, self._tap_hi, self.G)
             self._tap_lo = self._tap_hi = None
@@ -520,6 +521,8 @@ class FlatStore:
             return
         r = self.prefix_range(tuple(prefixes))
         if r is not None:
+            if self.G.is_cuda:
+                self.tn_fold_flush()      # a range leaves only with its deferred folds applied (no-op when nothing is pending: no head defers today -- ADVICE r5)
             self._ranges_done.append(r)
             self.on_range_ready(self, *r)
 
@@ -529,6 +532,12 @@ class FlatStore:
             self.pending_grad_scale *= factor
         else:
             self.G.mul_(factor)
+
+    def tn_fold_flush(self):
+        """fold what this store's weight-gradient launches left pending in its scratch (nothing allocated: nothing pending)"""
+        if getattr(self, "_tn_partials", None) is not None:
+            from . import ops
+            ops.tn_fold_flush(self._tn_partials)
 
     def tn_partials(self):
         """256 MiB of persistent scratch for the atomic-free reduction of the weight-gradient GEMMs (mvlt_gemm_tn_args.partials): bf16 partial tiles [splits][N1][N2].  The

@@ -42,6 +42,11 @@ CASES = {
     "tiny384_pretrain": dict(variant="pvlt_tiny", img=384, T=128, B=1, lt=dict(mlm=1, itm=1, t2i=1, cls=0), dp=0.0, train=False),
     "medium384_pretrain": dict(variant="pvlt_medium", img=384, T=128, B=1, lt=dict(mlm=1, itm=1, t2i=1, cls=0), dp=0.0, train=True),
     "small96_T20_ragged": dict(variant="pvlt_small", img=96, T=20, B=3, lt=dict(mlm=1, itm=1, t2i=1, cls=1), dp=0.1, train=True),
+    # round 6: the step at sizes that select the large-M kernel variants (store-once attention backward from
+    # B x heads >= 512, >= 8-split partial tiles + deferred folds, whole-round 8-phase tiles), config #4 at batch 8, and the fourth factory
+    "tiny256_pretrain_b64": dict(variant="pvlt_tiny", img=256, T=128, B=64, lt=dict(mlm=1, itm=1, t2i=1, cls=0), dp=0.1, train=True, steps=(1,)),
+    "medium384_pretrain_b8": dict(variant="pvlt_medium", img=384, T=128, B=8, lt=dict(mlm=1, itm=1, t2i=1, cls=0), dp=0.1, train=True, steps=(1,)),
+    "large96_T20": dict(variant="pvlt_large", img=96, T=20, B=3, lt=dict(mlm=1, itm=1, t2i=1, cls=1), dp=0.1, train=True, steps=(1,)),
 }
 
 
@@ -207,7 +212,10 @@ def run_case(name, c):
     if out_ref["t2i_logits"] is not None:
         t = out_ref["t2i_logits"]
         s = max(1, c["img"] // 16)
-        G["eval/t2i/grid"] = t[:, :, ::s, ::s].numpy().copy()
+        bs = max(1, c["B"] // 8)                 # large batches: every bs-th image (the fixtures stay small)
+        G["eval/t2i/grid"] = t[::bs, :, ::s, ::s].numpy().copy()
+        if bs > 1:
+            G["eval/t2i/grid_bstride"] = np.array(bs)
     l_eval = O.losses(out_ref, batch)
     for k, v in l_eval.items():
         G[f"eval/loss/{k}"] = np.array(float(v))
@@ -215,7 +223,7 @@ def run_case(name, c):
 
     # ---------------- train-mode step (forward + loss + backward), injected masks
     if c["train"]:
-        for step_idx in (0, 1):
+        for step_idx in c.get("steps", (0, 1)):
             if step_idx == 1 and not c["lt"]["t2i"]:
                 continue
             masks = make_masks(cfg, c["B"], c["T"], SEED + step_idx)

@@ -588,3 +588,75 @@ def test_tools_index_lists_every_script():
     missing = [f for f in sorted(os.listdir(os.path.join(ROOT, "tools")))
                if f.endswith((".py", ".sh")) and f != "job_tmp.sh" and f"`{f}" not in idx and f"`{f[:-3]}" not in idx and f not in idx]
     assert not missing, missing
+
+
+def test_timm_create_model_path(tmp_path):
+    """reference main_vl.py:25 + :259-270: `from libs import utils, pvlt` registers the factories in timm's registry as an import side effect and
+    `timm.models.create_model(args.model, pretrained=True, num_classes=1000, drop_rate=, drop_path_rate=, drop_block_rate=None, token_hidden_size=,
+    num_text_tokens=, loss_type=, pretrained_pth=)` builds the model.  timm is not installed here: a stand-in with the published behaviour of timm==0.3.2's
+    `register_model` (keyed by fn.__name__, appends to the defining module's __all__) and `create_model` (forwards pretrained / num_classes / in_chans=3,
+    drops drop_block_rate when it is None) is put on the path of a fresh interpreter, which then does exactly what main_vl.py does."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = tmp_path / "timm" / "models"
+    pkg.mkdir(parents=True)
+    (tmp_path / "timm" / "__init__.py").write_text("")
+    (pkg / "registry.py").write_text(textwrap.dedent("""
+        import sys
+        _model_entrypoints = {}
+        def register_model(fn):
+            mod = sys.modules[fn.__module__]
+            name = fn.__name__
+            if hasattr(mod, '__all__'):
+                mod.__all__.append(name)
+            else:
+                mod.__all__ = [name]
+            _model_entrypoints[name] = fn
+            return fn
+        def is_model(name):
+            return name in _model_entrypoints
+        def model_entrypoint(name):
+            return _model_entrypoints[name]
+    """))
+    (pkg / "__init__.py").write_text(textwrap.dedent("""
+        from .registry import is_model, model_entrypoint
+        def create_model(model_name, pretrained=False, num_classes=1000, in_chans=3, checkpoint_path='', **kwargs):
+            model_args = dict(pretrained=pretrained, num_classes=num_classes, in_chans=in_chans)
+            for k in ('bn_tf', 'bn_momentum', 'bn_eps'):
+                kwargs.pop(k, None)
+            if kwargs.get('drop_block_rate', None) is None:
+                kwargs.pop('drop_block_rate', None)
+            if kwargs.pop('drop_connect_rate', None) is not None and kwargs.get('drop_path_rate', None) is None:
+                raise AssertionError('not used by main_vl.py')
+            if not is_model(model_name):
+                raise RuntimeError('Unknown model (%s)' % model_name)
+            return model_entrypoint(model_name)(**model_args, **kwargs)
+    """))
+    script = textwrap.dedent(f"""
+        import sys
+        sys.path[:0] = [{str(tmp_path)!r}, {root!r}]
+        from libs import pvlt                              # main_vl.py:25 (the import registers)
+        from timm.models import create_model
+        from timm.models.registry import _model_entrypoints
+        assert sorted(_model_entrypoints) == ['pvlt_large', 'pvlt_medium', 'pvlt_small', 'pvlt_tiny'], sorted(_model_entrypoints)
+        lt = dict(mlm=1, itm=1, t2i=1, cls=0)
+        model = create_model('pvlt_tiny', pretrained=True, num_classes=1000, drop_rate=0.0, drop_path_rate=0.1, drop_block_rate=None,
+                             token_hidden_size=768, num_text_tokens=128, loss_type=lt, pretrained_pth=None)          # main_vl.py:259-270
+        from oracle import pvlt_oracle as O
+        cfg = O.Cfg('pvlt_tiny', lt, 224, 768, 128, 0.1)
+        want = [(k, tuple(s)) for k, s in O.param_shapes(cfg).items()]
+        got = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+        assert got == want
+        assert model.dpr == cfg.dpr and hasattr(model, 'default_cfg')
+        try:
+            create_model('pvlt_tiny', pretrained=True, drop_block_rate=0.1, token_hidden_size=768, num_text_tokens=128, loss_type=lt, pretrained_pth=None)
+        except TypeError:
+            pass                                           # a drop_block_rate that IS set reaches the factory and is refused there, as in the reference
+        print('CREATE_MODEL_OK', len(got))
+    """)
+    env = dict(os.environ)
+    env.pop("PYTHONPATH", None)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "CREATE_MODEL_OK 266" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -109,6 +109,40 @@ def test_gemm_nt_ragged_rows_and_columns(ops, M, N, K, ldc, odt):
     assert torch.equal(buf, again), "launch-to-launch difference"
 
 
+@pytest.mark.parametrize("M,N,K", [(45056, 320, 1280), (45056, 320, 320), (9000, 1600, 640)])
+def test_gemm_nt_ragged_rows_on_the_192x320_tile(ops, M, N, K):
+    """round 6: N % 320 == 0 with M not a multiple of 192 (pvlt_medium at 384 px: 45056 rows per stage-3 launch = 234.67 row tiles = one round at 92 %) on the ragged
+    form of the 8-phase 192 x 320 tile: the plain and the residual epilogue (the K = 320 residual product stays on the 128-wide kernel, as with whole tiles), guard
+    rows behind the last one untouched, bit-identical second launch, fp32 reference."""
+    from mvlt_amd._lib import last_kernel
+    dt = torch.bfloat16
+    A, W = rnd(M, K, dtype=dt), rnd(N, K, dtype=dt, seed=1, scale=0.2)
+    bias = rnd(N, dtype=torch.float32, seed=2)
+    ref = A.float() @ W.float().t() + bias
+    for odt in (dt, torch.float32):
+        buf = torch.full((M + 192, N), 7.0, device=dev(), dtype=odt)
+        ops.gemm_nt(A, W, buf, M, N, K, K, K, N, bias=bias)
+        assert "gemm_nt_p8_kernel<1, 3, 3, 2, true>" in last_kernel(), last_kernel()
+        assert maxrel(buf[:M].float(), ref) < TOL[dt]
+        assert (buf[M:] == 7.0).all(), "wrote behind the last row"
+        again = torch.full_like(buf, 7.0)
+        ops.gemm_nt(A, W, again, M, N, K, K, K, N, bias=bias)
+        assert torch.equal(buf, again), "launch-to-launch difference"
+    Bsz = 8
+    rps = (M + Bsz - 1) // Bsz
+    scale = torch.tensor([0.0, 1.0 / 0.9, 1.0, 1.0 / 0.9, 0.0, 1.0, 1.0, 1.0 / 0.9], device=dev())
+    Rres = rnd(M, N, dtype=torch.float32, seed=7)
+    want = ref * scale.repeat_interleave(rps)[:M, None] + Rres
+    out = torch.full((M + 192, N), 7.0, device=dev())
+    out[:M] = Rres
+    ops.gemm_nt(A, W, out, M, N, K, K, K, N, bias=bias, row_scale=scale, rows_per_scale=rps, R=out)
+    assert ("gemm_nt_p8_kernel<2, 3, 3, 2, true>" in last_kernel()) == (K >= 640), last_kernel()
+    assert maxrel(out[:M], want) < TOL[dt] and (out[M:] == 7.0).all()
+    o16 = torch.full((M + 192, N), 7.0, device=dev(), dtype=dt)                     # fp32 residual beside a bf16 C (the last block of a stage)
+    ops.gemm_nt(A, W, o16, M, N, K, K, K, N, bias=bias, row_scale=scale, rows_per_scale=rps, R=Rres)
+    assert torch.equal(o16[:M], out[:M].to(dt)) and (o16[M:] == 7.0).all()
+
+
 @pytest.mark.parametrize("M,N", [(6400, 2048), (6144, 2048), (7680, 1600)])      # -> 256 x 256, 192 x 256, 192 x 320 tiles (host dispatch by whole rounds)
 @pytest.mark.parametrize("K", [128, 320, 512, 64 * 7])
 def test_gemm_nt_8phase_tiles(ops, K, M, N):
@@ -401,6 +435,37 @@ def test_gemm_tn_deferred_folds_equal_immediate_ones(ops):
     ops.tn_fold_flush()
     torch.cuda.synchronize()
     assert all(bool((g == 0.25).all()) for g in got)
+    # ---- round 6: the pending table is kept PER SCRATCH.  Two owners (two parameter stores in one backward pass): discarding / flushing one leaves the
+    # other's entries alone; a launch on another stream folds what its scratch has pending on the OLD stream and orders itself behind that fold.
+    other = torch.empty(64 * 65536 * 8, device=dev(), dtype=dt)
+    (M, N1, N2), (A, B) = shapes[0], ops_in[0]
+    Ca, Cb = torch.full((N1, N2), 0.25, device=dev()), torch.full((N1, N2), 0.25, device=dev())
+    ops.gemm_tn(A, B, Ca, M, N1, N2, N1, N2, N2, partials=scratch, defer_fold=True)
+    ops.gemm_tn(A, B, Cb, M, N1, N2, N1, N2, N2, partials=other, defer_fold=True)
+    ops.tn_fold_discard(other)                                            # the second store starts a new pass: ITS entries go
+    ops.tn_fold_flush(other)
+    torch.cuda.synchronize()
+    assert bool((Ca == 0.25).all()) and bool((Cb == 0.25).all())          # the first store's fold is still pending, untouched
+    ops.tn_fold_flush(scratch)
+    torch.cuda.synchronize()
+    assert torch.equal(Ca, want[0]) and bool((Cb == 0.25).all())
+    side = torch.cuda.Stream()
+    Ca.fill_(0.25)
+    Cs = torch.full((N1, N2), 0.25, device=dev())
+    ops.gemm_tn(A, B, Ca, M, N1, N2, N1, N2, N2, partials=scratch, defer_fold=True)            # pending on the current stream
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.gemm_tn(A, B, Cs, M, N1, N2, N1, N2, N2, partials=scratch, defer_fold=True)        # region 0 again: folds Ca on the old stream first, waits for it
+        ops.tn_fold_flush(scratch)
+    torch.cuda.synchronize()
+    assert torch.equal(Ca, want[0]) and torch.equal(Cs, want[0])
+    with torch.cuda.stream(side):
+        Cs.fill_(0.25)
+        ops.gemm_tn(A, B, Cs, M, N1, N2, N1, N2, N2, partials=scratch, defer_fold=True)
+    ops.tn_fold_flush(scratch)                                            # a reader on ANOTHER stream than the producers': ordered behind the fold by an event
+    got_now = Cs.clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got_now, want[0])
     # a scratch that holds two of the partial sets but not three: folded when the next one does not fit
     small = scratch[: 48 * 512 * 512 * 2 + 4096]
     got = run(True, small=small)

@@ -18,7 +18,8 @@ CASES = {
     "tiny224_pretrain": dict(variant="pvlt_tiny", lt=dict(mlm=1, itm=1, t2i=1, cls=0), train=False),
     "tiny384_pretrain": dict(variant="pvlt_tiny", lt=dict(mlm=1, itm=1, t2i=1, cls=0), train=False),
     "small96_T20_ragged": dict(variant="pvlt_small", lt=dict(mlm=1, itm=1, t2i=1, cls=1), train=True),
-}
+    "large96_T20": dict(variant="pvlt_large", lt=dict(mlm=1, itm=1, t2i=1, cls=1), train=True),        # the fourth factory (round 6); the batch-64 / medium batch-8
+}                                                                                                          # fixtures are GPU-suite cases (minutes per pass on CPU)
 TOL = 2e-4   # fp32 CPU vs fp32 CPU on another host/thread count: summation-order noise only
 
 
@@ -72,7 +73,7 @@ def test_eval_forward_matches_reference_golden(golden_dir, name):
         assert abs(float(v) - float(g[f"eval/loss/{k}"])) <= TOL * max(1.0, abs(float(g[f"eval/loss/{k}"]))), k
 
 
-@pytest.mark.parametrize("name", ["tiny256_pretrain", "small96_T20_ragged"])
+@pytest.mark.parametrize("name", ["tiny256_pretrain", "small96_T20_ragged", "large96_T20"])
 def test_train_step_matches_reference_golden(golden_dir, name):
     """loss + every parameter gradient of one train-mode step with injected dropout/DropPath masks."""
     from tests.golden.make_golden import make_masks

@@ -3,6 +3,7 @@
 engine iteration, then re-times each distinct shape alone (HIP events, 10 reps) and prints count x time per step.
 
     gpurun -- 'python tools/gemm_shapes.py > gpurun_out/gemm_shapes.txt'
+    MODEL=pvlt_medium IMG=384 B=64 python tools/gemm_shapes.py        (BASELINE configuration #4)
 """
 import os
 import sys
@@ -21,10 +22,11 @@ def main():
     B = int(os.environ.get("B", "256"))
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    model = pvlt.pvlt_tiny(pretrained=False, token_hidden_size=768, num_text_tokens=128, loss_type=dict(mlm=1, itm=1, t2i=1, cls=0),
+    IMG = int(os.environ.get("IMG", "256"))
+    model = getattr(pvlt, os.environ.get("MODEL", "pvlt_tiny"))(pretrained=False, token_hidden_size=768, num_text_tokens=128, loss_type=dict(mlm=1, itm=1, t2i=1, cls=0),
                            pretrained_pth=None, drop_path_rate=0.1, drop_rate=0.0, num_classes=1000, in_chans=3).cuda(dev)
     model.train()
-    batch = bench.synth_batch(B, 256, 128, dev, 1)
+    batch = bench.synth_batch(B, IMG, 128, dev, 1)
     batch["mlm_positions"] = torch.nonzero(batch["mlm_labels"].reshape(-1) != -1).flatten().to(torch.int32)
     with torch.no_grad():
         model.eval(); model(batch["image"][:2], batch["input_ids"][:2]); model.train()
