@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, first GPU job: this box's baseline line + kernel trace / per-shape inventory of BASELINE configurations #4 (pvlt_medium, 384 px, batch 64) and #5 (fine-tune)
+# kernel trace / per-shape inventory of BASELINE configurations #4 (pvlt_medium, 384 px, batch 64) and #5 (fine-tune)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
