@@ -25,7 +25,8 @@ extern "C" {
  *                round 4's second half (the number had stayed 1 through those changes: ADVICE r4)
  *   3 (round 5): mvlt_gemm_tn_args.partials / partials_bytes; mvlt_last_kernel()
  *   4: mvlt_weight_prep blk_desc      5: mvlt_gemm_tn_args.defer_fold, mvlt_tn_fold_flush(), mvlt_tn_fold_discard()
- *   6 (round 6): mvlt_tn_fold_flush(partials, stream) / mvlt_tn_fold_discard(partials): the pending-fold table is kept per scratch (= per owner) */
+ *   6 (round 6): mvlt_tn_fold_flush(partials, stream) / mvlt_tn_fold_discard(partials): the pending-fold table is kept per scratch (= per owner);
+ *                mvlt_sr_attention_bwd_chunks() */
 #define MVLT_ABI_VERSION 6
 const char* mvlt_last_error(void);
 int mvlt_abi_version(void);
@@ -218,9 +219,14 @@ typedef struct mvlt_attn_bwd_args {
   float scale;
   int dtype;
   int dkv_dtype;   /* 1 (default use): dKV is fp32.  0: dKV is bf16 [B, M, lddkv] and takes the plain stores of the one-chunk case
-                      directly (allowed only when B*H >= 512 and dtype == 0: no atomics, so no fp32 staging buffer and no cast) */
+                      directly (dtype == 0 only; FORCES one query chunk per (batch, head): no atomics, so no fp32 staging buffer and no cast --
+                      worth it exactly when mvlt_sr_attention_bwd_chunks() says 1 anyway) */
 } mvlt_attn_bwd_args;
 int mvlt_sr_attention_bwd(const mvlt_attn_bwd_args* args, void* stream);
+/* number of query chunks per (batch, head) the backward would split an fp32-dKV launch of this shape into (dtype: MVLT_DT_*): 1 = every dK / dV element is
+ * stored exactly once -- the caller may then hand a bf16 dKV (dkv_dtype 0) and skip the zero fill and the cast; > 1 = the chunks meet in fp32 atomics on a
+ * caller-zeroed buffer.  Cost model in csrc/attention.hip (whole rounds of the chip x query tiles + atomics), fitted in round 6 (ABI 6). */
+int mvlt_sr_attention_bwd_chunks(int B, int H, int N, int M, int dtype);
 
 /* ---- HBM-bound helpers (mvlt_amd/csrc/elementwise.hip) ------------------------------------------------------- */
 

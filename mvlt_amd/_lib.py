@@ -125,7 +125,7 @@ EXPORTS = ["mvlt_last_error", "mvlt_last_kernel", "mvlt_abi_version", "mvlt_size
            "mvlt_ew_mul", "mvlt_upsample_fwd", "mvlt_upsample_bwd", "mvlt_mlp_fwd", "mvlt_mlp_bwd_dx", "mvlt_mlp_bwd_dw",
            "mvlt_grid_mask_flags", "mvlt_grid_mask_apply", "mvlt_token_mask", "mvlt_resize_bilinear_tokens", "mvlt_resize_bilinear_tokens_multi", "mvlt_gelu_bwd",
            "mvlt_keep_mask", "mvlt_droppath_scales", "mvlt_loss_compose", "mvlt_add_column_sums",
-           "mvlt_upsample_l1_fwd", "mvlt_upsample_l1_bwd", "mvlt_tn_fold_flush", "mvlt_tn_fold_discard"]
+           "mvlt_upsample_l1_fwd", "mvlt_upsample_l1_bwd", "mvlt_tn_fold_flush", "mvlt_tn_fold_discard", "mvlt_sr_attention_bwd_chunks"]
 
 DT = {torch.bfloat16: 0, torch.float32: 1}
 

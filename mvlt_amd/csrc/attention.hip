@@ -1122,20 +1122,40 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_dma_kernel(
       }
 }
 
+// Query chunks per (batch, head) of the backward.  With ONE chunk a workgroup sees every query of its (batch, head) and stores dK / dV plainly; every extra chunk
+// adds M x 128 fp32 atomics per (batch, head) and pays the prologue (K^T staging, K / V fragments) again.  Round 1-5 took ceil(512 / groups) -- fill the chip once --
+// which at pvlt_medium's stage 3 (320 (batch, head) pairs, 704 queries, 272 keys, one six-wave workgroup per CU) meant two chunks = 3 rounds of 11 query tiles + 22 M
+// atomics: 175 us, where ONE chunk (2 rounds of 22 tiles, no atomics, no zero fill, no cast) takes 149 us (tools/ubench_attn.py sweep, profiles/r06_attn_bwd_chunks.txt).
+// Round 6: the chunk count minimises a cost model fitted to that sweep and to the 256-px shapes -- rounds of the chip x (32-query tiles per chunk + 2 tiles of fixed
+// cost) x 3.2 us, + chunks x groups x M x 128 atomics at 0.5 per ns when there is more than one chunk.  `slots` = workgroups the chip holds at once (two per CU for
+// the four-wave bf16 instantiations, one otherwise).  It reproduces ceil(512 / groups) on every 256-px shape of the BASELINE configurations.
+inline int attn_bwd_chunks(int groups, int N, int M, int slots, bool one_chunk_only, int* q_per_wg) {
+  static const int force = getenv("MVLT_ATTN_BWD_NQ") ? atoi(getenv("MVLT_ATTN_BWD_NQ")) : 0;      // measurement switch (tools/ubench_attn.py)
+  int best_nq = 1;
+  double best = -1.0;
+  const int max_nq = one_chunk_only ? 1 : min(128, max(1, (N + 63) / 64));       // at least two query tiles per chunk
+  for (int nq = 1; nq <= max_nq; ++nq) {
+    const int qpw = ((N + nq - 1) / nq + 31) / 32 * 32;
+    if ((N + qpw - 1) / qpw != nq) continue;                        // the rounding to whole tiles merged two chunks
+    const long rounds = ((long)groups * nq + slots - 1) / slots;
+    double cost = (double)rounds * (qpw / 32 + 2) * 3.2;
+    if (nq > 1) cost += (double)nq * groups * M * 128.0 / 500.0 * 1e-3;
+    if (force > 0 && !one_chunk_only) cost = nq == force ? 0.0 : 1.0;
+    if (best < 0.0 || cost < best) { best = cost; best_nq = nq; }
+  }
+  *q_per_wg = ((N + best_nq - 1) / best_nq + 31) / 32 * 32;
+  return (N + *q_per_wg - 1) / *q_per_wg;
+}
+template <typename T, int NW> constexpr int attn_bwd_slots() { return (sizeof(T) == 2 && NW == 4) ? 512 : 256; }
+
 template <typename T, int NW, int TPW> int launch_bwd_n(const mvlt_attn_bwd_args& a, hipStream_t s) {
   constexpr int MP = NW * TPW * 16;
   constexpr int PAD = 16 / sizeof(T);
   const size_t lds = (size_t)(HD * (MP + PAD) + 32 * (MP + PAD) + 2 * HD * (32 + PAD)) * sizeof(T) + 64 * sizeof(float);
   MVLT_REQUIRE(lds <= 160 * 1024, "mvlt_sr_attention_bwd: LDS %zu B > 160 KB", lds);
-  // split the queries of one (batch, head) only as far as needed to fill the chip once (2 workgroups per CU): every
-  // extra chunk flushes another M x 64 x 2 fp32 atomics per (batch, head), and with one chunk the flush is a plain store
   const int groups = a.B * a.H;
-  int nq = (512 + groups - 1) / groups;
-  int maxq = (a.N + 63) / 64;
-  if (nq > maxq) nq = maxq;
-  if (nq < 1) nq = 1;
-  int q_per_wg = ((a.N + nq - 1) / nq + 31) / 32 * 32;
-  nq = (a.N + q_per_wg - 1) / q_per_wg;
+  int q_per_wg = 0;
+  const int nq = attn_bwd_chunks(groups, a.N, a.M, attn_bwd_slots<T, NW>(), a.dkv_dtype == 0, &q_per_wg);
   const int grid = 8 * ((groups + 7) / 8) * nq;
   if constexpr (sizeof(T) == 2) {
     {
@@ -1151,6 +1171,9 @@ template <typename T, int NW, int TPW> int launch_bwd_n(const mvlt_attn_bwd_args
     return mvlt_check_launch("mvlt_sr_attention_bwd");
   }
 }
+
+// workgroups per CU class of the instantiation launch_bwd picks for M keys (same ladder as below)
+template <typename T> int attn_bwd_slots_for(int M) { return (sizeof(T) == 2 && M <= 192) ? 512 : 256; }
 
 template <typename T> int launch_bwd(const mvlt_attn_bwd_args& a, hipStream_t s) {
   const int M = a.M;
@@ -1179,10 +1202,16 @@ extern "C" int mvlt_sr_attention_fwd(const mvlt_attn_args* a, void* stream) {
   return a->dtype == 0 ? launch_fwd<bf16>(*a, (hipStream_t)stream) : launch_fwd<float>(*a, (hipStream_t)stream);
 }
 
+extern "C" int mvlt_sr_attention_bwd_chunks(int B, int H, int N, int M, int dtype) {
+  int q_per_wg = 0;
+  if (B <= 0 || H <= 0 || N <= 0 || M <= 0) return 0;
+  return attn_bwd_chunks(B * H, N, M, dtype == 0 ? attn_bwd_slots_for<bf16>(M) : attn_bwd_slots_for<float>(M), false, &q_per_wg);
+}
+
 extern "C" int mvlt_sr_attention_bwd(const mvlt_attn_bwd_args* a, void* stream) {
   MVLT_REQUIRE(a && a->Q && a->KV && a->O && a->dO && a->lse && a->dQ && a->dKV, "mvlt_sr_attention_bwd: null pointer");
-  MVLT_REQUIRE(a->dkv_dtype == 1 || (a->dkv_dtype == 0 && a->dtype == 0 && (long)a->B * a->H >= 512),
-               "mvlt_sr_attention_bwd: bf16 dKV needs bf16 operands and B*H >= 512 (one query chunk per (batch, head), plain stores)");
+  MVLT_REQUIRE(a->dkv_dtype == 1 || (a->dkv_dtype == 0 && a->dtype == 0),
+               "mvlt_sr_attention_bwd: bf16 dKV needs bf16 operands (it forces one query chunk per (batch, head): plain stores)");
   MVLT_REQUIRE(a->B > 0 && a->H > 0 && a->N > 0 && a->M > 0, "mvlt_sr_attention_bwd: bad shape");
   MVLT_REQUIRE(a->dtype == 0 || a->dtype == 1, "mvlt_sr_attention_bwd: bad dtype");
   const int pc = a->dtype == 0 ? 8 : 4;

@@ -151,8 +151,13 @@ def sr_attention_fwd(Q, KV, O, lse, B, H, N, M, ldq, ldkv, ldo, k_off, v_off, sc
     return O
 
 
+def sr_attention_bwd_chunks(B, H, N, M, dtype):
+    """query chunks per (batch, head) the backward would use with an fp32 dKV; 1: hand it a bf16 dKV instead (every element stored once: no zero fill, no cast)"""
+    return int(L.lib.mvlt_sr_attention_bwd_chunks(B, H, N, M, DT[dtype]))
+
+
 def sr_attention_bwd(Q, KV, O, dO, lse, dQ, dKV, B, H, N, M, ldq, ldkv, ldo, lddkv, k_off, v_off, scale):
-    assert dKV.dtype == torch.float32 or (dKV.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16 and B * H >= 512)
+    assert dKV.dtype == torch.float32 or (dKV.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16)
     a = L.AttnBwdArgs(ptr(Q), ptr(KV), ptr(O), ptr(dO), ptr(lse), ptr(dQ), ptr(dKV), B, H, N, M,
                       ldq, ldkv, ldo, lddkv, k_off, v_off, scale, DT[Q.dtype], DT[dKV.dtype])
     check(L.lib.mvlt_sr_attention_bwd(C.byref(a), stream_ptr()), "mvlt_sr_attention_bwd")

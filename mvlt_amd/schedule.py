@@ -560,7 +560,7 @@ class TrunkStep:
         dq = _empty((B, N, C), dt, dev)
         # dK/dV: one query chunk per (batch, head) from B*heads >= 512 on (mvlt_sr_attention_bwd then stores plainly, every
         # element once); only the split case accumulates with atomics and needs the zero fill
-        if B * h >= 512 and dt == torch.bfloat16:
+        if dt == torch.bfloat16 and ops.sr_attention_bwd_chunks(B, h, N, Mk, dt) == 1:      # (every 256-px stage with B * heads >= 512; round 6: pvlt_medium's stage 3 at batch 64)
             dkv = _empty((B, Mk, 2 * C), dt, dev)              # written once, in the operand dtype
             ops.sr_attention_bwd(bs["q"], bs["kv"], bs["ao"], dao, bs["lse"], dq, dkv, B, h, N, Mk, C, 2 * C, C, 2 * C, 0, C, 64 ** -0.5)
         else:

@@ -714,9 +714,13 @@ def test_sr_attention_fwd_late_maximum(ops):
         assert ((lse - ref_lse).abs() / ref_lse.abs().clamp_min(1.0)).max().item() < 2e-2, boost
 
 
-def test_sr_attention_bwd_bf16_dkv(ops):
-    """B*H >= 512: one query chunk per (batch, head), dK/dV stored once and directly in bf16."""
-    B, H, N, M = 128, 4, 96, 80
+@pytest.mark.parametrize("B,H,N,M", [(128, 4, 96, 80), (64, 5, 704, 272), (2, 1, 4224, 192)])
+def test_sr_attention_bwd_bf16_dkv(ops, B, H, N, M):
+    """a bf16 dKV forces one query chunk per (batch, head): dK/dV stored once and directly in bf16 (B * heads >= 512 at 256 px; pvlt_medium's stage 3 at batch 64,
+    where mvlt_sr_attention_bwd_chunks says 1 by itself -- two rounds of whole-query workgroups beat three rounds + 22 M atomics; the last case would take two chunks
+    with an fp32 dKV and still has to be right with one)."""
+    assert ops.sr_attention_bwd_chunks(128, 4, 96, 80, torch.bfloat16) == 1 and ops.sr_attention_bwd_chunks(64, 5, 704, 272, torch.bfloat16) == 1
+    assert ops.sr_attention_bwd_chunks(256, 1, 4224, 192, torch.bfloat16) == 2 and ops.sr_attention_bwd_chunks(64, 2, 2432, 272, torch.bfloat16) == 2
     Cdim = 64 * H
     dtype = torch.bfloat16
     q = rnd(B, N, Cdim, dtype=dtype)

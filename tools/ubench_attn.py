@@ -10,8 +10,9 @@ def timeit(fn, reps=10):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-B = 256
-for H, N, M in ((1, 4224, 192), (2, 1152, 192), (5, 384, 192), (8, 192, 192)):
+B = int(os.environ.get("B", "256"))          # B=64 KEYS=272: pvlt_medium at 384 px (stage shapes 9344 / 2432 / 704 / 272 queries)
+SHAPES = ((1, 4224, 192), (2, 1152, 192), (5, 384, 192), (8, 192, 192)) if os.environ.get("KEYS", "192") == "192" else ((1, 9344, 272), (2, 2432, 272), (5, 704, 272), (8, 272, 272))
+for H, N, M in SHAPES:
     C = 64 * H
     q, kv = torch.randn(B, N, C, device=dev).to(bf), torch.randn(B, M, 2 * C, device=dev).to(bf)
     o, lse = torch.empty_like(q), torch.empty(B, H, N, device=dev)
