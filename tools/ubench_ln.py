@@ -23,5 +23,8 @@ for rows, C in [(1081344, 64), (294912, 128), (98304, 320), (49152, 512), (10485
     dxb = torch.empty(rows, C, device=dev, dtype=bf); xb = x.to(bf)
     t3 = timeit(lambda: ops.layernorm_bwd(dy, xb, dxb, g, mean, rstd, rows, C, C, C, C, dgamma=dg, dbeta=db, **kw))
     by3 = rows * C * 6 + rows * 8
-    print('ln rows=%d C=%d: fwd %.1f us %.2f TB/s | bwd(f32 x, dx+=) %.1f us %.2f TB/s | bwd(bf16) %.1f us %.2f TB/s' % (
-        rows, C, t * 1e3, by / t / 1e9, t2 * 1e3, by2 / t2 / 1e9, t3 * 1e3, by3 / t3 / 1e9))
+    dxa = torch.zeros(rows, C, device=dev, dtype=bf)           # the model's combination: bf16 dy, fp32 x, bf16 gradient stream accumulated in place
+    t4 = timeit(lambda: ops.layernorm_bwd(dy, x, dxa, g, mean, rstd, rows, C, C, C, C, dgamma=dg, dbeta=db, accumulate=True, **kw))
+    by4 = rows * C * (2 + 4 + 4) + rows * 8
+    print('ln rows=%d C=%d: fwd %.1f us %.2f TB/s | bwd(f32 x, dx+=) %.1f us %.2f TB/s | bwd(bf16) %.1f us %.2f TB/s | bwd(bf16 dy, f32 x, bf16 dx+=) %.1f us %.2f TB/s' % (
+        rows, C, t * 1e3, by / t / 1e9, t2 * 1e3, by2 / t2 / 1e9, t3 * 1e3, by3 / t3 / 1e9, t4 * 1e3, by4 / t4 / 1e9))
