@@ -2247,15 +2247,25 @@ template <int HM, int HN0, int HN1> bool dispatch_nt_p8(const mvlt_gemm_nt_args&
 // in memory).  The m range is split over workgroups (one per CU), partial tiles meet by fp32 atomics; bias gradients = ones-fragment MFMAs,
 // taken in turns by the workgroups that share an operand column range.
 template <int PITCH> __device__ __forceinline__ int tn_hash(int row) {
+  // pitch 192 (round 6, the 96-column A half-tile of the 192 x 320 tile): a row advances 6 windows mod 8, so rows m .. m+3 sit in windows {0, 6, 4, 2} + w and rows
+  // m+8 .. m+11 in the same ones: bit 3 of the row flips the window's low bit ({1, 7, 5, 3} + w) -- eight distinct windows for either read of a fragment
+  if (PITCH == 192) return (row >> 3) & 1;
   return PITCH == 256 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
 }
-template <int HM, int HN0, int HN1, bool TRANS>
+// Round 6: the 192 x 320 tile (<3, 3, 2>: 30 accumulator tiles per wave, as in gemm_nt_p8_kernel) for the fc weight gradients of stage 3 -- 1280 x 320 and 320 x 1280 over
+// 98304 (pvlt_medium at 384 px: 45056) rows.  The 320 side is one column tile; the 1280 side is 6.67 row tiles: RAG1 = the last row tile is ragged (its loader columns are
+// clamped to the last 8 valid ones, its rows / column sums past N1 are not stored: 7 tiles for 6.67 of work).  SWAP = the caller's N1 is the 320 side: the host swaps the
+// operands (A' = B, B' = A) and this instantiation stores its partial tiles TRANSPOSED, i.e. in the caller's [N1][N2] layout (needs the un-flipped MFMA operand order: a
+// lane then owns four consecutive kernel-n1 = caller-n2 of one caller-n1).
+template <int HM, int HN0, int HN1, bool TRANS, bool RAG1 = false, bool SWAP = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p, int kt_per, int t1, int t2, int splits, bf16* part) {
   constexpr int WMT = 2 * HM, WNT = HN0 + HN1;
   constexpr int AC = 2 * HM * 16, BC0 = 4 * HN0 * 16, BC1 = 4 * HN1 * 16;          // columns of the A / B0 / B1 half-tiles
   constexpr int PA = AC * 2, PB0 = BC0 * 2, PB1 = BC1 * 2;                         // row pitches in bytes
-  constexpr int A_IT = 64 * PA / 8192, B_IT0 = 64 * PB0 / 8192, B_IT1 = 64 * PB1 / 8192;
-  static_assert((PA == 128 || PA == 256) && (PB0 == 256 || PB0 == 384) && PB1 == 256, "half-tile pitches with a bank hash");
+  constexpr int A_IT = (64 * PA + 8191) / 8192, B_IT0 = 64 * PB0 / 8192, B_IT1 = 64 * PB1 / 8192;
+  constexpr bool A_PART = (64 * PA) % 8192 != 0;                                   // 12 KB half-tile: the second DMA instruction belongs to waves 0-3 only
+  static_assert((PA == 128 || PA == 192 || PA == 256) && (PB0 == 256 || PB0 == 384) && PB1 == 256, "half-tile pitches with a bank hash");
+  static_assert(!SWAP || !TRANS, "the transposed partial store needs the un-flipped accumulator layout");
   constexpr int OFF_A1 = 64 * PA, OFF_B0 = 2 * 64 * PA, OFF_B1 = OFF_B0 + 64 * PB0, BUF = OFF_B1 + 64 * PB1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2283,13 +2293,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p,
   const unsigned a_rs = 2u * (unsigned)p.lda, b_rs = 2u * (unsigned)p.ldb;
 
   // ---- loader: chunk q = tid + 512 i of a half-tile = (row q / CPR, slot q % CPR); the slot holds source chunk slot ^ (hash(row) << 1)
-  unsigned a_voff[A_IT], b_voff0[B_IT0], b_voff1[B_IT1];
+  unsigned a_voff[A_IT], a_voff1[RAG1 ? A_IT : 1], b_voff0[B_IT0], b_voff1[B_IT1];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     constexpr int CPR = PA / 16;
-    const int q = tid + 512 * i, row = q / CPR, lc = ((q - row * CPR) ^ (tn_hash<PA>(row) << 1)) * 8;
+    const int q = tid + 512 * i, row = (q / CPR) & 63, lc = ((q - (q / CPR) * CPR) ^ (tn_hash<PA>(row) << 1)) * 8;      // (& 63: the idle half of a partial instruction)
     const int w_ = lc / (HM * 16);
-    a_voff[i] = (unsigned)row * a_rs + 2u * (unsigned)(w_ * (WMT * 16) + (lc - w_ * (HM * 16)));
+    const int col = w_ * (WMT * 16) + (lc - w_ * (HM * 16));                      // column inside the tile, half 0; half 1 is HM * 16 further
+    a_voff[i] = (unsigned)row * a_rs + 2u * (unsigned)(RAG1 ? min(col, p.N1 - 8 - n1_0) : col);
+    if (RAG1) a_voff1[i] = (unsigned)row * a_rs + 2u * (unsigned)min(col + HM * 16, p.N1 - 8 - n1_0);
   }
 #pragma unroll
   for (int i = 0; i < B_IT0; ++i) {
@@ -2310,10 +2322,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p,
   const unsigned dst_wave = smem_lds + wave * 1024;
   auto stage = [&](int which, int t, int buf) {
     if (which < 2) {
-      const char* sb = a_base + (size_t)(t * 64) * a_rs + which * (HM * 16 * 2);
+      const char* sb = a_base + (size_t)(t * 64) * a_rs + (RAG1 ? 0 : which * (HM * 16 * 2));
       const unsigned dst = dst_wave + buf * BUF + which * OFF_A1;
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) glds16_s(sb, a_voff[i], dst + i * 8192);
+      for (int i = 0; i < A_IT; ++i)
+        if (!A_PART || i + 1 < A_IT || wave < 4) glds16_s(sb, (RAG1 && which == 1) ? a_voff1[i] : a_voff[i], dst + i * 8192);
     } else if (which == 2) {
       const char* sb = b_base + (size_t)(t * 64) * b_rs;
       const unsigned dst = dst_wave + buf * BUF + OFF_B0;
@@ -2326,7 +2339,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p,
       for (int i = 0; i < B_IT1; ++i) glds16_s(sb, b_voff1[i], dst + i * 8192);
     }
   };
-  constexpr int INFL = B_IT0 + A_IT + B_IT1;          // DMA instructions per thread in the three youngest half-tiles (B0, A0, B1)
+  // DMA instructions of THIS wave in the three youngest half-tiles (B0, A0, B1): what the wait of phase 4 leaves in flight
+  constexpr int INFL0 = B_IT0 + A_IT + B_IT1, INFL1 = B_IT0 + (A_PART ? A_IT - 1 : A_IT) + B_IT1;
+  auto wait_infl = [&]() { if (wr == 0) wait_vm<INFL0>(); else wait_vm<INFL1>(); };
 
   // ---- fragment geometry (transposed reads): lane (g, L) supplies k-row 8 g + (L >> 2) and the row 4 below, 8-byte piece L & 3 of a 16-column
   //      window; the k32 step ks adds 32 rows
@@ -2392,7 +2407,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p,
   }
 
   stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
-  if (nk > 1) { stage(2, 1, 1); stage(0, 1, 1); stage(3, 1, 1); wait_vm<INFL>(); }
+  if (nk > 1) { stage(2, 1, 1); stage(0, 1, 1); stage(3, 1, 1); wait_infl(); }
   else wait_vm<0>();
   MVLT_BAR();
   if (wr == 1) MVLT_BAR();
@@ -2431,7 +2446,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p,
     MVLT_TCSA(1)
     __builtin_amdgcn_s_setprio(0);
     MVLT_BAR();
-    if (t + 2 < nk) { stage(3, t + 2, B); wait_vm<INFL>(); }
+    if (t + 2 < nk) { stage(3, t + 2, B); wait_infl(); }
     else wait_vm<0>();
     MVLT_BAR();
     __builtin_amdgcn_s_setprio(1);
@@ -2455,14 +2470,46 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p,
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&p.colsum_a[n1_0 + wr * (WMT * 16) + (mh * HM + wc) * 16 + 4 * fg + r], csa[mh][r]);
+      for (int r = 0; r < 4; ++r) {
+        const int n1 = n1_0 + wr * (WMT * 16) + (mh * HM + wc) * 16 + 4 * fg + r;
+        if (!RAG1 || n1 < p.N1) atomicAdd(&p.colsum_a[n1], csa[mh][r]);
+      }
   }
   if (do_csb && fg == 0) {                        // csb[j >> 1][0]: column n2 = tile j, lane column fr
 #pragma unroll
     for (int j = 0; j < WNT; ++j)
       if ((j & 1) == wr) atomicAdd(&p.colsum_b[n2_0 + wc * (WNT * 16) + j * 16 + fr], csb[j >> 1][0]);
   }
-  if (part) {
+  if constexpr (SWAP) {
+    // PARTIAL-TILE mode, operands swapped by the host (kernel n1 = the caller's n2 and vice versa): the split's tile goes to part[split][caller N1 = p.N2][caller N2 = p.N1],
+    // the caller's layout, so that the same fold serves it.  Un-flipped accumulators: acc[i][j][r] = C'[n1 = tile i row 4 fg + r][n2 = tile j column fr]: a lane owns four
+    // consecutive kernel-n1 of one kernel-n2 = four consecutive columns of one row of the caller's matrix.  Per wave and kernel-n2 tile j: a [16 n2][WMT * 16 n1] LDS tile,
+    // out as whole 16-byte pieces of contiguous rows.
+    bf16* const P = part + (size_t)bz * p.N1 * p.N2;
+    constexpr int LDP = WMT * 16 + 8;
+    constexpr int CPR = WMT * 2;
+    MVLT_BAR();
+    bf16* const st = (bf16*)smem + wave * 16 * LDP;
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < WMT; ++i) {
+        const bf16x2 lo = __builtin_convertvector(f32x2{acc[i][j][0], acc[i][j][1]}, bf16x2), hi = __builtin_convertvector(f32x2{acc[i][j][2], acc[i][j][3]}, bf16x2);
+        *(u32x2*)(st + fr * LDP + i * 16 + 4 * fg) = u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = lane; q < 16 * CPR; q += 64) {
+        const int row = q / CPR, ch = q - row * CPR;
+        const int n2 = n2_0 + wc * (WNT * 16) + j * 16 + row, n1 = n1_0 + wr * (WMT * 16) + ch * 8;
+        if (!RAG1 || n1 < p.N1) st_g<MVLT_NT_GEMM>((u32x4*)(P + (size_t)n2 * p.N1 + n1), *(const u32x4*)(st + row * LDP + ch * 8));
+      }
+    }
+    return;
+  } else if (part) {
     // PARTIAL-TILE mode (round 5): no atomics.  The split's tile goes to part[split][N1][N2] in bf16 -- the MFMA operands are flipped (TRANS instantiation), so a lane owns
     // four consecutive n2 of one n1: one 8-byte store per accumulator tile -- and tn_fold_kernel adds the splits' tiles into C in a fixed order (deterministic).
     static_assert(TRANS, "partial tiles are stored from the flipped accumulator layout");
@@ -2487,7 +2534,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_p8_kernel(mvlt_gemm_tn_args p,
       for (int q = lane; q < 16 * CPR; q += 64) {
         const int row = q / CPR, ch = q - row * CPR;
         const int n1 = n1_0 + wr * (WMT * 16) + i * 16 + row, n2 = n2_0 + wc * (WNT * 16) + ch * 8;
-        st_g<MVLT_NT_GEMM>((u32x4*)(P + (size_t)n1 * p.N2 + n2), *(const u32x4*)(st + row * LDP + ch * 8));
+        if (!RAG1 || n1 < p.N1) st_g<MVLT_NT_GEMM>((u32x4*)(P + (size_t)n1 * p.N2 + n2), *(const u32x4*)(st + row * LDP + ch * 8));
       }
     }
     return;
@@ -2565,6 +2612,38 @@ template <int HM, int HN0, int HN1> int launch_tn_p8_partial(const mvlt_gemm_tn_
   bf16* const scratch = fold_acquire(a, (long)splits * a.N1 * a.N2 * 2, s);      // [splits][N1][N2] bf16 in the caller's scratch (mvlt_gemm_tn checked its size)
   dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * t1 * t2)), block(512);
   MVLT_LAUNCH((gemm_tn_p8_kernel<HM, HN0, HN1, true>), grid, block, LDS, s, a, kt_per, t1, t2, splits, scratch);
+  fold_launch(a, scratch, splits, s);
+  return mvlt_check_launch("mvlt_gemm_tn");
+}
+
+// 192 x 320 tiles (round 6): the caller's matrix is [N1][N2] with ONE side a multiple of 320 (taken as the kernel's column side, whole tiles) and the other covered by
+// ceil(. / 192) row tiles, the last one ragged.  swap: the 320 side is the caller's N1 -- operands exchanged, partial tiles stored transposed (in the caller's layout).
+template <bool SWAP> int launch_tn_p8_320(const mvlt_gemm_tn_args& a, hipStream_t s) {
+  constexpr int LDS = 2 * 64 * 2 * (2 * (2 * 3 * 16) + 320);
+  mvlt_gemm_tn_args k = a;
+  if (SWAP) {
+    k.A = a.B; k.B = a.A; k.lda = a.ldb; k.ldb = a.lda; k.N1 = a.N2; k.N2 = a.N1;
+    k.colsum_a = a.colsum_b; k.colsum_b = a.colsum_a;
+  }
+  const int t1 = (k.N1 + 191) / 192, t2 = k.N2 / 320, nkt = k.M / 64;
+  // all tiles of an m-split run on ONE XCD (32 CUs, one workgroup each): whole splits per XCD, the same number on each -- 7 tiles: 4 splits per XCD = 32 splits = 224
+  // workgroups (36 splits = 252 workgroups put 35 on four of the XCDs: a second round there, 184 us instead of the 128-wide kernel's 137)
+  int splits = (32 / (t1 * t2)) * 8;
+  if (splits < 8) splits = 256 / (t1 * t2);
+  if (splits > nkt) splits = nkt;
+  const int kt_per = (nkt + splits - 1) / splits;
+  splits = (nkt + kt_per - 1) / kt_per;
+  bf16* const scratch = fold_acquire(a, (long)splits * a.N1 * a.N2 * 2, s);      // [splits][caller N1][caller N2] bf16
+  if (!scratch) return 1;                                                          // (does not fit: the caller falls through to the 128-wide kernel)
+  dim3 grid((unsigned)((splits >= 8 ? 8 * ((splits + 7) / 8) : splits) * t1 * t2)), block(512);
+  const bool rag = k.N1 % 192 != 0;
+  if (SWAP) {
+    if (rag) { mvlt_max_lds<(gemm_tn_p8_kernel<3, 3, 2, false, true, true>)>(); MVLT_LAUNCH((gemm_tn_p8_kernel<3, 3, 2, false, true, true>), grid, block, LDS, s, k, kt_per, t1, t2, splits, scratch); }
+    else { mvlt_max_lds<(gemm_tn_p8_kernel<3, 3, 2, false, false, true>)>(); MVLT_LAUNCH((gemm_tn_p8_kernel<3, 3, 2, false, false, true>), grid, block, LDS, s, k, kt_per, t1, t2, splits, scratch); }
+  } else {
+    if (rag) { mvlt_max_lds<(gemm_tn_p8_kernel<3, 3, 2, true, true, false>)>(); MVLT_LAUNCH((gemm_tn_p8_kernel<3, 3, 2, true, true, false>), grid, block, LDS, s, k, kt_per, t1, t2, splits, scratch); }
+    else { mvlt_max_lds<(gemm_tn_p8_kernel<3, 3, 2, true, false, false>)>(); MVLT_LAUNCH((gemm_tn_p8_kernel<3, 3, 2, true, false, false>), grid, block, LDS, s, k, kt_per, t1, t2, splits, scratch); }
+  }
   fold_launch(a, scratch, splits, s);
   return mvlt_check_launch("mvlt_gemm_tn");
 }
@@ -2995,6 +3074,22 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
     const int tiles = (a->N1 / 256) * (a->N2 / 256), nkt = a->M / 64;
     if (tiles >= 16 && tiles <= 64 && nkt / (256 / tiles) >= 16 && a->partials_bytes >= (long)(256 / tiles) * a->N1 * a->N2 * 2)
       return launch_tn_p8_partial<4, 2, 2>(*a, s);
+  }
+  // round 6: one side a multiple of 320, the other >= 1024 (the fc weight gradients of stage 3: 1280 x 320 and 320 x 1280): 192 x 320 tiles of the 8-phase TN loop, 6-16 of
+  // them, the last row tile ragged when it is >= 85 % full overall; bf16 partial tiles + the ordered fold (MVLT_TN_P8_320=0: the 128-wide kernel as in round 5)
+  static const bool tn320 = !(getenv("MVLT_TN_P8_320") && atoi(getenv("MVLT_TN_P8_320")) == 0);
+  if (tnp8 && tn320 && a->partials && a->dtype == 0 && a->a_map.mode == 0 && a->b_map.mode == 0 && a->a_map.rows_per_batch == 0 && a->b_map.rows_per_batch == 0 && a->c_taps <= 1 &&
+      !a->trans_c && !a->dgrad_out && a->M % 64 == 0 && a->N1 % 8 == 0 && a->N2 % 8 == 0 && a->ldc % 4 == 0 && ((uintptr_t)a->C & 15) == 0 && ((uintptr_t)a->partials & 15) == 0 &&
+      a->lda % 8 == 0 && a->ldb % 8 == 0 && (((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0) {
+    const bool direct = a->N2 % 320 == 0 && a->N1 >= 1024, swapped = !direct && a->N1 % 320 == 0 && a->N2 >= 1024;
+    if (direct || swapped) {
+      const int rows = direct ? a->N1 : a->N2, cols = direct ? a->N2 : a->N1;
+      const int tiles = ((rows + 191) / 192) * (cols / 320), nkt = a->M / 64;
+      if (tiles >= 6 && tiles <= 16 && nkt / (256 / tiles) >= 16 && (double)rows >= 0.85 * 192.0 * ((rows + 191) / 192)) {
+        const int rc = direct ? launch_tn_p8_320<false>(*a, s) : launch_tn_p8_320<true>(*a, s);
+        if (rc <= 0) return rc;
+      }
+    }
   }
   if (a->dtype == 0 && a->M < (1 << 24)) {
     // LDS-DMA kernel: A tile 128 or 64 wide, B tile 128 or 64 wide; ~1024 workgroups, splits a multiple of the 8 XCDs

@@ -358,6 +358,37 @@ def test_gemm_tn_partial_tiles_reduce_without_atomics(ops, M, N1, N2):
     assert "gemm_tn_dma_kernel" in last_kernel() and maxrel(Cw, ref) < 1e-3
 
 
+@pytest.mark.parametrize("M,N1,N2", [(45056, 1280, 320), (45056, 320, 1280), (49152, 1152, 320), (32768, 640, 1600)])
+def test_gemm_tn_192x320_tiles_of_the_8phase_loop(ops, M, N1, N2):
+    """round 6: one side a multiple of 320, the other >= 1024 (the fc weight gradients of stage 3: dW1 1280 x 320, dW2 320 x 1280) on 192 x 320 tiles of the 8-wave /
+    8-phase TN loop -- the last row tile ragged (1280 = 6.67 x 192), the 320-side-first shapes computed with swapped operands and stored transposed -- bf16 partial tiles + the
+    ordered fold: accumulates into C within 5e-3 of the fp32 product, bias gradient (column sums of A) included on either side, bit-identical second launch, and the kernel that
+    ran is the 192 x 320 instantiation.  (The last case does not qualify -- 640 x 1600: neither side is one-to-two 320-wide column tiles beside >= 1024 rows -- and stays on
+    the 128-wide kernel.)"""
+    from mvlt_amd._lib import last_kernel
+    dt = torch.bfloat16
+    A, B = rnd(M, N1, dtype=dt, scale=0.5), rnd(M, N2, dtype=dt, seed=1, scale=0.5)
+    ref = A.float().t() @ B.float()
+    scratch = torch.empty(256 * 65536, device=dev(), dtype=dt)
+    outs = []
+    for _ in range(2):
+        Cw, cs = torch.full((N1 + 1, N2), 3.0, device=dev()), torch.zeros(N1 + 8, device=dev())
+        ops.gemm_tn(A, B, Cw, M, N1, N2, N1, N2, N2, colsum=cs[:N1], partials=scratch, defer_fold=True)
+        name = last_kernel()
+        ops.tn_fold_flush(scratch)
+        torch.cuda.synchronize()
+        outs.append((Cw, cs))
+    want = "gemm_tn_p8_kernel<3, 3, 2, " + ("true" if N2 % 320 == 0 and N1 >= 1024 else "false")
+    if (N1, N2) == (640, 1600):
+        assert "gemm_tn_dma_kernel" in name, name
+    else:
+        assert want in name, name
+    assert maxrel(outs[0][0][:N1] - 3.0, ref) < 5e-3
+    assert (outs[0][0][N1] == 3.0).all() and (outs[0][1][N1:] == 0).all(), "wrote past the ragged tile"
+    assert maxrel(outs[0][1][:N1], A.float().sum(0)) < 1e-3
+    assert torch.equal(outs[0][0], outs[1][0])
+
+
 @pytest.mark.parametrize("M,N1,N2", [(98304, 320, 320), (49152, 512, 512), (40000, 328, 512)])
 def test_gemm_tn_partial_tiles_on_the_128_wide_kernel(ops, M, N1, N2):
     """The 128 x 128 weight-gradient kernel in partial-tile mode (many m-splits on a mid-sized output: the q / proj gradients of stages 3-4): accumulates into C within 5e-3 of

@@ -19,6 +19,9 @@ dy = torch.randn(B * T, H, device=dev).to(bf)
 mean, rstd = torch.zeros(B * T, device=dev), torch.ones(B * T, device=dev)
 dword, dpos, dtyp = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)
 dg, db = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
-for name, idv in (("random ids", ids), ("32 distinct ids", ids % 32 + 1)):
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+step_ids = bench.synth_batch(B, 32, T, dev, 1)["input_ids"]          # the bench's own captions: ~11 % [MASK] (103), 101 / 102 once per row, PAD (0) behind
+for name, idv in (("random ids", ids), ("32 distinct ids", ids % 32 + 1), ("the step's ids", step_ids)):
     t = timeit(lambda: ops.bert_embed_bwd(dy, idv, word, pos, typ[0], gamma, None, 0.1, mean, rstd, dword, dpos, dtyp[0], dg, db, B * T, T))
     print(f"bert_embed_bwd {name}: {t:.1f} us")
