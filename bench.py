@@ -199,6 +199,8 @@ LIMITERS = {
                                 "bf16 pre-activation) next to 4 x 64 MACs on the matrix pipe, at two waves per SIMD (216 registers)",
     "conv3_nt_kernel<32, 192, 1>": "LDS-DMA issue + MFMA: 128 x 192 tile, 3x3-gather A from an LDS halo (MFMA-busy 0.48)",
     "gemm_nt_dma_kernel<64, 0, 1, 64, 128>": "HBM: K = 64, 128 x 64 tile, every operand byte read once",
+    "gemm_tn_p8_kernel<3, 3, 2, false, true, true>": "MFMA / LDS-DMA: 192 x 320 tiles of the 8-phase TN loop (seven row tiles for 6.67 of work, 224 of 256 CUs: whole m-splits per XCD), operands "
+                                                     "swapped and the bf16 partial tiles stored transposed; 32 m-splits folded by one ordered pass (timed with it)",
     "gemm_tn_dma_kernel<128, 128, 3, 2, false>": "neither HBM- nor MFMA-bound (2.8 TB/s, MFMA-busy 0.34; 11-13 TB/s of L2 -> LDS-DMA requests): 128 x 128 tiles behind a 2-stage "
                                                  "LDS-DMA ring, two workgroups per CU, 16 m-splits leaving as bf16 partial tiles + one ordered fold (timed with it)",
 }
@@ -274,8 +276,9 @@ def time_dominant_kernel(model, B, device, ms_step):
         entry("conv192", "MIM conv3x3 192->192 @32x32 as a gathered GEMM (M = B*1024, N = 192, K = 1728) -- round 2's roofline launch; 4 such forward / input-gradient "
               "launches per step", 4, "mfma"),
         entry("proj64", "K = 64, N = 64 projection with bias, M = B*4224 (the stage-1 q / proj forward)", 4, "hbm"),
-        entry("tn_s3dw2", f"weight gradient dW2[320, 1280] += dY^T G over M = B*384 = {M3} rows + bias gradient: the stage-3 fc2 shape, largest launch of the "
-              "trace's top instantiation (stage-3 dW1 / dW2: 4 launches per step)", 4, "mfma", alg_bytes=2.0 * (M3 * 320 + M3 * 1280) + 4.0 * 320 * 1280)]
+        entry("tn_s3dw2", f"weight gradient dW2[320, 1280] += dY^T G over M = B*384 = {M3} rows + bias gradient: the stage-3 fc2 shape (round 5: the largest launch of the "
+              "trace's top instantiation; stage-3 dW1 / dW2: 4 launches per step), partial tiles + fold as the step launches it", 4, "mfma",
+              alg_bytes=2.0 * (M3 * 320 + M3 * 1280) + 4.0 * 320 * 1280)]
     top.update({"traffic_stale": stale} if stale else {"traffic_source": f"profiles/{tj[-1]}" if tj else None})
     return top
 

@@ -126,6 +126,39 @@ def test_train_one_epoch_vl_matches_reference_loop(golden_dir, parity, name, dty
     _check_deltas(model, sd, g, parity, 2e-2 if dtype == torch.float32 else 0.25, opt_kind)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bf16_gradient_payload_stays_inside_the_loop_bounds(golden_dir, parity, dtype):
+    """`MVLT_DP_BF16=1` sends the gradient ranges of the data-parallel exchange in bf16 (76 MB instead of 153 MB per step; it halves the 95.8 MB tail that cannot be
+    overlapped).  On one GPU the wire cannot be timed, but what the payload does to TRAINING can: the reference's 4-iteration engine loop (fixture `tiny256_loop`) with every
+    gradient rounded to bf16 between backward and the fused AdamW -- exactly what a rank receives back from a bf16 all-reduce at world size 1, and a LOWER bound on the rounding at
+    world size N (RCCL sums in the payload dtype: one rounding per ring step) -- must keep the epoch-average losses and every parameter's delta inside the bounds the un-rounded
+    loop is held to.  The margins against those bounds are what DESIGN 7 quotes when it recommends the setting."""
+    from mvlt_amd.engine import BF16Scaler, train_one_epoch_vl
+    from mvlt_amd.optim import FusedAdamW
+    name = "tiny256_loop"
+    model, cfg, sd, batches, masks, g, lr, wd, iters = _setup(name, golden_dir, dtype)
+    dev = torch.device("cuda:0")
+    opt = FusedAdamW(model, lr=lr, weight_decay=wd)
+
+    class RoundingScaler(BF16Scaler):
+        def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False):
+            loss.backward()
+            S = optimizer.model.store
+            S.fold_copies()
+            S.G.copy_(S.G.to(torch.bfloat16).to(torch.float32))          # the payload's rounding, every range at once
+            optimizer.step()
+
+    args = types.SimpleNamespace(loss_type=cfg.loss_type)
+    res = train_one_epoch_vl(model, None, _Loader(model, batches, masks), opt, dev, 0, RoundingScaler(), None, None, None, True, False, args)
+    torch.cuda.synchronize()
+    ltol = 1e-3 if dtype == torch.float32 else 2e-2
+    for k in RESULT_KEYS - {"lr"}:
+        vals = [float(g[f"loop/loss/{it}/{k}"]) if f"loop/loss/{it}/{k}" in g.files else 0.0 for it in range(iters)]
+        ref = sum(vals) / iters
+        assert parity(f"bf16-payload-epoch-avg/{k}", abs(res[k] - ref) / max(1.0, abs(ref)), ltol), (k, res[k], ref)
+    _check_deltas(model, sd, g, parity, 2e-2 if dtype == torch.float32 else 0.25, "bf16-payload")
+
+
 def test_checkpoint_round_trip_resumes_identically(golden_dir, parity):
     """f2 / f4: train 2 iterations -> save {model, optimizer, scaler} the way main_vl.py:441-455 does -> fresh model and
     optimizer, state loaded BEFORE the first forward (main_vl.py:327-346) -> iterations 3-4 give the same parameters as

@@ -14,6 +14,7 @@ python3 tools/step_launches.py gpurun_out/prof_$tag/trace_kernel_trace.csv > gpu
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 MVLT_DP_FORCE_COLLECTIVES=1 python3 tools/overlap_trace.py > gpurun_out/${tag}_overlap.txt 2>/dev/null
 bash tools/l1_stalls.sh > /dev/null 2>&1; cp gpurun_out/l1_stalls.txt gpurun_out/${tag}_l1_stalls.txt 2>/dev/null
 bash tools/step_traffic.sh $tag > /dev/null 2>&1
+bash tools/step_sq.sh $tag > /dev/null 2>&1                      # SQ instruction counters per kernel over whole steps (tools/ceiling_table.py)
 python3 tools/gemm_shapes.py > gpurun_out/${tag}_gemm_shapes.txt 2>&1
 (python3 tools/host_time.py; python3 tools/host_waits.py 20) 2>&1 | grep -E "^host|^pretrain:|^finetune:" > gpurun_out/${tag}_host_time.txt
 bash tools/pmc_collect.sh $tag > /dev/null 2>&1

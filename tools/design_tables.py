@@ -48,18 +48,19 @@ rest_keys = [k for k in fam if k in ("adamw", "bert_embed_bwd", "bert_embed_fwd"
 rest_n, rest_us = sum(fam[k][0] for k in rest_keys), sum(fam[k][1] for k in rest_keys)
 g = lambda k: f"{R[k][0]} | {R[k][1]:.0f} | {R[k][2]:.1f} %"
 us = lambda k: fam.get(k, [0, 0.0])[1]
+prev_tag_early = "r%02d" % (int(tag[1:]) - 1)
 t31 = f"""### 3.1 One steady-state step: {n_launch} launches, kernels busy {busy_ms:.2f} ms (`profiles/{tag}_step_launches.txt`)
 
 (The span from the step's first kernel to the optimizer's end is {span_ms:.2f} ms under `rocprofv3 --kernel-trace` -- {busy_pct:.1f} % busy; {n_aten} of the launches are ATen kernels, {n_copy} `copyBuffer`.
-Unprofiled the bench step equals the sum of the kernel durations.  The boxes of the pool differ by up to 5 % (19.4-20.5 ms for this build): family differences to `r04_step_launches.txt` below that are spread; the kernel changes of the round are the weight-gradient families (`gemm_tn_*` + `tn_fold_kernel`, `conv3_wgrad_kernel`: split reductions without atomics) and the helper row (cross entropy, label selection, weight prep).)
+Unprofiled the bench step equals the sum of the kernel durations.  The boxes of the pool differ by up to 5 % (19.4-20.5 ms for this build): family differences to `{prev_tag_early}_step_launches.txt` below that are spread; the one kernel change of round 6 inside this step is the weight-gradient family (the stage-3 fc gradients on 192 x 320 tiles of the 8-phase TN loop: -0.04 ms).)
 
 | kernel family | launches | us / step | share | bound by (evidence) |
 |---|---|---|---|---|
-| `gemm_tn_dma_kernel` + `gemm_tn_p8_kernel` / `tn_fold_kernel` (weight gradients; 8 launches carry the input gradient too; the stage-4 MLP ones and every launch with >= 8 m-splits reduce through bf16 partial tiles + the batched fold (`tn_fold_multi_kernel`, 5 launches per step, the conv3x3 outputs included: counted here)) | {g('gemm_tn_dma')} | MFMA-bound shapes 0.24-0.38 of peak (3.2), the K <= 128 shapes HBM (4.5-5.6 TB/s); where atomics remain a split reduction costs outputs x splits / 0.3 ns (`experiments_r4.md` 2) |
+| `gemm_tn_dma_kernel` + `gemm_tn_p8_kernel` / `tn_fold_kernel` (weight gradients; 8 launches carry the input gradient too; the stage-4 MLP ones and every launch with >= 8 m-splits reduce through bf16 partial tiles + the batched fold (`tn_fold_multi_kernel`, 5 launches per step, the conv3x3 outputs included: counted here)) | {g('gemm_tn_dma')} | MFMA-bound shapes 0.24-0.41 of peak (3.2), the K <= 128 shapes HBM (4.5-5.6 TB/s); the 128 x 128 instantiation sits at 2.0 x its HBM time and 3.4 x its MFMA time behind 11-13 TB/s of L2 -> LDS-DMA requests (3.5); where atomics remain a split reduction costs outputs x splits / 0.3 ns (`experiments_r4.md` 2) |
 | `gemm_nt_dma_kernel` (128-wide NT GEMMs: K <= 128 projections, gathers, small heads) | {g('gemm_nt_dma')} | HBM for K = 64 / 128 (`proj64` sibling: 0.60-0.70 of 8 TB/s); TA / L1 path for the rest (`r03_l1_stalls.txt`) |
 | `gemm_nt_p8_kernel` (8-wave / 8-phase NT GEMMs, stage 3-4, MLM logits) | {g('gemm_nt_p8')} | K-loops alone 1.1-1.6 PFLOP/s (epilogue compiled out, `r05_p8_epilogue_ablation.txt`); the launches 0.23-0.57 of peak: whole-round quantisation + a VALU-bound epilogue (~15 instructions per output at two waves per SIMD) that a persistent grid does not hide (3.3, `experiments_r5.md` 3) |
 | `mlp_pipe_kernel` (fused MLP forward / input gradient, stages 1-2) | {g('mlp_pipe')} | VALU (GELU: 10 instructions per hidden element) + MFMA, partly overlapped: MFMA-busy 0.28-0.35, VALU-active 0.26-0.35 (`{tag}_mfma_counters.csv`) |
-| `mlp_wgrad2_kernel` (fused MLP weight gradients) | {g('mlp_wgrad2')} | VALU + MFMA add up (`roofline`: {_rf:.3f} algorithmic / {2 * _rf:.2f} executed); LDS table gather 0.43 conflicts (inherent, `experiments_r4.md` 4) |
+| `mlp_wgrad2_kernel` (fused MLP weight gradients) | {g('mlp_wgrad2')} | VALU + MFMA issue times ADD on a SIMD (1.3 x their sum; `roofline`: {_rf:.3f} algorithmic / {2 * _rf:.2f} executed); neither exposed LDS-gather latency nor two-against-four waves per SIMD moves it (`experiments_r6.md` 3) |
 | LayerNorm forward / backward (standalone launches) | {g('ln')} | HBM + Infinity Cache: 4.5-7.8 TB/s algorithmic (streaming passes over the fp32 residual stream); round 3 / first half of round 4: 2238 us (`experiments_r4.md` 7) |
 | `conv3_nt_kernel` (MIM conv3x3 forward / dgrad) | {g('conv3_nt')} | MFMA / LDS-DMA: 1.0-1.24 PFLOP/s (0.41-0.50), MFMA-busy 0.48 |
 | MIM decoder non-GEMM (BatchNorm, upsample, products, fused loss) | {g('mim')} | HBM streaming, fp16 z and product factors (first half of round 4: 1482 us, `experiments_r4.md` 8) |
@@ -129,7 +130,7 @@ rows = [
     line("stage-3 fc1 dgrad 98304 x 320 x 1280", "p8 192 x 320", "gemm_nt 98304 320 1280 A:- C:- act0 bfloat16", 50, 106.2),
 ]
 a, b = r("gemm_tn 98304 1280 320"), r("gemm_tn 98304 320 1280")
-rows.append(f"| stage-3 dW2 / dW1 (TN, 98304 rows) | tn 128 x 128 | {a[0]:.1f} / {b[0]:.1f} | {a[1]:.0f} / {b[1]:.0f} | {a[1] / 2500:.2f} / {b[1] / 2500:.2f} | 50 | {PV('gemm_tn 98304 1280 320', 'gemm_tn 98304 320 1280')} |")
+rows.append(f"| stage-3 dW1 / dW2 (TN, 98304 rows; round 6: 192 x 320 tiles of the 8-phase loop, ragged last row tile, bf16 partial tiles + fold) | tn p8 192 x 320 + fold | {a[0]:.1f} / {b[0]:.1f} | {a[1]:.0f} / {b[1]:.0f} | {a[1] / 2500:.2f} / {b[1] / 2500:.2f} | 50 | {PV('gemm_tn 98304 1280 320', 'gemm_tn 98304 320 1280')} |")
 rows += [
     line("stage-4 fc1 + GELU 49152 x 2048 x 512", "p8 256 x 256", "gemm_nt 49152 2048 512 A:- C:- b act1", 72, 150.3),
     line2("stage-4 fc2 + fp32 residual 49152 x 512 x 2048 (fp32 out / bf16 out)", "p8 192 x 256", "gemm_nt 49152 512 2048 A:- C:- b act0 R float32",
@@ -181,9 +182,8 @@ had left the K / V / dK / dV streams out of the stage 2-4 floors and showed 27 /
 |---|---|---|---|---|---|---|
 """ + "\n".join(rows) + f"""
 
-Blocks-only MFMA fraction (north_star's figure, `flops.blocks_only` of the bench line): **{bo['mfma_frac']:.3f}** ({bo['ms_per_step']:.2f} ms for 6.15 TFLOP; round 4: 0.182 builder / 0.180 driver, round 3: 0.165; target 0.40
--- the ceiling argument of round 3 stands: in stages 1-2, half of the block FLOPs, the VALU floor of the activation alone is 1.6-2.7 x the MFMA time of the GEMMs
-around it, `docs/experiments_r1-r3.md` B "Instruction issue rates").
+Blocks-only MFMA fraction (north_star's figure, `flops.blocks_only` of the bench line): **{bo['mfma_frac']:.3f}** ({bo['ms_per_step']:.2f} ms for 6.15 TFLOP; round 5: 0.182 driver, round 4: 0.180, round 3: 0.165; target 0.40
+-- 3.5 totals what this kernel decomposition could reach if every launch ran at the first limit it meets: ~0.30).
 """
 
 # ---------------------------------------------------------------- 6: the line of the final build
@@ -195,34 +195,51 @@ ks_calls, ks_avg_us = int(ks[0]), float(ks[2]) / 1e3
 mw, cal = tj["mlp_dw64"], tj["calib_cast"]
 pairs = lambda x: f"{x:,.0f}".replace(",", " ")
 t6 = f"""**The line of the final build** (`profiles/{tag}_bench_n1.json`, command `python bench.py`, sources `{tj['_source_hash']}`): **{pairs(bench['value'])} pairs/s, {bench['ms_per_step']:.2f} ms/step**
-(round 4: driver 12 532 / 20.43, builder's box 12 704 / 20.15; round 3's driver line: 11 428 / 22.40).  The boxes of the pool differ by +-2.5 %: the final tree measured 20.2 .. 20.9 ms on the boxes of this
-round.  Round 5 changed one hot path (the stage-4 MLP weight gradients without atomics: -0.09 ms same-box; `docs/experiments_r5.md`: five other kernel-level attempts measured same-box, none faster), so the step is round 4's within that spread; what changed in the LINE is that
-its roofline entries are named by the library (`mvlt_last_kernel()` after the timed launches), `share_of_step` is computed from the measured launch and step times, a `limiter` text is attached only to the
-instantiation it was written for, the top instantiation of the kernel trace (`gemm_tn_dma_kernel<128, 128, 3, 2, false>` on the stage-3 fc2 weight-gradient shape) is a third sibling, `other_configs` carries an
-MFMA fraction and an eval-forward entry.  Loss trajectory unchanged (epoch average {bench['config']['epoch_avg_loss']:.2f}, same synthetic batch).
+(round 5: driver 12 872 / 19.89; round 4: 12 532 / 20.43; round 3: 11 428 / 22.40).  The boxes of the pool differ by +-2.5 %: this tree measured 19.4 .. 20.2 ms on the boxes of this
+round.  Round 6 changed one hot path of this step (the stage-3 fc weight gradients: -0.04 ms same-box; `docs/experiments_r6.md`: five other kernel-level attempts measured same-box, none faster), so the step is round 5's within that spread; what changed in the LINE:
+the roofline launch runs with the step's own DropPath factors (4 of 256 samples dropped, `algorithmic_flops` counts the kept ones -- round 5 dropped one in ten while counting all: the `frac` erred upward), `frac_in_step` gives the same kernel's fraction from the
+committed kernel trace, the TN sibling is timed the way the step launches it (partial tiles + fold), `other_configs` are faster (pvlt_medium at 384 px: ragged 192 x 320 tiles + one-chunk attention backward), `config.parity_note` states the bf16 ITM exemption.
+Loss trajectory unchanged (epoch average {bench['config']['epoch_avg_loss']:.2f}, same synthetic batch).
 
 | field | value | how to recompute it |
 |---|---|---|
 | `value`, `ms_per_step` | {pairs(bench['value'])} pairs/s, {bench['ms_per_step']:.3f} ms | 256 pairs x 20 steps / wall time between `torch.cuda.synchronize()`s around `train_one_epoch_vl`; kernel sum of one step: {busy_ms:.2f} ms (`{tag}_step_launches.txt`) |
 | `flops.blocks_only` | {bo['ms_per_step']:.2f} ms, {bo['tflops']:.1f} TFLOP/s, **{bo['mfma_frac']:.3f}** | HIP events around the Block kernels of every stage, fwd + bwd, two extra iterations; 3 x 8.003 GFLOP x 256 / {bo['ms_per_step']:.2f} ms / 2.5 PFLOP/s |
 | `flops.mfma_frac_executed` | {fl_['mfma_frac_executed']:.3f} | {fl_['executed_gflop_per_pair']:.2f} GFLOP/pair executed (MLM head on the selected rows of 32768 only; + 2.32 fc1 recomputed) x {pairs(bench['value'])} / 2.5 PFLOP/s |
-| `roofline` (kernel as reported by the library: `{rf['kernel'].split(' (bf16)')[0]}`, the launch VERDICT r3 named) | achieved {rf['achieved']:.1f} TFLOP/s, **frac {rf['frac']:.3f}**, {rf['ms_per_launch']:.3f} ms; {rf['share_of_step']} | algorithmic FLOPs 2 x 2 M C hid = 4 x 1081344 x 64 x 512 = 141.73 GFLOP / {rf['ms_per_launch']:.3f} ms (HIP events, 20 launches, torch's current stream = the launch stream); `{tag}_kernel_stats.csv`: {ks_avg_us:.1f} us average over {ks_calls} calls (in-step + this timing) -> {141.73e9 / (ks_avg_us * 1e-6) / 1e12:.1f} TFLOP/s = {141.73e9 / (ks_avg_us * 1e-6) / 1e12 / 2500:.3f}; executed FLOPs are twice the algorithmic ones (h and dg recomputed on chip) |
+| `roofline` (kernel as reported by the library: `{rf['kernel'].split(' (bf16)')[0]}`, the launch VERDICT r3 named) | achieved {rf['achieved']:.1f} TFLOP/s, **frac {rf['frac']:.3f}**, {rf['ms_per_launch']:.3f} ms; {rf['share_of_step']} | algorithmic FLOPs 2 x 2 M C hid x kept samples = {rf['algorithmic_flops'] / 1e9:.2f} GFLOP / {rf['ms_per_launch']:.3f} ms (HIP events, 20 launches, torch's current stream = the launch stream); `{tag}_kernel_stats.csv`: {ks_avg_us:.1f} us average over {ks_calls} calls (in-step + this timing) -> {141.73e9 / (ks_avg_us * 1e-6) / 1e12:.1f} TFLOP/s = {141.73e9 / (ks_avg_us * 1e-6) / 1e12 / 2500:.3f}; executed FLOPs are twice the algorithmic ones (h and dg recomputed on chip); `frac_in_step` of the line: {rf.get('frac_in_step', {{}}).get('frac', float('nan')):.3f} |
 | `roofline.traffic` | {rf['traffic'] / 1e6:.1f} MB per launch | `{tag}_roofline_traffic.json`: 2 x FETCH_SIZE ({mw['fetch_size_kib']:,.0f} KiB) + WRITE_SIZE ({mw['write_size_kib']:,.0f} KiB), separate `--pmc` passes over `tools/roofline_launch.py`, {mw['dispatches']} dispatches; calibration in the same run: torch's fp32 -> bf16 cast of a 262144 x 192 tensor reads {cal['read_bytes'] / 1e6:.2f} MB (expected {cal['expected_read_bytes'] / 1e6:.2f}) and writes {cal['write_bytes'] / 1e6:.2f} ({cal['expected_write_bytes'] / 1e6:.2f}); algorithmic bytes 276.8 MB -> {rf['traffic'] / 276.824064e6:.2f} x (the partial-sum flushes) |
 | `roofline.siblings` | conv3x3 192 -> 192 (`{sib[0]['kernel'].split(' (bf16)')[0]}`): {sib[0]['achieved']:.0f} TFLOP/s = **{sib[0]['frac']:.2f}**, {sib[0]['traffic'] / 1e6:.1f} MB; K = 64 projection (`{sib[1]['kernel'].split(' (bf16)')[0]}`): {sib[1]['achieved'] / 1e3:.2f} TB/s = **{sib[1]['frac']:.2f}** of 8 TB/s, {sib[1]['traffic'] / 1e6:.0f} MB; stage-3 fc2 weight gradient (`{sib[2]['kernel'].split(' (bf16)')[0]}`, the trace's top instantiation): {sib[2]['achieved']:.0f} TFLOP/s = **{sib[2]['frac']:.2f}**, {sib[2]['ms_per_launch'] * 1e3:.1f} us, {(sib[2]['traffic'] or 0) / 1e6:.1f} MB against {sib[2]['algorithmic_bytes'] / 1e6:.1f} MB algorithmic | {sib[0]['algorithmic_flops'] / 1e9:.1f} GFLOP / {sib[0]['ms_per_launch']:.4f} ms; {sib[1]['algorithmic_bytes'] / 1e6:.1f} MB / {sib[1]['ms_per_launch']:.4f} ms; {sib[2]['algorithmic_flops'] / 1e9:.1f} GFLOP / {sib[2]['ms_per_launch']:.4f} ms |
-| `step.hbm_gb_per_step` | {st['hbm_gb_per_step']:.2f} GB, {st['hbm_tb_per_s']:.2f} TB/s | `{tag}_step_traffic.txt`: FETCH_SIZE x 2 + WRITE_SIZE over 6 whole steps of the bench process, per kernel (round 4: 63.19, round 3: 66.65) |
+| `step.hbm_gb_per_step` | {st['hbm_gb_per_step']:.2f} GB, {st['hbm_tb_per_s']:.2f} TB/s | `{tag}_step_traffic.txt`: FETCH_SIZE x 2 + WRITE_SIZE over 6 whole steps of the bench process, per kernel (round 5: 63.21, round 4: 63.19, round 3: 66.65) |
 | `cpu_baseline` | {cb['value']:.1f} pairs/s train step, {cb.get('forward_loss_value', 0):.1f} forward + loss, {cb['cores']} cores, `kind: {cb['kind']}` | the oracle at config #1 shapes (4 pairs, fp32), ~20 s sample on the box's host cores; a reported baseline, not a target |
 | `other_configs` | medium384_b64 **{pairs(oc['medium384_b64']['pairs_s'])} pairs/s** ({oc['medium384_b64']['ms_per_step']:.1f} ms, {oc['medium384_b64']['mfma_frac_reference_equivalent']:.3f} of peak reference-equivalent), finetune **{pairs(oc['finetune']['pairs_s'])} pairs/s** ({oc['finetune']['ms_per_step']:.1f} ms, {oc['finetune']['mfma_frac_reference_equivalent']:.3f}), eval forward **{pairs(oc['eval_forward']['pairs_s'])} pairs/s** ({oc['eval_forward']['ms_per_batch']:.2f} ms per batch of 256, {oc['eval_forward']['mfma_frac_executed']:.3f} executed) | BASELINE configurations #4 / #5 at one GPU, 5 + 10 / 5 + 20 iterations of the same engine entry behind the headline; the eval callers' model call (eval mode, no_grad, masked-row MLM head, BatchNorms folded) 3 + 10 times |
 """
 
+# ---------------------------------------------------------------- 3.5: what the step could take (tools/ceiling_table.py over the whole-step counter passes)
+import subprocess
+_ct = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ceiling_table.py"), P("step_sq.csv"), P("step_traffic.txt"), "--md", "--check"], capture_output=True, text=True)
+if _ct.returncode != 0:
+    print("tools/ceiling_table.py failed:", _ct.stdout[-400:], _ct.stderr[-400:])
+    sys.exit(1)
+t35 = f"""### 3.5 The ceiling of this kernel decomposition, totalled (`python tools/ceiling_table.py profiles/{tag}_step_sq.csv profiles/{tag}_step_traffic.txt --md`)
+
+Per kernel of one step, from two whole-step counter passes over the bench process (`tools/step_sq.sh`, `tools/step_traffic.sh`; times in us per step): t_bytes = its measured HBM bytes / 6.3 TB/s,
+t_mfma = its executed MFMA FLOPs (`SQ_INSTS_VALU_MFMA_MOPS_BF16` x 512) / 2.5 PFLOP/s, t_valu = its non-MFMA VALU wave-instructions / 1024 SIMDs x 1.5 ns (the measured issue rate of plain
+f32 VALU at four waves per SIMD); ceiling = the largest of the three, i.e. perfect overlap of the three pipes inside every kernel and nothing else in the way.
+
+""" + _ct.stdout + """
+Read with `docs/experiments_r6.md` 3 and 5: on ONE SIMD the matrix and the vector pipe mostly serialise (a {MFMA + 8 VALU} stream costs 15.9 ns where the two alone cost 8.05 + 12.4; at two
+waves per SIMD 28.7), so the fused-MLP kernels' real floor is the SUM of t_mfma and t_valu, not their maximum -- they run at 1.2-1.4 x that sum -- and the table's "ceiling" is an upper bound on what tuning can return.
+"""
+
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
-for name, text in (("3.1", t31), ("3.2", t32), ("6", t6)):
+for name, text in (("3.1", t31), ("3.2", t32), ("3.5", t35), ("6", t6)):
     b, e = f"<!-- BEGIN:{name} -->", f"<!-- END:{name} -->"
     i, j = s.index(b) + len(b), s.index(e)
     s = s[:i] + "\n" + text + s[j:]
 if CHECK:
     if s != open(p).read():
-        print("DESIGN.md sections 3.1 / 3.2 / 6 differ from profiles/%s_*: run python tools/design_tables.py %s" % (tag, tag))
+        print("DESIGN.md sections 3.1 / 3.2 / 3.5 / 6 differ from profiles/%s_*: run python tools/design_tables.py %s" % (tag, tag))
         sys.exit(1)
     print("DESIGN.md sections 3.1 / 3.2 / 6 match profiles/%s_*" % tag)
     sys.exit(0)

@@ -7,11 +7,11 @@ from mvlt_amd import pvlt
 from mvlt_amd.engine import BF16Scaler, train_step
 from mvlt_amd.optim import FusedAdamW
 dev = torch.device('cuda', 0)
-model = pvlt.pvlt_tiny(pretrained=False, token_hidden_size=768, num_text_tokens=128, loss_type=dict(mlm=1, itm=1, t2i=1, cls=0),
+model = getattr(pvlt, os.environ.get("MODEL", "pvlt_tiny"))(pretrained=False, token_hidden_size=768, num_text_tokens=128, loss_type=dict(mlm=1, itm=1, t2i=1, cls=0),
                        pretrained_pth=None, drop_path_rate=0.1, drop_rate=0.0, num_classes=1000, in_chans=3).cuda(dev)
 model.train()
-B = 256
-batch = bench.synth_batch(B, 256, 128, dev, 1)
+B, IMG = int(os.environ.get("B", "256")), int(os.environ.get("IMG", "256"))        # MODEL=pvlt_medium IMG=384 B=64: BASELINE configuration #4
+batch = bench.synth_batch(B, IMG, 128, dev, 1)
 batch["mlm_count"] = int((batch["mlm_labels"] != -1).sum())
 opt = FusedAdamW(model, lr=1e-4, weight_decay=0.01); scaler = BF16Scaler()
 def step(i):

@@ -20,7 +20,7 @@ from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvlt_amd.build import source_hash  # noqa: E402
 
-CASE = {"gemm_tn_dma_kernel<128, 128, 3, 2, false>": "tn_s3dw2", "mlp_wgrad2_kernel<64": "mlp_dw64", "mlp_wgrad_kernel<64": "mlp_dw64", "conv3_nt_kernel<32, 192": "conv192", "gemm_nt_dma_kernel<192": "conv192", "gemm_nt_dma_kernel<128": "conv192", "gemm_nt_dma_kernel<64": "proj64", "gemm_nt_kernelIDF16bLi128": "conv192",
+CASE = {"gemm_tn_p8_kernel<3, 3, 2": "tn_s3dw2", "gemm_tn_dma_kernel<128, 128, 3, 2, false>": "tn_s3dw2", "mlp_wgrad2_kernel<64": "mlp_dw64", "mlp_wgrad_kernel<64": "mlp_dw64", "conv3_nt_kernel<32, 192": "conv192", "gemm_nt_dma_kernel<192": "conv192", "gemm_nt_dma_kernel<128": "conv192", "gemm_nt_dma_kernel<64": "proj64", "gemm_nt_kernelIDF16bLi128": "conv192",
         "gemm_nt_kernelIDF16bLi64": "proj64", "bfloat16_copy_kernel": "calib_cast"}
 
 
