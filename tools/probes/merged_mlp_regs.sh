@@ -1,0 +1,10 @@
+#!/bin/bash
+# Register / scratch bill of the weight-gradient HALF of a merged fused-MLP backward kernel, read off the ISA without a GPU:
+# mlp_wgrad2_kernel<64, 4> compiled with 8 / 4 / 2 hidden tiles per wave = 512 / 256 / 128 hidden units per workgroup (2 = the product).  A merged kernel needs the
+# accumulators of ALL the hidden units whose input-gradient contribution it finishes on chip, plus the dx consumer's own 16-64 accumulator registers and W1^T fragments on top.
+#   bash tools/probes/merged_mlp_regs.sh > profiles/r06_merged_mlp_isa.txt
+cd "$(dirname "$0")/../.."
+for jt in 8 4 2; do
+  echo "== hidden tiles per wave: $jt (hidden units per four-wave workgroup: $((jt * 64)), one wave per SIMD allowed: 512 registers)"
+  MVLT_ISA_FLAGS="-DMVLT_WGRAD2_JT_PROBE=$jt" python3 tools/isa_mix.py mvlt_amd/csrc/mlp.hip "mlp_wgrad2_kernel<64, 4>" 2>&1 | cut -c1-220
+done
