@@ -962,15 +962,10 @@ __device__ __forceinline__ void gelu_fast_both1(float x, float& g, float& dg) {
   dg = __builtin_fmaf(x * up, __builtin_fmaf(-sg, sg, sg), sg);          // s + x u' s (1 - s)
 }
 
-// MVLT_WGRAD2_JT_PROBE (compile-only, tools/probes/merged_mlp_regs.sh): the hidden tiles per wave a MERGED backward kernel would have to hold -- 8 at C = 64 on four waves = all 512
-// hidden units' weight-gradient accumulators on one CU -- to read the register / scratch bill off the ISA.  Never set in the product build.
-#ifndef MVLT_WGRAD2_JT_PROBE
-#define MVLT_WGRAD2_JT_PROBE 0
-#endif
 template <int C, int NW>
-__global__ __launch_bounds__(NW * 64, MVLT_WGRAD2_JT_PROBE ? 1 : 2) void mlp_wgrad2_kernel(mvlt_mlp_args p, int m_per_split, int splits, int ny) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void mlp_wgrad2_kernel(mvlt_mlp_args p, int m_per_split, int splits, int ny) {
   constexpr int NTH = NW * 64;
-  constexpr int JT = MVLT_WGRAD2_JT_PROBE ? MVLT_WGRAD2_JT_PROBE : 8 / NW;                   // 16-unit hidden tiles per wave: 2 (4 waves) / 1 (8 waves)
+  constexpr int JT = 8 / NW;                   // 16-unit hidden tiles per wave: 2 (4 waves) / 1 (8 waves)
   constexpr int KS_C = C / 32, CT16 = C / 16;
   constexpr int ROWB = 2 * C;                  // bytes per token row
   constexpr int CH = C / 8;                    // 16-B slots per row
