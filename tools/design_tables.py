@@ -194,6 +194,7 @@ ks = [l for l in open(P("kernel_stats.csv")) if "mlp_wgrad2_kernel<64" in l][0].
 ks_calls, ks_avg_us = int(ks[0]), float(ks[2]) / 1e3
 mw, cal = tj["mlp_dw64"], tj["calib_cast"]
 pairs = lambda x: f"{x:,.0f}".replace(",", " ")
+_fis = (rf.get("frac_in_step") or {}).get("frac", float("nan"))
 t6 = f"""**The line of the final build** (`profiles/{tag}_bench_n1.json`, command `python bench.py`, sources `{tj['_source_hash']}`): **{pairs(bench['value'])} pairs/s, {bench['ms_per_step']:.2f} ms/step**
 (round 5: driver 12 872 / 19.89; round 4: 12 532 / 20.43; round 3: 11 428 / 22.40).  The boxes of the pool differ by +-2.5 %: this tree measured 19.4 .. 20.2 ms on the boxes of this
 round.  Round 6 changed one hot path of this step (the stage-3 fc weight gradients: -0.04 ms same-box; `docs/experiments_r6.md`: five other kernel-level attempts measured same-box, none faster), so the step is round 5's within that spread; what changed in the LINE:
@@ -206,7 +207,7 @@ Loss trajectory unchanged (epoch average {bench['config']['epoch_avg_loss']:.2f}
 | `value`, `ms_per_step` | {pairs(bench['value'])} pairs/s, {bench['ms_per_step']:.3f} ms | 256 pairs x 20 steps / wall time between `torch.cuda.synchronize()`s around `train_one_epoch_vl`; kernel sum of one step: {busy_ms:.2f} ms (`{tag}_step_launches.txt`) |
 | `flops.blocks_only` | {bo['ms_per_step']:.2f} ms, {bo['tflops']:.1f} TFLOP/s, **{bo['mfma_frac']:.3f}** | HIP events around the Block kernels of every stage, fwd + bwd, two extra iterations; 3 x 8.003 GFLOP x 256 / {bo['ms_per_step']:.2f} ms / 2.5 PFLOP/s |
 | `flops.mfma_frac_executed` | {fl_['mfma_frac_executed']:.3f} | {fl_['executed_gflop_per_pair']:.2f} GFLOP/pair executed (MLM head on the selected rows of 32768 only; + 2.32 fc1 recomputed) x {pairs(bench['value'])} / 2.5 PFLOP/s |
-| `roofline` (kernel as reported by the library: `{rf['kernel'].split(' (bf16)')[0]}`, the launch VERDICT r3 named) | achieved {rf['achieved']:.1f} TFLOP/s, **frac {rf['frac']:.3f}**, {rf['ms_per_launch']:.3f} ms; {rf['share_of_step']} | algorithmic FLOPs 2 x 2 M C hid x kept samples = {rf['algorithmic_flops'] / 1e9:.2f} GFLOP / {rf['ms_per_launch']:.3f} ms (HIP events, 20 launches, torch's current stream = the launch stream); `{tag}_kernel_stats.csv`: {ks_avg_us:.1f} us average over {ks_calls} calls (in-step + this timing) -> {141.73e9 / (ks_avg_us * 1e-6) / 1e12:.1f} TFLOP/s = {141.73e9 / (ks_avg_us * 1e-6) / 1e12 / 2500:.3f}; executed FLOPs are twice the algorithmic ones (h and dg recomputed on chip); `frac_in_step` of the line: {rf.get('frac_in_step', {{}}).get('frac', float('nan')):.3f} |
+| `roofline` (kernel as reported by the library: `{rf['kernel'].split(' (bf16)')[0]}`, the launch VERDICT r3 named) | achieved {rf['achieved']:.1f} TFLOP/s, **frac {rf['frac']:.3f}**, {rf['ms_per_launch']:.3f} ms; {rf['share_of_step']} | algorithmic FLOPs 2 x 2 M C hid x kept samples = {rf['algorithmic_flops'] / 1e9:.2f} GFLOP / {rf['ms_per_launch']:.3f} ms (HIP events, 20 launches, torch's current stream = the launch stream); `{tag}_kernel_stats.csv`: {ks_avg_us:.1f} us average over {ks_calls} calls (in-step + this timing) -> {141.73e9 / (ks_avg_us * 1e-6) / 1e12:.1f} TFLOP/s = {141.73e9 / (ks_avg_us * 1e-6) / 1e12 / 2500:.3f}; executed FLOPs are twice the algorithmic ones (h and dg recomputed on chip); `frac_in_step` of the line: {_fis:.3f} |
 | `roofline.traffic` | {rf['traffic'] / 1e6:.1f} MB per launch | `{tag}_roofline_traffic.json`: 2 x FETCH_SIZE ({mw['fetch_size_kib']:,.0f} KiB) + WRITE_SIZE ({mw['write_size_kib']:,.0f} KiB), separate `--pmc` passes over `tools/roofline_launch.py`, {mw['dispatches']} dispatches; calibration in the same run: torch's fp32 -> bf16 cast of a 262144 x 192 tensor reads {cal['read_bytes'] / 1e6:.2f} MB (expected {cal['expected_read_bytes'] / 1e6:.2f}) and writes {cal['write_bytes'] / 1e6:.2f} ({cal['expected_write_bytes'] / 1e6:.2f}); algorithmic bytes 276.8 MB -> {rf['traffic'] / 276.824064e6:.2f} x (the partial-sum flushes) |
 | `roofline.siblings` | conv3x3 192 -> 192 (`{sib[0]['kernel'].split(' (bf16)')[0]}`): {sib[0]['achieved']:.0f} TFLOP/s = **{sib[0]['frac']:.2f}**, {sib[0]['traffic'] / 1e6:.1f} MB; K = 64 projection (`{sib[1]['kernel'].split(' (bf16)')[0]}`): {sib[1]['achieved'] / 1e3:.2f} TB/s = **{sib[1]['frac']:.2f}** of 8 TB/s, {sib[1]['traffic'] / 1e6:.0f} MB; stage-3 fc2 weight gradient (`{sib[2]['kernel'].split(' (bf16)')[0]}`, the trace's top instantiation): {sib[2]['achieved']:.0f} TFLOP/s = **{sib[2]['frac']:.2f}**, {sib[2]['ms_per_launch'] * 1e3:.1f} us, {(sib[2]['traffic'] or 0) / 1e6:.1f} MB against {sib[2]['algorithmic_bytes'] / 1e6:.1f} MB algorithmic | {sib[0]['algorithmic_flops'] / 1e9:.1f} GFLOP / {sib[0]['ms_per_launch']:.4f} ms; {sib[1]['algorithmic_bytes'] / 1e6:.1f} MB / {sib[1]['ms_per_launch']:.4f} ms; {sib[2]['algorithmic_flops'] / 1e9:.1f} GFLOP / {sib[2]['ms_per_launch']:.4f} ms |
 | `step.hbm_gb_per_step` | {st['hbm_gb_per_step']:.2f} GB, {st['hbm_tb_per_s']:.2f} TB/s | `{tag}_step_traffic.txt`: FETCH_SIZE x 2 + WRITE_SIZE over 6 whole steps of the bench process, per kernel (round 5: 63.21, round 4: 63.19, round 3: 66.65) |
