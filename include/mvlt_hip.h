@@ -26,7 +26,7 @@ extern "C" {
  *   3 (round 5): mvlt_gemm_tn_args.partials / partials_bytes; mvlt_last_kernel()
  *   4: mvlt_weight_prep blk_desc      5: mvlt_gemm_tn_args.defer_fold, mvlt_tn_fold_flush(), mvlt_tn_fold_discard()
  *   6 (round 6): mvlt_tn_fold_flush(partials, stream) / mvlt_tn_fold_discard(partials): the pending-fold table is kept per scratch (= per owner);
- *                mvlt_sr_attention_bwd_chunks() */
+ *                mvlt_sr_attention_bwd_chunks(); mvlt_gemm_tn_args.c_overwrite; mvlt_mlp_args.partials / partials_bytes / defer_fold */
 #define MVLT_ABI_VERSION 6
 const char* mvlt_last_error(void);
 int mvlt_abi_version(void);
@@ -128,6 +128,11 @@ typedef struct mvlt_gemm_tn_args {
    * launch; the library folds by itself when its table or the scratch is full or when a non-deferring launch needs the scratch, and when the caller says
    * mvlt_tn_fold_flush(): REQUIRED before anything reads a gradient a deferring launch produced.  0: fold right behind the GEMM (ABI 5). */
   int defer_fold;
+  /* 1: C = A^T B instead of C += (round 6, ABI 6): the caller knows C holds zeros -- the vocabulary decoder's weight gradient, the first writer of its 94 MB slice of a gradient
+   * buffer zeroed at the start of the backward pass -- so the ONE m-split the launch is then made of stores its tiles plainly (16-byte row pieces through LDS) instead of 23 M
+   * fire-and-forget fp32 atomics (141 -> ~80 us).  bf16 operands, plain or mapped rows, trans_c == 0, c_taps <= 1, N2 % 4 == 0, ldc % 4 == 0, C 16-byte aligned; forces splits = 1,
+   * ignores partials. */
+  int c_overwrite;
 } mvlt_gemm_tn_args;
 int mvlt_gemm_tn(const mvlt_gemm_tn_args* args, void* stream);
 /* fold the deferred partial-tile reductions of the scratch `partials` (NULL: of every scratch) now: one launch per scratch on the stream their producers ran on; when `stream`
@@ -389,6 +394,11 @@ typedef struct mvlt_mlp_args {
   const float* lnb_x; const float* lnb_mean; const float* lnb_rstd; const float* lnb_gamma;
   void* lnb_dx; void* lnb_dx2; const float* lnb_dx2_scale; int lnb_dx2_rows_per_scale;
   float* lnb_partials;
+  /* bwd_dw only, optional (round 6, ABI 6): scratch for the token-split reduction WITHOUT atomics, shared with mvlt_gemm_tn (same pointer = same pending-fold table).  Every
+   * token split stores its dW1 [hid][C] and dW2 [C][hid] partial sums in bf16 ([splits][hid][C] + [splits][C][hid], 2 x splits x hid x C x 2 bytes) and the ordered fold adds
+   * them to dw1 / dw2 -- deterministic, and no 8.4 M fp32 atomics per launch; db1 / db2 (hid + C floats per split) keep their atomics.  defer_fold as in mvlt_gemm_tn_args.
+   * Taken by the kernel with a DropPath factor per 64-token tile (rows_per_scale % 64 == 0 or no row_scale); NULL or too small: atomics. */
+  void* partials; long partials_bytes; int defer_fold;
 } mvlt_mlp_args;
 int mvlt_mlp_fwd(const mvlt_mlp_args* args, void* stream);
 int mvlt_mlp_bwd_dx(const mvlt_mlp_args* args, void* stream);

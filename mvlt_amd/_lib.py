@@ -53,7 +53,7 @@ class GemmTNArgs(C.Structure):
                 ("dtype", c_int), ("a_map", RowMap), ("b_map", RowMap),
                 ("colsum_a", c_void_p), ("splits", c_int), ("colsum_b", c_void_p), ("trans_c", c_int),
                 ("c_taps", c_int), ("c_seg", c_int), ("dgrad_wt", c_void_p), ("dgrad_out", c_void_p), ("dgrad_ld", c_int),
-                ("partials", c_void_p), ("partials_bytes", c_long), ("defer_fold", c_int)]
+                ("partials", c_void_p), ("partials_bytes", c_long), ("defer_fold", c_int), ("c_overwrite", c_int)]
 
 
 class LayerNormArgs(C.Structure):
@@ -101,7 +101,7 @@ class MlpArgs(C.Structure):
                 ("post_y", c_void_p), ("post_mean", c_void_p), ("post_rstd", c_void_p),
                 ("lnb_x", c_void_p), ("lnb_mean", c_void_p), ("lnb_rstd", c_void_p), ("lnb_gamma", c_void_p),
                 ("lnb_dx", c_void_p), ("lnb_dx2", c_void_p), ("lnb_dx2_scale", c_void_p), ("lnb_dx2_rows_per_scale", c_int),
-                ("lnb_partials", c_void_p)]
+                ("lnb_partials", c_void_p), ("partials", c_void_p), ("partials_bytes", c_long), ("defer_fold", c_int)]
 
 
 lib.mvlt_last_error.restype = C.c_char_p

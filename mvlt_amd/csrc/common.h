@@ -85,6 +85,12 @@ template <auto K> inline void mvlt_max_lds() {
   done.fetch_or(bit, std::memory_order_relaxed);
 }
 
+// partial-tile reductions of the weight-gradient kernels (gemm.hip): the scratch region for `need` bytes of bf16 partial tiles of the output a.C [a.N1][a.N2] (nullptr: they do
+// not fit / no scratch), and the fold of `splits` tiles [splits][N1][N2] into it (at once, or appended to the scratch's pending table: a.defer_fold).  Also used by mlp.hip.
+struct mvlt_gemm_tn_args;
+bf16* mvlt_fold_acquire_ext(const mvlt_gemm_tn_args& a, long need, hipStream_t s, int descriptors);       // room for that many fold_launch calls behind it
+void mvlt_fold_launch_ext(const mvlt_gemm_tn_args& a, const bf16* part, int splits, hipStream_t s);
+
 #define MVLT_REQUIRE(cond, ...)                 \
   do {                                          \
     if (!(cond)) {                              \

@@ -1421,6 +1421,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_dma_kernel(mvlt_gemm_tn_a
     }
     return;
   }
+  if (p.c_overwrite) {
+    // round 6: C = (not +=) this launch's single m-split (the caller vouches for a zeroed C: the vocabulary decoder's weight gradient, 30522 x 768 = 23 M outputs whose
+    // fire-and-forget fp32 atomics were most of the launch).  16 rows of the wave tile at a time through a per-wave LDS tile, out as 16-byte pieces of contiguous rows.
+    constexpr int LDP = WN + 4;
+    constexpr int CPR = WN / 4;
+    __syncthreads();                                   // every wave is done with the operand tiles this overlays
+    float* const st = (float*)smem + wave * 16 * LDP;
+#pragma unroll
+    for (int i = 0; i < TM_; ++i) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < TN_; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[(4 * fg + r) * LDP + j * 16 + fr] = acc[i][j][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = lane; q < 16 * CPR; q += 64) {
+        const int row = q / CPR, ch = q - row * CPR;
+        const int n1 = n1_0 + wm * WM + i * 16 + row, n2 = n2_0 + wn * WN + ch * 4;
+        if (n1 < p.N1 && n2 < p.N2) st_g<MVLT_NT_GEMM>((f32x4*)(p.C + (size_t)n1 * p.ldc + n2), *(const f32x4*)(st + row * LDP + ch * 4));
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM_; ++i)
 #pragma unroll
@@ -1643,11 +1669,11 @@ void fold_flush_locked(FoldPending& f, hipStream_t reader, bool order_reader) {
   f.used = 0;
 }
 // the scratch region of this launch's partial tiles, or nullptr when they do not fit
-bf16* fold_acquire(const mvlt_gemm_tn_args& a, long need, hipStream_t s) {
+bf16* fold_acquire(const mvlt_gemm_tn_args& a, long need, hipStream_t s, int room = 1) {
   if (!a.partials || ((uintptr_t)a.partials & 15) || need > a.partials_bytes) return nullptr;
   std::lock_guard<std::mutex> lk(g_fold_mu);
   FoldPending& f = g_fold[a.partials];
-  bool flush = f.b.n > 0 && (!a.defer_fold || f.stream != s || f.b.n == FOLD_MAX || f.used + need > a.partials_bytes);
+  bool flush = f.b.n > 0 && (!a.defer_fold || f.stream != s || f.b.n + room > FOLD_MAX || f.used + need > a.partials_bytes);
   // two pending folds into the same gradient would be two unordered read-modify-writes in one launch (the kv weight gradient takes its text rows and its image rows from two
   // GEMMs): an output that overlaps a pending one folds the pending ones first
   const float* c_lo = a.C;
@@ -3011,6 +3037,9 @@ extern "C" int mvlt_gemm_nt(const mvlt_gemm_nt_args* a, void* stream) {
   return mvlt_check_launch("mvlt_gemm_nt");
 }
 
+bf16* mvlt_fold_acquire_ext(const mvlt_gemm_tn_args& a, long need, hipStream_t s, int descriptors) { return fold_acquire(a, need, s, descriptors); }
+void mvlt_fold_launch_ext(const mvlt_gemm_tn_args& a, const bf16* part, int splits, hipStream_t s) { fold_launch(a, part, splits, s); }
+
 extern "C" int mvlt_tn_fold_discard(const void* partials) {
   // forget the pending folds of one scratch (NULL: of every scratch) without launching anything: their producers belong to a pass that was abandoned
   std::lock_guard<std::mutex> lk(g_fold_mu);
@@ -3124,10 +3153,12 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
       }
       return mvlt_check_launch("mvlt_gemm_tn");
     }
+    MVLT_REQUIRE(!a->c_overwrite || (!a->trans_c && a->c_taps <= 1 && a->N2 % 4 == 0 && a->ldc % 4 == 0 && ((uintptr_t)a->C & 15) == 0),
+                 "mvlt_gemm_tn: c_overwrite needs the plain output layout, N2 % 4 == 0, ldc % 4 == 0 and a 16-byte aligned C");
     const bool small_out = a->N1 <= 128 && a->N2 <= 128 && !getenv("MVLT_TN_NO64");
     const int bmt = (a->N1 <= 64 || small_out) ? 64 : 128, bn = (a->N2 <= 64 || small_out) ? 64 : 128;
     const int t1 = (a->N1 + bmt - 1) / bmt, t2 = (a->N2 + bn - 1) / bn;
-    int splits = a->splits;
+    int splits = a->c_overwrite ? 1 : a->splits;
     if (splits <= 0) {
       // 2 workgroups per CU in one round: every extra split is another N1*N2 fp32 atomics through the fabric
       splits = ((t1 * t2 == 1 ? 384 : 512) + t1 * t2 - 1) / (t1 * t2);     // a single output tile: 384 (1081344 x 64 x 64: 54.7 -> 48.9 us)
@@ -3149,7 +3180,7 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
     // batched folds 16 / 8 / 4 / 2 all measure 12.98-13.00 k pairs/s against 12.90 at 24): bf16 partial tiles into the caller's scratch
     // + an ordered fold instead of the atomics (14-21 us of a 53-56 us launch, profiles/r05_tn_small_atomics_ablation.txt).  Fewer splits: the atomics are cheaper than a fold launch.
     static const int part_min = getenv("MVLT_TN_PART_MIN") ? atoi(getenv("MVLT_TN_PART_MIN")) : 8;
-    bf16* const part = (tnp8 && a->partials && splits >= part_min && !a->trans_c && a->c_taps <= 1 && a->N2 % 8 == 0 && a->ldc % 4 == 0 && ((uintptr_t)a->C & 15) == 0 &&
+    bf16* const part = (tnp8 && a->partials && !a->c_overwrite && splits >= part_min && !a->trans_c && a->c_taps <= 1 && a->N2 % 8 == 0 && a->ldc % 4 == 0 && ((uintptr_t)a->C & 15) == 0 &&
                         (long)a->N1 * a->N2 >= 65536)
                            ? fold_acquire(*a, (long)splits * a->N1 * a->N2 * 2, s) : nullptr;
 #define MVLT_TN_LAUNCH(BMT_, BN_, NS_)                                                                                          \

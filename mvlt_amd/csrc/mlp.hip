@@ -963,7 +963,7 @@ __device__ __forceinline__ void gelu_fast_both1(float x, float& g, float& dg) {
 }
 
 template <int C, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void mlp_wgrad2_kernel(mvlt_mlp_args p, int m_per_split, int splits, int ny) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void mlp_wgrad2_kernel(mvlt_mlp_args p, int m_per_split, int splits, int ny, bf16* part1, bf16* part2) {
   constexpr int NTH = NW * 64;
   constexpr int JT = 8 / NW;                   // 16-unit hidden tiles per wave: 2 (4 waves) / 1 (8 waves)
   constexpr int KS_C = C / 32, CT16 = C / 16;
@@ -1191,9 +1191,55 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void mlp_wgrad2_kernel(mv
     consume(I1{}, I0{}, IF{});
   }
   // ---- flush (true sums = run_sc x accumulators)
+  if (part1) {
+    // round 6: no atomics for the two weight gradients -- this token split's sums leave as bf16 PARTIAL tiles, part1[bz][hid][C] and part2[bz][C][hid], and the ordered fold of
+    // the TN GEMMs (tn_fold_multi_kernel) adds the splits into dw1 / dw2: 8.4 M fp32 atomics per launch less, and bit-identical fc gradients from run to run.  Through a
+    // per-wave LDS tile so that the partials leave as 16-byte pieces of contiguous rows (the operand tiles are dead: every wave is past the token loop).
+    constexpr int LD1 = C + 8;                 // dW1 rows: [16 hidden units][C]
+    constexpr int LD2 = 16 * JT + 8;           // dW2 rows: [16 channels][this wave's 16 JT hidden units]
+    constexpr int PERW = 16 * (LD1 > LD2 ? LD1 : LD2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16* const st = (bf16*)smem + wave * PERW;
+    bf16* const P1 = part1 + (size_t)bz * p.hid * C;
+    bf16* const P2 = part2 + (size_t)bz * p.hid * C;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+      const int jb = j0 + jw + jt * 16;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ct = 0; ct < CT16; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[(4 * fg + r) * LD1 + ct * 16 + fr] = (bf16)(dw1[jt][ct][r] * run_sc);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = lane; q < 16 * (C / 8); q += 64) {
+        const int row = q / (C / 8), ch = q - row * (C / 8);
+        *(u32x4*)(P1 + (size_t)(jb + row) * C + ch * 8) = *(const u32x4*)(st + row * LD1 + ch * 8);
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT16; ++ct) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[(4 * fg + r) * LD2 + jt * 16 + fr] = (bf16)(dw2[ct][jt][r] * run_sc);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane < 16 * 2 * JT) {
+        const int row = lane / (2 * JT), ch = lane - row * (2 * JT);
+        *(u32x4*)(P2 + (size_t)(ct * 16 + row) * p.hid + j0 + jw + ch * 8) = *(const u32x4*)(st + row * LD2 + ch * 8);
+      }
+    }
+  }
 #pragma unroll
   for (int jt = 0; jt < JT; ++jt) {
     const int jb = j0 + jw + jt * 16;
+    if (!part1) {
 #pragma unroll
     for (int ct = 0; ct < CT16; ++ct)
 #pragma unroll
@@ -1201,6 +1247,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void mlp_wgrad2_kernel(mv
         atomicAdd(&p.dw1[(long)(jb + 4 * fg + r) * C + ct * 16 + fr], dw1[jt][ct][r] * run_sc);
         atomicAdd(&p.dw2[(long)(ct * 16 + 4 * fg + r) * p.hid + jb + fr], dw2[ct][jt][r] * run_sc);
       }
+    }
     if (fr == 0) {                             // every column of the ones-product holds the same sums: column 0 adds them
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(&p.db1[jb + 4 * fg + r], db1m[jt][r] * run_sc);
@@ -1227,7 +1274,24 @@ template <int C> int launch_wgrad(const mvlt_mlp_args& a, hipStream_t s) {
     constexpr int NW = C == 64 ? 4 : 8;
     const size_t lds_t = lds + ((MVLT_GELU_LUT & 1) ? GELU_LUT_BYTES : 0);
     mvlt_max_lds<(mlp_wgrad2_kernel<C, NW>)>();
-    MVLT_LAUNCH((mlp_wgrad2_kernel<C, NW>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NW * 64), lds_t, s, a, m_per_split, splits, ny);
+    // the token splits' partial tiles of dW1 and dW2 in the caller's scratch (ONE region for both, room for two descriptors) + two folds behind the kernel -- launched at
+    // once, or appended to the scratch's pending table when the caller defers (MVLT_MLP_DW_PARTIALS=0: fp32 atomics as in round 5)
+    static const bool part_ok = !(getenv("MVLT_MLP_DW_PARTIALS") && atoi(getenv("MVLT_MLP_DW_PARTIALS")) == 0);
+    bf16 *part1 = nullptr, *part2 = nullptr;
+    mvlt_gemm_tn_args f1 = {}, f2 = {};
+    const long pbytes = (long)splits * a.hid * C * 2;
+    if (part_ok && a.partials && ((uintptr_t)a.dw1 & 15) == 0 && ((uintptr_t)a.dw2 & 15) == 0) {
+      f1.C = a.dw1; f1.N1 = a.hid; f1.N2 = C; f1.ldc = C;
+      f2.C = a.dw2; f2.N1 = C; f2.N2 = a.hid; f2.ldc = a.hid;
+      f1.partials = f2.partials = a.partials; f1.partials_bytes = f2.partials_bytes = a.partials_bytes; f1.defer_fold = f2.defer_fold = a.defer_fold;
+      part1 = mvlt_fold_acquire_ext(f1, 2 * pbytes, s, 2);
+      if (part1) part2 = part1 + pbytes / 2;
+    }
+    MVLT_LAUNCH((mlp_wgrad2_kernel<C, NW>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NW * 64), lds_t, s, a, m_per_split, splits, ny, part1, part2);
+    if (part1) {
+      mvlt_fold_launch_ext(f1, part1, splits, s);
+      mvlt_fold_launch_ext(f2, part2, splits, s);
+    }
     return mvlt_check_launch("mvlt_mlp_bwd_dw");
   }
   mvlt_max_lds<(mlp_wgrad_kernel<C>)>();

@@ -58,7 +58,7 @@ def weight_prep(desc_dev, blk_dev, ndesc, total_blocks, dtype, blk_desc=None):
           "mvlt_weight_prep")
 
 
-def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, colsum=None, splits=0, taps=0, seg=0, dgrad=None, partials=None, defer_fold=False):
+def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, colsum=None, splits=0, taps=0, seg=0, dgrad=None, partials=None, defer_fold=False, overwrite=False):
     """C[N1,N2] += A[M,N1]^T @ B[M,N2] (fp32 atomics); colsum[N1] += A.sum(0).  taps > 1: logical column tap*seg + c is
     accumulated at column c*taps + tap (conv weight gradients straight into the [out][cin][kh][kw] layout).
     dgrad = (W^T [N2][N1] bf16, out [M, N2] bf16): the Linear's input gradient out = A @ W from the same pass over A (N1 == N2 in {64, 128}).
@@ -90,6 +90,9 @@ def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, co
         if partials is not None:       # scratch for the atomic-free reduction of whole 256 x 256 output tiles (mvlt_gemm_tn_args.partials); ignored for other shapes
             a.partials, a.partials_bytes = ptr(partials), partials.numel() * partials.element_size()
             a.defer_fold = 1 if defer_fold else 0       # the caller promises tn_fold_flush() before anything reads C_out
+    if overwrite:
+        assert not a.trans_c and taps <= 1 and N2 % 4 == 0 and ldc % 4 == 0 and A.dtype == torch.bfloat16, "gemm_tn(overwrite=True): bf16, plain output layout, N2 and ldc multiples of 4"
+        a.c_overwrite = 1                               # C_out holds zeros (the caller's word): one m-split, plain stores instead of atomics
     check(L.lib.mvlt_gemm_tn(C.byref(a), stream_ptr()), "mvlt_gemm_tn")
     return C_out
 
@@ -459,10 +462,14 @@ def add_column_sums(partials, dst0, dst1):
     check(L.lib.mvlt_add_column_sums(_p(partials), rows, cols, cols, _p(dst0), dst0.numel(), _p(dst1), stream_ptr()), "mvlt_add_column_sums")
 
 
-def mlp_bwd_dw(x, dy, w1, w2t, b1, dw1, db1, dw2, db2, M, Cdim, hid, *, row_scale=None, rows_per_scale=0):
+def mlp_bwd_dw(x, dy, w1, w2t, b1, dw1, db1, dw2, db2, M, Cdim, hid, *, row_scale=None, rows_per_scale=0, partials=None, defer_fold=False):
+    """partials = the weight-gradient scratch of gemm_tn (FlatStore.tn_partials()): the token splits leave as bf16 partial tiles + the ordered fold instead of fp32 atomics;
+    defer_fold: folded with the other pending ones (tn_fold_flush before anything reads dw1 / dw2)"""
     assert x.dtype == dy.dtype == torch.bfloat16 and dw1.dtype == torch.float32
     a = L.MlpArgs(ptr(x), ptr(dy), ptr(w1), None, ptr(w2t), ptr(b1), None, None, ptr(row_scale), rows_per_scale,
                   None, None, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), M, Cdim, hid, None, None, None, 0.0, None, None, None)
+    if partials is not None:
+        a.partials, a.partials_bytes, a.defer_fold = ptr(partials), partials.numel() * partials.element_size(), 1 if defer_fold else 0
     check(L.lib.mvlt_mlp_bwd_dw(C.byref(a), stream_ptr()), "mvlt_mlp_bwd_dw")
 
 

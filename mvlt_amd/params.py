@@ -144,6 +144,8 @@ class FlatStore:
         self.on_range_ready = None        # optional callable(store, lo, hi): G[lo:hi] is final (overlapped all-reduce)
         self.on_pass_aborted = None       # optional callable(store): a backward pass died before its final callback (see new_pass)
         self._ranges_done = []
+        self.all_zeroed_this_pass = False        # set by begin_backward: the whole gradient buffer was zeroed for the running pass
+        self.touched_this_pass = set()           # gradient slices a kernel of the running pass has written (first writers may store instead of add)
         self.scale_in_optimizer = False   # set by engine.BF16Scaler around backward + FusedAdamW.step: that kernel applies `pending_grad_scale`
         self.pending_grad_scale = 1.0     # factor still owed to G (1/world after a data-parallel SUM all-reduce)
         # gradient collectives still in flight when the backward pass returned: [(work, lo, hi, g_view, payload or None, early)].  Only set while
@@ -341,6 +343,8 @@ class FlatStore:
                 ops.tn_fold_discard(self._tn_partials)         # THIS store's folds (the table is kept per scratch) a pass that raised left pending (nothing, normally): dropped, never run -- their gradients are void, their buffers may be gone
         live = [(n, q) for n, q in self.fn_params if q.requires_grad]
         alias = [q.grad is not None and q.grad.data_ptr() == self.grad(n).data_ptr() for n, q in live]
+        self.all_zeroed_this_pass = not any(alias)     # G is all zeros now: a pass's FIRST writer of a slice may store instead of add (schedule._mlm_decoder_bwd)
+        self.touched_this_pass = set()
         if not any(alias):
             self.G.zero_()
             self.pending_grad_scale = 1.0

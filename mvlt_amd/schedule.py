@@ -41,6 +41,7 @@ WGRAD_TAPS = bool(os.environ.get("MVLT_WGRAD_TAPS"))
 WGRAD_ADD = bool(os.environ.get("MVLT_WGRAD_ADD"))
 
 
+_NO_OVERWRITE = bool(os.environ.get("MVLT_TN_NO_OVERWRITE"))     # 1: the vocabulary decoder's weight gradient back on fp32 atomics (round 5)
 _DEFER_FOLD = os.environ.get("MVLT_TN_DEFER_FOLD", "1") != "0"     # the weight-gradient folds batched into a few launches (FlatStore.fold_copies flushes); 0 = one fold per GEMM
 
 
@@ -509,7 +510,8 @@ class TrunkStep:
         if bs["fused_mlp"]:
             w1, w2t = self.w(p + "mlp.fc1.weight"), self.wT(p + "mlp.fc2.weight")
             ops.mlp_bwd_dw(bs["xn2"], dx, w1, w2t, self.f32(p + "mlp.fc1.bias"), self.g(p + "mlp.fc1.weight"), self.g(p + "mlp.fc1.bias"),
-                           self.g(p + "mlp.fc2.weight"), self.g(p + "mlp.fc2.bias"), M, C, hid, row_scale=bs["s2"], rows_per_scale=N)
+                           self.g(p + "mlp.fc2.weight"), self.g(p + "mlp.fc2.bias"), M, C, hid, row_scale=bs["s2"], rows_per_scale=N,
+                           partials=self.S.tn_partials(), defer_fold=_DEFER_FOLD)
             if not _NO_LNB_FUSE:
                 # ... and norm2's backward rides on the dx kernel's epilogue (the row of d(LN output) is in registers there): dx is
                 # updated in place, the DropPath-scaled copy for the attention branch comes out of the same pass, no dxn2 round trip
@@ -805,7 +807,11 @@ def _mlm_decoder_bwd(model, dl, t, sv_t, e, sv_e, A, a_map, R, lda, dA, c_map=No
     S, dt, dev = model.store, model.compute_dtype, dl.device
     Hd = model.hidden
     wname = "text_embeddings.word_embeddings.weight"
-    ops.gemm_tn(dl, t, S.grad(wname), R, VOCAB, Hd, VOCAB_LD, Hd, Hd, colsum=S.grad("mlm_head.bias"))
+    # the first writer of the word table's gradient in a pass (bert_embed_bwd adds its lookup rows at the very end): when begin_backward zeroed the whole buffer for THIS
+    # pass the 23 M outputs are stored, not added by atomics (mvlt_gemm_tn_args.c_overwrite; a pass that accumulates onto earlier gradients keeps the atomics)
+    ops.gemm_tn(dl, t, S.grad(wname), R, VOCAB, Hd, VOCAB_LD, Hd, Hd, colsum=S.grad("mlm_head.bias"),
+                overwrite=dt == torch.bfloat16 and S.all_zeroed_this_pass and wname not in S.touched_this_pass and not _NO_OVERWRITE)
+    S.touched_this_pass.add(wname)
     wT = S.extra[wname + "::T"]                                   # [768, VOCAB_LD], zero padded
     if dt == torch.bfloat16:
         # few output tiles (R x 768), K = 30528: cut K over 4 workgroups per tile, partial sums meet in an fp32 buffer

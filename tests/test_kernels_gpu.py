@@ -358,6 +358,29 @@ def test_gemm_tn_partial_tiles_reduce_without_atomics(ops, M, N1, N2):
     assert "gemm_tn_dma_kernel" in last_kernel() and maxrel(Cw, ref) < 1e-3
 
 
+@pytest.mark.parametrize("M,N1,N2,ldc", [(1490, 30522, 768, 768), (1000, 500, 264, 272), (4096, 128, 128, 128)])
+def test_gemm_tn_overwrite_stores_instead_of_adding(ops, M, N1, N2, ldc):
+    """mvlt_gemm_tn_args.c_overwrite (round 6): C = A^T B by ONE m-split and plain 16-byte stores instead of fp32 atomics -- the vocabulary decoder's weight gradient
+    (1490 selected rows x 30522 words x 768, the first writer of its slice of the zeroed gradient buffer).  The buffer is pre-filled with 7 to show that nothing is added to
+    what was there, the columns behind N2 and the row behind N1 keep their 7s, the bias gradient (column sums of A) still accumulates, second launch bit-identical."""
+    dt = torch.bfloat16
+    A, B = rnd(M, N1, dtype=dt, scale=0.5), rnd(M, N2, dtype=dt, seed=1, scale=0.5)
+    lda = (N1 + 7) // 8 * 8
+    Ap = torch.zeros(M, lda, device=dev(), dtype=dt)
+    Ap[:, :N1] = A
+    ref = A.float().t() @ B.float()
+    outs = []
+    for _ in range(2):
+        Cw, cs = torch.full((N1 + 1, ldc), 7.0, device=dev()), torch.full((N1,), 1.0, device=dev())
+        ops.gemm_tn(Ap, B, Cw, M, N1, N2, lda, N2, ldc, colsum=cs, overwrite=True)
+        torch.cuda.synchronize()
+        outs.append((Cw, cs))
+    assert maxrel(outs[0][0][:N1, :N2], ref) < 1e-3
+    assert (outs[0][0][N1] == 7.0).all() and (outs[0][0][:, N2:] == 7.0).all()
+    assert maxrel(outs[0][1] - 1.0, A.float().sum(0)) < 1e-3
+    assert torch.equal(outs[0][0], outs[1][0])
+
+
 @pytest.mark.parametrize("M,N1,N2", [(45056, 1280, 320), (45056, 320, 1280), (49152, 1152, 320), (32768, 640, 1600)])
 def test_gemm_tn_192x320_tiles_of_the_8phase_loop(ops, M, N1, N2):
     """round 6: one side a multiple of 320, the other >= 1024 (the fc weight gradients of stage 3: dW1 1280 x 320, dW2 320 x 1280) on 192 x 320 tiles of the 8-wave /
@@ -1033,6 +1056,26 @@ def test_fused_mlp(ops, Cdim, hid, M, Bsz):
     ops.mlp_bwd_dw(x, dy, w1, w2.t().contiguous(), b1, dw1, db1, dw2, db2, M, Cdim, hid, row_scale=scale, rows_per_scale=rps)
     for a, r, nm in ((dw1, w1r.grad, "dw1"), (db1, b1r.grad, "db1"), (dw2, w2r.grad, "dw2"), (db2, b2r.grad, "db2")):
         assert maxrel(a, r) < 3e-2, nm
+    # round 6: the same gradients with the token splits leaving as bf16 partial tiles + the ordered fold (mvlt_mlp_args.partials; taken by the tile-uniform kernel): accumulates
+    # into dw1 / dw2 like the atomic path, equals it to the partial tiles' bf16 rounding, is bit-identical from launch to launch, folded at once or with the pending ones
+    if rps % 64 == 0:
+        from mvlt_amd._lib import last_kernel
+        scratch = torch.empty(64 * 65536, device=dev(), dtype=bf)
+        got = []
+        for defer in (False, True, True):
+            e1, eb1 = torch.full((hid, Cdim), 0.5, device=dev()), torch.zeros(hid, device=dev())
+            e2, eb2 = torch.full((Cdim, hid), -0.25, device=dev()), torch.zeros(Cdim, device=dev())
+            ops.mlp_bwd_dw(x, dy, w1, w2.t().contiguous(), b1, e1, eb1, e2, eb2, M, Cdim, hid, row_scale=scale, rows_per_scale=rps, partials=scratch, defer_fold=defer)
+            if defer:
+                torch.cuda.synchronize()
+                assert bool((e1 == 0.5).all()) and bool((e2 == -0.25).all())            # nothing folded yet
+                ops.tn_fold_flush(scratch)
+            torch.cuda.synchronize()
+            assert "tn_fold" in last_kernel()
+            got.append((e1, e2))
+            assert maxrel(e1 - 0.5, dw1) < 5e-3 and maxrel(e2 + 0.25, dw2) < 5e-3
+            assert maxrel(eb1, db1) < 1e-3 and maxrel(eb2, db2) < 1e-3
+        assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[1][0], got[2][0]) and torch.equal(got[0][1], got[2][1])
 
 
 @pytest.mark.parametrize("Cdim,hid,M,Bsz", [(64, 512, 3 * 400, 3), (128, 1024, 2 * 333, 2), (64, 512, 130, 1)])
