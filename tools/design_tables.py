@@ -52,7 +52,7 @@ prev_tag_early = "r%02d" % (int(tag[1:]) - 1)
 t31 = f"""### 3.1 One steady-state step: {n_launch} launches, kernels busy {busy_ms:.2f} ms (`profiles/{tag}_step_launches.txt`)
 
 (The span from the step's first kernel to the optimizer's end is {span_ms:.2f} ms under `rocprofv3 --kernel-trace` -- {busy_pct:.1f} % busy; {n_aten} of the launches are ATen kernels, {n_copy} `copyBuffer`.
-Unprofiled the bench step equals the sum of the kernel durations.  The boxes of the pool differ by up to 5 % (19.4-20.5 ms for this build): family differences to `{prev_tag_early}_step_launches.txt` below that are spread; the one kernel change of round 6 inside this step is the weight-gradient family (the stage-3 fc gradients on 192 x 320 tiles of the 8-phase TN loop: -0.04 ms).)
+Unprofiled the bench step equals the sum of the kernel durations.  The boxes of the pool differ by up to 5 % (19.4-20.5 ms for this build): family differences to `{prev_tag_early}_step_launches.txt` below that are spread; the kernel changes of round 6 inside this step are in the weight-gradient family (the stage-3 fc gradients on 192 x 320 tiles of the 8-phase TN loop: -0.04 ms; the vocabulary decoder's gradient stored instead of added: -0.1 ms).)
 
 | kernel family | launches | us / step | share | bound by (evidence) |
 |---|---|---|---|---|
@@ -197,7 +197,7 @@ pairs = lambda x: f"{x:,.0f}".replace(",", " ")
 _fis = (rf.get("frac_in_step") or {}).get("frac", float("nan"))
 t6 = f"""**The line of the final build** (`profiles/{tag}_bench_n1.json`, command `python bench.py`, sources `{tj['_source_hash']}`): **{pairs(bench['value'])} pairs/s, {bench['ms_per_step']:.2f} ms/step**
 (round 5: driver 12 872 / 19.89; round 4: 12 532 / 20.43; round 3: 11 428 / 22.40).  The boxes of the pool differ by +-2.5 %: this tree measured 19.4 .. 20.2 ms on the boxes of this
-round.  Round 6 changed one hot path of this step (the stage-3 fc weight gradients: -0.04 ms same-box; `docs/experiments_r6.md`: five other kernel-level attempts measured same-box, none faster), so the step is round 5's within that spread; what changed in the LINE:
+round.  Round 6 changed two hot paths of this step (the stage-3 fc weight gradients: -0.04 ms same-box; the vocabulary decoder's weight gradient without atomics: -0.1 ms; `docs/experiments_r6.md`: seven other kernel-level attempts measured same-box, none faster), so the step is round 5's within that spread; what changed in the LINE:
 the roofline launch runs with the step's own DropPath factors (4 of 256 samples dropped, `algorithmic_flops` counts the kept ones -- round 5 dropped one in ten while counting all: the `frac` erred upward), `frac_in_step` gives the same kernel's fraction from the
 committed kernel trace, the TN sibling is timed the way the step launches it (partial tiles + fold), `other_configs` are faster (pvlt_medium at 384 px: ragged 192 x 320 tiles + one-chunk attention backward), `config.parity_note` states the bf16 ITM exemption.
 Loss trajectory unchanged (epoch average {bench['config']['epoch_avg_loss']:.2f}, same synthetic batch).
