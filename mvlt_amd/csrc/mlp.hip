@@ -963,7 +963,10 @@ __device__ __forceinline__ void gelu_fast_both1(float x, float& g, float& dg) {
 }
 
 template <int C, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void mlp_wgrad2_kernel(mvlt_mlp_args p, int m_per_split, int splits, int ny, bf16* part1, bf16* part2) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void mlp_wgrad2_kernel(mvlt_mlp_args p, int m_per_split, int splits, int ny, void* part1_, void* part2_) {
+  // (void*: a __bf16* parameter makes rocprofv3 print the kernel's MANGLED name -- its demangler does not know DF16b -- and every name-keyed tool of tools/ loses the kernel)
+  bf16* const part1 = (bf16*)part1_;
+  bf16* const part2 = (bf16*)part2_;
   constexpr int NTH = NW * 64;
   constexpr int JT = 8 / NW;                   // 16-unit hidden tiles per wave: 2 (4 waves) / 1 (8 waves)
   constexpr int KS_C = C / 32, CT16 = C / 16;
@@ -1287,7 +1290,7 @@ template <int C> int launch_wgrad(const mvlt_mlp_args& a, hipStream_t s) {
       part1 = mvlt_fold_acquire_ext(f1, 2 * pbytes, s, 2);
       if (part1) part2 = part1 + pbytes / 2;
     }
-    MVLT_LAUNCH((mlp_wgrad2_kernel<C, NW>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NW * 64), lds_t, s, a, m_per_split, splits, ny, part1, part2);
+    MVLT_LAUNCH((mlp_wgrad2_kernel<C, NW>), dim3(8 * ((splits + 7) / 8) * ny), dim3(NW * 64), lds_t, s, a, m_per_split, splits, ny, (void*)part1, (void*)part2);
     if (part1) {
       mvlt_fold_launch_ext(f1, part1, splits, s);
       mvlt_fold_launch_ext(f2, part2, splits, s);
