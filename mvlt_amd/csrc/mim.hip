@@ -883,7 +883,10 @@ extern "C" int mvlt_bn_finalize_norm(const void* z_, int ldz, const float* sum, 
   MVLT_REQUIRE(C % 8 == 0 && C <= 256 && ldz % 8 == 0 && al16(z_) && al16(gamma) && al16(beta) && (!y32_ || (al16(y32_) && ld32 % (y32_dtype == 2 ? 8 : 4) == 0 && (y32_dtype == 1 || y32_dtype == 2))) &&
                (!y16 || (al16(y16) && ld16 % 8 == 0)),
                "mvlt_bn_finalize_norm: fp16 z, C a multiple of 8 and <= 256, row strides multiples of 8, 16-byte aligned tensors (the bf16 training path of the MIM decoder)");
-  const dim3 grid(grid_for(M * (C / 8)));
+  // every workgroup re-derives the C channels' statistics from copies x 2 x C floats before its first row: with the default cap (8192 workgroups: three 8-element chunks per
+  // thread at 262144 x 192) that prologue outweighed the rows (round 6: the launches ran at 2.2-2.8 x their HBM time, tools/ceiling_table.py)
+  static const int fin_cap = getenv("MVLT_BN_FIN_CAP") ? atoi(getenv("MVLT_BN_FIN_CAP")) : 2048;
+  const dim3 grid(grid_for(M * (C / 8), fin_cap));
   if (y32_ && y32_dtype == 2)
     MVLT_LAUNCH((bn_fin_norm8_kernel<_Float16>), grid, dim3(NT), 0, (hipStream_t)stream, (const _Float16*)z_, ldz, sum, sumsq, copies, M, eps, momentum, mean, rstd, running_mean, running_var,
                        gamma, beta, M, C, (_Float16*)y32_, ld32, (bf16*)y16, ld16);
