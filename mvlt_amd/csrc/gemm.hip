@@ -3180,8 +3180,11 @@ extern "C" int mvlt_gemm_tn(const mvlt_gemm_tn_args* a, void* stream) {
     // batched folds 16 / 8 / 4 / 2 all measure 12.98-13.00 k pairs/s against 12.90 at 24): bf16 partial tiles into the caller's scratch
     // + an ordered fold instead of the atomics (14-21 us of a 53-56 us launch, profiles/r05_tn_small_atomics_ablation.txt).  Fewer splits: the atomics are cheaper than a fold launch.
     static const int part_min = getenv("MVLT_TN_PART_MIN") ? atoi(getenv("MVLT_TN_PART_MIN")) : 8;
+    // ... and from 16384 output elements on (65536 through round 5): the SMALL outputs are where many splits hurt most -- text_embed1's 64 x 768 weight gradient over 32768 rows:
+    // 64 splits x 49152 atomics on the same 1536 cache lines = 56 us where its operands are 9 us of HBM time (tools/ubench_tn_smallk.py; MVLT_TN_PART_MINOUT)
+    static const long part_min_out = getenv("MVLT_TN_PART_MINOUT") ? atol(getenv("MVLT_TN_PART_MINOUT")) : 16384;
     bf16* const part = (tnp8 && a->partials && !a->c_overwrite && splits >= part_min && !a->trans_c && a->c_taps <= 1 && a->N2 % 8 == 0 && a->ldc % 4 == 0 && ((uintptr_t)a->C & 15) == 0 &&
-                        (long)a->N1 * a->N2 >= 65536)
+                        (long)a->N1 * a->N2 >= part_min_out)
                            ? fold_acquire(*a, (long)splits * a->N1 * a->N2 * 2, s) : nullptr;
 #define MVLT_TN_LAUNCH(BMT_, BN_, NS_)                                                                                          \
   do {                                                                                                                         \

@@ -81,7 +81,7 @@ def gemm_tn(A, B, C_out, M, N1, N2, lda, ldb, ldc, *, a_map=None, b_map=None, co
                          ptr(wt), ptr(dx), dgrad_ld)
         check(L.lib.mvlt_gemm_tn(C.byref(a), stream_ptr()), "mvlt_gemm_tn")
         return C_out
-    if N1 <= 64 < N2 and b_map.mode == 0 and taps <= 1:
+    if N1 <= 64 < N2 and b_map.mode == 0 and taps <= 1 and partials is None:          # (with a partial-tile scratch the 64 x 128 tile of the LDS-DMA kernel takes the shape as it is)
         # the kernel's tile is 128 (N1 side) x 64/128 (N2 side): give the narrow operand the 64-wide side by computing
         # C^T = B^T A and storing it transposed; the bias gradient becomes the column sum of the (now) B operand
         a = L.GemmTNArgs(ptr(B), ptr(A), ptr(C_out), M, N2, N1, ldb, lda, ldc, DT[A.dtype], b_map, a_map, None, splits, ptr(colsum), 1, 0, 0)

@@ -454,7 +454,9 @@ class TrunkStep:
         if i == 0:
             K = m.in_chans * m.patch_size ** 2
             ops.gemm_tn(d_pe, sv["P1"], self.g(pe + "proj.weight").view(C, K), B * HW, C, K, C, K, K, colsum=self.g(pe + "proj.bias"))
-            ops.gemm_tn(d_te, self.emb, self.g(ten + "0.weight"), B * T, C, m.hidden, C, m.hidden, m.hidden, colsum=self.g(ten + "0.bias"))
+            # (round 6: the text-embedding weight gradients leave as partial tiles too -- 64 x 768 over 32768 rows: 64 splits' atomics on 1536 cache lines were 56 us)
+            ops.gemm_tn(d_te, self.emb, self.g(ten + "0.weight"), B * T, C, m.hidden, C, m.hidden, m.hidden, colsum=self.g(ten + "0.bias"),
+                        partials=self.S.tn_partials(), defer_fold=_DEFER_FOLD)
             d_emb = _empty((B * T, m.hidden), dt, dev)
             ops.gemm_nt(d_te, self.wT(ten + "0.weight"), d_emb, B * T, m.hidden, C, C, C, m.hidden)
             self._bert_backward(d_emb)
@@ -464,7 +466,8 @@ class TrunkStep:
         pm = sv["pm_in"]
         # conv weight gradient: computed in the gather's [out][kh][kw][cin] order, accumulated at its [out][cin][kh][kw] place
         conv_wgrad(self.S, pe + "proj.weight", d_pe, xp, B * HW, C, 4 * Cp, C, Cp, pm, 4, Cp, colsum=self.g(pe + "proj.bias"))
-        ops.gemm_tn(d_te, xp, self.g(ten + "0.weight"), B * T, C, Cp, C, Cp, Cp, b_map=rowmap(T, Np, HWp), colsum=self.g(ten + "0.bias"))
+        ops.gemm_tn(d_te, xp, self.g(ten + "0.weight"), B * T, C, Cp, C, Cp, Cp, b_map=rowmap(T, Np, HWp), colsum=self.g(ten + "0.bias"),
+                    partials=self.S.tn_partials(), defer_fold=_DEFER_FOLD)
         dxp = into.view(B, Np, Cp) if into is not None else _empty((B, Np, Cp), dt, dev)
         ops.gemm_nt(d_pe, self.wKT(pe + "proj.weight"), dxp, B * HW, 4 * Cp, C, C, C, Cp, c_map=pm, R=into)          # image rows (each once)
         ops.gemm_nt(d_te, self.wT(ten + "0.weight"), dxp, B * T, Cp, C, C, C, Cp, c_map=rowmap(T, Np, HWp), R=into)   # text rows
