@@ -13,7 +13,7 @@ Recipe: the reference model imports on CPU given
 Train-mode randomness (BertEmbeddings dropout, DropPath) is injected as fixed keep-masks
 from the filler, in both the reference and the oracle.
 
-usage: python tests/golden/make_golden.py [case ...]
+usage: python tests/golden/make_golden.py [--add] [case ...]
 """
 import os
 import sys
@@ -137,7 +137,7 @@ def relerr(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def run_case(name, c):
+def run_case(name, c, add_only=False):
     from libs import pvlt as ref_pvlt
     from timm.models.layers import DropPath
     cfg = O.Cfg(c["variant"], c["lt"], 224, 768, c["T"], c["dp"])
@@ -237,9 +237,18 @@ def run_case(name, c):
             DropPath.QUEUE = q
             ref.zero_grad()
             img = batch["masked_images"] if (step_idx % 2 == 1) else batch["image"]
+            # how far the per-pair terms of itm_head_embed.0.bias's gradient cancel in the batch sum: c = sqrt(B sum_b |g_b|^2) / |sum_b g_b| >= 1 (the
+            # bf16 gate of tests/test_model_gpu.py prices that tensor against the un-cancelled scale, as it does the three ITM biases behind it)
+            caught, hk = {}, None
+            if c["lt"]["itm"]:
+                hk = ref.itm_head_embed[0].register_full_backward_hook(lambda m, gi, go: caught.__setitem__("g", go[0].detach().double()))
             out_r = ref(img, batch["input_ids"])
             l_r = O.losses(out_r, batch)
             l_r["total_loss"].backward()
+            if hk is not None:
+                hk.remove()
+                gb = caught["g"].reshape(c["B"], -1)
+                G[f"train{step_idx}/cancel/itm_head_embed.0.bias"] = np.array(float(np.sqrt(c["B"] * (gb ** 2).sum().item()) / max(1e-30, gb.sum(0).norm().item())))
             assert len(q) == 0
             DropPath.QUEUE = None
             g_ref = {k: p.grad for k, p in ref.named_parameters()}
@@ -274,6 +283,14 @@ def run_case(name, c):
             ref.text_embeddings.dropout = torch.nn.Dropout(0.1)
 
     path = os.path.join(HERE, name + ".npz")
+    if add_only:
+        # keep the committed arrays byte for byte, add the new keys only -- after checking that this run reproduces the committed ones
+        old = dict(np.load(path))
+        for k, v in old.items():
+            assert k in G and np.allclose(np.asarray(G[k], dtype=np.float64), np.asarray(v, dtype=np.float64), rtol=1e-4, atol=1e-6), (name, "this run does not reproduce the committed fixture", k)
+        added = [k for k in G if k not in old]
+        G = {**old, **{k: G[k] for k in added}}
+        print(f"[{name}] --add: {len(old)} committed arrays reproduced and kept, added {added}")
     np.savez_compressed(path, **G)
     print(f"[{name}] wrote {path} ({os.path.getsize(path)/1024:.1f} KiB, {len(G)} arrays)")
 
@@ -572,7 +589,8 @@ def main():
     install_shims()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    names = sys.argv[1:] or (list(CASES) + list(LOOP_CASES) + list(EVAL_CASES) + ["batchprep_ref"])
+    add_only = "--add" in sys.argv[1:]          # CASES only: keep the committed arrays, add the keys a newer generator knows
+    names = [a for a in sys.argv[1:] if a != "--add"] or (list(CASES) + list(LOOP_CASES) + list(EVAL_CASES) + ["batchprep_ref"])
     for n in names:
         if n == "batchprep_ref":
             run_batchprep_case(n)
@@ -581,7 +599,7 @@ def main():
         elif n in EVAL_CASES:
             run_eval_case(n, EVAL_CASES[n])
         else:
-            run_case(n, CASES[n])
+            run_case(n, CASES[n], add_only)
 
 
 if __name__ == "__main__":
