@@ -47,6 +47,8 @@ CASES = {
     "tiny256_pretrain_b64": dict(variant="pvlt_tiny", img=256, T=128, B=64, lt=dict(mlm=1, itm=1, t2i=1, cls=0), dp=0.1, train=True, steps=(1,)),
     "medium384_pretrain_b8": dict(variant="pvlt_medium", img=384, T=128, B=8, lt=dict(mlm=1, itm=1, t2i=1, cls=0), dp=0.1, train=True, steps=(1,)),
     "large96_T20": dict(variant="pvlt_large", img=96, T=20, B=3, lt=dict(mlm=1, itm=1, t2i=1, cls=1), dp=0.1, train=True, steps=(1,)),
+    # BASELINE configuration #5 (CLS fine-tune, scripts_dws/configs/dws_mvlt_ft_exp48.py:11) at a batch that selects the same large-M kernel variants on the CLS-only path
+    "tiny256_ft_b64": dict(variant="pvlt_tiny", img=256, T=128, B=64, lt=dict(mlm=0, itm=0, t2i=0, cls=1), dp=0.1, train=True, steps=(0,)),
 }
 
 

@@ -29,6 +29,8 @@ CASES = {
     "tiny256_pretrain_b64": dict(variant="pvlt_tiny", lt=dict(mlm=1, itm=1, t2i=1, cls=0)),
     "medium384_pretrain_b8": dict(variant="pvlt_medium", lt=dict(mlm=1, itm=1, t2i=1, cls=0)),
     "large96_T20": dict(variant="pvlt_large", lt=dict(mlm=1, itm=1, t2i=1, cls=1)),
+    # BASELINE configuration #5's heads (CLS fine-tune) at batch 64
+    "tiny256_ft_b64": dict(variant="pvlt_tiny", lt=dict(mlm=0, itm=0, t2i=0, cls=1)),
 }
 
 
@@ -237,7 +239,7 @@ def _losses_like_engine(out, batch, dev):
 
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("name", ["tiny256_pretrain", "small96_T20_ragged", "tiny256_ft", "medium384_pretrain", "tiny256_pretrain_b64", "medium384_pretrain_b8", "large96_T20"])
+@pytest.mark.parametrize("name", ["tiny256_pretrain", "small96_T20_ragged", "tiny256_ft", "medium384_pretrain", "tiny256_pretrain_b64", "medium384_pretrain_b8", "large96_T20", "tiny256_ft_b64"])
 def test_train_step_parity(golden_dir, parity, name, dtype, fused):
     """one train-mode step with injected dropout / DropPath masks: losses, every parameter-gradient norm and a strided
     sample of every gradient vs the REFERENCE's values in the golden fixture; the small ragged case also compares every
