@@ -172,7 +172,8 @@ def test_full_batch_gradients_equal_the_mean_of_its_chunks(parity, heads, lt, va
     (fewer m-splits, other tile rounds, more query chunks per head), the full batch the large-M ones, so a variant that only the bench's shapes select is
     compared with one that is pinned.  Heads: MLM + ITM (the MLM mean is over the selected positions: the labels of the first quarter are reused by the others so
     that every quarter has the same count) and the two CLS heads (BASELINE configuration #5); the MIM decoder stays out -- its BatchNorm uses batch statistics,
-    for which no such identity holds (it is covered at full size by the loss check and the repeatability test above).  BASELINE configuration #4 the same way:
+    for which no such identity holds (at full size it is covered by the loss check and the repeatability test above, and -- forward, BN statistics, every gradient --
+    against PyTorch's own ops at batch 256 by tests/test_model_gpu.py::test_mim_decoder_hip_vs_torch_twin).  BASELINE configuration #4 the same way:
     pvlt_medium at 384 px, batch 64 against its eight batch-8 chunks, the size of `medium384_pretrain_b8`."""
     from mvlt_amd import pvlt
     from mvlt_amd.engine import train_step
